@@ -1,0 +1,205 @@
+"""ctypes binding of the CPU oracle (``oracle/liboc_oracle.so``).
+
+TEST INFRASTRUCTURE ONLY.  Importable from ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg -- never from ``opencorr_amd``.  The
+library is a float32 CPU restatement of OpenCorr's FFTCC -> ICGN path; every
+native function cites the reference file:line it follows (``oc_oracle.cpp``).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboc_oracle.so")
+
+ORDER_SEQ = 0
+ORDER_LANES = 1
+POI2D_FLOATS = 25
+POI3D_FLOATS = 31
+
+# float offsets inside a POI2D record (src/oc_poi.h:102-136 of the reference)
+P2 = dict(x=0, y=1, u=2, ux=3, uy=4, uxx=5, uxy=6, uyy=7, v=8, vx=9, vy=10, vxx=11, vxy=12, vyy=13,
+          u0=14, v0=15, zncc=16, iteration=17, convergence=18, feature=19, exx=20, eyy=21, exy=22,
+          srx=23, sry=24)
+# float offsets inside a POI3D record (src/oc_poi.h:187-222)
+P3 = dict(x=0, y=1, z=2, u=3, ux=4, uy=5, uz=6, v=7, vx=8, vy=9, vz=10, w=11, wx=12, wy=13, wz=14,
+          u0=15, v0=16, w0=17, zncc=18, iteration=19, convergence=20, feature=21,
+          srx=28, sry=29, srz=30)
+
+
+def build(force=False):
+    """Compile the oracle with its Makefile (g++ only, no third-party deps)."""
+    src = os.path.join(_HERE, "oc_oracle.cpp")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src),
+                                                   os.path.getmtime(os.path.join(_HERE, "oc_oracle.h")))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        fp = ctypes.POINTER(ctypes.c_float)
+        i, f, l = ctypes.c_int, ctypes.c_float, ctypes.c_long
+        L.oc_oracle_gradient2d.argtypes = [fp, i, i, fp, fp, i]
+        L.oc_oracle_bspline2d_lut.argtypes = [fp, i, i, fp, i]
+        L.oc_oracle_bspline2d_eval.argtypes = [fp, i, i, f, f]
+        L.oc_oracle_bspline2d_eval.restype = f
+        L.oc_oracle_fftcc2d.argtypes = [fp, fp, i, i, i, i, fp, l, i, fp]
+        L.oc_oracle_icgn2d1.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i]
+        L.oc_oracle_icgn2d2.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i]
+        L.oc_oracle_gradient3d.argtypes = [fp, i, i, i, fp, fp, fp, i]
+        L.oc_oracle_bspline3d_prefilter.argtypes = [fp, i, i, i, fp, i]
+        L.oc_oracle_bspline3d_eval.argtypes = [fp, i, i, i, f, f, f]
+        L.oc_oracle_bspline3d_eval.restype = f
+        L.oc_oracle_fftcc3d.argtypes = [fp, fp, i, i, i, i, i, i, fp, l, i]
+        L.oc_oracle_icgn3d1.argtypes = [fp, fp, fp, fp, fp, i, i, i, i, i, i, f, f, fp, l, i, i, i]
+        L.oc_oracle_max_threads.restype = i
+        for name in ("oc_oracle_gradient2d", "oc_oracle_bspline2d_lut", "oc_oracle_fftcc2d", "oc_oracle_icgn2d1",
+                     "oc_oracle_icgn2d2", "oc_oracle_gradient3d", "oc_oracle_bspline3d_prefilter",
+                     "oc_oracle_fftcc3d", "oc_oracle_icgn3d1"):
+            getattr(L, name).restype = None
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _img(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+def max_threads():
+    return lib().oc_oracle_max_threads()
+
+
+def make_pois2d(xs, ys):
+    """Zero-initialised POI2D records (POI2D ctor, src/oc_poi.h:108-135)."""
+    xs = np.asarray(xs, dtype=np.float32).ravel()
+    ys = np.asarray(ys, dtype=np.float32).ravel()
+    pois = np.zeros((xs.size, POI2D_FLOATS), dtype=np.float32)
+    pois[:, 0] = xs
+    pois[:, 1] = ys
+    return pois
+
+
+def make_pois3d(xs, ys, zs):
+    xs = np.asarray(xs, dtype=np.float32).ravel()
+    pois = np.zeros((xs.size, POI3D_FLOATS), dtype=np.float32)
+    pois[:, 0] = xs
+    pois[:, 1] = np.asarray(ys, dtype=np.float32).ravel()
+    pois[:, 2] = np.asarray(zs, dtype=np.float32).ravel()
+    return pois
+
+
+def gradient2d(img, threads=0):
+    img = _img(img)
+    h, w = img.shape
+    gx = np.empty_like(img)
+    gy = np.empty_like(img)
+    lib().oc_oracle_gradient2d(_fp(img), h, w, _fp(gx), _fp(gy), threads)
+    return gx, gy
+
+
+def bspline2d_lut(img, threads=0):
+    img = _img(img)
+    h, w = img.shape
+    lut = np.empty((h, w, 16), dtype=np.float32)
+    lib().oc_oracle_bspline2d_lut(_fp(img), h, w, _fp(lut), threads)
+    return lut
+
+
+def bspline2d_eval(lut, x, y):
+    h, w, _ = lut.shape
+    return lib().oc_oracle_bspline2d_eval(_fp(lut), h, w, float(x), float(y))
+
+
+def fftcc2d(ref, tar, rx, ry, pois, threads=0, want_surface=False):
+    """In-place FFTCC2D::compute(poi_queue) on ``pois`` (n x 25 float32)."""
+    ref, tar = _img(ref), _img(tar)
+    assert pois.dtype == np.float32 and pois.flags.c_contiguous and pois.shape[1] == POI2D_FLOATS
+    h, w = ref.shape
+    surf = np.zeros((2 * ry, 2 * rx), dtype=np.float32) if want_surface else None
+    lib().oc_oracle_fftcc2d(_fp(ref), _fp(tar), h, w, rx, ry, _fp(pois), pois.shape[0], threads,
+                            _fp(surf) if want_surface else None)
+    return surf
+
+
+class Prepared2D:
+    """What ICGN2D1/2D2::prepare() builds: reference gradients + target LUT."""
+
+    def __init__(self, ref, tar, threads=0):
+        self.ref = _img(ref)
+        self.tar = _img(tar)
+        self.gx, self.gy = gradient2d(self.ref, threads)
+        self.lut = bspline2d_lut(self.tar, threads)
+
+
+def icgn2d1(prep, rx, ry, conv, stop, pois, order=ORDER_SEQ, lanes=64, threads=0):
+    assert pois.dtype == np.float32 and pois.flags.c_contiguous and pois.shape[1] == POI2D_FLOATS
+    h, w = prep.ref.shape
+    lib().oc_oracle_icgn2d1(_fp(prep.ref), _fp(prep.gx), _fp(prep.gy), _fp(prep.lut), h, w, rx, ry,
+                            float(conv), float(stop), _fp(pois), pois.shape[0], order, lanes, threads)
+
+
+def icgn2d2(prep, rx, ry, conv, stop, pois, order=ORDER_SEQ, lanes=64, threads=0):
+    assert pois.dtype == np.float32 and pois.flags.c_contiguous and pois.shape[1] == POI2D_FLOATS
+    h, w = prep.ref.shape
+    lib().oc_oracle_icgn2d2(_fp(prep.ref), _fp(prep.gx), _fp(prep.gy), _fp(prep.lut), h, w, rx, ry,
+                            float(conv), float(stop), _fp(pois), pois.shape[0], order, lanes, threads)
+
+
+def gradient3d(vol, threads=0):
+    vol = _img(vol)
+    dz, dy, dx = vol.shape
+    gx, gy, gz = np.empty_like(vol), np.empty_like(vol), np.empty_like(vol)
+    lib().oc_oracle_gradient3d(_fp(vol), dz, dy, dx, _fp(gx), _fp(gy), _fp(gz), threads)
+    return gx, gy, gz
+
+
+def bspline3d_prefilter(vol, threads=0):
+    vol = _img(vol)
+    dz, dy, dx = vol.shape
+    coef = np.empty_like(vol)
+    lib().oc_oracle_bspline3d_prefilter(_fp(vol), dz, dy, dx, _fp(coef), threads)
+    return coef
+
+
+def bspline3d_eval(coef, x, y, z):
+    dz, dy, dx = coef.shape
+    return lib().oc_oracle_bspline3d_eval(_fp(coef), dz, dy, dx, float(x), float(y), float(z))
+
+
+def fftcc3d(ref, tar, rx, ry, rz, pois, threads=0):
+    ref, tar = _img(ref), _img(tar)
+    assert pois.dtype == np.float32 and pois.flags.c_contiguous and pois.shape[1] == POI3D_FLOATS
+    dz, dy, dx = ref.shape
+    lib().oc_oracle_fftcc3d(_fp(ref), _fp(tar), dz, dy, dx, rx, ry, rz, _fp(pois), pois.shape[0], threads)
+
+
+class Prepared3D:
+    def __init__(self, ref, tar, threads=0):
+        self.ref = _img(ref)
+        self.tar = _img(tar)
+        self.gx, self.gy, self.gz = gradient3d(self.ref, threads)
+        self.coef = bspline3d_prefilter(self.tar, threads)
+
+
+def icgn3d1(prep, rx, ry, rz, conv, stop, pois, order=ORDER_SEQ, lanes=256, threads=0):
+    assert pois.dtype == np.float32 and pois.flags.c_contiguous and pois.shape[1] == POI3D_FLOATS
+    dz, dy, dx = prep.ref.shape
+    lib().oc_oracle_icgn3d1(_fp(prep.ref), _fp(prep.gx), _fp(prep.gy), _fp(prep.gz), _fp(prep.coef), dz, dy, dx,
+                            rx, ry, rz, float(conv), float(stop), _fp(pois), pois.shape[0], order, lanes, threads)

@@ -1,0 +1,1141 @@
+/*
+ * oc_oracle.cpp -- CPU oracle (float32 restatement of OpenCorr's FFTCC -> ICGN path).
+ *
+ * TEST INFRASTRUCTURE ONLY -- see oc_oracle.h for the contract and for the
+ * parity status of each entry point.  Build: oracle/Makefile
+ * (g++ -O2 -ffp-contract=off -fopenmp, no third-party dependencies).
+ *
+ * Every function cites the reference lines it restates (paths relative to the
+ * OpenCorr tree).  The arithmetic that the reference delegates to Eigen/FFTW
+ * (un-vendored: Eigen 3.4.0, FFTW 3.3.5 per 1_Get_started.md:9-12) is restated
+ * from the published algorithms:
+ *   - Matrix6f/Matrix12f::inverse()  -> partial-pivot LU, solve against identity
+ *   - Matrix3f/4f inverse            -> cofactor / determinant formula
+ *   - small fixed products           -> coefficient-wise, inner index ascending
+ *   - fftwf r2c/c2r                  -> mixed-radix DFT evaluated in double
+ *     precision (the oracle's correlation surface is therefore *more* exact than
+ *     either FFTW's or rocFFT's float32 result; only the arg-max and the float
+ *     ZNCC derived from it are compared).
+ */
+#include "oc_oracle.h"
+
+#include <omp.h>
+
+#include <cmath>
+#include <complex>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------
+// K simultaneous sums over samples s = 0..N-1.  SEQ: one running float per sum.
+// LANES: P strided partials per sum + ascending xor butterfly (oc_oracle.h).
+template <int K>
+struct AccSeq {
+    float a[K];
+    explicit AccSeq(int /*lanes*/) { for (int k = 0; k < K; k++) a[k] = 0.f; }
+    inline void add(int /*s*/, int k, float v) { a[k] += v; }
+    inline void finish() {}
+    inline float get(int k) const { return a[k]; }
+};
+
+template <int K>
+struct AccLanes {
+    int P;
+    std::vector<float> part;  // [K][P]
+    explicit AccLanes(int lanes) : P(lanes), part((size_t)K * lanes, 0.f) {}
+    inline void add(int s, int k, float v) { part[(size_t)k * P + (s & (P - 1))] += v; }
+    inline void finish() {
+        std::vector<float> tmp(P);
+        for (int k = 0; k < K; k++) {
+            float* p = &part[(size_t)k * P];
+            for (int off = 1; off < P; off <<= 1) {
+                for (int l = 0; l < P; l++) tmp[l] = p[l] + p[l ^ off];
+                for (int l = 0; l < P; l++) p[l] = tmp[l];
+            }
+        }
+    }
+    inline float get(int k) const { return part[(size_t)k * P]; }
+};
+
+// ---------------------------------------------------------------------------
+// small dense algebra (restating what the reference gets from Eigen)
+// ---------------------------------------------------------------------------
+// inverse of an n x n row-major matrix by LU with partial (row) pivoting and a
+// solve against the identity -- Eigen::PartialPivLU::inverse(), which is what
+// MatrixBase::inverse() uses for fixed sizes > 4 (src/oc_icgn.cpp:210,759,1339;
+// src/oc_icgn.cpp:831 for the 6x6 warp).
+static void lu_inverse(const float* A, float* Ainv, int n) {
+    float lu[12 * 12];
+    int perm[12];
+    for (int i = 0; i < n * n; i++) lu[i] = A[i];
+    for (int i = 0; i < n; i++) perm[i] = i;
+    for (int k = 0; k < n; k++) {
+        int piv = k;
+        float best = std::fabs(lu[k * n + k]);
+        for (int r = k + 1; r < n; r++) {
+            float v = std::fabs(lu[r * n + k]);
+            if (v > best) { best = v; piv = r; }
+        }
+        if (piv != k) {
+            for (int c = 0; c < n; c++) { float t = lu[k * n + c]; lu[k * n + c] = lu[piv * n + c]; lu[piv * n + c] = t; }
+            int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+        }
+        float d = lu[k * n + k];
+        for (int r = k + 1; r < n; r++) {
+            float f = lu[r * n + k] / d;
+            lu[r * n + k] = f;
+            for (int c = k + 1; c < n; c++) lu[r * n + c] = lu[r * n + c] - f * lu[k * n + c];
+        }
+    }
+    // solve L U X = P I, column by column
+    for (int col = 0; col < n; col++) {
+        float y[12];
+        for (int i = 0; i < n; i++) {
+            float v = (perm[i] == col) ? 1.f : 0.f;
+            for (int j = 0; j < i; j++) v = v - lu[i * n + j] * y[j];
+            y[i] = v;
+        }
+        for (int i = n - 1; i >= 0; i--) {
+            float v = y[i];
+            for (int j = i + 1; j < n; j++) v = v - lu[i * n + j] * y[j];
+            y[i] = v / lu[i * n + i];
+        }
+        for (int i = 0; i < n; i++) Ainv[i * n + col] = y[i];
+    }
+}
+
+// c = a * b, n x n row-major, coefficient-wise with ascending inner index
+// (Eigen lazy product for small fixed sizes; src/oc_icgn.cpp:290,831,1439).
+static void mat_mul(const float* a, const float* b, float* c, int n) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            float v = a[i * n + 0] * b[0 * n + j];
+            for (int k = 1; k < n; k++) v = v + a[i * n + k] * b[k * n + j];
+            c[i * n + j] = v;
+        }
+}
+
+// 3x3 inverse by cofactors / determinant (Eigen compute_inverse<.,.,3>).
+static inline float cof3(const float* m, int i, int j) {
+    int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];
+}
+static void inverse3(const float* m, float* r) {
+    float c0 = cof3(m, 0, 0), c1 = cof3(m, 1, 0), c2 = cof3(m, 2, 0);
+    float det = (c0 * m[0] + c1 * m[3]) + c2 * m[6];
+    float invdet = 1.f / det;
+    r[0] = c0 * invdet; r[1] = c1 * invdet; r[2] = c2 * invdet;
+    r[3] = cof3(m, 0, 1) * invdet; r[4] = cof3(m, 1, 1) * invdet; r[5] = cof3(m, 2, 1) * invdet;
+    r[6] = cof3(m, 0, 2) * invdet; r[7] = cof3(m, 1, 2) * invdet; r[8] = cof3(m, 2, 2) * invdet;
+}
+
+// 4x4 inverse by cofactor expansion (adjugate / determinant).
+static inline float det3(float a, float b, float c, float d, float e, float f, float g, float h, float i) {
+    return (a * (e * i - f * h) - b * (d * i - f * g)) + c * (d * h - e * g);
+}
+static void inverse4(const float* m, float* r) {
+    float cofm[16];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float s[9];
+            int t = 0;
+            for (int a = 0; a < 4; a++) {
+                if (a == i) continue;
+                for (int b = 0; b < 4; b++) {
+                    if (b == j) continue;
+                    s[t++] = m[a * 4 + b];
+                }
+            }
+            float d = det3(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
+            cofm[i * 4 + j] = ((i + j) & 1) ? -d : d;
+        }
+    float det = ((m[0] * cofm[0] + m[1] * cofm[1]) + m[2] * cofm[2]) + m[3] * cofm[3];
+    float invdet = 1.f / det;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) r[i * 4 + j] = cofm[j * 4 + i] * invdet;
+}
+
+// ---------------------------------------------------------------------------
+// bicubic B-spline (src/oc_cubic_bspline.h:52-58, src/oc_cubic_bspline.cpp:84-181)
+// ---------------------------------------------------------------------------
+static const float BC[4][4] = {
+    {-144.0f / 336.0f, 384.0f / 336.0f, -384.0f / 336.0f, 144.0f / 336.0f},
+    {342.0f / 336.0f, -702.0f / 336.0f, 450.0f / 336.0f, -90.0f / 336.0f},
+    {-198.0f / 336.0f, -18.0f / 336.0f, 270.0f / 336.0f, -54.0f / 336.0f},
+    {0.0f, 1.0f, 0.0f, 0.0f}};
+
+static inline float bspline2d_eval(const float* lut, int height, int width, float x, float y) {
+    // src/oc_cubic_bspline.cpp:137-142
+    if (x < 1 || y < 1 || x >= width - 2 || y >= height - 2 || std::isnan(x) || std::isnan(y)) return -1.f;
+    int xi = (int)std::floor(x);
+    int yi = (int)std::floor(y);
+    float dx = x - xi, dy = y - yi;
+    float dx2 = dx * dx, dy2 = dy * dy;
+    float dx3 = dx2 * dx, dy3 = dy2 * dy;
+    const float* c = lut + ((size_t)yi * width + xi) * 16;
+    // explicit 16-term left-to-right sum of src/oc_cubic_bspline.cpp:159-177
+    float v = c[0];
+    v = v + c[1] * dx;
+    v = v + c[2] * dx2;
+    v = v + c[3] * dx3;
+    v = v + c[4] * dy;
+    v = v + c[5] * dy * dx;
+    v = v + c[6] * dy * dx2;
+    v = v + c[7] * dy * dx3;
+    v = v + c[8] * dy2;
+    v = v + c[9] * dy2 * dx;
+    v = v + c[10] * dy2 * dx2;
+    v = v + c[11] * dy2 * dx3;
+    v = v + c[12] * dy3;
+    v = v + c[13] * dy3 * dx;
+    v = v + c[14] * dy3 * dx2;
+    v = v + c[15] * dy3 * dx3;
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// tricubic B-spline (src/oc_cubic_bspline.h:80-90, src/oc_cubic_bspline.cpp:35-53,214-405)
+// ---------------------------------------------------------------------------
+static const float PREF[8] = {1.732176555412860f,  -0.464135309171000f, 0.124364681271139f,  -0.033323415913556f,
+                              0.008928982383084f,  -0.002392513618779f, 0.000641072092032f,  -0.000171774749350f};
+
+static inline float basis0(float t) { return (1.f / 6.f) * (t * (t * (-t + 3.f) - 3.f) + 1.f); }
+static inline float basis1(float t) { return (1.f / 6.f) * (t * t * (3.f * t - 6.f) + 4.f); }
+static inline float basis2(float t) { return (1.f / 6.f) * (t * (t * (-3.f * t + 3.f) + 3.f) + 1.f); }
+static inline float basis3(float t) { return (1.f / 6.f) * (t * t * t); }
+
+static inline float bspline3d_eval(const float* coef, int dz, int dy, int dx, float x, float y, float z) {
+    if (x < 1 || y < 1 || z < 1 || x >= dx - 2 || y >= dy - 2 || z >= dz - 2 || std::isnan(x) || std::isnan(y) ||
+        std::isnan(z))
+        return -1.f;
+    int xi = (int)std::floor(x), yi = (int)std::floor(y), zi = (int)std::floor(z);
+    float fx = x - xi, fy = y - yi, fz = z - zi;
+    float bx[4] = {basis0(fx), basis1(fx), basis2(fx), basis3(fx)};
+    float by[4] = {basis0(fy), basis1(fy), basis2(fy), basis3(fy)};
+    float bz[4] = {basis0(fz), basis1(fz), basis2(fz), basis3(fz)};
+    float sum_y[4];
+    for (int i = 0; i < 4; i++) {
+        float sum_x[4];
+        for (int j = 0; j < 4; j++) {
+            const float* row = coef + ((size_t)(zi + i - 1) * dy + (yi + j - 1)) * dx + (xi - 1);
+            sum_x[j] = ((bx[0] * row[0] + bx[1] * row[1]) + bx[2] * row[2]) + bx[3] * row[3];
+        }
+        sum_y[i] = ((by[0] * sum_x[0] + by[1] * sum_x[1]) + by[2] * sum_x[2]) + by[3] * sum_x[3];
+    }
+    return ((bz[0] * sum_y[0] + bz[1] * sum_y[1]) + bz[2] * sum_y[2]) + bz[3] * sum_y[3];
+}
+
+// ---------------------------------------------------------------------------
+// double-precision mixed-radix FFT (stands in for FFTW, see file header)
+// ---------------------------------------------------------------------------
+typedef std::complex<double> cplx;
+
+// Stockham autosort, decimation in frequency, generic radix (4, 2, 3, 5, then any prime).
+struct FFT1D {
+    int n;
+    std::vector<int> factors;
+    std::vector<cplx> tw;  // tw[k] = exp(-2 pi i k / n)
+    explicit FFT1D(int n_) : n(n_), tw(n_ > 0 ? n_ : 1) {
+        int m = n;
+        while (m % 4 == 0) { factors.push_back(4); m /= 4; }
+        for (int p = 2; p * p <= m; p++)
+            while (m % p == 0) { factors.push_back(p); m /= p; }
+        if (m > 1) factors.push_back(m);
+        const double two_pi = 6.283185307179586476925286766559;
+        for (int k = 0; k < n; k++) tw[k] = cplx(std::cos(two_pi * k / n), -std::sin(two_pi * k / n));
+    }
+    inline cplx w(long idx, int sign) const {
+        cplx v = tw[(size_t)(idx % n)];
+        return sign > 0 ? std::conj(v) : v;
+    }
+    // idx known to be < n
+    inline cplx wd(int idx, int sign) const {
+        cplx v = tw[(size_t)idx];
+        return sign > 0 ? std::conj(v) : v;
+    }
+    // transforms x (length n, contiguous) in place using y as ping-pong scratch
+    void run(cplx* x, cplx* y, int sign) const {
+        cplx* src = x;
+        cplx* dst = y;
+        int len = n, s = 1;
+        for (int r : factors) {
+            const int m = len / r;
+            const int tstep = n / len;  // W_len^k = tw[k * tstep]
+            const int rstep = n / r;    // W_r^k   = tw[k * rstep]
+            for (int p = 0; p < m; p++) {
+                for (int q = 0; q < s; q++) {
+                    if (r == 2) {
+                        cplx a = src[q + s * p], b = src[q + s * (p + m)];
+                        dst[q + s * (2 * p)] = a + b;
+                        dst[q + s * (2 * p + 1)] = (a - b) * wd(p * tstep, sign);
+                    } else if (r == 4) {
+                        cplx a0 = src[q + s * p], a1 = src[q + s * (p + m)], a2 = src[q + s * (p + 2 * m)],
+                             a3 = src[q + s * (p + 3 * m)];
+                        cplx s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+                        // multiply d13 by -i (forward) or +i (inverse)
+                        cplx jd = sign > 0 ? cplx(-d13.imag(), d13.real()) : cplx(d13.imag(), -d13.real());
+                        dst[q + s * (4 * p)] = s02 + s13;
+                        dst[q + s * (4 * p + 1)] = (d02 + jd) * wd(p * tstep, sign);
+                        dst[q + s * (4 * p + 2)] = (s02 - s13) * wd(2 * p * tstep, sign);
+                        dst[q + s * (4 * p + 3)] = (d02 - jd) * wd(3 * p * tstep, sign);
+                    } else {
+                        for (int k = 0; k < r; k++) {
+                            cplx acc = src[q + s * p];
+                            for (int j = 1; j < r; j++) acc += src[q + s * (p + j * m)] * w((long)j * k * rstep, sign);
+                            dst[q + s * (r * p + k)] = acc * w((long)p * k * tstep, sign);
+                        }
+                    }
+                }
+            }
+            len = m;
+            s *= r;
+            cplx* t = src; src = dst; dst = t;
+        }
+        if (src != x)
+            for (int i = 0; i < n; i++) x[i] = src[i];
+    }
+};
+
+struct FFTCache {
+    std::vector<FFT1D*> plans;
+    ~FFTCache() { for (FFT1D* p : plans) delete p; }
+    const FFT1D& get(int n) {
+        for (FFT1D* p : plans) if (p->n == n) return *p;
+        plans.push_back(new FFT1D(n));
+        return *plans.back();
+    }
+};
+
+// in-place N-d complex DFT over a row-major array with dims[0] slowest
+static void fft_nd(std::vector<cplx>& a, const std::vector<int>& dims, int sign, FFTCache& cache) {
+    size_t total = 1;
+    for (int d : dims) total *= d;
+    int maxd = 0;
+    for (int d : dims) maxd = d > maxd ? d : maxd;
+    std::vector<cplx> line(maxd), scratch(maxd);
+    size_t stride = total;
+    for (size_t ax = 0; ax < dims.size(); ax++) {
+        int n = dims[ax];
+        stride /= n;
+        const FFT1D& f = cache.get(n);
+        size_t outer = total / ((size_t)n * stride);
+        for (size_t o = 0; o < outer; o++)
+            for (size_t i = 0; i < stride; i++) {
+                cplx* base = &a[o * n * stride + i];
+                if (stride == 1) {
+                    f.run(base, scratch.data(), sign);
+                } else {
+                    for (int k = 0; k < n; k++) line[k] = base[(size_t)k * stride];
+                    f.run(line.data(), scratch.data(), sign);
+                    for (int k = 0; k < n; k++) base[(size_t)k * stride] = line[k];
+                }
+            }
+    }
+}
+
+// circular cross-correlation surface  c = IDFT( conj(DFT(ref)) * DFT(tar) )  (unnormalised,
+// like fftwf c2r), both inputs real, via one forward transform of ref + i*tar.
+static void xcorr_nd(const float* ref, const float* tar, const std::vector<int>& dims, std::vector<cplx>& buf,
+                     std::vector<cplx>& spec, float* surface, FFTCache& cache) {
+    size_t total = 1;
+    for (int d : dims) total *= d;
+    buf.resize(total);
+    spec.resize(total);
+    for (size_t i = 0; i < total; i++) buf[i] = cplx((double)ref[i], (double)tar[i]);
+    fft_nd(buf, dims, -1, cache);
+    // index of -k
+    std::vector<size_t> strides(dims.size());
+    size_t s = 1;
+    for (int ax = (int)dims.size() - 1; ax >= 0; ax--) { strides[ax] = s; s *= dims[ax]; }
+    for (size_t i = 0; i < total; i++) {
+        size_t rem = i, neg = 0;
+        for (size_t ax = 0; ax < dims.size(); ax++) {
+            size_t k = rem / strides[ax];
+            rem -= k * strides[ax];
+            neg += ((dims[ax] - k) % dims[ax]) * strides[ax];
+        }
+        cplx zk = buf[i], znk = std::conj(buf[neg]);
+        cplx R = 0.5 * (zk + znk);
+        cplx T = cplx(0.0, -0.5) * (zk - znk);
+        spec[i] = std::conj(R) * T;
+    }
+    fft_nd(spec, dims, +1, cache);
+    for (size_t i = 0; i < total; i++) surface[i] = (float)spec[i].real();
+}
+
+// ---------------------------------------------------------------------------
+// ICGN 2D (first and second order) -- src/oc_icgn.cpp:144-341, 685-898
+// ---------------------------------------------------------------------------
+struct Images2D {
+    const float *ref, *gx, *gy, *lut;
+    int height, width;
+};
+
+// steepest-descent row for one sample (src/oc_icgn.cpp:191-196; 2D2: 725-745)
+template <int DOF>
+static inline void sd_row(float g_x, float g_y, int xl, int yl, float* sd) {
+    if constexpr (DOF == 6) {
+        sd[0] = g_x; sd[1] = g_x * xl; sd[2] = g_x * yl;
+        sd[3] = g_y; sd[4] = g_y * xl; sd[5] = g_y * yl;
+    } else {
+        float xx = (xl * xl) * 0.5f, xy = (float)(xl * yl), yy = (yl * yl) * 0.5f;
+        sd[0] = g_x; sd[1] = g_x * xl; sd[2] = g_x * yl; sd[3] = g_x * xx; sd[4] = g_x * xy; sd[5] = g_x * yy;
+        sd[6] = g_y; sd[7] = g_y * xl; sd[8] = g_y * yl; sd[9] = g_y * xx; sd[10] = g_y * xy; sd[11] = g_y * yy;
+    }
+}
+
+// src/oc_deformation.cpp:117-128
+static inline void set_warp_2d1(float* w, float u, float ux, float uy, float v, float vx, float vy) {
+    w[0] = 1.f + ux; w[1] = uy; w[2] = u;
+    w[3] = vx; w[4] = 1.f + vy; w[5] = v;
+    w[6] = 0.f; w[7] = 0.f; w[8] = 1.f;
+}
+
+// src/oc_deformation.cpp:301-350; q = u ux uy uxx uxy uyy v vx vy vxx vxy vyy
+static inline void set_warp_2d2(float* w, const float* q) {
+    float u = q[0], ux = q[1], uy = q[2], uxx = q[3], uxy = q[4], uyy = q[5];
+    float v = q[6], vx = q[7], vy = q[8], vxx = q[9], vxy = q[10], vyy = q[11];
+    w[0] = 1.f + 2.f * ux + ux * ux + u * uxx;
+    w[1] = 2.f * u * uxy + 2.f * (1.f + ux) * uy;
+    w[2] = uy * uy + u * uyy;
+    w[3] = 2.f * u * (1 + ux);
+    w[4] = 2.f * u * uy;
+    w[5] = u * u;
+    w[6] = 0.5f * (v * uxx + 2.f * (1.f + ux) * vx + u * vxx);
+    w[7] = 1.f + uy * vx + ux * vy + v * uxy + u * vxy + vy + ux;
+    w[8] = 0.5f * (v * uyy + 2.f * uy * (1.f + vy) + u * vyy);
+    w[9] = v + v * ux + u * vx;
+    w[10] = u + v * uy + u * vy;
+    w[11] = u * v;
+    w[12] = vx * vx + v * vxx;
+    w[13] = 2.f * v * vxy + 2.f * vx * (1.f + vy);
+    w[14] = 1.f + 2.f * vy + vy * vy + v * vyy;
+    w[15] = 2.f * v * vx;
+    w[16] = 2.f * v * (1.f + vy);
+    w[17] = v * v;
+    w[18] = 0.5f * uxx; w[19] = uxy; w[20] = 0.5f * uyy; w[21] = 1.f + ux; w[22] = uy; w[23] = u;
+    w[24] = 0.5f * vxx; w[25] = vxy; w[26] = 0.5f * vyy; w[27] = vx; w[28] = 1.f + vy; w[29] = v;
+    w[30] = 0.f; w[31] = 0.f; w[32] = 0.f; w[33] = 0.f; w[34] = 0.f; w[35] = 1.f;
+}
+
+// DOF = 6 -> ICGN2D1, DOF = 12 -> ICGN2D2
+template <int DOF, template <int> class Acc>
+static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float stop, float* poi, int lanes,
+                       std::vector<float>& scratch) {
+    const float px = poi[0], py = poi[1];
+    float* p = poi + 2;        // deformation.p[12]: u ux uy uxx uxy uyy v vx vy vxx vxy vyy
+    float* res = poi + 14;     // u0 v0 zncc iteration convergence feature
+    float* srad = poi + 23;    // subset_radius x,y
+    const int height = im.height, width = im.width;
+
+    // guard, src/oc_icgn.cpp:160-167 (2D2: 705-712)
+    const float u_in = p[0], v_in = p[6];
+    if (py - ry < 0 || px - rx < 0 || py + ry > height - 1 || px + rx > width - 1 || std::fabs(u_in) >= width ||
+        std::fabs(v_in) >= height || res[2] < 0 || std::isnan(u_in) || std::isnan(v_in)) {
+        res[2] = res[2] >= 0 ? -3.f : res[2];
+        return;
+    }
+    const int W = 2 * rx + 1, H = 2 * ry + 1, N = W * H;
+    scratch.resize((size_t)N * 4);
+    float* rs = scratch.data();  // zero-mean reference subset
+    float* sgx = rs + N;         // reference gradients over the subset
+    float* sgy = sgx + N;
+    float* ts = sgy + N;         // target subset
+
+    // reference subset + zeroMeanNorm, src/oc_subset.cpp:39-53
+    const int x0 = (int)(px - rx), y0 = (int)(py - ry);
+    float ref_norm;
+    {
+        Acc<1> a(lanes);
+        for (int r = 0; r < H; r++)
+            for (int c = 0; c < W; c++) {
+                int s = r * W + c;
+                float v = im.ref[(size_t)(y0 + r) * width + (x0 + c)];
+                rs[s] = v;
+                a.add(s, 0, v);
+            }
+        a.finish();
+        float mean = a.get(0) / (float)N;
+        Acc<1> b(lanes);
+        for (int s = 0; s < N; s++) {
+            rs[s] = rs[s] - mean;
+            b.add(s, 0, rs[s] * rs[s]);
+        }
+        b.finish();
+        ref_norm = std::sqrt(b.get(0));
+    }
+
+    // steepest-descent image and Hessian, src/oc_icgn.cpp:179-207 (2D2: 716-756)
+    constexpr int NH = DOF * (DOF + 1) / 2;
+    float hess[DOF * DOF];
+    {
+        Acc<NH> a(lanes);
+        const int gx0 = (int)px, gy0 = (int)py;
+        for (int r = 0; r < H; r++)
+            for (int c = 0; c < W; c++) {
+                int s = r * W + c;
+                int xl = c - rx, yl = r - ry;
+                float g_x = im.gx[(size_t)(gy0 + yl) * width + (gx0 + xl)];
+                float g_y = im.gy[(size_t)(gy0 + yl) * width + (gx0 + xl)];
+                sgx[s] = g_x;
+                sgy[s] = g_y;
+                float sd[DOF];
+                sd_row<DOF>(g_x, g_y, xl, yl, sd);
+                int t = 0;
+                for (int i = 0; i < DOF; i++)
+                    for (int j = 0; j <= i; j++) a.add(s, t++, sd[i] * sd[j]);
+            }
+        a.finish();
+        int t = 0;
+        for (int i = 0; i < DOF; i++)
+            for (int j = 0; j <= i; j++) {
+                hess[i * DOF + j] = a.get(t);
+                hess[j * DOF + i] = a.get(t);
+                t++;
+            }
+    }
+    float hinv[DOF * DOF];
+    lu_inverse(hess, hinv, DOF);
+
+    // initial guess: first-order terms only (src/oc_icgn.cpp:216, 2D2: 765-770 + src/oc_deformation.cpp:249-266)
+    const float u0 = p[0], ux0 = p[1], uy0 = p[2], v0 = p[6], vx0 = p[7], vy0 = p[8];
+    constexpr int WN = (DOF == 6) ? 3 : 6;
+    float Wm[WN * WN];
+    if constexpr (DOF == 6) {
+        set_warp_2d1(Wm, u0, ux0, uy0, v0, vx0, vy0);
+    } else {
+        float q[12] = {u0, ux0, uy0, 0.f, 0.f, 0.f, v0, vx0, vy0, 0.f, 0.f, 0.f};
+        set_warp_2d2(Wm, q);
+    }
+
+    int iter = 0;
+    float dp_norm = 0.f, znssd = 0.f;
+    float cur[12] = {0.f};
+    do {
+        iter++;
+        // warped target subset, src/oc_icgn.cpp:230-242 (2D2: 784-796)
+        bool negative = false;
+        Acc<1> am(lanes);
+        for (int r = 0; r < H; r++)
+            for (int c = 0; c < W; c++) {
+                int s = r * W + c;
+                float xl = (float)(c - rx), yl = (float)(r - ry);
+                float wx, wy;
+                if constexpr (DOF == 6) {
+                    // src/oc_deformation.cpp:94-105
+                    wx = (Wm[0] * xl + Wm[1] * yl) + Wm[2] * 1.f;
+                    wy = (Wm[3] * xl + Wm[4] * yl) + Wm[5] * 1.f;
+                } else {
+                    // src/oc_deformation.cpp:268-282: rows 3 and 4 of W * [x^2 xy y^2 x y 1]
+                    float pv[6] = {xl * xl, xl * yl, yl * yl, xl, yl, 1.f};
+                    const float* r3 = Wm + 3 * WN;
+                    const float* r4 = Wm + 4 * WN;
+                    wx = r3[0] * pv[0];
+                    wy = r4[0] * pv[0];
+                    for (int k = 1; k < 6; k++) {
+                        wx = wx + r3[k] * pv[k];
+                        wy = wy + r4[k] * pv[k];
+                    }
+                }
+                float v = bspline2d_eval(im.lut, height, width, px + wx, py + wy);
+                if (v < 0.f) negative = true;
+                ts[s] = v;
+                am.add(s, 0, v);
+            }
+        // src/oc_icgn.cpp:251-255
+        if (negative) {
+            res[2] = -3.f;
+            return;
+        }
+        am.finish();
+        float tmean = am.get(0) / (float)N;
+        Acc<1> an(lanes);
+        for (int s = 0; s < N; s++) {
+            ts[s] = ts[s] - tmean;
+            an.add(s, 0, ts[s] * ts[s]);
+        }
+        an.finish();
+        float tar_norm = std::sqrt(an.get(0));
+        // error image, ZNSSD, numerator: src/oc_icgn.cpp:260-276
+        float factor = ref_norm / tar_norm;
+        Acc<DOF + 1> ae(lanes);
+        for (int r = 0; r < H; r++)
+            for (int c = 0; c < W; c++) {
+                int s = r * W + c;
+                float e = ts[s] * factor - rs[s];
+                ae.add(s, DOF, e * e);
+                float sd[DOF];
+                sd_row<DOF>(sgx[s], sgy[s], c - rx, r - ry, sd);
+                for (int i = 0; i < DOF; i++) ae.add(s, i, sd[i] * e);
+            }
+        ae.finish();
+        znssd = ae.get(DOF) / (ref_norm * ref_norm);
+        float dp[DOF];
+        for (int i = 0; i < DOF; i++) {  // src/oc_icgn.cpp:279-286
+            float v = 0.f;
+            for (int j = 0; j < DOF; j++) v += hinv[i * DOF + j] * ae.get(j);
+            dp[i] = v;
+        }
+        // warp update W <- W * (dW)^-1, then p <- W: src/oc_icgn.cpp:287-293 (2D2: 828-834)
+        float dW[WN * WN], dWi[WN * WN], Wn[WN * WN];
+        if constexpr (DOF == 6) {
+            set_warp_2d1(dW, dp[0], dp[1], dp[2], dp[3], dp[4], dp[5]);
+            inverse3(dW, dWi);
+        } else {
+            set_warp_2d2(dW, dp);
+            lu_inverse(dW, dWi, WN);
+        }
+        mat_mul(Wm, dWi, Wn, WN);
+        for (int i = 0; i < WN * WN; i++) Wm[i] = Wn[i];
+        const int rx2 = rx * rx, ry2 = ry * ry;
+        if constexpr (DOF == 6) {
+            // src/oc_deformation.cpp:107-115
+            cur[0] = Wm[2]; cur[1] = Wm[0] - 1.f; cur[2] = Wm[1];
+            cur[6] = Wm[5]; cur[7] = Wm[3]; cur[8] = Wm[4] - 1.f;
+            // src/oc_icgn.cpp:296-306; dp = u ux uy v vx vy
+            float d = dp[0] * dp[0] + dp[1] * dp[1] * rx2 + dp[2] * dp[2] * ry2 + dp[3] * dp[3] + dp[4] * dp[4] * rx2 +
+                      dp[5] * dp[5] * ry2;
+            dp_norm = std::sqrt(d);
+        } else {
+            // src/oc_deformation.cpp:284-299
+            const float* r3 = Wm + 3 * WN;
+            const float* r4 = Wm + 4 * WN;
+            cur[0] = r3[5]; cur[1] = r3[3] - 1.f; cur[2] = r3[4]; cur[3] = r3[0] * 2.f; cur[4] = r3[1]; cur[5] = r3[2] * 2.f;
+            cur[6] = r4[5]; cur[7] = r4[3]; cur[8] = r4[4] - 1.f; cur[9] = r4[0] * 2.f; cur[10] = r4[1]; cur[11] = r4[2] * 2.f;
+            // src/oc_icgn.cpp:837-857 (the integer-truncated weights are reference behaviour)
+            const int rxy2 = rx2 * ry2;
+            const int rx4 = (int)(rx2 * rx2 * 0.25f), ry4 = (int)(ry2 * ry2 * 0.25f);
+            const float* q = dp;  // u ux uy uxx uxy uyy v vx vy vxx vxy vyy
+            float d = q[0] * q[0] + q[1] * q[1] * rx2 + q[2] * q[2] * ry2 + q[3] * q[3] * rx4 + q[5] * q[5] * ry4 +
+                      q[4] * q[4] * rxy2 + q[6] * q[6] + q[7] * q[7] * rx2 + q[8] * q[8] * ry2 + q[9] * q[9] * rx4 +
+                      q[11] * q[11] * ry4 + q[10] * q[10] * rxy2;
+            dp_norm = std::sqrt(d);
+        }
+    } while (iter < stop && dp_norm >= conv);
+
+    // outputs, src/oc_icgn.cpp:310-340 (2D2: 860-897)
+    if constexpr (DOF == 6) {
+        p[0] = cur[0]; p[1] = cur[1]; p[2] = cur[2];
+        p[6] = cur[6]; p[7] = cur[7]; p[8] = cur[8];
+    } else {
+        for (int i = 0; i < 12; i++) p[i] = cur[i];
+    }
+    res[0] = u0;
+    res[1] = v0;
+    res[2] = 0.5f * (2 - znssd);
+    res[3] = (float)iter;
+    res[4] = dp_norm;
+    srad[0] = (float)rx;
+    srad[1] = (float)ry;
+    if (res[4] >= conv && res[3] >= stop) res[2] = -4.f;
+    if (std::isnan(res[2]) || std::isnan(p[0]) || std::isnan(p[6])) {
+        p[0] = res[0];
+        p[6] = res[1];
+        res[2] = -5.f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// ICGN3D1 -- src/oc_icgn.cpp:1270-1490
+// ---------------------------------------------------------------------------
+struct Images3D {
+    const float *ref, *gx, *gy, *gz, *coef;
+    int dz, dy, dx;
+};
+
+template <template <int> class Acc>
+static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, float stop, float* poi, int lanes,
+                        std::vector<float>& scratch) {
+    const float px = poi[0], py = poi[1], pz = poi[2];
+    float* p = poi + 3;      // u ux uy uz v vx vy vz w wx wy wz
+    float* res = poi + 15;   // u0 v0 w0 zncc iteration convergence feature
+    float* srad = poi + 28;  // subset_radius
+    const int DX = im.dx, DY = im.dy, DZ = im.dz;
+    // guard, src/oc_icgn.cpp:1279-1286
+    if ((px - rx) < 0 || (py - ry) < 0 || (pz - rz) < 0 || (px + rx) > (DX - 1) || (py + ry) > (DY - 1) ||
+        (pz + rz) > (DZ - 1) || std::fabs(p[0]) >= DX || std::fabs(p[4]) >= DY || std::fabs(p[8]) >= DZ || res[3] < 0 ||
+        std::isnan(p[0]) || std::isnan(p[4]) || std::isnan(p[8])) {
+        res[3] = res[3] >= 0 ? -3.f : res[3];
+        return;
+    }
+    const int SX = 2 * rx + 1, SY = 2 * ry + 1, SZ = 2 * rz + 1;
+    const int N = SX * SY * SZ;
+    scratch.resize((size_t)N * 5);
+    float* rs = scratch.data();
+    float* sgx = rs + N;
+    float* sgy = sgx + N;
+    float* sgz = sgy + N;
+    float* ts = sgz + N;
+
+    // reference subvolume, src/oc_subset.cpp:89-135
+    float ref_norm;
+    {
+        const float sx = px - rx, sy = py - ry, sz = pz - rz;
+        Acc<1> a(lanes);
+        int s = 0;
+        for (int i = 0; i < SZ; i++)
+            for (int j = 0; j < SY; j++)
+                for (int k = 0; k < SX; k++, s++) {
+                    float v = im.ref[((size_t)(int)(sz + i) * DY + (int)(sy + j)) * DX + (int)(sx + k)];
+                    rs[s] = v;
+                    a.add(s, 0, v);
+                }
+        a.finish();
+        float mean = a.get(0) / (float)N;
+        Acc<1> b(lanes);
+        for (s = 0; s < N; s++) {
+            rs[s] = rs[s] - mean;
+            b.add(s, 0, rs[s] * rs[s]);
+        }
+        b.finish();
+        ref_norm = std::sqrt(b.get(0));
+    }
+
+    // SD image + Hessian, src/oc_icgn.cpp:1299-1337
+    float hess[144];
+    {
+        Acc<78> a(lanes);
+        const int cx = (int)px, cy = (int)py, cz = (int)pz;
+        int s = 0;
+        for (int i = 0; i < SZ; i++)
+            for (int j = 0; j < SY; j++)
+                for (int k = 0; k < SX; k++, s++) {
+                    int xl = k - rx, yl = j - ry, zl = i - rz;
+                    size_t g = ((size_t)(cz + zl) * DY + (cy + yl)) * DX + (cx + xl);
+                    float g_x = im.gx[g], g_y = im.gy[g], g_z = im.gz[g];
+                    sgx[s] = g_x; sgy[s] = g_y; sgz[s] = g_z;
+                    float sd[12] = {g_x, g_x * xl, g_x * yl, g_x * zl, g_y, g_y * xl, g_y * yl, g_y * zl,
+                                    g_z, g_z * xl, g_z * yl, g_z * zl};
+                    int t = 0;
+                    for (int r = 0; r < 12; r++)
+                        for (int c = 0; c <= r; c++) a.add(s, t++, sd[r] * sd[c]);
+                }
+        a.finish();
+        int t = 0;
+        for (int r = 0; r < 12; r++)
+            for (int c = 0; c <= r; c++) {
+                hess[r * 12 + c] = a.get(t);
+                hess[c * 12 + r] = a.get(t);
+                t++;
+            }
+    }
+    float hinv[144];
+    lu_inverse(hess, hinv, 12);
+
+    auto set_warp = [](float* w, const float* q) {
+        // src/oc_deformation.cpp:495-516
+        w[0] = 1.f + q[1]; w[1] = q[2]; w[2] = q[3]; w[3] = q[0];
+        w[4] = q[5]; w[5] = 1.f + q[6]; w[6] = q[7]; w[7] = q[4];
+        w[8] = q[9]; w[9] = q[10]; w[10] = 1.f + q[11]; w[11] = q[8];
+        w[12] = 0.f; w[13] = 0.f; w[14] = 0.f; w[15] = 1.f;
+    };
+    float init[12];
+    for (int i = 0; i < 12; i++) init[i] = p[i];
+    float Wm[16];
+    set_warp(Wm, init);
+    float cur[12];
+    int iter = 0;
+    float dp_norm = 0.f, znssd = 0.f;
+    do {
+        iter++;
+        bool out_of_range = false;
+        Acc<1> am(lanes);
+        int s = 0;
+        for (int i = 0; i < SZ; i++)
+            for (int j = 0; j < SY; j++)
+                for (int k = 0; k < SX; k++, s++) {
+                    float xl = (float)(k - rx), yl = (float)(j - ry), zl = (float)(i - rz);
+                    // src/oc_deformation.cpp:518-530
+                    float wx = ((Wm[0] * xl + Wm[1] * yl) + Wm[2] * zl) + Wm[3] * 1.f;
+                    float wy = ((Wm[4] * xl + Wm[5] * yl) + Wm[6] * zl) + Wm[7] * 1.f;
+                    float wz = ((Wm[8] * xl + Wm[9] * yl) + Wm[10] * zl) + Wm[11] * 1.f;
+                    float v = bspline3d_eval(im.coef, DZ, DY, DX, px + wx, py + wy, pz + wz);
+                    if (v < 0.f) out_of_range = true;
+                    ts[s] = v;
+                    am.add(s, 0, v);
+                }
+        if (out_of_range) { res[3] = -3.f; return; }
+        am.finish();
+        float tmean = am.get(0) / (float)N;
+        Acc<1> an(lanes);
+        for (s = 0; s < N; s++) {
+            ts[s] = ts[s] - tmean;
+            an.add(s, 0, ts[s] * ts[s]);
+        }
+        an.finish();
+        float tar_norm = std::sqrt(an.get(0));
+        float factor = ref_norm / tar_norm;
+        Acc<13> ae(lanes);
+        s = 0;
+        for (int i = 0; i < SZ; i++)
+            for (int j = 0; j < SY; j++)
+                for (int k = 0; k < SX; k++, s++) {
+                    int xl = k - rx, yl = j - ry, zl = i - rz;
+                    float e = factor * ts[s] - rs[s];
+                    ae.add(s, 12, e * e);
+                    float g_x = sgx[s], g_y = sgy[s], g_z = sgz[s];
+                    ae.add(s, 0, g_x * e); ae.add(s, 1, (g_x * xl) * e); ae.add(s, 2, (g_x * yl) * e); ae.add(s, 3, (g_x * zl) * e);
+                    ae.add(s, 4, g_y * e); ae.add(s, 5, (g_y * xl) * e); ae.add(s, 6, (g_y * yl) * e); ae.add(s, 7, (g_y * zl) * e);
+                    ae.add(s, 8, g_z * e); ae.add(s, 9, (g_z * xl) * e); ae.add(s, 10, (g_z * yl) * e); ae.add(s, 11, (g_z * zl) * e);
+                }
+        ae.finish();
+        znssd = ae.get(12) / (ref_norm * ref_norm);
+        float dp[12];
+        for (int i = 0; i < 12; i++) {
+            float v = 0.f;
+            for (int j = 0; j < 12; j++) v += hinv[i * 12 + j] * ae.get(j);
+            dp[i] = v;
+        }
+        float dW[16], dWi[16], Wn[16];
+        set_warp(dW, dp);
+        inverse4(dW, dWi);
+        mat_mul(Wm, dWi, Wn, 4);
+        for (int i = 0; i < 16; i++) Wm[i] = Wn[i];
+        // src/oc_deformation.cpp:416-432
+        cur[0] = Wm[3]; cur[1] = Wm[0] - 1.f; cur[2] = Wm[1]; cur[3] = Wm[2];
+        cur[4] = Wm[7]; cur[5] = Wm[4]; cur[6] = Wm[5] - 1.f; cur[7] = Wm[6];
+        cur[8] = Wm[11]; cur[9] = Wm[8]; cur[10] = Wm[9]; cur[11] = Wm[10] - 1.f;
+        // src/oc_icgn.cpp:1445
+        dp_norm = std::sqrt(dp[0] * dp[0] + dp[4] * dp[4] + dp[8] * dp[8]);
+    } while (iter < stop && dp_norm >= conv);
+
+    for (int i = 0; i < 12; i++) p[i] = cur[i];
+    res[0] = init[0];
+    res[1] = init[4];
+    res[2] = init[8];
+    res[3] = 0.5f * (2 - znssd);
+    res[4] = (float)iter;
+    res[5] = dp_norm;
+    srad[0] = (float)rx; srad[1] = (float)ry; srad[2] = (float)rz;
+    if (res[5] >= conv && res[4] >= stop) res[3] = -4.f;
+    if (std::isnan(res[3]) || std::isnan(p[0]) || std::isnan(p[4]) || std::isnan(p[8])) {
+        p[0] = res[0]; p[4] = res[1]; p[8] = res[2];
+        res[3] = -5.f;
+    }
+}
+
+static int resolve_threads(int threads) {
+    if (threads <= 0) return omp_get_max_threads();
+    return threads;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C entry points
+// ===========================================================================
+extern "C" {
+
+int oc_oracle_max_threads(void) { return omp_get_max_threads(); }
+
+void oc_oracle_gradient2d(const float* img, int height, int width, float* gx, float* gy, int threads) {
+    const float first_factor = 1.f / 12.f;   // src/oc_gradient.cpp:21-22
+    const float second_factor = 2.f / 3.f;
+    std::memset(gx, 0, sizeof(float) * (size_t)height * width);
+    std::memset(gy, 0, sizeof(float) * (size_t)height * width);
+    threads = resolve_threads(threads);
+#pragma omp parallel for num_threads(threads)
+    for (int r = 0; r < height; r++) {
+        const float* row = img + (size_t)r * width;
+        for (int c = 2; c < width - 2; c++) {  // src/oc_gradient.cpp:45-56
+            float result = 0.0f;
+            result -= row[c + 2] * first_factor;
+            result += row[c + 1] * second_factor;
+            result -= row[c - 1] * second_factor;
+            result += row[c - 2] * first_factor;
+            gx[(size_t)r * width + c] = result;
+        }
+        if (r >= 2 && r < height - 2) {  // src/oc_gradient.cpp:67-78
+            for (int c = 0; c < width; c++) {
+                float result = 0.0f;
+                result -= img[(size_t)(r + 2) * width + c] * first_factor;
+                result += img[(size_t)(r + 1) * width + c] * second_factor;
+                result -= img[(size_t)(r - 1) * width + c] * second_factor;
+                result += img[(size_t)(r - 2) * width + c] * first_factor;
+                gy[(size_t)r * width + c] = result;
+            }
+        }
+    }
+}
+
+void oc_oracle_bspline2d_lut(const float* img, int height, int width, float* lut, int threads) {
+    std::memset(lut, 0, sizeof(float) * (size_t)height * width * 16);
+    threads = resolve_threads(threads);
+#pragma omp parallel for num_threads(threads)
+    for (int r = 1; r < height - 2; r++) {
+        for (int c = 1; c < width - 2; c++) {
+            float q[4][4];
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 4; j++) q[i][j] = img[(size_t)(r - 1 + i) * width + (c - 1 + j)];
+            float pm[4][4];
+            for (int k = 0; k < 4; k++)
+                for (int l = 0; l < 4; l++) {
+                    float acc = 0.f;  // src/oc_cubic_bspline.cpp:108-120
+                    for (int m = 0; m < 4; m++)
+                        for (int n = 0; n < 4; n++) acc += BC[l][m] * BC[k][n] * q[n][m];
+                    pm[k][l] = acc;
+                }
+            float* e = lut + ((size_t)r * width + c) * 16;
+            for (int k = 0; k < 4; k++)
+                for (int l = 0; l < 4; l++) e[4 * k + l] = pm[3 - k][3 - l];  // src/oc_cubic_bspline.cpp:123-129
+        }
+    }
+}
+
+float oc_oracle_bspline2d_eval(const float* lut, int height, int width, float x, float y) {
+    return bspline2d_eval(lut, height, width, x, y);
+}
+
+void oc_oracle_fftcc2d(const float* ref, const float* tar, int height, int width, int rx, int ry, float* pois, long n,
+                       int threads, float* surface_out) {
+    threads = resolve_threads(threads);
+    const int sw = 2 * rx, sh = 2 * ry, size = sw * sh;
+    // FFTW is planned as (n0 = width, n1 = height) over a buffer filled [r*width + c]
+    // (src/oc_fftcc.cpp:40-42, 204-221); restated as-is.
+    std::vector<int> dims = {sw, sh};
+#pragma omp parallel num_threads(threads)
+    {
+        std::vector<float> rsub(size), tsub(size), surf(size);
+        std::vector<cplx> buf, spec;
+        FFTCache cache;
+#pragma omp for schedule(static)
+        for (long i = 0; i < n; i++) {
+            float* poi = pois + i * OC_POI2D_FLOATS;
+            float px = poi[0], py = poi[1];
+            float gu = poi[2], gv = poi[8];  // deformation.u, deformation.v
+            // src/oc_fftcc.cpp:190-196
+            if ((int)px < rx || (int)px >= width - rx || (int)py < ry || (int)py >= height - ry ||
+                (int)(px + gu) < rx || (int)(px + gu) >= width - rx || (int)(py + gv) < ry ||
+                (int)(py + gv) >= height - ry)
+                continue;
+            float ref_mean = 0.f, tar_mean = 0.f, ref_norm = 0.f, tar_norm = 0.f;
+            for (int r = 0; r < sh; r++)
+                for (int c = 0; c < sw; c++) {  // src/oc_fftcc.cpp:204-221
+                    float rxp = px + c - rx, ryp = py + r - ry;
+                    float v = ref[(size_t)(int)ryp * width + (int)rxp];
+                    rsub[r * sw + c] = v;
+                    ref_mean += v;
+                    float txp = rxp + gu, typ = ryp + gv;
+                    v = tar[(size_t)(int)typ * width + (int)txp];
+                    tsub[r * sw + c] = v;
+                    tar_mean += v;
+                }
+            ref_mean /= size;
+            tar_mean /= size;
+            for (int k = 0; k < size; k++) {  // src/oc_fftcc.cpp:225-231
+                rsub[k] -= ref_mean;
+                tsub[k] -= tar_mean;
+                ref_norm += rsub[k] * rsub[k];
+                tar_norm += tsub[k] * tsub[k];
+            }
+            xcorr_nd(rsub.data(), tsub.data(), dims, buf, spec, surf.data(), cache);
+            if (surface_out && i == 0) std::memcpy(surface_out, surf.data(), sizeof(float) * size);
+            float max_zncc = -2.f;  // src/oc_fftcc.cpp:246-255
+            int idx = 0;
+            for (int k = 0; k < size; k++)
+                if (surf[k] > max_zncc) { max_zncc = surf[k]; idx = k; }
+            int du = idx % sw, dv = idx / sw;
+            if (du > rx) du -= sw;
+            if (dv > ry) dv -= sh;
+            poi[2] = (float)du + gu;
+            poi[8] = (float)dv + gv;
+            poi[14] = gu;
+            poi[15] = gv;
+            poi[16] = max_zncc / (std::sqrt(ref_norm * tar_norm) * size);
+        }
+    }
+}
+
+void oc_oracle_icgn2d1(const float* ref, const float* gx, const float* gy, const float* tar_lut, int height, int width,
+                       int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes, int threads) {
+    threads = resolve_threads(threads);
+    Images2D im = {ref, gx, gy, tar_lut, height, width};
+#pragma omp parallel num_threads(threads)
+    {
+        std::vector<float> scratch;
+#pragma omp for schedule(static)
+        for (long i = 0; i < n; i++) {
+            if (order == OC_ORDER_SEQ)
+                icgn2d_poi<6, AccSeq>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch);
+            else
+                icgn2d_poi<6, AccLanes>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch);
+        }
+    }
+}
+
+void oc_oracle_icgn2d2(const float* ref, const float* gx, const float* gy, const float* tar_lut, int height, int width,
+                       int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes, int threads) {
+    threads = resolve_threads(threads);
+    Images2D im = {ref, gx, gy, tar_lut, height, width};
+#pragma omp parallel num_threads(threads)
+    {
+        std::vector<float> scratch;
+#pragma omp for schedule(static)
+        for (long i = 0; i < n; i++) {
+            if (order == OC_ORDER_SEQ)
+                icgn2d_poi<12, AccSeq>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch);
+            else
+                icgn2d_poi<12, AccLanes>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch);
+        }
+    }
+}
+
+void oc_oracle_gradient3d(const float* vol, int dz, int dy, int dx, float* gx, float* gy, float* gz, int threads) {
+    const float first_factor = 1.f / 12.f;
+    const float second_factor = 2.f / 3.f;
+    size_t total = (size_t)dz * dy * dx;
+    std::memset(gx, 0, sizeof(float) * total);
+    std::memset(gy, 0, sizeof(float) * total);
+    std::memset(gz, 0, sizeof(float) * total);
+    threads = resolve_threads(threads);
+    const size_t sy = dx, sz = (size_t)dy * dx;
+#pragma omp parallel for num_threads(threads)
+    for (int i = 0; i < dz; i++)
+        for (int j = 0; j < dy; j++)
+            for (int k = 0; k < dx; k++) {
+                size_t g = (size_t)i * sz + (size_t)j * sy + k;
+                if (k >= 2 && k < dx - 2) {  // src/oc_gradient.cpp:158-170
+                    float result = 0.0f;
+                    result -= vol[g + 2] * first_factor;
+                    result += vol[g + 1] * second_factor;
+                    result -= vol[g - 1] * second_factor;
+                    result += vol[g - 2] * first_factor;
+                    gx[g] = result;
+                }
+                if (j >= 2 && j < dy - 2) {  // src/oc_gradient.cpp:187-199
+                    float result = 0.0f;
+                    result -= vol[g + 2 * sy] * first_factor;
+                    result += vol[g + sy] * second_factor;
+                    result -= vol[g - sy] * second_factor;
+                    result += vol[g - 2 * sy] * first_factor;
+                    gy[g] = result;
+                }
+                if (i >= 2 && i < dz - 2) {  // src/oc_gradient.cpp:216-228
+                    float result = 0.0f;
+                    result -= vol[g + 2 * sz] * first_factor;
+                    result += vol[g + sz] * second_factor;
+                    result -= vol[g - sz] * second_factor;
+                    result += vol[g - 2 * sz] * first_factor;
+                    gz[g] = result;
+                }
+            }
+}
+
+// one 15-tap symmetric pass with clamp-to-edge (src/oc_cubic_bspline.cpp:224-347)
+static void prefilter_axis(const float* in, float* out, int dz, int dy, int dx, int axis, int threads) {
+    const size_t strides[3] = {(size_t)dy * dx, (size_t)dx, 1};  // z, y, x
+    const int dims[3] = {dz, dy, dx};
+    const int n = dims[axis];
+    const size_t st = strides[axis];
+#pragma omp parallel for num_threads(threads)
+    for (int i = 0; i < dz; i++)
+        for (int j = 0; j < dy; j++)
+            for (int k = 0; k < dx; k++) {
+                size_t g = (size_t)i * strides[0] + (size_t)j * strides[1] + k;
+                int pos = axis == 0 ? i : (axis == 1 ? j : k);
+                const float* base = in + g - (size_t)pos * st;
+                float acc = PREF[0] * base[(size_t)pos * st];
+                for (int t = 1; t <= 7; t++) {
+                    int lo = pos - t < 0 ? 0 : pos - t;
+                    int hi = pos + t > n - 1 ? n - 1 : pos + t;
+                    acc = acc + PREF[t] * (base[(size_t)lo * st] + base[(size_t)hi * st]);
+                }
+                out[g] = acc;
+            }
+}
+
+void oc_oracle_bspline3d_prefilter(const float* vol, int dz, int dy, int dx, float* coef, int threads) {
+    threads = resolve_threads(threads);
+    std::vector<float> tmp((size_t)dz * dy * dx);
+    prefilter_axis(vol, coef, dz, dy, dx, 2, threads);          // x: image -> coefficient
+    prefilter_axis(coef, tmp.data(), dz, dy, dx, 1, threads);   // y: coefficient -> buffer
+    prefilter_axis(tmp.data(), coef, dz, dy, dx, 0, threads);   // z: buffer -> coefficient
+}
+
+float oc_oracle_bspline3d_eval(const float* coef, int dz, int dy, int dx, float x, float y, float z) {
+    return bspline3d_eval(coef, dz, dy, dx, x, y, z);
+}
+
+void oc_oracle_fftcc3d(const float* ref, const float* tar, int dz, int dy, int dx, int rx, int ry, int rz, float* pois,
+                       long n, int threads) {
+    threads = resolve_threads(threads);
+    const int sx = 2 * rx, sy = 2 * ry, sz = 2 * rz;
+    const int size = sx * sy * sz;
+    // planned as (dim_x, dim_y, dim_z) over a buffer filled [(i*dim_y + j)*dim_x + k]
+    // (src/oc_fftcc.cpp:68-70, 349-360); restated as-is.
+    std::vector<int> dims = {sx, sy, sz};
+#pragma omp parallel num_threads(threads)
+    {
+        std::vector<float> rsub(size), tsub(size), surf(size);
+        std::vector<cplx> buf, spec;
+        FFTCache cache;
+#pragma omp for schedule(dynamic, 1)
+        for (long q = 0; q < n; q++) {
+            float* poi = pois + q * OC_POI3D_FLOATS;
+            float px = poi[0], py = poi[1], pz = poi[2];
+            float gu = poi[3], gv = poi[7], gw = poi[11];
+            float ref_mean = 0.f, tar_mean = 0.f, ref_norm = 0.f, tar_norm = 0.f;
+            for (int i = 0; i < sz; i++)
+                for (int j = 0; j < sy; j++)
+                    for (int k = 0; k < sx; k++) {
+                        float rxp = px + k - rx, ryp = py + j - ry, rzp = pz + i - rz;
+                        float v = ref[((size_t)(int)rzp * dy + (int)ryp) * dx + (int)rxp];
+                        rsub[(i * sy + j) * sx + k] = v;
+                        ref_mean += v;
+                        float txp = rxp + gu, typ = ryp + gv, tzp = rzp + gw;
+                        v = tar[((size_t)(int)tzp * dy + (int)typ) * dx + (int)txp];
+                        tsub[(i * sy + j) * sx + k] = v;
+                        tar_mean += v;
+                    }
+            ref_mean /= size;
+            tar_mean /= size;
+            for (int k = 0; k < size; k++) {
+                rsub[k] -= ref_mean;
+                tsub[k] -= tar_mean;
+                ref_norm += rsub[k] * rsub[k];
+                tar_norm += tsub[k] * tsub[k];
+            }
+            xcorr_nd(rsub.data(), tsub.data(), dims, buf, spec, surf.data(), cache);
+            float max_zncc = -2.f;
+            int idx = 0;
+            for (int k = 0; k < size; k++)
+                if (surf[k] > max_zncc) { max_zncc = surf[k]; idx = k; }
+            int du = idx % sx, dv = (idx / sx) % sy, dw = idx / (sx * sy);
+            if (du > rx) du -= sx;
+            if (dv > ry) dv -= sy;
+            if (dw > rz) dw -= sz;
+            poi[3] = (float)du + gu;
+            poi[7] = (float)dv + gv;
+            poi[11] = (float)dw + gw;
+            poi[15] = gu;
+            poi[16] = gv;
+            poi[17] = gw;
+            poi[18] = max_zncc / (std::sqrt(ref_norm * tar_norm) * size);
+        }
+    }
+}
+
+void oc_oracle_icgn3d1(const float* ref, const float* gx, const float* gy, const float* gz, const float* tar_coef,
+                       int dz, int dy, int dx, int rx, int ry, int rz, float conv, float stop, float* pois, long n,
+                       int order, int lanes, int threads) {
+    threads = resolve_threads(threads);
+    Images3D im = {ref, gx, gy, gz, tar_coef, dz, dy, dx};
+#pragma omp parallel num_threads(threads)
+    {
+        std::vector<float> scratch;
+#pragma omp for schedule(dynamic, 1)
+        for (long i = 0; i < n; i++) {
+            if (order == OC_ORDER_SEQ)
+                icgn3d1_poi<AccSeq>(im, rx, ry, rz, conv, stop, pois + i * OC_POI3D_FLOATS, lanes, scratch);
+            else
+                icgn3d1_poi<AccLanes>(im, rx, ry, rz, conv, stop, pois + i * OC_POI3D_FLOATS, lanes, scratch);
+        }
+    }
+}
+
+}  // extern "C"

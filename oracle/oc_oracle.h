@@ -1,0 +1,93 @@
+/*
+ * oc_oracle.h -- CPU oracle for the FFTCC -> ICGN hot path of OpenCorr.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This library is a from-scratch float32 CPU
+ * restatement of the reference algorithm (file:line citations are relative to
+ * the OpenCorr tree).  It is the checker for the HIP engine and the timed
+ * "CPU baseline"; nothing in the product path (opencorr_amd/, include/) may
+ * link or call it.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg load it.
+ *
+ * Parity status of the oracle itself:
+ *   - FFTCC2D + ICGN2D1: pinned against the reference's own golden vectors
+ *     (examples/2d_dic/oht_cfrp_4_fftcc_icgn1_r16*.csv) in tests/test_oracle_golden.py.
+ *   - ICGN2D2, FFTCC3D, ICGN3D1: "parity unpinned" -- the reference ships no
+ *     usable fixture for them in this mount; they are checked
+ *     against analytic warps only.
+ *
+ * All images are row-major float32 (x fastest): img[y*width + x]; volumes are
+ * vol[(z*dim_y + y)*dim_x + x] (same as Image3D::vol_mat, src/oc_array.h:57-74).
+ * POIs are passed as the reference's own AoS records:
+ *   POI2D = 25 floats {x,y | p[12] | r[6] | e[3] | subset_radius x,y}   (src/oc_poi.h:102-136)
+ *   POI3D = 31 floats {x,y,z | p[12] | r[7] | e[6] | subset_radius xyz} (src/oc_poi.h:187-222)
+ *
+ * Summation order ("order" argument of the ICGN entry points):
+ *   OC_ORDER_SEQ    : every reduction is one sequential float32 loop in
+ *                     row-major sample order -- the order the reference's hand
+ *                     written loops use (src/oc_icgn.cpp:198-205,266-276).
+ *                     Reductions the reference delegates to Eigen (mean(),
+ *                     squaredNorm()) have no defined order there; SEQ uses the
+ *                     same row-major loop for them.
+ *   OC_ORDER_LANES  : the association the GPU engine uses: `lanes` strided
+ *                     partial sums (sample s belongs to lane s % lanes, each
+ *                     lane adds its samples in increasing s) combined by an
+ *                     xor-butterfly with ascending offsets 1,2,4,...,lanes/2.
+ *                     The HIP kernels are bit-exact against this mode.
+ * Everything else (interpolation polynomial, warp algebra, LU inverse, guards,
+ * flags) is identical in both modes.  No FMA contraction anywhere
+ * (-ffp-contract=off on both the oracle and the HIP side).
+ */
+#ifndef OC_ORACLE_H_
+#define OC_ORACLE_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OC_ORDER_SEQ 0
+#define OC_ORDER_LANES 1
+
+#define OC_POI2D_FLOATS 25
+#define OC_POI3D_FLOATS 31
+
+/* src/oc_gradient.cpp:37-79 */
+void oc_oracle_gradient2d(const float* img, int height, int width, float* gx, float* gy, int threads);
+/* src/oc_cubic_bspline.cpp:84-132; lut is height*width*16 floats, entry [k][l] at 4*k+l */
+void oc_oracle_bspline2d_lut(const float* img, int height, int width, float* lut, int threads);
+/* src/oc_cubic_bspline.cpp:134-181 (single sample, for unit tests) */
+float oc_oracle_bspline2d_eval(const float* lut, int height, int width, float x, float y);
+
+/* src/oc_fftcc.cpp:177-285.  If surface != NULL it receives, for POI 0 only,
+ * the (2rx*2ry) float correlation surface (test hook for tie analysis). */
+void oc_oracle_fftcc2d(const float* ref, const float* tar, int height, int width,
+                       int rx, int ry, float* pois, long n, int threads, float* surface);
+
+/* src/oc_icgn.cpp:144-351 */
+void oc_oracle_icgn2d1(const float* ref, const float* gx, const float* gy, const float* tar_lut,
+                       int height, int width, int rx, int ry, float conv, float stop,
+                       float* pois, long n, int order, int lanes, int threads);
+/* src/oc_icgn.cpp:685-908 */
+void oc_oracle_icgn2d2(const float* ref, const float* gx, const float* gy, const float* tar_lut,
+                       int height, int width, int rx, int ry, float conv, float stop,
+                       float* pois, long n, int order, int lanes, int threads);
+
+/* src/oc_gradient.cpp:143-231 */
+void oc_oracle_gradient3d(const float* vol, int dz, int dy, int dx, float* gx, float* gy, float* gz, int threads);
+/* src/oc_cubic_bspline.cpp:214-351 */
+void oc_oracle_bspline3d_prefilter(const float* vol, int dz, int dy, int dx, float* coef, int threads);
+/* src/oc_cubic_bspline.cpp:353-405 */
+float oc_oracle_bspline3d_eval(const float* coef, int dz, int dy, int dx, float x, float y, float z);
+/* src/oc_fftcc.cpp:327-436 */
+void oc_oracle_fftcc3d(const float* ref, const float* tar, int dz, int dy, int dx,
+                       int rx, int ry, int rz, float* pois, long n, int threads);
+/* src/oc_icgn.cpp:1270-1500 */
+void oc_oracle_icgn3d1(const float* ref, const float* gx, const float* gy, const float* gz,
+                       const float* tar_coef, int dz, int dy, int dx, int rx, int ry, int rz,
+                       float conv, float stop, float* pois, long n, int order, int lanes, int threads);
+
+int oc_oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,46 @@
+"""Builds tests/golden/oht_cfrp_r16.npz from the reference's own example data.
+
+Run in the build container (needs /root/reference, which does not exist on the
+GPU box):  python tests/golden/make_golden.py
+
+Inputs (all under /root/reference/examples/2d_dic/):
+  oht_cfrp_0.bmp, oht_cfrp_4.bmp           8-bit gray, 280 x 900 (cv::IMREAD_GRAYSCALE,
+                                            src/oc_image.cpp:39)
+  oht_cfrp_4_fftcc_icgn1_r16.csv           x,y,u,v,u0,v0,ZNCC,iteration,convergence,...
+  oht_cfrp_4_fftcc_icgn1_r16_deformation.csv   x,y,u,ux,uy,v,vx,vy
+produced by examples/test_2d_dic_fftcc_icgn1.cpp (r=16, conv 1e-3, stop 10,
+POI grid 100 x 300, step 2, origin (30,30)).  Only data is stored -- no
+reference source code.
+"""
+import os
+
+import numpy as np
+from PIL import Image
+
+REF = "/root/reference/examples/2d_dic"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oht_cfrp_r16.npz")
+
+
+def main():
+    ref = np.asarray(Image.open(os.path.join(REF, "oht_cfrp_0.bmp")))
+    tar = np.asarray(Image.open(os.path.join(REF, "oht_cfrp_4.bmp")))
+    assert ref.dtype == np.uint8 and ref.shape == (900, 280) and tar.shape == ref.shape
+    table = np.genfromtxt(os.path.join(REF, "oht_cfrp_4_fftcc_icgn1_r16.csv"), delimiter=",", skip_header=1,
+                          usecols=range(9))
+    deform = np.genfromtxt(os.path.join(REF, "oht_cfrp_4_fftcc_icgn1_r16_deformation.csv"), delimiter=",",
+                           skip_header=1, usecols=range(8))
+    assert table.shape == (30000, 9) and deform.shape == (30000, 8)
+    assert np.array_equal(table[:, :2], deform[:, :2])
+    np.savez_compressed(
+        OUT,
+        ref=ref, tar=tar,
+        # x y u v u0 v0 zncc iteration convergence
+        table=table.astype(np.float32),
+        # x y u ux uy v vx vy
+        deformation=deform.astype(np.float32),
+        params=np.array([16, 16, 10], dtype=np.int32), conv=np.float32(0.001))
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()
