@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""bench.py -- converged POIs/s of the FFTCC2D -> ICGN2D1 hot path on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over the rank's POI block with everything
+resident in HBM: reset the POI records, FFTCC2D::compute (integer-pixel guess),
+ICGN2D1::compute (sub-pixel refinement), then -- for N > 1 -- the RCCL all-gather of
+the POI records.  prepare() (gradients + 64 B/px bicubic LUT) is done once before the
+timed region and reported separately.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "B"): 4096 x 4096 synthetic speckle
+pair, r = 16 (33 x 33 subset, 32 x 32 FFTCC window), 500 x 500 = 250 000 POIs,
+conv 1e-3, stop 10.  N > 1 is weak scaling: 250 000 POIs per GPU cut from one
+N*250 000-POI queue over an 8192 x 8192 pair replicated on every GPU (N = 8 is
+BASELINE config "D").
+
+Besides the contract fields the JSON line carries
+  roofline     -- ICGN2D1 kernel: algorithmic bytes (3*N2*4 + k*N2*64 + 200 per
+                  POI with each POI's own iteration count k) / hipEvent-timed kernel duration
+                  vs the 8 TB/s HBM3E peak,
+  cpu_baseline -- the CPU oracle (float32 restatement of the reference, OpenMP) timed on a
+                  bounded sample of the same workload on this box's host cores (rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+RX = RY = 16
+CONV, STOP = 0.001, 10.0
+POIS_PER_GPU_SIDE = 500
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=0, help="override image side (debug)")
+    ap.add_argument("--pois", type=int, default=0, help="override POIs per GPU side (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=20000)
+    return ap.parse_args()
+
+
+def algorithmic_bytes_icgn2d1(pois_np, rx, ry):
+    """B1 = 3*N2*4 + k*N2*64 + 200 per POI that ran k iterations; 200 B otherwise."""
+    n2 = (2 * rx + 1) * (2 * ry + 1)
+    it = pois_np[:, 17].astype(np.float64)
+    ran = it > 0
+    return float(ran.sum() * (3 * n2 * 4 + 200) + it[ran].sum() * n2 * 64 + (~ran).sum() * 200), float(it[ran].mean() if ran.any() else 0.0)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import opencorr_amd
+    from opencorr_amd import synth
+    from opencorr_amd.dist import allgather_pois, shard_bounds
+
+    # ---- workload ---------------------------------------------------------------------
+    side = args.size or (4096 if world == 1 else 8192)
+    per_side = args.pois or POIS_PER_GPU_SIDE
+    n_total = world * per_side * per_side
+    if world == 1:
+        nx = ny = per_side
+    else:
+        nx = int(np.floor(np.sqrt(n_total)))
+        ny = -(-n_total // nx)
+    t0 = time.time()
+    ref, tar = synth.speckle_pair_2d(side, side, seed=20260925, device=dev)
+    xs, ys = synth.poi_grid_2d(side, side, nx, ny, RX + 8)
+    xs, ys = xs[:n_total], ys[:n_total]
+    n_total = len(xs)
+    lo, hi = shard_bounds(n_total, world, rank)
+    pristine = torch.from_numpy(opencorr_amd.make_pois2d(xs[lo:hi], ys[lo:hi])).to(dev)
+    pois = pristine.clone()
+    gen_s = time.time() - t0
+
+    stream = torch.cuda.current_stream().cuda_stream
+    fftcc = opencorr_amd.FFTCC2D(RX, RY, device=local_rank)
+    fftcc.set_stream(stream)
+    fftcc.set_images(ref, tar)
+    icgn = opencorr_amd.ICGN2D1(RX, RY, CONV, STOP, device=local_rank)
+    icgn.set_stream(stream)
+    icgn.share_images(fftcc)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    icgn.prepare()
+    torch.cuda.synchronize()
+    prepare_ms = (time.time() - t0) * 1e3
+
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        pois.copy_(pristine)
+        fftcc.compute(pois)
+        icgn.compute(pois)
+        if world > 1:
+            gathered = allgather_pois(pois, n_total)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    icgn.profile_enable(True)
+    fftcc.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    icgn_ms, icgn_launches = icgn.profile_read()
+    fftcc_ms, fftcc_launches = fftcc.profile_read()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    full = gathered if world > 1 else pois
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    full_np = full.cpu().numpy()
+    converged = int((full_np[:, 16] >= 0).sum())
+    local_np = pois.cpu().numpy()
+
+    if rank == 0:
+        value = converged * args.steps / elapsed
+        alg_bytes, mean_iter = algorithmic_bytes_icgn2d1(local_np, RX, RY)
+        icgn_avg_ms = icgn_ms / max(icgn_launches, 1)
+        achieved = alg_bytes / (icgn_avg_ms * 1e-3) / 1e9 if icgn_avg_ms > 0 else 0.0
+        out = {
+            "metric": "converged POIs/sec (FFTCC+ICGN2D1, 33x33 subset)",
+            "value": value,
+            "unit": "POI/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": ("B: %dx%d speckle pair, r=16 (33x33 subset, 32x32 FFTCC window), %d POIs/GPU, "
+                             "FFTCC2D init -> ICGN2D1 conv=1e-3 stop=10" % (side, side, hi - lo)),
+                "total_pois": n_total,
+                "converged_pois": converged,
+                "mean_iterations": mean_iter,
+                "collective": "RCCL all_gather of POI records" if world > 1 else "none",
+            },
+            "roofline": {
+                "kernel": "icgn2d1_kernel",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": icgn_avg_ms,
+                "launches_timed": icgn_launches,
+            },
+            "stage_ms": {
+                "fftcc_pipeline_avg": fftcc_ms / max(fftcc_launches, 1),
+                "icgn_kernel_avg": icgn_avg_ms,
+                "prepare_once": prepare_ms,
+                "generate_inputs_s": gen_s,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ref, tar, xs, ys, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ref, tar, xs, ys, sample):
+    """The CPU oracle (OC_ORDER_SEQ, i.e. the reference's loop order) on a strided sample of the
+    same POI queue, all host cores, best of 3, FFTCC + ICGN compute only (prepare excluded like
+    on the GPU side)."""
+    import oracle
+    ref_h = ref.cpu().numpy()
+    tar_h = tar.cpu().numpy()
+    stride = max(1, len(xs) // sample)
+    sx, sy = xs[::stride], ys[::stride]
+    cores = oracle.max_threads()
+    prep = oracle.Prepared2D(ref_h, tar_h)
+    best, conv = None, 0
+    for _ in range(3):
+        p = oracle.make_pois2d(sx, sy)
+        t0 = time.perf_counter()
+        oracle.fftcc2d(ref_h, tar_h, RX, RY, p, threads=cores)
+        t1 = time.perf_counter()
+        oracle.icgn2d1(prep, RX, RY, CONV, STOP, p, order=oracle.ORDER_SEQ, threads=cores)
+        t2 = time.perf_counter()
+        if best is None or (t2 - t0) < best[0]:
+            best = (t2 - t0, t1 - t0, t2 - t1)
+            conv = int((p[:, 16] >= 0).sum())
+    return {
+        "value": conv / best[0],
+        "unit": "POI/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "every %d-th POI of the same queue (%d POIs), FFTCC2D+ICGN2D1 compute, best of 3; "
+                  "fftcc %.3f s, icgn %.3f s" % (stride, len(sx), best[1], best[2]),
+    }
+
+
+if __name__ == "__main__":
+    main()

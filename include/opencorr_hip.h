@@ -1,0 +1,154 @@
+/*
+ * opencorr_hip.h -- C-ABI of the MI355X-native FFTCC -> ICGN engines.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Every entry point replaces one piece of OpenCorr's host interface for the
+ * hot path (citations are file:line in the OpenCorr tree).  The OpenCorr-shaped
+ * C++ classes in include/opencorr_compat/ (FFTCC2D, ICGN2D1, ...) are thin
+ * shims over these functions; INTEGRATION.md shows the binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - All functions return an oc_hip_status (0 = OK).  On failure
+ *     oc_hip_last_error() returns a thread-local description; the C++ shim turns
+ *     it into `throw std::string`, the reference's only exception type
+ *     (src/oc_fftcc.cpp:145, src/oc_icgn.cpp:65, src/oc_image.cpp:43).
+ *   - Per-POI failures stay in-band exactly like the reference: result.zncc is
+ *     set to -3 / -4 / -5 (src/oc_dic.h:28-34) and nothing else is written.
+ *   - POIs are passed as the reference's own AoS records, updated in place:
+ *     POI2D = 25 floats / 100 B (src/oc_poi.h:102-136), POI3D = 31 floats / 124 B
+ *     (src/oc_poi.h:187-222).  `stride_bytes` lets a caller embed them in a
+ *     larger struct (must be a multiple of 4).
+ *   - `memory` says where a buffer lives: OC_HIP_HOST buffers are copied by the
+ *     engine (pageable or pinned), OC_HIP_DEVICE buffers are used in place on the
+ *     engine's device and stream (no copy, no synchronisation).
+ *   - Images are snapshotted at set_images time (like the CUDA module of the
+ *     reference, examples/test_2d_dic_gpu_icgn.cpp:99-136): later edits of the
+ *     host image need another set_images + prepare.
+ *   - The engines never fall back to a CPU path.  If the HIP runtime, rocFFT or
+ *     the device is unavailable the call fails with OC_HIP_ERR_HIP / _ROCFFT.
+ */
+#ifndef OPENCORR_HIP_H_
+#define OPENCORR_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum oc_hip_status {
+    OC_HIP_OK = 0,
+    OC_HIP_ERR_INVALID = 1, /* bad argument or call order (e.g. compute before prepare) */
+    OC_HIP_ERR_HIP = 2,     /* HIP runtime error (no device, launch failure, ...) */
+    OC_HIP_ERR_ROCFFT = 3,  /* rocFFT plan / execute failure */
+    OC_HIP_ERR_NOMEM = 4,   /* device allocation failed */
+    OC_HIP_ERR_UNSUPPORTED = 5 /* subset too large for the on-chip working set */
+} oc_hip_status;
+
+typedef enum oc_hip_memory { OC_HIP_HOST = 0, OC_HIP_DEVICE = 1 } oc_hip_memory;
+
+/* Image2D::eg_mat is an Eigen::MatrixXf, i.e. column-major (src/oc_image.h:37);
+ * Img2D of the CUDA module is row-major (gpu_lib/opencorr_gpu.h:31-35). */
+typedef enum oc_hip_layout { OC_HIP_ROW_MAJOR = 0, OC_HIP_COL_MAJOR = 1 } oc_hip_layout;
+
+typedef enum oc_hip_kind {
+    OC_HIP_FFTCC2D = 1,
+    OC_HIP_ICGN2D1 = 2,
+    OC_HIP_ICGN2D2 = 3,
+    OC_HIP_FFTCC3D = 4,
+    OC_HIP_ICGN3D1 = 5
+} oc_hip_kind;
+
+#define OC_HIP_POI2D_BYTES 100
+#define OC_HIP_POI3D_BYTES 124
+
+typedef struct oc_hip_engine oc_hip_engine; /* opaque */
+
+/* thread-local text of the last failure on the calling thread */
+const char* oc_hip_last_error(void);
+/* number of visible HIP devices (0 + OC_HIP_ERR_HIP when the runtime is unusable) */
+int oc_hip_device_count(int* count);
+/* library / ABI version, bumped on any signature change */
+int oc_hip_abi_version(void);
+
+/* ---- construction: one per reference class ------------------------------ */
+/* FFTCC2D(int subset_radius_x, int subset_radius_y, int thread_number)  src/oc_fftcc.cpp:151-163 */
+int oc_hip_fftcc2d_create(int radius_x, int radius_y, int device, oc_hip_engine** out);
+/* ICGN2D1(int rx, int ry, float conv_criterion, float stop_condition, int thread_number)  src/oc_icgn.cpp:71-88 */
+int oc_hip_icgn2d1_create(int radius_x, int radius_y, float conv_criterion, float stop_condition, int device,
+                          oc_hip_engine** out);
+/* ICGN2D2(int rx, int ry, float conv, float stop, int thread_number)  src/oc_icgn.cpp:612-629 */
+int oc_hip_icgn2d2_create(int radius_x, int radius_y, float conv_criterion, float stop_condition, int device,
+                          oc_hip_engine** out);
+/* FFTCC3D(int rx, int ry, int rz, int thread_number)  src/oc_fftcc.cpp:300-313 */
+int oc_hip_fftcc3d_create(int radius_x, int radius_y, int radius_z, int device, oc_hip_engine** out);
+/* ICGN3D1(int rx, int ry, int rz, float conv, float stop, int thread_number)  src/oc_icgn.cpp:1197-1213 */
+int oc_hip_icgn3d1_create(int radius_x, int radius_y, int radius_z, float conv_criterion, float stop_condition,
+                          int device, oc_hip_engine** out);
+/* ~FFTCC2D / ~ICGN2D1 ...  src/oc_fftcc.cpp:165-173, src/oc_icgn.cpp:90-101 */
+int oc_hip_destroy(oc_hip_engine* engine);
+
+/* ---- configuration ------------------------------------------------------- */
+/* DIC::setImages(Image2D&, Image2D&)  src/oc_dic.cpp:22-26 (pointer stored there; snapshotted here) */
+int oc_hip_set_images2d(oc_hip_engine* engine, const float* ref, const float* tar, int height, int width,
+                        int layout, int memory);
+/* DVC::setImages(Image3D&, Image3D&)  src/oc_dic.cpp:45-49; data = &vol_mat[0][0][0] (z,y,x contiguous) */
+int oc_hip_set_images3d(oc_hip_engine* engine, const float* ref, const float* tar, int dim_x, int dim_y, int dim_z,
+                        int memory);
+/* Reuse the device-resident images of another engine on the same device (an
+ * FFTCC and an ICGN engine working on one image pair upload it once).  The
+ * donor must outlive the borrower or call set_images again. */
+int oc_hip_share_images(oc_hip_engine* engine, oc_hip_engine* donor);
+/* DIC::setSubset / DVC::setSubset  src/oc_dic.cpp:28-32,51-56 (radius_z ignored by 2D engines) */
+int oc_hip_set_subset(oc_hip_engine* engine, int radius_x, int radius_y, int radius_z);
+/* ICGN2D1::setIteration(float, float)  src/oc_icgn.cpp:103-107 (also 2D2 :644-648, 3D1 :1228-1232) */
+int oc_hip_set_iteration(oc_hip_engine* engine, float conv_criterion, float stop_condition);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of
+ * the engine's own stream.  NULL restores the engine's stream. */
+int oc_hip_set_stream(oc_hip_engine* engine, void* hip_stream);
+
+/* ---- precompute ----------------------------------------------------------- */
+/* ICGN2D1::prepare()  src/oc_icgn.cpp:138-142 (prepareRef + prepareTar); FFTCC::prepare() is a no-op
+ * in the reference (src/oc_fftcc.cpp:175) and here. */
+int oc_hip_prepare(oc_hip_engine* engine);
+/* ICGN2D1::prepareRef()  src/oc_icgn.cpp:115-125: reference gradients (Gradient2D4 / Gradient3D4) */
+int oc_hip_prepare_ref(oc_hip_engine* engine);
+/* ICGN2D1::prepareTar()  src/oc_icgn.cpp:127-136: target B-spline coefficients */
+int oc_hip_prepare_tar(oc_hip_engine* engine);
+
+/* ---- compute --------------------------------------------------------------- */
+/* FFTCC2D::compute(std::vector<POI2D>&)  src/oc_fftcc.cpp:277-285
+ * ICGN2D1::compute(std::vector<POI2D>&)  src/oc_icgn.cpp:343-351   (2D2 :900-908, 3D1 :1492-1500,
+ * FFTCC3D :429-436).  `pois` = poi_queue.data(), `count` = poi_queue.size().
+ * With OC_HIP_HOST the call returns after the results are back in `pois`; with
+ * OC_HIP_DEVICE it only enqueues work on the engine's stream. */
+int oc_hip_compute(oc_hip_engine* engine, void* pois, size_t count, size_t stride_bytes, int memory);
+/* FFTCC2D::compute(POI2D*) / ICGN2D1::compute(POI2D*)  src/oc_fftcc.cpp:177, src/oc_icgn.cpp:144:
+ * a mutex-guarded batch of one, safe to call from the caller's own OpenMP region
+ * (src/oc_epipolar_search.cpp:184-188). */
+int oc_hip_compute_one(oc_hip_engine* engine, void* poi);
+/* wait for everything enqueued on the engine's stream */
+int oc_hip_synchronize(oc_hip_engine* engine);
+
+/* ---- introspection (tests, bench, profiling) ------------------------------ */
+int oc_hip_get_kind(const oc_hip_engine* engine, int* kind);
+/* Device pointers of the precomputed fields (row-major float32):
+ *   "ref","tar"           height*width            (3D: dz*dy*dx)
+ *   "gx","gy"[,"gz"]      same shape              ICGN engines after prepare_ref
+ *   "lut"                 height*width*16         ICGN2D* after prepare_tar  (3D: "coef", dz*dy*dx)
+ * Returns OC_HIP_ERR_INVALID for an unknown name or a field not built yet. */
+int oc_hip_get_field(const oc_hip_engine* engine, const char* name, const float** device_ptr, size_t* count);
+/* Copy a field to host memory (test helper). */
+int oc_hip_read_field(oc_hip_engine* engine, const char* name, float* host_dst, size_t count);
+/* Per-kernel timing with hipEvents recorded on the engine's stream around every
+ * launch of the engine's dominant kernel ("icgn" / "fftcc" pipeline).  Enable,
+ * run compute() any number of times, synchronize, then read.  */
+int oc_hip_profile_enable(oc_hip_engine* engine, int enable);
+int oc_hip_profile_read(oc_hip_engine* engine, double* total_ms, long* launches);
+int oc_hip_profile_reset(oc_hip_engine* engine);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENCORR_HIP_H_ */

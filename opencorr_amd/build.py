@@ -1,0 +1,66 @@
+"""Builds opencorr_amd/lib/libopencorr_hip.so (gfx950 only) with hipcc.
+
+    python -m opencorr_amd.build [--force]
+
+Flags that matter for parity: -ffp-contract=off (no FMA
+contraction; every multiply and add rounds separately, like the oracle) and no
+fast-math; hipcc's default correctly-rounded fp32 divide/sqrt is kept.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libopencorr_hip.so")
+SOURCES = ["capi.hip", "prepare2d.hip", "icgn2d.hip", "fftcc2d.hip"]
+HEADERS = ["oc_device.h", "oc_kernels.h", os.path.join("..", "..", "include", "opencorr_hip.h")]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs = []
+    cc = hipcc()
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [cc, "--offload-arch=" + ARCH, "-c", s, "-o", o] + FLAGS
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on " + src)
+    if force or procs or _stale(LIB, objs):
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrocfft"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,99 @@
+"""ctypes binding of the C-ABI in ``include/opencorr_hip.h``.
+
+Nothing here computes: every call goes to ``lib/libopencorr_hip.so`` (hand-written
+HIP kernels for gfx950 + rocFFT).  If the library is missing the import fails
+loudly -- there is no CPU fallback anywhere in ``opencorr_amd``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libopencorr_hip.so")
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_ROCFFT, ERR_NOMEM, ERR_UNSUPPORTED = 1, 2, 3, 4, 5
+HOST, DEVICE = 0, 1
+ROW_MAJOR, COL_MAJOR = 0, 1
+FFTCC2D, ICGN2D1, ICGN2D2, FFTCC3D, ICGN3D1 = 1, 2, 3, 4, 5
+POI2D_BYTES, POI3D_BYTES = 100, 124
+POI2D_FLOATS, POI3D_FLOATS = 25, 31
+
+# every symbol include/opencorr_hip.h declares (tests check the .so exports them all)
+SYMBOLS = [
+    "oc_hip_last_error", "oc_hip_device_count", "oc_hip_abi_version",
+    "oc_hip_fftcc2d_create", "oc_hip_icgn2d1_create", "oc_hip_icgn2d2_create",
+    "oc_hip_fftcc3d_create", "oc_hip_icgn3d1_create", "oc_hip_destroy",
+    "oc_hip_set_images2d", "oc_hip_set_images3d", "oc_hip_share_images", "oc_hip_set_subset",
+    "oc_hip_set_iteration", "oc_hip_set_stream",
+    "oc_hip_prepare", "oc_hip_prepare_ref", "oc_hip_prepare_tar",
+    "oc_hip_compute", "oc_hip_compute_one", "oc_hip_synchronize",
+    "oc_hip_get_kind", "oc_hip_get_field", "oc_hip_read_field",
+    "oc_hip_profile_enable", "oc_hip_profile_read", "oc_hip_profile_reset",
+]
+
+
+class OpenCorrHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("opencorr_hip status %d: %s" % (status, message))
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """Loads libopencorr_hip.so (built by ``python -m opencorr_amd.build``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -m opencorr_amd.build` (hipcc, gfx950). "
+            "opencorr_amd has no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    vp, i, f, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    pp = ctypes.POINTER(vp)
+    L.oc_hip_last_error.restype = ctypes.c_char_p
+    L.oc_hip_last_error.argtypes = []
+    L.oc_hip_device_count.argtypes = [ctypes.POINTER(i)]
+    L.oc_hip_abi_version.argtypes = []
+    L.oc_hip_fftcc2d_create.argtypes = [i, i, i, pp]
+    L.oc_hip_icgn2d1_create.argtypes = [i, i, f, f, i, pp]
+    L.oc_hip_icgn2d2_create.argtypes = [i, i, f, f, i, pp]
+    L.oc_hip_fftcc3d_create.argtypes = [i, i, i, i, pp]
+    L.oc_hip_icgn3d1_create.argtypes = [i, i, i, f, f, i, pp]
+    L.oc_hip_destroy.argtypes = [vp]
+    L.oc_hip_set_images2d.argtypes = [vp, vp, vp, i, i, i, i]
+    L.oc_hip_set_images3d.argtypes = [vp, vp, vp, i, i, i, i]
+    L.oc_hip_share_images.argtypes = [vp, vp]
+    L.oc_hip_set_subset.argtypes = [vp, i, i, i]
+    L.oc_hip_set_iteration.argtypes = [vp, f, f]
+    L.oc_hip_set_stream.argtypes = [vp, vp]
+    L.oc_hip_prepare.argtypes = [vp]
+    L.oc_hip_prepare_ref.argtypes = [vp]
+    L.oc_hip_prepare_tar.argtypes = [vp]
+    L.oc_hip_compute.argtypes = [vp, vp, sz, sz, i]
+    L.oc_hip_compute_one.argtypes = [vp, vp]
+    L.oc_hip_synchronize.argtypes = [vp]
+    L.oc_hip_get_kind.argtypes = [vp, ctypes.POINTER(i)]
+    L.oc_hip_get_field.argtypes = [vp, ctypes.c_char_p, pp, ctypes.POINTER(sz)]
+    L.oc_hip_read_field.argtypes = [vp, ctypes.c_char_p, vp, sz]
+    L.oc_hip_profile_enable.argtypes = [vp, i]
+    L.oc_hip_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
+    L.oc_hip_profile_reset.argtypes = [vp]
+    for name in SYMBOLS:
+        if name != "oc_hip_last_error":
+            getattr(L, name).restype = i
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != OK:
+        raise OpenCorrHipError(status, lib().oc_hip_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(lib().oc_hip_device_count(ctypes.byref(n)))
+    return n.value

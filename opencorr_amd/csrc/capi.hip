@@ -1,0 +1,629 @@
+// capi.hip -- implementation of the C-ABI declared in include/opencorr_hip.h.
+//
+// Host-side engine objects: device-resident image pair, precomputed fields,
+// POI staging, rocFFT plans, stream and profiling events.  No CPU compute path
+// exists here: every compute call ends in HIP kernel launches or fails.
+#include "../../include/opencorr_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "oc_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define OC_HIP_TRY(expr)                                                                              \
+    do {                                                                                              \
+        hipError_t err__ = (expr);                                                                    \
+        if (err__ != hipSuccess)                                                                      \
+            return fail(err__ == hipErrorOutOfMemory ? OC_HIP_ERR_NOMEM : OC_HIP_ERR_HIP,             \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__), __FILE__, __LINE__); \
+    } while (0)
+
+#define OC_FFT_TRY(expr)                                                                               \
+    do {                                                                                               \
+        rocfft_status st__ = (expr);                                                                   \
+        if (st__ != rocfft_status_success)                                                             \
+            return fail(OC_HIP_ERR_ROCFFT, "%s failed: rocfft_status %d (%s:%d)", #expr, (int)st__, __FILE__, __LINE__); \
+    } while (0)
+
+#define OC_TRY(expr)                  \
+    do {                              \
+        int rc__ = (expr);            \
+        if (rc__ != OC_HIP_OK) return rc__; \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    // grow-only allocation
+    int reserve(size_t n) {
+        if (n <= bytes) return OC_HIP_OK;
+        release();
+        hipError_t err = hipMalloc(&p, n);
+        if (err != hipSuccess) {
+            p = nullptr;
+            return fail(OC_HIP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(err));
+        }
+        bytes = n;
+        return OC_HIP_OK;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// device copy of a reference/target image pair (2D) or volume pair (3D), row-major, x fastest
+struct ImagePair {
+    int ndim = 0;
+    int dx = 0, dy = 0, dz = 1;  // width, height, depth
+    DevBuf ref, tar;
+    const float* ref_ext = nullptr;  // used in place when the caller handed device memory
+    const float* tar_ext = nullptr;
+    const float* ref_ptr() const { return ref_ext ? ref_ext : ref.as<float>(); }
+    const float* tar_ptr() const { return tar_ext ? tar_ext : tar.as<float>(); }
+    size_t count() const { return (size_t)dx * dy * dz; }
+};
+
+struct FftPlans {
+    int n0 = 0, n1 = 0, n2 = 0;  // slowest .. fastest (n2 == 0 for 2D)
+    size_t chunk = 0;
+    rocfft_plan fwd = nullptr, inv = nullptr;
+    rocfft_execution_info info_fwd = nullptr, info_inv = nullptr;
+    DevBuf work_fwd, work_inv;
+    void destroy() {
+        if (fwd) rocfft_plan_destroy(fwd);
+        if (inv) rocfft_plan_destroy(inv);
+        if (info_fwd) rocfft_execution_info_destroy(info_fwd);
+        if (info_inv) rocfft_execution_info_destroy(info_inv);
+        fwd = inv = nullptr;
+        info_fwd = info_inv = nullptr;
+        chunk = 0;
+    }
+    ~FftPlans() { destroy(); }
+};
+
+std::once_flag g_rocfft_once;
+void rocfft_init_once() {
+    std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+}
+
+}  // namespace
+
+struct oc_hip_engine {
+    int kind = 0;
+    int device = 0;
+    int rx = 0, ry = 0, rz = 0;
+    float conv = 0.001f, stop = 10.f;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::shared_ptr<ImagePair> img;
+    DevBuf gx, gy, gz, coef;  // coef: 2D LUT (16 floats / px) or 3D coefficient volume
+    DevBuf tmp;               // scratch for layout conversion / 3D prefilter passes
+    bool ref_ready = false, tar_ready = false;
+    DevBuf poi_stage;
+    // FFTCC working set
+    FftPlans fft;
+    DevBuf win, freq, norms, flags;
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::mutex mu;
+
+    bool is3d() const { return kind == OC_HIP_FFTCC3D || kind == OC_HIP_ICGN3D1; }
+    bool is_icgn() const { return kind == OC_HIP_ICGN2D1 || kind == OC_HIP_ICGN2D2 || kind == OC_HIP_ICGN3D1; }
+    size_t poi_bytes() const { return is3d() ? OC_HIP_POI3D_BYTES : OC_HIP_POI2D_BYTES; }
+};
+
+namespace {
+
+int check_engine(const oc_hip_engine* e) {
+    if (!e) return fail(OC_HIP_ERR_INVALID, "null engine handle");
+    return OC_HIP_OK;
+}
+
+int activate(const oc_hip_engine* e) {
+    OC_TRY(check_engine(e));
+    OC_HIP_TRY(hipSetDevice(e->device));
+    return OC_HIP_OK;
+}
+
+int create_engine(int kind, int rx, int ry, int rz, float conv, float stop, int device, oc_hip_engine** out) {
+    if (!out) return fail(OC_HIP_ERR_INVALID, "null output handle");
+    *out = nullptr;
+    if (rx < 1 || ry < 1 || ((kind == OC_HIP_FFTCC3D || kind == OC_HIP_ICGN3D1) && rz < 1))
+        return fail(OC_HIP_ERR_INVALID, "subset radius must be >= 1 (got %d, %d, %d)", rx, ry, rz);
+    int ndev = 0;
+    hipError_t err = hipGetDeviceCount(&ndev);
+    if (err != hipSuccess || ndev <= 0)
+        return fail(OC_HIP_ERR_HIP, "no usable HIP device: %s", err == hipSuccess ? "device count is 0" : hipGetErrorString(err));
+    if (device < 0 || device >= ndev) return fail(OC_HIP_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    OC_HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<oc_hip_engine> e(new oc_hip_engine);
+    e->kind = kind;
+    e->device = device;
+    e->rx = rx;
+    e->ry = ry;
+    e->rz = rz;
+    e->conv = conv;
+    e->stop = stop;
+    OC_HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    e->stream = e->own_stream;
+    *out = e.release();
+    return OC_HIP_OK;
+}
+
+void clear_events(oc_hip_engine* e) {
+    for (auto& ev : e->events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    e->events.clear();
+}
+
+struct ProfScope {
+    oc_hip_engine* e;
+    hipEvent_t stop = nullptr;
+    explicit ProfScope(oc_hip_engine* e_) : e(e_) {
+        if (!e->prof) return;
+        hipEvent_t start = nullptr;
+        if (hipEventCreate(&start) != hipSuccess) return;
+        if (hipEventCreate(&stop) != hipSuccess) { (void)hipEventDestroy(start); stop = nullptr; return; }
+        (void)hipEventRecord(start, e->stream);
+        e->events.emplace_back(start, stop);
+    }
+    ~ProfScope() {
+        if (stop) (void)hipEventRecord(stop, e->stream);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// FFTCC2D pipeline
+// ---------------------------------------------------------------------------
+size_t fftcc_chunk_limit() {
+    const char* s = getenv("OC_HIP_FFTCC_CHUNK");
+    if (s && *s) {
+        long v = atol(s);
+        if (v > 0) return (size_t)v;
+    }
+    return 32768;
+}
+
+int ensure_fft2d(oc_hip_engine* e, size_t chunk) {
+    // The reference plans fftwf_plan_dft_r2c_2d(width, height, ...) over a buffer filled
+    // [r*width + c] (src/oc_fftcc.cpp:40-42, 204-221): n0 = 2rx is the slow dimension of
+    // the transform, n1 = 2ry the fast one.  rocFFT takes lengths fastest-first.
+    const int n0 = 2 * e->rx, n1 = 2 * e->ry;
+    FftPlans& f = e->fft;
+    if (f.fwd && f.n0 == n0 && f.n1 == n1 && f.chunk == chunk) return OC_HIP_OK;
+    rocfft_init_once();
+    f.destroy();
+    const size_t lengths[2] = {(size_t)n1, (size_t)n0};
+    OC_FFT_TRY(rocfft_plan_create(&f.fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                  rocfft_precision_single, 2, lengths, 2 * chunk, nullptr));
+    OC_FFT_TRY(rocfft_plan_create(&f.inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                  rocfft_precision_single, 2, lengths, chunk, nullptr));
+    OC_FFT_TRY(rocfft_execution_info_create(&f.info_fwd));
+    OC_FFT_TRY(rocfft_execution_info_create(&f.info_inv));
+    size_t wf = 0, wi = 0;
+    OC_FFT_TRY(rocfft_plan_get_work_buffer_size(f.fwd, &wf));
+    OC_FFT_TRY(rocfft_plan_get_work_buffer_size(f.inv, &wi));
+    if (wf) {
+        OC_TRY(f.work_fwd.reserve(wf));
+        OC_FFT_TRY(rocfft_execution_info_set_work_buffer(f.info_fwd, f.work_fwd.p, wf));
+    }
+    if (wi) {
+        OC_TRY(f.work_inv.reserve(wi));
+        OC_FFT_TRY(rocfft_execution_info_set_work_buffer(f.info_inv, f.work_inv.p, wi));
+    }
+    f.n0 = n0;
+    f.n1 = n1;
+    f.n2 = 0;
+    f.chunk = chunk;
+    return OC_HIP_OK;
+}
+
+int run_fftcc2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
+    if (!e->img || e->img->ndim != 2) return fail(OC_HIP_ERR_INVALID, "FFTCC2D: set_images2d has not been called");
+    const ImagePair& im = *e->img;
+    const size_t chunk = count < fftcc_chunk_limit() ? count : fftcc_chunk_limit();
+    if (chunk == 0) return OC_HIP_OK;
+    OC_TRY(ensure_fft2d(e, chunk));
+    const size_t M = (size_t)4 * e->rx * e->ry;                   // 2rx * 2ry
+    const size_t F = (size_t)(2 * e->rx) * (size_t)(e->ry + 1);   // n0 * (n1/2 + 1)
+    OC_TRY(e->win.reserve(2 * chunk * M * sizeof(float)));
+    OC_TRY(e->freq.reserve(2 * chunk * F * sizeof(float2)));
+    OC_TRY(e->norms.reserve(2 * chunk * sizeof(float)));
+    OC_TRY(e->flags.reserve(chunk * sizeof(int)));
+    OC_FFT_TRY(rocfft_execution_info_set_stream(e->fft.info_fwd, e->stream));
+    OC_FFT_TRY(rocfft_execution_info_set_stream(e->fft.info_inv, e->stream));
+    ochip::Fftcc2dParams P = {im.ref_ptr(), im.tar_ptr(), im.dy, im.dx, e->rx, e->ry};
+    float* ref_win = e->win.as<float>();
+    float* tar_win = ref_win + chunk * M;
+    float2* ref_freq = e->freq.as<float2>();
+    float2* tar_freq = ref_freq + chunk * F;
+    ProfScope prof(e);
+    for (size_t first = 0; first < count; first += chunk) {
+        const size_t n = (count - first) < chunk ? (count - first) : chunk;
+        float* pois = d_pois + first * (size_t)stride_f;
+        if (n < chunk) {
+            // the plans are built for a full chunk: clear the tail so stale windows stay finite
+            OC_HIP_TRY(hipMemsetAsync(ref_win + n * M, 0, (chunk - n) * M * sizeof(float), e->stream));
+            OC_HIP_TRY(hipMemsetAsync(tar_win + n * M, 0, (chunk - n) * M * sizeof(float), e->stream));
+        }
+        OC_HIP_TRY(ochip::launch_fftcc2d_gather(P, pois, stride_f, n, ref_win, tar_win, e->norms.as<float>(),
+                                                e->flags.as<int>(), e->stream));
+        void* in_fwd[1] = {ref_win};
+        void* out_fwd[1] = {ref_freq};
+        OC_FFT_TRY(rocfft_execute(e->fft.fwd, in_fwd, out_fwd, e->fft.info_fwd));
+        OC_HIP_TRY(ochip::launch_fftcc_conjmul(ref_freq, tar_freq, ref_freq, n * F, e->stream));
+        void* in_inv[1] = {ref_freq};
+        void* out_inv[1] = {ref_win};  // correlation surfaces overwrite the reference windows
+        OC_FFT_TRY(rocfft_execute(e->fft.inv, in_inv, out_inv, e->fft.info_inv));
+        OC_HIP_TRY(ochip::launch_fftcc2d_argmax(P, ref_win, e->norms.as<float>(), e->flags.as<int>(), pois, stride_f,
+                                                n, e->stream));
+    }
+    return OC_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// ICGN2D
+// ---------------------------------------------------------------------------
+int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
+    if (!e->img || e->img->ndim != 2) return fail(OC_HIP_ERR_INVALID, "ICGN2D: set_images2d has not been called");
+    if (!e->ref_ready || !e->tar_ready)
+        return fail(OC_HIP_ERR_INVALID, "ICGN2D: prepare() has not been called since the last set_images");
+    const ImagePair& im = *e->img;
+    ochip::Icgn2dParams P = {im.ref_ptr(), e->gx.as<float>(), e->gy.as<float>(), e->coef.as<float>(),
+                             im.dy,        im.dx,              e->rx,             e->ry,
+                             e->conv,      e->stop};
+    const int dof = e->kind == OC_HIP_ICGN2D1 ? 6 : 12;
+    const int N = (2 * e->rx + 1) * (2 * e->ry + 1);
+    if (N > ochip::icgn2d_max_samples(dof))
+        return fail(OC_HIP_ERR_UNSUPPORTED, "ICGN2D%d: subset %dx%d (%d samples) exceeds the on-chip limit of %d samples",
+                    dof == 6 ? 1 : 2, 2 * e->rx + 1, 2 * e->ry + 1, N, ochip::icgn2d_max_samples(dof));
+    ProfScope prof(e);
+    // one wave-sized workgroup per POI; grid.x is limited to 2^31-1
+    const size_t kMaxGrid = 1u << 30;
+    for (size_t first = 0; first < count; first += kMaxGrid) {
+        const size_t n = (count - first) < kMaxGrid ? (count - first) : kMaxGrid;
+        float* pois = d_pois + first * (size_t)stride_f;
+        hipError_t err = dof == 6 ? ochip::launch_icgn2d1(P, pois, stride_f, n, e->stream)
+                                  : ochip::launch_icgn2d2(P, pois, stride_f, n, e->stream);
+        if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "ICGN2D kernel launch failed: %s", hipGetErrorString(err));
+    }
+    return OC_HIP_OK;
+}
+
+int run_compute_device(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
+    switch (e->kind) {
+        case OC_HIP_FFTCC2D: return run_fftcc2d(e, d_pois, stride_f, count);
+        case OC_HIP_ICGN2D1:
+        case OC_HIP_ICGN2D2: return run_icgn2d(e, d_pois, stride_f, count);
+        default: return fail(OC_HIP_ERR_UNSUPPORTED, "engine kind %d has no device path yet", e->kind);
+    }
+}
+
+}  // namespace
+
+// ===========================================================================
+// C entry points
+// ===========================================================================
+extern "C" {
+
+const char* oc_hip_last_error(void) { return g_last_error.c_str(); }
+
+int oc_hip_abi_version(void) { return 1; }
+
+int oc_hip_device_count(int* count) {
+    if (!count) return fail(OC_HIP_ERR_INVALID, "null count");
+    *count = 0;
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(err));
+    *count = n;
+    return OC_HIP_OK;
+}
+
+int oc_hip_fftcc2d_create(int rx, int ry, int device, oc_hip_engine** out) {
+    return create_engine(OC_HIP_FFTCC2D, rx, ry, 0, 0.f, 0.f, device, out);
+}
+int oc_hip_icgn2d1_create(int rx, int ry, float conv, float stop, int device, oc_hip_engine** out) {
+    return create_engine(OC_HIP_ICGN2D1, rx, ry, 0, conv, stop, device, out);
+}
+int oc_hip_icgn2d2_create(int rx, int ry, float conv, float stop, int device, oc_hip_engine** out) {
+    return create_engine(OC_HIP_ICGN2D2, rx, ry, 0, conv, stop, device, out);
+}
+int oc_hip_fftcc3d_create(int rx, int ry, int rz, int device, oc_hip_engine** out) {
+    return create_engine(OC_HIP_FFTCC3D, rx, ry, rz, 0.f, 0.f, device, out);
+}
+int oc_hip_icgn3d1_create(int rx, int ry, int rz, float conv, float stop, int device, oc_hip_engine** out) {
+    return create_engine(OC_HIP_ICGN3D1, rx, ry, rz, conv, stop, device, out);
+}
+
+int oc_hip_destroy(oc_hip_engine* e) {
+    if (!e) return OC_HIP_OK;
+    (void)hipSetDevice(e->device);
+    if (e->own_stream) {
+        (void)hipStreamSynchronize(e->stream);
+        if (e->stream != e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+    }
+    clear_events(e);
+    e->fft.destroy();
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+    return OC_HIP_OK;
+}
+
+static int upload_image(oc_hip_engine* e, const float* src, size_t count, int memory, DevBuf& dst) {
+    OC_TRY(dst.reserve(count * sizeof(float)));
+    OC_HIP_TRY(hipMemcpyAsync(dst.p, src, count * sizeof(float),
+                              memory == OC_HIP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    return OC_HIP_OK;
+}
+
+int oc_hip_set_images2d(oc_hip_engine* e, const float* ref, const float* tar, int height, int width, int layout,
+                        int memory) {
+    OC_TRY(activate(e));
+    if (e->is3d()) return fail(OC_HIP_ERR_INVALID, "set_images2d called on a 3D engine");
+    if (!ref || !tar) return fail(OC_HIP_ERR_INVALID, "null image pointer");
+    if (height < 5 || width < 5) return fail(OC_HIP_ERR_INVALID, "image too small: %d x %d", width, height);
+    if (layout != OC_HIP_ROW_MAJOR && layout != OC_HIP_COL_MAJOR) return fail(OC_HIP_ERR_INVALID, "bad layout %d", layout);
+    std::lock_guard<std::mutex> lock(e->mu);
+    auto img = std::make_shared<ImagePair>();
+    img->ndim = 2;
+    img->dx = width;
+    img->dy = height;
+    img->dz = 1;
+    const size_t count = img->count();
+    if (memory == OC_HIP_DEVICE && layout == OC_HIP_ROW_MAJOR) {
+        img->ref_ext = ref;  // used in place
+        img->tar_ext = tar;
+    } else if (layout == OC_HIP_ROW_MAJOR) {
+        OC_TRY(upload_image(e, ref, count, memory, img->ref));
+        OC_TRY(upload_image(e, tar, count, memory, img->tar));
+    } else {
+        OC_TRY(img->ref.reserve(count * sizeof(float)));
+        OC_TRY(img->tar.reserve(count * sizeof(float)));
+        OC_TRY(upload_image(e, ref, count, memory, e->tmp));
+        OC_HIP_TRY(ochip::launch_colmajor_to_rowmajor(e->tmp.as<float>(), height, width, img->ref.as<float>(), e->stream));
+        OC_HIP_TRY(hipStreamSynchronize(e->stream));
+        OC_TRY(upload_image(e, tar, count, memory, e->tmp));
+        OC_HIP_TRY(ochip::launch_colmajor_to_rowmajor(e->tmp.as<float>(), height, width, img->tar.as<float>(), e->stream));
+    }
+    OC_HIP_TRY(hipStreamSynchronize(e->stream));  // host buffers may be released by the caller
+    e->img = img;
+    e->ref_ready = e->tar_ready = false;
+    return OC_HIP_OK;
+}
+
+int oc_hip_set_images3d(oc_hip_engine* e, const float* ref, const float* tar, int dim_x, int dim_y, int dim_z,
+                        int memory) {
+    OC_TRY(activate(e));
+    if (!e->is3d()) return fail(OC_HIP_ERR_INVALID, "set_images3d called on a 2D engine");
+    if (!ref || !tar) return fail(OC_HIP_ERR_INVALID, "null volume pointer");
+    if (dim_x < 15 || dim_y < 15 || dim_z < 15)
+        return fail(OC_HIP_ERR_INVALID, "volume too small: %d x %d x %d", dim_x, dim_y, dim_z);
+    std::lock_guard<std::mutex> lock(e->mu);
+    auto img = std::make_shared<ImagePair>();
+    img->ndim = 3;
+    img->dx = dim_x;
+    img->dy = dim_y;
+    img->dz = dim_z;
+    const size_t count = img->count();
+    if (memory == OC_HIP_DEVICE) {
+        img->ref_ext = ref;
+        img->tar_ext = tar;
+    } else {
+        OC_TRY(upload_image(e, ref, count, memory, img->ref));
+        OC_TRY(upload_image(e, tar, count, memory, img->tar));
+    }
+    OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    e->img = img;
+    e->ref_ready = e->tar_ready = false;
+    return OC_HIP_OK;
+}
+
+int oc_hip_share_images(oc_hip_engine* e, oc_hip_engine* donor) {
+    OC_TRY(activate(e));
+    OC_TRY(check_engine(donor));
+    if (donor->device != e->device) return fail(OC_HIP_ERR_INVALID, "share_images: engines live on different devices");
+    if (!donor->img) return fail(OC_HIP_ERR_INVALID, "share_images: donor has no images");
+    if ((donor->img->ndim == 3) != e->is3d()) return fail(OC_HIP_ERR_INVALID, "share_images: 2D/3D mismatch");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->img = donor->img;
+    e->ref_ready = e->tar_ready = false;
+    return OC_HIP_OK;
+}
+
+int oc_hip_set_subset(oc_hip_engine* e, int rx, int ry, int rz) {
+    OC_TRY(check_engine(e));
+    if (rx < 1 || ry < 1 || (e->is3d() && rz < 1)) return fail(OC_HIP_ERR_INVALID, "subset radius must be >= 1");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->rx = rx;
+    e->ry = ry;
+    if (e->is3d()) e->rz = rz;
+    return OC_HIP_OK;
+}
+
+int oc_hip_set_iteration(oc_hip_engine* e, float conv, float stop) {
+    OC_TRY(check_engine(e));
+    if (!e->is_icgn()) return fail(OC_HIP_ERR_INVALID, "set_iteration on a non-ICGN engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->conv = conv;
+    e->stop = stop;
+    return OC_HIP_OK;
+}
+
+int oc_hip_set_stream(oc_hip_engine* e, void* hip_stream) {
+    OC_TRY(check_engine(e));
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : e->own_stream;
+    return OC_HIP_OK;
+}
+
+int oc_hip_prepare_ref(oc_hip_engine* e) {
+    OC_TRY(activate(e));
+    if (!e->is_icgn()) return OC_HIP_OK;  // FFTCC::prepare() is empty in the reference
+    if (!e->img) return fail(OC_HIP_ERR_INVALID, "prepare: set_images has not been called");
+    std::lock_guard<std::mutex> lock(e->mu);
+    const ImagePair& im = *e->img;
+    const size_t bytes = im.count() * sizeof(float);
+    if (im.ndim == 2) {
+        OC_TRY(e->gx.reserve(bytes));
+        OC_TRY(e->gy.reserve(bytes));
+        OC_HIP_TRY(ochip::launch_grad2d(im.ref_ptr(), im.dy, im.dx, e->gx.as<float>(), e->gy.as<float>(), e->stream));
+    } else {
+        return fail(OC_HIP_ERR_UNSUPPORTED, "3D prepare is not implemented yet");
+    }
+    e->ref_ready = true;
+    return OC_HIP_OK;
+}
+
+int oc_hip_prepare_tar(oc_hip_engine* e) {
+    OC_TRY(activate(e));
+    if (!e->is_icgn()) return OC_HIP_OK;
+    if (!e->img) return fail(OC_HIP_ERR_INVALID, "prepare: set_images has not been called");
+    std::lock_guard<std::mutex> lock(e->mu);
+    const ImagePair& im = *e->img;
+    if (im.ndim == 2) {
+        OC_TRY(e->coef.reserve(im.count() * 16 * sizeof(float)));
+        OC_HIP_TRY(ochip::launch_bspline2d_lut(im.tar_ptr(), im.dy, im.dx, e->coef.as<float>(), e->stream));
+    } else {
+        return fail(OC_HIP_ERR_UNSUPPORTED, "3D prepare is not implemented yet");
+    }
+    e->tar_ready = true;
+    return OC_HIP_OK;
+}
+
+int oc_hip_prepare(oc_hip_engine* e) {
+    OC_TRY(oc_hip_prepare_ref(e));
+    return oc_hip_prepare_tar(e);
+}
+
+int oc_hip_compute(oc_hip_engine* e, void* pois, size_t count, size_t stride_bytes, int memory) {
+    OC_TRY(activate(e));
+    if (count == 0) return OC_HIP_OK;
+    if (!pois) return fail(OC_HIP_ERR_INVALID, "null POI buffer");
+    if (stride_bytes < e->poi_bytes() || (stride_bytes & 3))
+        return fail(OC_HIP_ERR_INVALID, "bad POI stride %zu (record is %zu bytes, stride must be a multiple of 4)",
+                    stride_bytes, e->poi_bytes());
+    std::lock_guard<std::mutex> lock(e->mu);
+    const int stride_f = (int)(stride_bytes / 4);
+    if (memory == OC_HIP_DEVICE) return run_compute_device(e, static_cast<float*>(pois), stride_f, count);
+    // host queue: H2D of the AoS, kernels, D2H (the reference's CUDA module does the same,
+    // examples/test_2d_dic_gpu_icgn.cpp:136-149)
+    const size_t bytes = count * stride_bytes;
+    OC_TRY(e->poi_stage.reserve(bytes));
+    OC_HIP_TRY(hipMemcpyAsync(e->poi_stage.p, pois, bytes, hipMemcpyHostToDevice, e->stream));
+    OC_TRY(run_compute_device(e, e->poi_stage.as<float>(), stride_f, count));
+    OC_HIP_TRY(hipMemcpyAsync(pois, e->poi_stage.p, bytes, hipMemcpyDeviceToHost, e->stream));
+    OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    return OC_HIP_OK;
+}
+
+int oc_hip_compute_one(oc_hip_engine* e, void* poi) {
+    OC_TRY(check_engine(e));
+    return oc_hip_compute(e, poi, 1, e->poi_bytes(), OC_HIP_HOST);
+}
+
+int oc_hip_synchronize(oc_hip_engine* e) {
+    OC_TRY(activate(e));
+    OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    return OC_HIP_OK;
+}
+
+int oc_hip_get_kind(const oc_hip_engine* e, int* kind) {
+    OC_TRY(check_engine(e));
+    if (!kind) return fail(OC_HIP_ERR_INVALID, "null kind");
+    *kind = e->kind;
+    return OC_HIP_OK;
+}
+
+int oc_hip_get_field(const oc_hip_engine* e, const char* name, const float** ptr, size_t* count) {
+    OC_TRY(check_engine(e));
+    if (!name || !ptr || !count) return fail(OC_HIP_ERR_INVALID, "null argument");
+    *ptr = nullptr;
+    *count = 0;
+    if (!e->img) return fail(OC_HIP_ERR_INVALID, "get_field(%s): no images set", name);
+    const size_t n = e->img->count();
+    const std::string s(name);
+    if (s == "ref") { *ptr = e->img->ref_ptr(); *count = n; }
+    else if (s == "tar") { *ptr = e->img->tar_ptr(); *count = n; }
+    else if (s == "gx" && e->ref_ready) { *ptr = e->gx.as<float>(); *count = n; }
+    else if (s == "gy" && e->ref_ready) { *ptr = e->gy.as<float>(); *count = n; }
+    else if (s == "gz" && e->ref_ready && e->is3d()) { *ptr = e->gz.as<float>(); *count = n; }
+    else if (s == "lut" && e->tar_ready && !e->is3d()) { *ptr = e->coef.as<float>(); *count = n * 16; }
+    else if (s == "coef" && e->tar_ready && e->is3d()) { *ptr = e->coef.as<float>(); *count = n; }
+    else return fail(OC_HIP_ERR_INVALID, "get_field: '%s' is unknown or not built yet", name);
+    return OC_HIP_OK;
+}
+
+int oc_hip_read_field(oc_hip_engine* e, const char* name, float* host_dst, size_t count) {
+    OC_TRY(activate(e));
+    const float* p = nullptr;
+    size_t n = 0;
+    OC_TRY(oc_hip_get_field(e, name, &p, &n));
+    if (!host_dst || count != n) return fail(OC_HIP_ERR_INVALID, "read_field(%s): expected %zu floats, got %zu", name, n, count);
+    OC_HIP_TRY(hipMemcpyAsync(host_dst, p, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    return OC_HIP_OK;
+}
+
+int oc_hip_profile_enable(oc_hip_engine* e, int enable) {
+    OC_TRY(check_engine(e));
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->prof = enable != 0;
+    return OC_HIP_OK;
+}
+
+int oc_hip_profile_reset(oc_hip_engine* e) {
+    OC_TRY(activate(e));
+    std::lock_guard<std::mutex> lock(e->mu);
+    OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    clear_events(e);
+    return OC_HIP_OK;
+}
+
+int oc_hip_profile_read(oc_hip_engine* e, double* total_ms, long* launches) {
+    OC_TRY(activate(e));
+    if (!total_ms || !launches) return fail(OC_HIP_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lock(e->mu);
+    OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    double total = 0.0;
+    for (auto& ev : e->events) {
+        float ms = 0.f;
+        OC_HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        total += ms;
+    }
+    *total_ms = total;
+    *launches = (long)e->events.size();
+    return OC_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// oc_device.h -- device-side helpers shared by the gfx950 kernels.
+//
+// Arithmetic contract: IEEE float32, every multiply and add
+// rounded separately (the library is built with -ffp-contract=off), correctly
+// rounded division and sqrt (hipcc default), no fast-math.  Reductions over the
+// samples of a subset use ONE fixed association: sample s is owned by lane
+// (s % P) which adds its samples in increasing s, and the P partials are
+// combined by an xor butterfly with ascending offsets 1, 2, 4, ... P/2.  The CPU
+// oracle implements the same association (OC_ORDER_LANES) so results are
+// bit-identical.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace ochip {
+
+constexpr int kWave = 64;
+
+// offsets inside a POI2D / POI3D record, in floats (src/oc_poi.h:25-222)
+namespace poi2d {
+constexpr int X = 0, Y = 1, U = 2, UX = 3, UY = 4, UXX = 5, UXY = 6, UYY = 7, V = 8, VX = 9, VY = 10, VXX = 11,
+              VXY = 12, VYY = 13, U0 = 14, V0 = 15, ZNCC = 16, ITER = 17, CONV = 18, FEATURE = 19, SRX = 23, SRY = 24;
+constexpr int FLOATS = 25;
+}  // namespace poi2d
+namespace poi3d {
+constexpr int X = 0, Y = 1, Z = 2, P = 3, U = 3, V = 7, W = 11, U0 = 15, V0 = 16, W0 = 17, ZNCC = 18, ITER = 19,
+              CONV = 20, SRX = 28, SRY = 29, SRZ = 30;
+constexpr int FLOATS = 31;
+}  // namespace poi3d
+
+// xor-butterfly all-reduce over the 64 lanes of a wave, ascending offsets.
+// a + b is commutative in IEEE arithmetic, so both partners compute the same
+// bits and every lane ends with the same value.
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) v = v + __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// broadcast lane `src`'s value as a wave-uniform value
+__device__ __forceinline__ float wave_bcast(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+
+__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+
+}  // namespace ochip

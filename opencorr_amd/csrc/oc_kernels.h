@@ -1,0 +1,47 @@
+// oc_kernels.h -- host-side launch interface of the gfx950 kernels (internal).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace ochip {
+
+// ---- prepare2d.hip ---------------------------------------------------------
+hipError_t launch_grad2d(const float* img, int height, int width, float* gx, float* gy, hipStream_t stream);
+hipError_t launch_bspline2d_lut(const float* img, int height, int width, float* lut, hipStream_t stream);
+hipError_t launch_colmajor_to_rowmajor(const float* src, int height, int width, float* dst, hipStream_t stream);
+
+// ---- icgn2d.hip ------------------------------------------------------------
+struct Icgn2dParams {
+    const float* ref;  // reference image, row-major
+    const float* gx;   // reference gradients
+    const float* gy;
+    const float* lut;  // target bicubic coefficient LUT, 16 floats per pixel
+    int height, width;
+    int rx, ry;
+    float conv, stop;
+};
+// returns hipErrorInvalidValue if the subset does not fit the register-resident kernels
+hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);
+hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);
+// largest (2rx+1)*(2ry+1) the ICGN2D kernels accept
+int icgn2d_max_samples(int dof);
+
+// ---- fftcc2d.hip -----------------------------------------------------------
+struct Fftcc2dParams {
+    const float* ref;
+    const float* tar;
+    int height, width;
+    int rx, ry;
+};
+// gathers zero-mean windows of POIs [first, first+count) into ref_win/tar_win (count x (2ry*2rx)),
+// writes norms[2*i], norms[2*i+1] = sum of squares, flags[i] = 1 if the bounds guard fired
+hipError_t launch_fftcc2d_gather(const Fftcc2dParams& p, const float* pois, int stride_floats, size_t count,
+                                 float* ref_win, float* tar_win, float* norms, int* flags, hipStream_t stream);
+// zf = conj(rf) * tf over `bins` complex values
+hipError_t launch_fftcc_conjmul(const float2* rf, const float2* tf, float2* zf, size_t bins, hipStream_t stream);
+// arg-max of each (2ry*2rx) surface with the first-max rule, writes u,v,u0,v0,zncc into the POIs
+hipError_t launch_fftcc2d_argmax(const Fftcc2dParams& p, const float* surf, const float* norms, const int* flags,
+                                 float* pois, int stride_floats, size_t count, hipStream_t stream);
+
+}  // namespace ochip

@@ -1,0 +1,125 @@
+// prepare2d.hip -- image-level precompute of ICGN2D1/2D2::prepare() on gfx950.
+//
+//   grad2d_kernel        Gradient2D4::getGradientX/Y   (src/oc_gradient.cpp:37-79)
+//   bspline2d_lut_kernel BicubicBspline::prepare       (src/oc_cubic_bspline.cpp:84-132)
+//   colmajor_to_rowmajor Eigen::MatrixXf (column-major, src/oc_image.h:37) -> x-fastest
+//
+// All three are HBM streaming kernels: one thread per pixel, 4 B read (neighbours
+// come from L1/L2), 8 B (gradients) or 64 B (LUT) written per pixel.
+#include "oc_device.h"
+#include "oc_kernels.h"
+
+namespace ochip {
+
+// 4th-order central difference with the reference's operation order:
+// result = 0; result -= f[+2]*(1/12); result += f[+1]*(2/3); result -= f[-1]*(2/3); result += f[-2]*(1/12)
+// (src/oc_gradient.cpp:21-22, 50-54).  Two-pixel zero border.
+__global__ __launch_bounds__(256) void grad2d_kernel(const float* __restrict__ img, int height, int width,
+                                                     float* __restrict__ gx, float* __restrict__ gy) {
+    const float first_factor = 1.f / 12.f;
+    const float second_factor = 2.f / 3.f;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= width) return;
+    const size_t g = (size_t)r * width + c;
+    float vx = 0.f, vy = 0.f;
+    if (c >= 2 && c < width - 2) {
+        float result = 0.0f;
+        result -= img[g + 2] * first_factor;
+        result += img[g + 1] * second_factor;
+        result -= img[g - 1] * second_factor;
+        result += img[g - 2] * first_factor;
+        vx = result;
+    }
+    if (r >= 2 && r < height - 2) {
+        float result = 0.0f;
+        result -= img[g + 2 * (size_t)width] * first_factor;
+        result += img[g + (size_t)width] * second_factor;
+        result -= img[g - (size_t)width] * second_factor;
+        result += img[g - 2 * (size_t)width] * first_factor;
+        vy = result;
+    }
+    gx[g] = vx;
+    gy[g] = vy;
+}
+
+// BC = B * C of src/oc_cubic_bspline.h:52-58
+__device__ constexpr float kBC[4][4] = {
+    {-144.0f / 336.0f, 384.0f / 336.0f, -384.0f / 336.0f, 144.0f / 336.0f},
+    {342.0f / 336.0f, -702.0f / 336.0f, 450.0f / 336.0f, -90.0f / 336.0f},
+    {-198.0f / 336.0f, -18.0f / 336.0f, 270.0f / 336.0f, -54.0f / 336.0f},
+    {0.0f, 1.0f, 0.0f, 0.0f}};
+
+// Per interior pixel (1 <= r < H-2, 1 <= c < W-2): P = BC * Q * BC^T over the 4x4
+// neighbourhood accumulated in the reference's k,l,m,n loop order
+// (acc += BC[l][m] * BC[k][n] * q[n][m], src/oc_cubic_bspline.cpp:108-120), stored
+// flipped coef[k][l] = P[3-k][3-l] (:123-129).  Border entries are zero (calloc in
+// the reference, src/oc_array.h:92).  LUT entry = 16 floats = 64 B, [k][l] at 4k+l.
+__global__ __launch_bounds__(256) void bspline2d_lut_kernel(const float* __restrict__ img, int height, int width,
+                                                            float* __restrict__ lut) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= width) return;
+    float4* out = reinterpret_cast<float4*>(lut + ((size_t)r * width + c) * 16);
+    if (r < 1 || r >= height - 2 || c < 1 || c >= width - 2) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        out[0] = z; out[1] = z; out[2] = z; out[3] = z;
+        return;
+    }
+    float q[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[i][j] = img[(size_t)(r - 1 + i) * width + (c - 1 + j)];
+    float pm[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int n = 0; n < 4; n++) acc += kBC[l][m] * kBC[k][n] * q[n][m];
+            pm[k][l] = acc;
+        }
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = make_float4(pm[3 - k][3], pm[3 - k][2], pm[3 - k][1], pm[3 - k][0]);
+}
+
+// dst[r*width + c] = src[c*height + r]; LDS-tiled so both sides stay coalesced.
+__global__ __launch_bounds__(256) void colmajor_to_rowmajor_kernel(const float* __restrict__ src, int height,
+                                                                   int width, float* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int j = ty; j < 32; j += 8) {
+        int c = c0 + j, r = r0 + tx;  // src is contiguous in r
+        if (c < width && r < height) tile[j][tx] = src[(size_t)c * height + r];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int r = r0 + j, c = c0 + tx;  // dst is contiguous in c
+        if (r < height && c < width) dst[(size_t)r * width + c] = tile[tx][j];
+    }
+}
+
+hipError_t launch_grad2d(const float* img, int height, int width, float* gx, float* gy, hipStream_t stream) {
+    dim3 block(256), grid((width + 255) / 256, height);
+    hipLaunchKernelGGL(grad2d_kernel, grid, block, 0, stream, img, height, width, gx, gy);
+    return hipGetLastError();
+}
+
+hipError_t launch_bspline2d_lut(const float* img, int height, int width, float* lut, hipStream_t stream) {
+    dim3 block(256), grid((width + 255) / 256, height);
+    hipLaunchKernelGGL(bspline2d_lut_kernel, grid, block, 0, stream, img, height, width, lut);
+    return hipGetLastError();
+}
+
+hipError_t launch_colmajor_to_rowmajor(const float* src, int height, int width, float* dst, hipStream_t stream) {
+    dim3 block(256), grid((width + 31) / 32, (height + 31) / 32);
+    hipLaunchKernelGGL(colmajor_to_rowmajor_kernel, grid, block, 0, stream, src, height, width, dst);
+    return hipGetLastError();
+}
+
+}  // namespace ochip

@@ -1,0 +1,216 @@
+"""Python mirror of OpenCorr's hot-path classes over the HIP C-ABI.
+
+Same names, constructor arguments and call order as the reference
+(``src/oc_fftcc.h:54-89``, ``src/oc_icgn.h:45-180``, ``src/oc_dic.h:43-84``):
+
+    fftcc = FFTCC2D(rx, ry);            fftcc.set_images(ref, tar); fftcc.compute(pois)
+    icgn  = ICGN2D1(rx, ry, conv, stop); icgn.set_images(ref, tar);  icgn.prepare(); icgn.compute(pois)
+
+``pois`` is the reference's POI2D/POI3D AoS as a float32 array of shape (n, 25) /
+(n, 31), updated in place: a NumPy array takes the host path (H2D, kernels,
+D2H), a CUDA torch tensor is used in place on the device.  Images are NumPy
+arrays (uploaded) or CUDA torch tensors (row-major, used in place).
+"""
+import ctypes
+
+import numpy as np
+
+from . import capi
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _buf(x, floats_per_row=None):
+    """(pointer, memory kind, keep-alive) of a float32 NumPy array or CUDA torch tensor."""
+    if _is_torch(x):
+        import torch
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            raise ValueError("torch buffers must be contiguous float32")
+        if not x.is_cuda:
+            raise ValueError("torch buffers must live on the GPU (pass NumPy arrays for host data)")
+        return ctypes.c_void_p(x.data_ptr()), capi.DEVICE, x
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    return ctypes.c_void_p(a.ctypes.data), capi.HOST, a
+
+
+class _Engine:
+    _ndim = 2
+
+    def __init__(self):
+        self._h = ctypes.c_void_p()
+        self._keep = []
+
+    # -- lifecycle ---------------------------------------------------------
+    def close(self):
+        if self._h:
+            capi.lib().oc_hip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- DIC::setImages / DVC::setImages ------------------------------------
+    def set_images(self, ref, tar, layout=capi.ROW_MAJOR):
+        rp, rmem, rkeep = _buf(ref)
+        tp, tmem, tkeep = _buf(tar)
+        if rmem != tmem:
+            raise ValueError("reference and target image must live in the same memory space")
+        shape = tuple(rkeep.shape)
+        if tuple(tkeep.shape) != shape or len(shape) != self._ndim:
+            raise ValueError("bad image shapes %r / %r" % (shape, tuple(tkeep.shape)))
+        if self._ndim == 2:
+            h, w = shape
+            capi.check(capi.lib().oc_hip_set_images2d(self._h, rp, tp, h, w, layout, rmem))
+        else:
+            dz, dy, dx = shape
+            capi.check(capi.lib().oc_hip_set_images3d(self._h, rp, tp, dx, dy, dz, rmem))
+        # device images are used in place: keep them alive
+        self._keep = [rkeep, tkeep] if rmem == capi.DEVICE else []
+        self.shape = shape
+
+    def share_images(self, donor):
+        capi.check(capi.lib().oc_hip_share_images(self._h, donor._h))
+        self._keep = [donor]
+        self.shape = donor.shape
+
+    def set_subset(self, rx, ry, rz=0):
+        capi.check(capi.lib().oc_hip_set_subset(self._h, rx, ry, rz))
+
+    def set_stream(self, stream_handle):
+        capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(stream_handle)))
+
+    def prepare(self):
+        capi.check(capi.lib().oc_hip_prepare(self._h))
+
+    def prepare_ref(self):
+        capi.check(capi.lib().oc_hip_prepare_ref(self._h))
+
+    def prepare_tar(self):
+        capi.check(capi.lib().oc_hip_prepare_tar(self._h))
+
+    # -- compute(std::vector<POI>&) -------------------------------------------
+    def compute(self, pois):
+        floats = capi.POI2D_FLOATS if self._ndim == 2 else capi.POI3D_FLOATS
+        if _is_torch(pois):
+            p, mem, _ = _buf(pois)
+            n, stride = pois.shape[0], pois.stride(0) * 4
+            if pois.shape[1] < floats:
+                raise ValueError("POI records need %d floats" % floats)
+        else:
+            if pois.dtype != np.float32 or not pois.flags.c_contiguous or pois.ndim != 2 or pois.shape[1] < floats:
+                raise ValueError("pois must be a C-contiguous float32 array of shape (n, >=%d)" % floats)
+            p, mem = ctypes.c_void_p(pois.ctypes.data), capi.HOST
+            n, stride = pois.shape[0], pois.strides[0]
+        capi.check(capi.lib().oc_hip_compute(self._h, p, n, stride, mem))
+        return pois
+
+    def compute_one(self, poi):
+        assert poi.dtype == np.float32 and poi.flags.c_contiguous
+        capi.check(capi.lib().oc_hip_compute_one(self._h, ctypes.c_void_p(poi.ctypes.data)))
+        return poi
+
+    def synchronize(self):
+        capi.check(capi.lib().oc_hip_synchronize(self._h))
+
+    # -- introspection ----------------------------------------------------------
+    def read_field(self, name):
+        ptr = ctypes.c_void_p()
+        count = ctypes.c_size_t()
+        capi.check(capi.lib().oc_hip_get_field(self._h, name.encode(), ctypes.byref(ptr), ctypes.byref(count)))
+        out = np.empty(count.value, dtype=np.float32)
+        capi.check(capi.lib().oc_hip_read_field(self._h, name.encode(), ctypes.c_void_p(out.ctypes.data), count.value))
+        if name == "lut":
+            return out.reshape(self.shape + (16,))
+        return out.reshape(self.shape)
+
+    def profile_enable(self, on=True):
+        capi.check(capi.lib().oc_hip_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        capi.check(capi.lib().oc_hip_profile_reset(self._h))
+
+    def profile_read(self):
+        ms = ctypes.c_double()
+        n = ctypes.c_long()
+        capi.check(capi.lib().oc_hip_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+
+class _IcgnMixin:
+    def set_iteration(self, conv_criterion, stop_condition):
+        capi.check(capi.lib().oc_hip_set_iteration(self._h, conv_criterion, stop_condition))
+
+
+class FFTCC2D(_Engine):
+    """FFTCC2D(subset_radius_x, subset_radius_y, thread_number) -- src/oc_fftcc.h:54-68."""
+
+    def __init__(self, subset_radius_x, subset_radius_y, thread_number=1, device=0):
+        super().__init__()
+        self.thread_number = thread_number  # kept for signature compatibility
+        capi.check(capi.lib().oc_hip_fftcc2d_create(subset_radius_x, subset_radius_y, device, ctypes.byref(self._h)))
+
+
+class ICGN2D1(_Engine, _IcgnMixin):
+    """ICGN2D1(rx, ry, conv_criterion, stop_condition, thread_number) -- src/oc_icgn.h:45-77."""
+
+    def __init__(self, subset_radius_x, subset_radius_y, conv_criterion, stop_condition, thread_number=1, device=0):
+        super().__init__()
+        self.thread_number = thread_number
+        capi.check(capi.lib().oc_hip_icgn2d1_create(subset_radius_x, subset_radius_y, conv_criterion, stop_condition,
+                                                    device, ctypes.byref(self._h)))
+
+
+class ICGN2D2(_Engine, _IcgnMixin):
+    """ICGN2D2(rx, ry, conv_criterion, stop_condition, thread_number) -- src/oc_icgn.h:100-132."""
+
+    def __init__(self, subset_radius_x, subset_radius_y, conv_criterion, stop_condition, thread_number=1, device=0):
+        super().__init__()
+        self.thread_number = thread_number
+        capi.check(capi.lib().oc_hip_icgn2d2_create(subset_radius_x, subset_radius_y, conv_criterion, stop_condition,
+                                                    device, ctypes.byref(self._h)))
+
+
+class FFTCC3D(_Engine):
+    """FFTCC3D(rx, ry, rz, thread_number) -- src/oc_fftcc.h:75-89."""
+    _ndim = 3
+
+    def __init__(self, subset_radius_x, subset_radius_y, subset_radius_z, thread_number=1, device=0):
+        super().__init__()
+        self.thread_number = thread_number
+        capi.check(capi.lib().oc_hip_fftcc3d_create(subset_radius_x, subset_radius_y, subset_radius_z, device,
+                                                    ctypes.byref(self._h)))
+
+
+class ICGN3D1(_Engine, _IcgnMixin):
+    """ICGN3D1(rx, ry, rz, conv_criterion, stop_condition, thread_number) -- src/oc_icgn.h:155-180."""
+    _ndim = 3
+
+    def __init__(self, subset_radius_x, subset_radius_y, subset_radius_z, conv_criterion, stop_condition,
+                 thread_number=1, device=0):
+        super().__init__()
+        self.thread_number = thread_number
+        capi.check(capi.lib().oc_hip_icgn3d1_create(subset_radius_x, subset_radius_y, subset_radius_z, conv_criterion,
+                                                    stop_condition, device, ctypes.byref(self._h)))
+
+
+def make_pois2d(xs, ys):
+    """Zero-initialised POI2D records (POI2D ctor, src/oc_poi.h:108-135)."""
+    xs = np.asarray(xs, dtype=np.float32).ravel()
+    pois = np.zeros((xs.size, capi.POI2D_FLOATS), dtype=np.float32)
+    pois[:, 0] = xs
+    pois[:, 1] = np.asarray(ys, dtype=np.float32).ravel()
+    return pois
+
+
+def make_pois3d(xs, ys, zs):
+    xs = np.asarray(xs, dtype=np.float32).ravel()
+    pois = np.zeros((xs.size, capi.POI3D_FLOATS), dtype=np.float32)
+    pois[:, 0] = xs
+    pois[:, 1] = np.asarray(ys, dtype=np.float32).ravel()
+    pois[:, 2] = np.asarray(zs, dtype=np.float32).ravel()
+    return pois

@@ -1,0 +1,189 @@
+"""GPU parity: HIP engines (through the C-ABI) vs the CPU oracle and the golden vectors.
+
+Bars:
+  * prepare() fields (gradients, bicubic LUT): bit-exact vs the oracle.
+  * FFTCC2D: integer u, v identical; ZNCC within 1e-5 (rocFFT float32 vs the oracle's
+    double-precision DFT).
+  * ICGN2D1: bit-exact vs the oracle in OC_ORDER_LANES (same reduction association),
+    i.e. identical iteration counts, flags and float bits for every POI.
+  * Golden OHT-CFRP example of the reference: same acceptance as the oracle's own test.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import opencorr_amd
+    assert opencorr_amd.capi.device_count() >= 1
+    return opencorr_amd
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_prepare_fields_bit_exact(eng, speckle_small):
+    import oracle
+    ref, tar = speckle_small
+    icgn = eng.ICGN2D1(16, 16, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    gx, gy = oracle.gradient2d(ref)
+    lut = oracle.bspline2d_lut(tar)
+    assert np.array_equal(_bits(icgn.read_field("gx")), _bits(gx))
+    assert np.array_equal(_bits(icgn.read_field("gy")), _bits(gy))
+    assert np.array_equal(_bits(icgn.read_field("lut")), _bits(lut))
+    assert np.array_equal(icgn.read_field("ref"), ref)
+
+
+def test_column_major_images_match_row_major(eng, speckle_small):
+    """Image2D::eg_mat is column-major (src/oc_image.h:37); the engine transposes on upload."""
+    ref, tar = speckle_small
+    a = eng.ICGN2D1(16, 16, 0.001, 10)
+    a.set_images(np.asfortranarray(ref).T.copy(), np.asfortranarray(tar).T.copy(), layout=eng.capi.COL_MAJOR)
+    assert np.array_equal(a.read_field("ref"), ref)
+    assert np.array_equal(a.read_field("tar"), tar)
+
+
+@pytest.mark.parametrize("rx,ry", [(16, 16), (15, 15), (8, 12)])
+def test_fftcc2d_matches_oracle(eng, speckle_small, rx, ry):
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    xs, ys = synth.poi_grid_2d(h, w, 23, 19, 24)
+    # a few POIs that trip the bounds guard (left untouched by the reference, src/oc_fftcc.cpp:190-196)
+    xs = np.concatenate([xs, [3, w - 2, 150]]).astype(np.float32)
+    ys = np.concatenate([ys, [100, 100, 2]]).astype(np.float32)
+    want = oracle.make_pois2d(xs, ys)
+    got = want.copy()
+    oracle.fftcc2d(ref, tar, rx, ry, want)
+    f = eng.FFTCC2D(rx, ry)
+    f.set_images(ref, tar)
+    f.compute(got)
+    P = oracle.P2
+    assert np.array_equal(got[:, P["u"]], want[:, P["u"]])
+    assert np.array_equal(got[:, P["v"]], want[:, P["v"]])
+    assert np.array_equal(got[:, [P["u0"], P["v0"]]], want[:, [P["u0"], P["v0"]]])
+    assert np.abs(got[:, P["zncc"]] - want[:, P["zncc"]]).max() <= 1e-5
+    # guarded POIs are bit-for-bit untouched
+    assert np.array_equal(_bits(got[-3:]), _bits(want[-3:]))
+    # fields FFTCC never writes stay as they were
+    untouched = [c for c in range(25) if c not in (P["u"], P["v"], P["u0"], P["v0"], P["zncc"])]
+    assert np.array_equal(_bits(got[:, untouched]), _bits(want[:, untouched]))
+
+
+@pytest.mark.parametrize("rx,ry", [(16, 16), (15, 15), (7, 9), (20, 20)])
+def test_icgn2d1_bit_exact_vs_oracle(eng, speckle_small, rx, ry):
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    xs, ys = synth.poi_grid_2d(h, w, 21, 17, 26)
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, rx, ry, pois)
+    # edge cases: outside the guard, a wild initial guess (warped subset leaves the image ->
+    # -3 from inside the loop), a negative ZNCC on entry, a NaN guess
+    extra = oracle.make_pois2d([5, 160, 160, 160], [150, 150, 150, 150])
+    extra[1, oracle.P2["u"]] = 140.0
+    extra[2, oracle.P2["zncc"]] = -1.0
+    extra[3, oracle.P2["u"]] = np.nan
+    pois = np.concatenate([pois, extra]).astype(np.float32)
+    want = pois.copy()
+    prep = oracle.Prepared2D(ref, tar)
+    oracle.icgn2d1(prep, rx, ry, 0.001, 10, want, order=oracle.ORDER_LANES, lanes=64)
+    got = pois.copy()
+    icgn = eng.ICGN2D1(rx, ry, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    icgn.compute(got)
+    P = oracle.P2
+    assert np.array_equal(got[:, P["iteration"]], want[:, P["iteration"]])
+    assert np.array_equal(got[:, P["zncc"]] < 0, want[:, P["zncc"]] < 0)
+    mism = np.argwhere(_bits(got) != _bits(want))
+    assert mism.size == 0, "first mismatches (poi, field): %s" % mism[:10].tolist()
+    assert want[-4, P["zncc"]] == -3.0 and want[-3, P["zncc"]] == -3.0 and want[-2, P["zncc"]] == -1.0
+    assert (want[:-4, P["zncc"]] > 0.9).all()  # the regular grid converges
+
+
+def test_icgn2d1_stop_condition_and_not_converged_flag(eng, speckle_small):
+    """stop = 2 forces the -4 path (src/oc_icgn.cpp:329-332); set_iteration mirrors setIteration."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 9, 9, 30)
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, 16, 16, pois)
+    want = pois.copy()
+    prep = oracle.Prepared2D(ref, tar)
+    oracle.icgn2d1(prep, 16, 16, 1e-7, 2, want, order=oracle.ORDER_LANES)
+    icgn = eng.ICGN2D1(16, 16, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    icgn.set_iteration(1e-7, 2)
+    got = icgn.compute(pois.copy())
+    assert np.array_equal(_bits(got), _bits(want))
+    assert (want[:, oracle.P2["zncc"]] == -4.0).all()
+
+
+def test_device_resident_pois_and_images(eng, speckle_small):
+    """OC_HIP_DEVICE buffers (torch tensors) are used in place on the caller's stream."""
+    import torch
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 16, 16, 30)
+    host = oracle.make_pois2d(xs, ys)
+    f = eng.FFTCC2D(16, 16)
+    f.set_images(ref, tar)
+    icgn = eng.ICGN2D1(16, 16, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    want = icgn.compute(f.compute(host.copy()))
+    dref, dtar = torch.from_numpy(ref).cuda(), torch.from_numpy(tar).cuda()
+    dpois = torch.from_numpy(host).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    f2 = eng.FFTCC2D(16, 16)
+    f2.set_stream(stream)
+    f2.set_images(dref, dtar)
+    i2 = eng.ICGN2D1(16, 16, 0.001, 10)
+    i2.set_stream(stream)
+    i2.share_images(f2)
+    i2.prepare()
+    f2.compute(dpois)
+    i2.compute(dpois)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(dpois.cpu().numpy()), _bits(want))
+
+
+def test_golden_oht_on_gpu(eng, golden):
+    """The reference's own example end to end on the GPU (FFTCC2D -> ICGN2D1, 30 000 POIs)."""
+    import oracle
+    P = oracle.P2
+    tab, de = golden["table"], golden["deformation"]
+    pois = oracle.make_pois2d(tab[:, 0], tab[:, 1])
+    f = eng.FFTCC2D(golden["rx"], golden["ry"])
+    f.set_images(golden["ref"], golden["tar"])
+    f.compute(pois)
+    same = (pois[:, P["u"]] == tab[:, 4]) & (pois[:, P["v"]] == tab[:, 5])
+    assert same.mean() >= 0.999
+    icgn = eng.ICGN2D1(golden["rx"], golden["ry"], golden["conv"], golden["stop"])
+    icgn.share_images(f)
+    icgn.prepare()
+    after_fftcc = pois.copy()
+    icgn.compute(pois)
+    m = (tab[:, 7] < golden["stop"]) & same
+    assert np.abs(pois[m, P["u"]] - tab[m, 2]).max() <= 2e-4
+    assert np.abs(pois[m, P["v"]] - tab[m, 3]).max() <= 2e-4
+    assert np.abs(pois[m, P["zncc"]] - tab[m, 6]).max() <= 1e-5
+    assert (pois[m, P["iteration"]] == tab[m, 7]).mean() >= 0.99
+    got = pois[m][:, [P["ux"], P["uy"], P["vx"], P["vy"]]]
+    assert np.abs(got - de[m][:, [3, 4, 6, 7]]).max() <= 5e-5
+    # and bit-exact against the oracle fed with the GPU's own FFTCC output
+    want = after_fftcc.copy()
+    prep = oracle.Prepared2D(golden["ref"], golden["tar"])
+    oracle.icgn2d1(prep, golden["rx"], golden["ry"], golden["conv"], golden["stop"], want, order=oracle.ORDER_LANES)
+    assert np.array_equal(_bits(pois), _bits(want))
