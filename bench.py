@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--size", type=int, default=0, help="override image side (debug)")
     ap.add_argument("--pois", type=int, default=0, help="override POIs per GPU side (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=20000)
+    ap.add_argument("--cpu-sample", type=int, default=125000)
     return ap.parse_args()
 
 

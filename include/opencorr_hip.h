@@ -105,8 +105,12 @@ int oc_hip_set_subset(oc_hip_engine* engine, int radius_x, int radius_y, int rad
 /* ICGN2D1::setIteration(float, float)  src/oc_icgn.cpp:103-107 (also 2D2 :644-648, 3D1 :1228-1232) */
 int oc_hip_set_iteration(oc_hip_engine* engine, float conv_criterion, float stop_condition);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of
- * the engine's own stream.  NULL restores the engine's stream. */
+ * the engine's own stream.  The handle is used as given: NULL is HIP's default
+ * (null) stream, which is what torch.cuda.current_stream().cuda_stream returns
+ * for torch's default stream. */
 int oc_hip_set_stream(oc_hip_engine* engine, void* hip_stream);
+/* Go back to the engine's own (non-blocking) stream. */
+int oc_hip_reset_stream(oc_hip_engine* engine);
 
 /* ---- precompute ----------------------------------------------------------- */
 /* ICGN2D1::prepare()  src/oc_icgn.cpp:138-142 (prepareRef + prepareTar); FFTCC::prepare() is a no-op

@@ -483,7 +483,14 @@ int oc_hip_set_iteration(oc_hip_engine* e, float conv, float stop) {
 int oc_hip_set_stream(oc_hip_engine* e, void* hip_stream) {
     OC_TRY(check_engine(e));
     std::lock_guard<std::mutex> lock(e->mu);
-    e->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : e->own_stream;
+    e->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return OC_HIP_OK;
+}
+
+int oc_hip_reset_stream(oc_hip_engine* e) {
+    OC_TRY(check_engine(e));
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->stream = e->own_stream;
     return OC_HIP_OK;
 }
 

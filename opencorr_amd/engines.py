@@ -56,8 +56,16 @@ class _Engine:
 
     # -- DIC::setImages / DVC::setImages ------------------------------------
     def set_images(self, ref, tar, layout=capi.ROW_MAJOR):
-        rp, rmem, rkeep = _buf(ref)
-        tp, tmem, tkeep = _buf(tar)
+        """``layout=COL_MAJOR``: the arrays have the logical shape (height, width) but Fortran
+        (Eigen::MatrixXf) memory order; NumPy inputs are converted with ``np.asfortranarray``."""
+        if layout == capi.COL_MAJOR and not _is_torch(ref):
+            ref = np.asfortranarray(ref, dtype=np.float32)
+            tar = np.asfortranarray(tar, dtype=np.float32)
+            rp, rmem, rkeep = ctypes.c_void_p(ref.ctypes.data), capi.HOST, ref
+            tp, tmem, tkeep = ctypes.c_void_p(tar.ctypes.data), capi.HOST, tar
+        else:
+            rp, rmem, rkeep = _buf(ref)
+            tp, tmem, tkeep = _buf(tar)
         if rmem != tmem:
             raise ValueError("reference and target image must live in the same memory space")
         shape = tuple(rkeep.shape)
@@ -82,7 +90,11 @@ class _Engine:
         capi.check(capi.lib().oc_hip_set_subset(self._h, rx, ry, rz))
 
     def set_stream(self, stream_handle):
-        capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(stream_handle)))
+        """Run on a caller-owned hipStream_t (0 / None = HIP's default stream, as torch reports it)."""
+        capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(stream_handle or None)))
+
+    def reset_stream(self):
+        capi.check(capi.lib().oc_hip_reset_stream(self._h))
 
     def prepare(self):
         capi.check(capi.lib().oc_hip_prepare(self._h))
