@@ -1,0 +1,291 @@
+// oc_engines.h -- OpenCorr's hot-path classes as thin shims over the HIP C-ABI.
+//
+// Same class names, constructor signatures and call order as the reference:
+//   DIC / DVC bases                     src/oc_dic.h:43-84
+//   FFTCC2D(int,int,int), FFTCC3D(int,int,int,int)                     src/oc_fftcc.h:54-89
+//   ICGN2D1/2D2(int,int,float,float,int), ICGN3D1(int,int,int,float,float,int)   src/oc_icgn.h:45-180
+// plus prepare(), prepareRef(), prepareTar(), compute(POI*), compute(std::vector<POI>&),
+// setIteration(float,float), setIteration(POI*), setImages, setSubset.
+// `thread_number` is kept for signature compatibility (the GPU parallelises internally);
+// the device is chosen with the extra setter setDevice() or the OC_HIP_DEVICE environment variable
+// BEFORE the first call that needs the GPU.  Failures of the engine (no GPU, bad call order, ...)
+// are thrown as std::string like the reference does (src/oc_fftcc.cpp:145, src/oc_icgn.cpp:65).
+//
+// Differences a caller can observe (documented):
+//   * images are snapshotted to HBM when needed (first prepare()/compute() after setImages);
+//     editing the host image afterwards requires setImages() again, as with the reference's CUDA
+//     module (examples/test_2d_dic_gpu_icgn.cpp:99-136);
+//   * self_adaptive subsets are not supported by the GPU engines yet.
+#pragma once
+
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../opencorr_hip.h"
+#include "oc_types.h"
+
+namespace opencorr {
+
+namespace hipdetail {
+inline void check(int status) {
+    if (status != OC_HIP_OK) throw std::string(oc_hip_last_error());
+}
+inline int default_device() {
+    const char* e = std::getenv("OC_HIP_DEVICE");
+    return e ? std::atoi(e) : 0;
+}
+}  // namespace hipdetail
+
+class DIC {
+public:
+    Image2D* ref_img = nullptr;
+    Image2D* tar_img = nullptr;
+    int subset_radius_x = 0, subset_radius_y = 0;
+    int thread_number = 1;
+    bool self_adaptive = false;
+
+    DIC() {}
+    virtual ~DIC() { if (engine_) oc_hip_destroy(engine_); }
+    DIC(const DIC&) = delete;
+    DIC& operator=(const DIC&) = delete;
+
+    void setImages(Image2D& ref, Image2D& tar) {
+        ref_img = &ref;
+        tar_img = &tar;
+        images_dirty_ = true;
+    }
+    void setSubset(int radius_x, int radius_y) {
+        subset_radius_x = radius_x;
+        subset_radius_y = radius_y;
+        if (engine_) hipdetail::check(oc_hip_set_subset(engine_, radius_x, radius_y, 0));
+    }
+    void setSelfAdaptive(bool is_self_adaptive) {
+        if (is_self_adaptive) throw std::string("self-adaptive subsets are not supported by the HIP engines");
+        self_adaptive = false;
+    }
+    void setDevice(int device) { device_ = device; }
+
+    virtual void prepare() = 0;
+    virtual void compute(POI2D* poi) = 0;
+    virtual void compute(std::vector<POI2D>& poi_queue) = 0;
+
+    oc_hip_engine* handle() { return engine_; }
+
+protected:
+    oc_hip_engine* engine_ = nullptr;
+    int device_ = hipdetail::default_device();
+    bool images_dirty_ = false;
+
+    void uploadIfNeeded() {
+        if (!engine_) throw std::string("engine not created");
+        if (!images_dirty_) return;
+        if (!ref_img || !tar_img) throw std::string("setImages() has not been called");
+        if (ref_img->height != tar_img->height || ref_img->width != tar_img->width)
+            throw std::string("reference and target image sizes differ");
+        hipdetail::check(oc_hip_set_images2d(engine_, ref_img->eg_mat.data(), tar_img->eg_mat.data(), ref_img->height,
+                                             ref_img->width, OC_HIP_COL_MAJOR, OC_HIP_HOST));
+        images_dirty_ = false;
+    }
+    void computeBatch(POI2D* pois, size_t n) {
+        uploadIfNeeded();
+        hipdetail::check(oc_hip_compute(engine_, pois, n, sizeof(POI2D), OC_HIP_HOST));
+    }
+};
+
+class DVC {
+public:
+    Image3D* ref_img = nullptr;
+    Image3D* tar_img = nullptr;
+    int subset_radius_x = 0, subset_radius_y = 0, subset_radius_z = 0;
+    int thread_number = 1;
+
+    DVC() {}
+    virtual ~DVC() { if (engine_) oc_hip_destroy(engine_); }
+    DVC(const DVC&) = delete;
+    DVC& operator=(const DVC&) = delete;
+
+    void setImages(Image3D& ref, Image3D& tar) {
+        ref_img = &ref;
+        tar_img = &tar;
+        images_dirty_ = true;
+    }
+    void setSubset(int radius_x, int radius_y, int radius_z) {
+        subset_radius_x = radius_x;
+        subset_radius_y = radius_y;
+        subset_radius_z = radius_z;
+        if (engine_) hipdetail::check(oc_hip_set_subset(engine_, radius_x, radius_y, radius_z));
+    }
+    void setDevice(int device) { device_ = device; }
+
+    virtual void prepare() = 0;
+    virtual void compute(POI3D* poi) = 0;
+    virtual void compute(std::vector<POI3D>& poi_queue) = 0;
+
+    oc_hip_engine* handle() { return engine_; }
+
+protected:
+    oc_hip_engine* engine_ = nullptr;
+    int device_ = hipdetail::default_device();
+    bool images_dirty_ = false;
+
+    void uploadIfNeeded() {
+        if (!engine_) throw std::string("engine not created");
+        if (!images_dirty_) return;
+        if (!ref_img || !tar_img) throw std::string("setImages() has not been called");
+        hipdetail::check(oc_hip_set_images3d(engine_, &ref_img->vol_mat[0][0][0], &tar_img->vol_mat[0][0][0],
+                                             ref_img->dim_x, ref_img->dim_y, ref_img->dim_z, OC_HIP_HOST));
+        images_dirty_ = false;
+    }
+    void computeBatch(POI3D* pois, size_t n) {
+        uploadIfNeeded();
+        hipdetail::check(oc_hip_compute(engine_, pois, n, sizeof(POI3D), OC_HIP_HOST));
+    }
+};
+
+// ---- FFT-accelerated cross correlation (integer-pixel initial guess) -----------------------------
+class FFTCC2D : public DIC {
+public:
+    FFTCC2D(int subset_radius_x_, int subset_radius_y_, int thread_number_) {
+        subset_radius_x = subset_radius_x_;
+        subset_radius_y = subset_radius_y_;
+        thread_number = thread_number_;
+        hipdetail::check(oc_hip_fftcc2d_create(subset_radius_x_, subset_radius_y_, device_, &engine_));
+    }
+    void prepare() override {}  // empty in the reference too (src/oc_fftcc.cpp:175)
+    void compute(POI2D* poi) override { computeBatch(poi, 1); }
+    void compute(std::vector<POI2D>& poi_queue) override { computeBatch(poi_queue.data(), poi_queue.size()); }
+};
+
+class FFTCC3D : public DVC {
+public:
+    FFTCC3D(int rx, int ry, int rz, int thread_number_) {
+        subset_radius_x = rx;
+        subset_radius_y = ry;
+        subset_radius_z = rz;
+        thread_number = thread_number_;
+        hipdetail::check(oc_hip_fftcc3d_create(rx, ry, rz, device_, &engine_));
+    }
+    void prepare() override {}
+    void compute(POI3D* poi) override { computeBatch(poi, 1); }
+    void compute(std::vector<POI3D>& poi_queue) override { computeBatch(poi_queue.data(), poi_queue.size()); }
+};
+
+// ---- inverse-compositional Gauss-Newton ---------------------------------------------------------------
+template <class Base, class Poi>
+class IcgnShim : public Base {
+public:
+    void setIteration(float conv_criterion_, float stop_condition_) {
+        conv_criterion = conv_criterion_;
+        stop_condition = stop_condition_;
+        hipdetail::check(oc_hip_set_iteration(this->engine_, conv_criterion_, stop_condition_));
+    }
+    // setIteration(POI*): conv = poi->result.convergence, stop = (int)poi->result.iteration
+    // (src/oc_icgn.cpp:109-113)
+    void setIteration(Poi* poi) { setIteration(poi->result.convergence, (float)(int)poi->result.iteration); }
+
+    void prepareRef() {
+        this->uploadIfNeeded();
+        hipdetail::check(oc_hip_prepare_ref(this->engine_));
+    }
+    void prepareTar() {
+        this->uploadIfNeeded();
+        hipdetail::check(oc_hip_prepare_tar(this->engine_));
+    }
+    void prepare() override {
+        prepareRef();
+        prepareTar();
+    }
+    void compute(Poi* poi) override { this->computeBatch(poi, 1); }
+    void compute(std::vector<Poi>& poi_queue) override { this->computeBatch(poi_queue.data(), poi_queue.size()); }
+
+protected:
+    float conv_criterion = 0.001f;
+    float stop_condition = 10.f;
+};
+
+class ICGN2D1 : public IcgnShim<DIC, POI2D> {
+public:
+    ICGN2D1(int rx, int ry, float conv_criterion_, float stop_condition_, int thread_number_) {
+        subset_radius_x = rx;
+        subset_radius_y = ry;
+        conv_criterion = conv_criterion_;
+        stop_condition = stop_condition_;
+        thread_number = thread_number_;
+        hipdetail::check(oc_hip_icgn2d1_create(rx, ry, conv_criterion_, stop_condition_, device_, &engine_));
+    }
+};
+
+class ICGN2D2 : public IcgnShim<DIC, POI2D> {
+public:
+    ICGN2D2(int rx, int ry, float conv_criterion_, float stop_condition_, int thread_number_) {
+        subset_radius_x = rx;
+        subset_radius_y = ry;
+        conv_criterion = conv_criterion_;
+        stop_condition = stop_condition_;
+        thread_number = thread_number_;
+        hipdetail::check(oc_hip_icgn2d2_create(rx, ry, conv_criterion_, stop_condition_, device_, &engine_));
+    }
+};
+
+class ICGN3D1 : public IcgnShim<DVC, POI3D> {
+public:
+    ICGN3D1(int rx, int ry, int rz, float conv_criterion_, float stop_condition_, int thread_number_) {
+        subset_radius_x = rx;
+        subset_radius_y = ry;
+        subset_radius_z = rz;
+        conv_criterion = conv_criterion_;
+        stop_condition = stop_condition_;
+        thread_number = thread_number_;
+        hipdetail::check(oc_hip_icgn3d1_create(rx, ry, rz, conv_criterion_, stop_condition_, device_, &engine_));
+    }
+};
+
+// ---- the reference's CUDA-module shapes (gpu_lib/opencorr_gpu.h:31-101), so that
+// examples/test_2d_dic_gpu_icgn.cpp / test_dvc_gpu_icgn.cpp compile against this header --------------
+struct Img2D { int width, height; float* data; };           // row-major
+struct Img3D { int dim_x, dim_y, dim_z; float* data; };     // z, y, x contiguous
+
+template <int KIND>
+class IcgnGpu2D {
+    oc_hip_engine* e_ = nullptr;
+
+public:
+    IcgnGpu2D(int rx, int ry, float conv, int stop) {
+        hipdetail::check(KIND == OC_HIP_ICGN2D1 ? oc_hip_icgn2d1_create(rx, ry, conv, (float)stop, hipdetail::default_device(), &e_)
+                                                : oc_hip_icgn2d2_create(rx, ry, conv, (float)stop, hipdetail::default_device(), &e_));
+    }
+    ~IcgnGpu2D() { if (e_) oc_hip_destroy(e_); }
+    IcgnGpu2D(const IcgnGpu2D&) = delete;
+    IcgnGpu2D& operator=(const IcgnGpu2D&) = delete;
+    void setImages(Img2D ref, Img2D tar) {
+        hipdetail::check(oc_hip_set_images2d(e_, ref.data, tar.data, ref.height, ref.width, OC_HIP_ROW_MAJOR, OC_HIP_HOST));
+    }
+    void setSubset(int rx, int ry) { hipdetail::check(oc_hip_set_subset(e_, rx, ry, 0)); }
+    void setIteration(float conv, int stop) { hipdetail::check(oc_hip_set_iteration(e_, conv, (float)stop)); }
+    void prepare() { hipdetail::check(oc_hip_prepare(e_)); }
+    void compute(std::vector<POI2D>& q) { hipdetail::check(oc_hip_compute(e_, q.data(), q.size(), sizeof(POI2D), OC_HIP_HOST)); }
+};
+typedef IcgnGpu2D<OC_HIP_ICGN2D1> ICGN2D1GPU;
+typedef IcgnGpu2D<OC_HIP_ICGN2D2> ICGN2D2GPU;
+
+class ICGN3D1GPU {
+    oc_hip_engine* e_ = nullptr;
+
+public:
+    ICGN3D1GPU(int rx, int ry, int rz, float conv, int stop) {
+        hipdetail::check(oc_hip_icgn3d1_create(rx, ry, rz, conv, (float)stop, hipdetail::default_device(), &e_));
+    }
+    ~ICGN3D1GPU() { if (e_) oc_hip_destroy(e_); }
+    ICGN3D1GPU(const ICGN3D1GPU&) = delete;
+    ICGN3D1GPU& operator=(const ICGN3D1GPU&) = delete;
+    void setImages(Img3D ref, Img3D tar) {
+        hipdetail::check(oc_hip_set_images3d(e_, ref.data, tar.data, ref.dim_x, ref.dim_y, ref.dim_z, OC_HIP_HOST));
+    }
+    void setSubset(int rx, int ry, int rz) { hipdetail::check(oc_hip_set_subset(e_, rx, ry, rz)); }
+    void setIteration(float conv, int stop) { hipdetail::check(oc_hip_set_iteration(e_, conv, (float)stop)); }
+    void prepare() { hipdetail::check(oc_hip_prepare(e_)); }
+    void compute(std::vector<POI3D>& q) { hipdetail::check(oc_hip_compute(e_, q.data(), q.size(), sizeof(POI3D), OC_HIP_HOST)); }
+};
+
+}  // namespace opencorr

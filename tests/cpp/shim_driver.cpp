@@ -1,0 +1,76 @@
+// shim_driver.cpp -- exercises the OpenCorr-shaped C++ classes (include/opencorr_compat) the way
+// examples/test_2d_dic_fftcc_icgn1.cpp of the reference does, on data handed over by pytest.
+//
+//   shim_driver <in.bin> <out.bin>
+// in.bin : int32 height, width, rx, ry, n; float32 conv, stop; ref[h*w], tar[h*w] (row-major); x[n], y[n]
+// out.bin: n POI2D records (100 bytes each) after FFTCC2D::compute + ICGN2D1::prepare/compute
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <vector>
+
+#include "opencorr_compat/opencorr.h"
+
+using namespace opencorr;
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    FILE* f = std::fopen(argv[1], "rb");
+    if (!f) return 3;
+    int hdr[5];
+    float it[2];
+    if (std::fread(hdr, 4, 5, f) != 5 || std::fread(it, 4, 2, f) != 2) return 4;
+    const int h = hdr[0], w = hdr[1], rx = hdr[2], ry = hdr[3], n = hdr[4];
+    std::vector<float> ref((size_t)h * w), tar((size_t)h * w), xs(n), ys(n);
+    if (std::fread(ref.data(), 4, ref.size(), f) != ref.size() || std::fread(tar.data(), 4, tar.size(), f) != tar.size() ||
+        std::fread(xs.data(), 4, n, f) != (size_t)n || std::fread(ys.data(), 4, n, f) != (size_t)n)
+        return 5;
+    std::fclose(f);
+    try {
+        Image2D ref_img(w, h), tar_img(w, h);
+        ref_img.fromRowMajor(ref.data());
+        tar_img.fromRowMajor(tar.data());
+        std::vector<POI2D> poi_queue;
+        for (int i = 0; i < n; i++) poi_queue.push_back(POI2D(Point2D(xs[i], ys[i])));
+        const int cpu_thread_number = 4;
+
+        FFTCC2D* fftcc = new FFTCC2D(rx, ry, cpu_thread_number);
+        fftcc->setImages(ref_img, tar_img);
+        fftcc->compute(poi_queue);
+
+        ICGN2D1* icgn1 = new ICGN2D1(rx, ry, it[0], it[1], cpu_thread_number);
+        icgn1->setImages(ref_img, tar_img);
+        icgn1->prepare();
+        icgn1->compute(poi_queue);
+        // single-POI entry point: recompute the first POI from its FFTCC state and check it agrees
+        if (n > 0) {
+            POI2D one(Point2D(xs[0], ys[0]));
+            fftcc->compute(&one);
+            icgn1->compute(&one);
+            if (one.deformation.u != poi_queue[0].deformation.u || one.result.iteration != poi_queue[0].result.iteration) {
+                std::cerr << "compute(POI2D*) disagrees with compute(vector&)" << std::endl;
+                return 7;
+            }
+        }
+        // error path: compute before prepare must throw std::string
+        bool threw = false;
+        try {
+            ICGN2D1 bad(rx, ry, it[0], it[1], 1);
+            bad.setImages(ref_img, tar_img);
+            bad.compute(poi_queue);
+        } catch (const std::string& msg) {
+            threw = true;
+        }
+        if (!threw) { std::cerr << "missing prepare() was not reported" << std::endl; return 8; }
+        delete fftcc;
+        delete icgn1;
+        FILE* o = std::fopen(argv[2], "wb");
+        if (!o) return 6;
+        std::fwrite(poi_queue.data(), sizeof(POI2D), poi_queue.size(), o);
+        std::fclose(o);
+    } catch (const std::string& msg) {
+        std::cerr << "OpenCorr shim error: " << msg << std::endl;
+        return 1;
+    }
+    return 0;
+}

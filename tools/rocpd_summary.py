@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Turns a rocprofv3 rocpd SQLite database (`rocprofv3 --kernel-trace --stats`) into the
+per-kernel summary committed under profiles/ (name, calls, total/avg/min/max duration in us, %).
+
+    python tools/rocpd_summary.py gpurun_out/prof/x_results.db profiles/r01_x_kernel_stats.csv
+"""
+import csv
+import sqlite3
+import sys
+
+
+def main(db_path, out_path, top=40):
+    db = sqlite3.connect(db_path)
+    rows = db.execute(
+        "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
+        "max(vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size) from kernels group by name "
+        "order by sum(duration) desc").fetchall()
+    total = sum(r[2] for r in rows) or 1
+    with open(out_path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "percent", "vgpr", "sgpr", "lds_bytes",
+                    "scratch_bytes"])
+        for r in rows[:top]:
+            name = r[0] if len(r[0]) < 160 else r[0][:157] + "..."
+            w.writerow([name, r[1], "%.3f" % (r[2] / 1e3), "%.3f" % (r[3] / 1e3), "%.3f" % (r[4] / 1e3),
+                        "%.3f" % (r[5] / 1e3), "%.2f" % (100.0 * r[2] / total), r[6], r[7], r[8], r[9]])
+    for r in rows[:12]:
+        print("%-90s calls %5d  avg %10.3f us  %5.1f%%" % (r[0][:90], r[1], r[3] / 1e3, 100.0 * r[2] / total))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
