@@ -190,16 +190,61 @@ __device__ __forceinline__ float lut_eval(const LutFetch& f) {
     return f.out ? -1.f : v;
 }
 
+// Deformation2D2::setWarp, src/oc_deformation.cpp:301-350; q = u ux uy uxx uxy uyy v vx vy vxx vxy vyy
+__device__ __forceinline__ void set_warp_2d2(float (&w)[36], const float (&q)[12]) {
+    const float u = q[0], ux = q[1], uy = q[2], uxx = q[3], uxy = q[4], uyy = q[5];
+    const float v = q[6], vx = q[7], vy = q[8], vxx = q[9], vxy = q[10], vyy = q[11];
+    w[0] = 1.f + 2.f * ux + ux * ux + u * uxx;
+    w[1] = 2.f * u * uxy + 2.f * (1.f + ux) * uy;
+    w[2] = uy * uy + u * uyy;
+    w[3] = 2.f * u * (1 + ux);
+    w[4] = 2.f * u * uy;
+    w[5] = u * u;
+    w[6] = 0.5f * (v * uxx + 2.f * (1.f + ux) * vx + u * vxx);
+    w[7] = 1.f + uy * vx + ux * vy + v * uxy + u * vxy + vy + ux;
+    w[8] = 0.5f * (v * uyy + 2.f * uy * (1.f + vy) + u * vyy);
+    w[9] = v + v * ux + u * vx;
+    w[10] = u + v * uy + u * vy;
+    w[11] = u * v;
+    w[12] = vx * vx + v * vxx;
+    w[13] = 2.f * v * vxy + 2.f * vx * (1.f + vy);
+    w[14] = 1.f + 2.f * vy + vy * vy + v * vyy;
+    w[15] = 2.f * v * vx;
+    w[16] = 2.f * v * (1.f + vy);
+    w[17] = v * v;
+    w[18] = 0.5f * uxx; w[19] = uxy; w[20] = 0.5f * uyy; w[21] = 1.f + ux; w[22] = uy; w[23] = u;
+    w[24] = 0.5f * vxx; w[25] = vxy; w[26] = 0.5f * vyy; w[27] = vx; w[28] = 1.f + vy; w[29] = v;
+    w[30] = 0.f; w[31] = 0.f; w[32] = 0.f; w[33] = 0.f; w[34] = 0.f; w[35] = 1.f;
+}
+
+// steepest-descent row of one sample (src/oc_icgn.cpp:191-196; 2D2: 725-745)
+template <int DOF>
+__device__ __forceinline__ void sd_row(float g_x, float g_y, int xl, int yl, float (&sd)[DOF]) {
+    const float fxl = (float)xl, fyl = (float)yl;
+    if constexpr (DOF == 6) {
+        sd[0] = g_x; sd[1] = g_x * fxl; sd[2] = g_x * fyl;
+        sd[3] = g_y; sd[4] = g_y * fxl; sd[5] = g_y * fyl;
+    } else {
+        const float xx = (float)(xl * xl) * 0.5f, xy = (float)(xl * yl), yy = (float)(yl * yl) * 0.5f;
+        sd[0] = g_x; sd[1] = g_x * fxl; sd[2] = g_x * fyl; sd[3] = g_x * xx; sd[4] = g_x * xy; sd[5] = g_x * yy;
+        sd[6] = g_y; sd[7] = g_y * fxl; sd[8] = g_y * fyl; sd[9] = g_y * xx; sd[10] = g_y * xy; sd[11] = g_y * yy;
+    }
+}
+
 // ---------------------------------------------------------------------------
-// ICGN2D1: 6 DoF, 3x3 warp.  One wave per POI; per-sample state lives in LDS as
-// [t][lane] arrays (conflict-free ds_read/write_b32), NT = ceil(N/64) at run time.
+// ICGN2D1 (DOF = 6, 3x3 warp) and ICGN2D2 (DOF = 12, 6x6 warp).  One wave per POI;
+// per-sample state lives in LDS as [t][lane] arrays (conflict-free ds_read/write_b32),
+// NT = ceil(N/64) at run time.
 //   LDS layout (floats): rs[NT*64] | gx[NT*64] | gy[NT*64] | ts[NT*64]
 // G = samples whose LUT gathers are issued back to back (template).
+// Wave-uniform small matrices are kept one COLUMN per lane (lane j < n holds column j):
+// the inverse Hessian, and for 2D2 also the 6x6 warp matrix.
 // ---------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(64) void icgn2d1_kernel(Icgn2dParams P, float* __restrict__ pois, int stride_f,
-                                                     unsigned long long count, int NT) {
+template <int DOF, int G>
+__global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __restrict__ pois, int stride_f,
+                                                    unsigned long long count, int NT) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NH = DOF * (DOF + 1) / 2;
     const unsigned long long idx = blockIdx.x;
     if (idx >= count) return;
     const int lane = threadIdx.x;
@@ -216,7 +261,7 @@ __global__ __launch_bounds__(64) void icgn2d1_kernel(Icgn2dParams P, float* __re
     const float zncc_in = wave_bcast(rec, poi2d::ZNCC);
     const int rx = P.rx, ry = P.ry, height = P.height, width = P.width;
 
-    // guard, src/oc_icgn.cpp:160-167
+    // guard, src/oc_icgn.cpp:160-167 (2D2: 705-712)
     if (py - ry < 0 || px - rx < 0 || py + ry > height - 1 || px + rx > width - 1 || fabsf(u_in) >= width ||
         fabsf(v_in) >= height || zncc_in < 0 || isnan(u_in) || isnan(v_in)) {
         if (lane == 0) poi[poi2d::ZNCC] = zncc_in >= 0 ? -3.f : zncc_in;
@@ -254,17 +299,17 @@ __global__ __launch_bounds__(64) void icgn2d1_kernel(Icgn2dParams P, float* __re
         ref_norm = uni(sqrtf(wave_allreduce_sum(acc)));
     }
 
-    // ---- steepest-descent image + Hessian (src/oc_icgn.cpp:179-207), inverse (:210)
-    float hinv_col[6];  // lane j < 6: column j of H^-1
+    // ---- steepest-descent image + Hessian (src/oc_icgn.cpp:179-207; 2D2: 716-756), inverse (:210 / :759)
+    float hinv_col[DOF];  // lane j < DOF: column j of H^-1
     {
-        float h[21];
+        float h[NH];
 #pragma unroll
-        for (int i = 0; i < 21; i++) h[i] = 0.f;
+        for (int i = 0; i < NH; i++) h[i] = 0.f;
         const size_t goff = (size_t)((int)py - ry) * width + ((int)px - rx);
         const float* __restrict__ bgx = P.gx + goff;
         const float* __restrict__ bgy = P.gy + goff;
         SampleWalk w(lane, r0, c0, W, q64, r64);
-#pragma unroll 2
+#pragma unroll 1
         for (int t = 0; t < NT; t++, w.next()) {
             const bool valid = w.s < N;
             const int off = w.r * width + w.c;
@@ -272,38 +317,69 @@ __global__ __launch_bounds__(64) void icgn2d1_kernel(Icgn2dParams P, float* __re
             const float g_y = valid ? bgy[off] : 0.f;
             l_gx[t * kWave] = g_x;
             l_gy[t * kWave] = g_y;
-            const float fxl = (float)(w.c - rx), fyl = (float)(w.r - ry);
-            const float sd[6] = {g_x, g_x * fxl, g_x * fyl, g_y, g_y * fxl, g_y * fyl};
+            float sd[DOF];
+            sd_row<DOF>(g_x, g_y, w.c - rx, w.r - ry, sd);
             int k = 0;
 #pragma unroll
-            for (int i = 0; i < 6; i++)
+            for (int i = 0; i < DOF; i++)
 #pragma unroll
                 for (int j = 0; j <= i; j++, k++) h[k] = valid ? h[k] + sd[i] * sd[j] : h[k];
         }
-        // lane j < 6 assembles column j of the symmetric Hessian
-        float col[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // lane j < DOF assembles column j of the symmetric Hessian
+        float col[DOF];
+#pragma unroll
+        for (int i = 0; i < DOF; i++) col[i] = 0.f;
         int k = 0;
 #pragma unroll
-        for (int i = 0; i < 6; i++)
+        for (int i = 0; i < DOF; i++)
 #pragma unroll
             for (int j = 0; j <= i; j++) {
                 const float v = wave_allreduce_sum(h[k++]);
                 if (lane == j) col[i] = v;  // H(i,j)
                 if (lane == i) col[j] = v;  // H(j,i)
             }
-        lu_inverse_lanes<6>(col, hinv_col, lane);
+        lu_inverse_lanes<DOF>(col, hinv_col, lane);
     }
 
-    // ---- IC-GN loop (src/oc_icgn.cpp:216-307)
-    float Wm[9];
-    set_warp_2d1(Wm, u_in, ux_in, uy_in, v_in, vx_in, vy_in);
+    // ---- IC-GN loop (src/oc_icgn.cpp:216-307; 2D2: 762-858)
+    // 2D1: 3x3 warp matrix, wave-uniform in SGPRs.  2D2: 6x6 warp matrix, column j in lane j;
+    // rows 3 and 4 (the ones Deformation2D2::warp needs) are broadcast once per iteration.
+    constexpr int WN = (DOF == 6) ? 3 : 6;
+    float Wm[9];      // 2D1
+    float Wcol[6];    // 2D2
+    float row3[6], row4[6];
+    if constexpr (DOF == 6) {
+        set_warp_2d1(Wm, u_in, ux_in, uy_in, v_in, vx_in, vy_in);
+    } else {
+        // first-order initial guess promoted to second order (src/oc_icgn.cpp:765-770,
+        // src/oc_deformation.cpp:249-266)
+        const float q[12] = {u_in, ux_in, uy_in, 0.f, 0.f, 0.f, v_in, vx_in, vy_in, 0.f, 0.f, 0.f};
+        float w36[36];
+        set_warp_2d2(w36, q);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            float c = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; j++) c = lane == j ? w36[i * 6 + j] : c;
+            Wcol[i] = c;
+        }
+    }
     int iter = 0;
     float dp_norm = 0.f, znssd = 0.f;
-    float cu = 0.f, cux = 0.f, cuy = 0.f, cv = 0.f, cvx = 0.f, cvy = 0.f;
+    float cur[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) cur[i] = 0.f;
 #pragma nounroll
     do {
         iter++;
-        // warped target subset (src/oc_icgn.cpp:230-242)
+        if constexpr (DOF == 12) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                row3[k] = wave_bcast(Wcol[3], k);
+                row4[k] = wave_bcast(Wcol[4], k);
+            }
+        }
+        // warped target subset (src/oc_icgn.cpp:230-242; 2D2: 784-796)
         bool negative = false;
         float acc = 0.f;
         {
@@ -316,9 +392,22 @@ __global__ __launch_bounds__(64) void icgn2d1_kernel(Icgn2dParams P, float* __re
                 for (int g = 0; g < G; g++, w.next()) {
                     valid[g] = w.s < N;
                     const float xl = (float)(w.c - rx), yl = (float)(w.r - ry);
-                    // Deformation2D1::warp, src/oc_deformation.cpp:94-105
-                    const float wx = (Wm[0] * xl + Wm[1] * yl) + Wm[2] * 1.f;
-                    const float wy = (Wm[3] * xl + Wm[4] * yl) + Wm[5] * 1.f;
+                    float wx, wy;
+                    if constexpr (DOF == 6) {
+                        // Deformation2D1::warp, src/oc_deformation.cpp:94-105
+                        wx = (Wm[0] * xl + Wm[1] * yl) + Wm[2] * 1.f;
+                        wy = (Wm[3] * xl + Wm[4] * yl) + Wm[5] * 1.f;
+                    } else {
+                        // Deformation2D2::warp, src/oc_deformation.cpp:268-282: rows 3, 4 of W * [x^2 xy y^2 x y 1]
+                        const float pv[6] = {xl * xl, xl * yl, yl * yl, xl, yl, 1.f};
+                        wx = row3[0] * pv[0];
+                        wy = row4[0] * pv[0];
+#pragma unroll
+                        for (int k = 1; k < 6; k++) {
+                            wx = wx + row3[k] * pv[k];
+                            wy = wy + row4[k] * pv[k];
+                        }
+                    }
                     // a lane past the end of the subset fetches a harmless in-range point
                     lut_fetch(f[g], P.lut, height, width, valid[g] ? px + wx : 1.f, valid[g] ? py + wy : 1.f);
                 }
@@ -350,7 +439,9 @@ __global__ __launch_bounds__(64) void icgn2d1_kernel(Icgn2dParams P, float* __re
         const float tar_norm = uni(sqrtf(wave_allreduce_sum(acc)));
         // error image, ZNSSD, numerator (src/oc_icgn.cpp:260-276)
         const float factor = ref_norm / tar_norm;
-        float num[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float num[DOF];
+#pragma unroll
+        for (int i = 0; i < DOF; i++) num[i] = 0.f;
         float ssd = 0.f;
         {
             SampleWalk w(lane, r0, c0, W, q64, r64);
@@ -359,71 +450,119 @@ __global__ __launch_bounds__(64) void icgn2d1_kernel(Icgn2dParams P, float* __re
                 const bool valid = w.s < N;
                 const float tz = l_ts[t * kWave] - tmean;  // same bits as in the norm pass
                 const float e = tz * factor - l_rs[t * kWave];
-                const float fxl = (float)(w.c - rx), fyl = (float)(w.r - ry);
-                const float g_x = l_gx[t * kWave], g_y = l_gy[t * kWave];
+                float sd[DOF];
+                sd_row<DOF>(l_gx[t * kWave], l_gy[t * kWave], w.c - rx, w.r - ry, sd);
                 const float e2 = e * e;
-                const float n0 = g_x * e, n1 = (g_x * fxl) * e, n2 = (g_x * fyl) * e;
-                const float n3 = g_y * e, n4 = (g_y * fxl) * e, n5 = (g_y * fyl) * e;
                 ssd = valid ? ssd + e2 : ssd;
-                num[0] = valid ? num[0] + n0 : num[0];
-                num[1] = valid ? num[1] + n1 : num[1];
-                num[2] = valid ? num[2] + n2 : num[2];
-                num[3] = valid ? num[3] + n3 : num[3];
-                num[4] = valid ? num[4] + n4 : num[4];
-                num[5] = valid ? num[5] + n5 : num[5];
+#pragma unroll
+                for (int i = 0; i < DOF; i++) {
+                    const float n = sd[i] * e;
+                    num[i] = valid ? num[i] + n : num[i];
+                }
             }
         }
         znssd = uni(wave_allreduce_sum(ssd)) / (ref_norm * ref_norm);
         // dp = H^-1 * numerator (src/oc_icgn.cpp:279-286): lane j forms H^-1(i,j) * num[j], the
-        // six products of row i are then added in ascending j exactly like the reference loop
+        // products of row i are then added in ascending j exactly like the reference loop
         float numj = 0.f;
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
+        for (int j = 0; j < DOF; j++) {
             const float v = wave_allreduce_sum(num[j]);
             numj = lane == j ? v : numj;
         }
-        float dp[6];
+        float dp[DOF];
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
+        for (int i = 0; i < DOF; i++) {
             const float prod = hinv_col[i] * numj;
             float v = 0.f;
 #pragma unroll
-            for (int j = 0; j < 6; j++) v += wave_bcast(prod, j);
+            for (int j = 0; j < DOF; j++) v += wave_bcast(prod, j);
             dp[i] = v;
         }
-        // W <- W * (dW)^-1 ; p <- W (src/oc_icgn.cpp:287-293, src/oc_deformation.cpp:107-115)
-        float dW[9], dWi[9], Wn[9];
-        set_warp_2d1(dW, dp[0], dp[1], dp[2], dp[3], dp[4], dp[5]);
-        inverse3(dW, dWi);
-        mat_mul<3>(Wm, dWi, Wn);
-#pragma unroll
-        for (int i = 0; i < 9; i++) Wm[i] = uni(Wn[i]);
-        cu = Wm[2]; cux = Wm[0] - 1.f; cuy = Wm[1];
-        cv = Wm[5]; cvx = Wm[3]; cvy = Wm[4] - 1.f;
-        // convergence norm (src/oc_icgn.cpp:296-306)
+        // W <- W * (dW)^-1 ; p <- W (src/oc_icgn.cpp:287-293 / 828-834)
         const int rx2 = rx * rx, ry2 = ry * ry;
-        const float d = dp[0] * dp[0] + dp[1] * dp[1] * rx2 + dp[2] * dp[2] * ry2 + dp[3] * dp[3] +
-                        dp[4] * dp[4] * rx2 + dp[5] * dp[5] * ry2;
-        dp_norm = uni(sqrtf(d));
+        if constexpr (DOF == 6) {
+            float dW[9], dWi[9], Wn[9];
+            set_warp_2d1(dW, dp[0], dp[1], dp[2], dp[3], dp[4], dp[5]);
+            inverse3(dW, dWi);
+            mat_mul<3>(Wm, dWi, Wn);
+#pragma unroll
+            for (int i = 0; i < 9; i++) Wm[i] = uni(Wn[i]);
+            // src/oc_deformation.cpp:107-115
+            cur[0] = Wm[2]; cur[1] = Wm[0] - 1.f; cur[2] = Wm[1];
+            cur[6] = Wm[5]; cur[7] = Wm[3]; cur[8] = Wm[4] - 1.f;
+            // convergence norm (src/oc_icgn.cpp:296-306)
+            const float d = dp[0] * dp[0] + dp[1] * dp[1] * rx2 + dp[2] * dp[2] * ry2 + dp[3] * dp[3] +
+                            dp[4] * dp[4] * rx2 + dp[5] * dp[5] * ry2;
+            dp_norm = uni(sqrtf(d));
+        } else {
+            float dW[36];
+            set_warp_2d2(dW, dp);
+            // (dW)^-1 by the lane-distributed LU (Eigen PartialPivLU for 6x6, src/oc_icgn.cpp:831)
+            float dcol[6], dinv[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                float c = 0.f;
+#pragma unroll
+                for (int j = 0; j < 6; j++) c = lane == j ? dW[i * 6 + j] : c;
+                dcol[i] = c;
+            }
+            lu_inverse_lanes<6>(dcol, dinv, lane);
+            // lane j: column j of W * dW^-1, inner index ascending
+            float ncol[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                float v = wave_bcast(Wcol[i], 0) * dinv[0];
+#pragma unroll
+                for (int k = 1; k < 6; k++) v = v + wave_bcast(Wcol[i], k) * dinv[k];
+                ncol[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) Wcol[i] = ncol[i];
+            // Deformation2D2::setDeformation(), src/oc_deformation.cpp:284-299
+            const float r30 = wave_bcast(Wcol[3], 0), r31 = wave_bcast(Wcol[3], 1), r32 = wave_bcast(Wcol[3], 2);
+            const float r33 = wave_bcast(Wcol[3], 3), r34 = wave_bcast(Wcol[3], 4), r35 = wave_bcast(Wcol[3], 5);
+            const float r40 = wave_bcast(Wcol[4], 0), r41 = wave_bcast(Wcol[4], 1), r42 = wave_bcast(Wcol[4], 2);
+            const float r43 = wave_bcast(Wcol[4], 3), r44 = wave_bcast(Wcol[4], 4), r45 = wave_bcast(Wcol[4], 5);
+            cur[0] = r35; cur[1] = r33 - 1.f; cur[2] = r34; cur[3] = r30 * 2.f; cur[4] = r31; cur[5] = r32 * 2.f;
+            cur[6] = r45; cur[7] = r43; cur[8] = r44 - 1.f; cur[9] = r40 * 2.f; cur[10] = r41; cur[11] = r42 * 2.f;
+            // src/oc_icgn.cpp:837-857 (integer-truncated weights are reference behaviour)
+            const int rxy2 = rx2 * ry2;
+            const int rx4 = (int)(rx2 * rx2 * 0.25f), ry4 = (int)(ry2 * ry2 * 0.25f);
+            const float d = dp[0] * dp[0] + dp[1] * dp[1] * rx2 + dp[2] * dp[2] * ry2 + dp[3 % DOF] * dp[3 % DOF] * rx4 +
+                            dp[5 % DOF] * dp[5 % DOF] * ry4 + dp[4 % DOF] * dp[4 % DOF] * rxy2 + dp[6 % DOF] * dp[6 % DOF] +
+                            dp[7 % DOF] * dp[7 % DOF] * rx2 + dp[8 % DOF] * dp[8 % DOF] * ry2 +
+                            dp[9 % DOF] * dp[9 % DOF] * rx4 + dp[11 % DOF] * dp[11 % DOF] * ry4 +
+                            dp[10 % DOF] * dp[10 % DOF] * rxy2;
+            dp_norm = uni(sqrtf(d));
+        }
     } while (iter < P.stop && dp_norm >= P.conv);
 
-    // ---- outputs (src/oc_icgn.cpp:310-340)
+    // ---- outputs (src/oc_icgn.cpp:310-340; 2D2: 860-897)
     if (lane == 0) {
         float zncc = 0.5f * (2 - znssd);
         const float fiter = (float)iter;
         if (dp_norm >= P.conv && fiter >= P.stop) zncc = -4.f;
-        float out_u = cu, out_v = cv;
+        float out_u = cur[0], out_v = cur[6];
         if (isnan(zncc) || isnan(out_u) || isnan(out_v)) {
             out_u = u_in;
             out_v = v_in;
             zncc = -5.f;
         }
         poi[poi2d::U] = out_u;
-        poi[poi2d::UX] = cux;
-        poi[poi2d::UY] = cuy;
+        poi[poi2d::UX] = cur[1];
+        poi[poi2d::UY] = cur[2];
         poi[poi2d::V] = out_v;
-        poi[poi2d::VX] = cvx;
-        poi[poi2d::VY] = cvy;
+        poi[poi2d::VX] = cur[7];
+        poi[poi2d::VY] = cur[8];
+        if constexpr (DOF == 12) {
+            poi[poi2d::UXX] = cur[3];
+            poi[poi2d::UXY] = cur[4];
+            poi[poi2d::UYY] = cur[5];
+            poi[poi2d::VXX] = cur[9];
+            poi[poi2d::VXY] = cur[10];
+            poi[poi2d::VYY] = cur[11];
+        }
         poi[poi2d::U0] = u_in;
         poi[poi2d::V0] = v_in;
         poi[poi2d::ZNCC] = zncc;
@@ -435,48 +574,58 @@ __global__ __launch_bounds__(64) void icgn2d1_kernel(Icgn2dParams P, float* __re
 }
 
 // LDS bytes per one-wave workgroup: 4 per-sample arrays
-static size_t icgn2d1_lds_bytes(int nt) { return (size_t)4 * nt * kWave * sizeof(float); }
+static size_t icgn2d_lds_bytes(int nt) { return (size_t)4 * nt * kWave * sizeof(float); }
 constexpr int kIcgn2dMaxNT = 128;  // 4 * 128 * 256 B = 128 KiB of the 160 KiB LDS
 
-template <int G>
-static hipError_t launch1(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int nt, hipStream_t stream) {
-    const size_t lds = icgn2d1_lds_bytes(nt);
+template <int DOF, int G>
+static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int nt, hipStream_t stream) {
+    const size_t lds = icgn2d_lds_bytes(nt);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(icgn2d1_kernel<G>),
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(icgn2d_kernel<DOF, G>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, kIcgn2dMaxNT * 4 * kWave * 4);
         if (err != hipSuccess) return err;
         attr_set = true;
     }
-    hipLaunchKernelGGL(icgn2d1_kernel<G>, dim3((unsigned)count), dim3(64), lds, stream, p, pois, stride_f,
+    hipLaunchKernelGGL((icgn2d_kernel<DOF, G>), dim3((unsigned)count), dim3(64), lds, stream, p, pois, stride_f,
                        (unsigned long long)count, nt);
     return hipGetLastError();
 }
 
-int icgn2d_max_samples(int dof) { return dof == 6 ? kIcgn2dMaxNT * kWave : 0; }
+int icgn2d_max_samples(int) { return kIcgn2dMaxNT * kWave; }
 
-hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
-    if (count == 0) return hipSuccess;
-    const int N = (2 * p.rx + 1) * (2 * p.ry + 1);
-    const int nt = (N + 63) / 64;
-    if (nt > kIcgn2dMaxNT) return hipErrorInvalidValue;
-    // gather depth G (LUT entries in flight per lane).  OC_HIP_ICGN_GATHER overrides the
-    // default, which prefers a group size that divides the per-lane sample count.
+// gather depth G (LUT entries in flight per lane).  OC_HIP_ICGN_GATHER overrides the default,
+// which prefers a group size that divides the per-lane sample count.
+static int pick_gather(int nt) {
     static const int forced = [] {
         const char* e = getenv("OC_HIP_ICGN_GATHER");
         return e ? atoi(e) : 0;
     }();
-    int g = forced;
-    if (g != 2 && g != 3 && g != 4 && g != 6 && g != 8) g = (nt % 4 == 0) ? 4 : ((nt % 3 == 0) ? 3 : 4);
-    switch (g) {
-        case 2: return launch1<2>(p, pois, stride_f, count, nt, stream);
-        case 3: return launch1<3>(p, pois, stride_f, count, nt, stream);
-        case 6: return launch1<6>(p, pois, stride_f, count, nt, stream);
-        case 8: return launch1<8>(p, pois, stride_f, count, nt, stream);
-        default: return launch1<4>(p, pois, stride_f, count, nt, stream);
+    if (forced == 2 || forced == 3 || forced == 4 || forced == 6 || forced == 8) return forced;
+    return (nt % 4 == 0) ? 4 : ((nt % 3 == 0) ? 3 : 4);
+}
+
+template <int DOF>
+static hipError_t launch_dof(const Icgn2dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    const int N = (2 * p.rx + 1) * (2 * p.ry + 1);
+    const int nt = (N + 63) / 64;
+    if (nt > kIcgn2dMaxNT) return hipErrorInvalidValue;
+    switch (pick_gather(nt)) {
+        case 2: return launch_t<DOF, 2>(p, pois, stride_f, count, nt, stream);
+        case 3: return launch_t<DOF, 3>(p, pois, stride_f, count, nt, stream);
+        case 6: return launch_t<DOF, 6>(p, pois, stride_f, count, nt, stream);
+        case 8: return launch_t<DOF, 8>(p, pois, stride_f, count, nt, stream);
+        default: return launch_t<DOF, 4>(p, pois, stride_f, count, nt, stream);
     }
 }
 
-hipError_t launch_icgn2d2(const Icgn2dParams&, float*, int, size_t, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
+    return launch_dof<6>(p, pois, stride_f, count, stream);
+}
+
+hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
+    return launch_dof<12>(p, pois, stride_f, count, stream);
+}
 
 }  // namespace ochip

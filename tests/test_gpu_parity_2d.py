@@ -189,3 +189,37 @@ def test_golden_oht_on_gpu(eng, golden):
     prep = oracle.Prepared2D(golden["ref"], golden["tar"])
     oracle.icgn2d1(prep, golden["rx"], golden["ry"], golden["conv"], golden["stop"], want, order=oracle.ORDER_LANES)
     assert np.array_equal(_bits(pois), _bits(want))
+
+
+@pytest.mark.parametrize("rx,ry", [(20, 20), (12, 16)])
+def test_icgn2d2_bit_exact_vs_oracle(eng, rx, ry):
+    """ICGN2D2 (12 DoF, src/oc_icgn.cpp:685-898) on a pair with a second-order displacement field."""
+    import oracle
+    from opencorr_amd import synth
+    so = dict(uxx=4e-5, uxy=-2e-5, uyy=3e-5, vxx=-3e-5, vxy=2e-5, vyy=-4e-5)
+    ref, tar = synth.speckle_pair_2d(320, 340, seed=11, second_order=so)
+    xs, ys = synth.poi_grid_2d(320, 340, 17, 15, 32)
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, rx, ry, pois)
+    extra = oracle.make_pois2d([4, 170, 170], [160, 160, 160])
+    extra[1, oracle.P2["u"]] = 250.0
+    extra[2, oracle.P2["zncc"]] = -2.0
+    pois = np.concatenate([pois, extra]).astype(np.float32)
+    want = pois.copy()
+    prep = oracle.Prepared2D(ref, tar)
+    oracle.icgn2d2(prep, rx, ry, 0.001, 10, want, order=oracle.ORDER_LANES, lanes=64)
+    icgn = eng.ICGN2D2(rx, ry, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    got = icgn.compute(pois.copy())
+    P = oracle.P2
+    assert np.array_equal(got[:, P["iteration"]], want[:, P["iteration"]])
+    mism = np.argwhere(_bits(got) != _bits(want))
+    assert mism.size == 0, "first mismatches (poi, field): %s" % mism[:10].tolist()
+    ok = want[:-3, P["zncc"]] > 0.9
+    assert ok.mean() > 0.95
+    # the second-order terms are recovered (analytic field, tolerance set by image noise)
+    m = np.flatnonzero(ok)
+    assert np.abs(np.median(want[m, P["uxx"]]) - so["uxx"]) < 2e-5
+    assert np.abs(np.median(want[m, P["vyy"]]) - so["vyy"]) < 2e-5
+    assert want[-3, P["zncc"]] == -3.0 and want[-2, P["zncc"]] == -3.0 and want[-1, P["zncc"]] == -2.0
