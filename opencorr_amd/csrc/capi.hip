@@ -214,20 +214,25 @@ size_t fftcc_chunk_limit() {
     return 32768;
 }
 
-int ensure_fft2d(oc_hip_engine* e, size_t chunk) {
+int ensure_fft(oc_hip_engine* e, size_t chunk) {
     // The reference plans fftwf_plan_dft_r2c_2d(width, height, ...) over a buffer filled
     // [r*width + c] (src/oc_fftcc.cpp:40-42, 204-221): n0 = 2rx is the slow dimension of
-    // the transform, n1 = 2ry the fast one.  rocFFT takes lengths fastest-first.
-    const int n0 = 2 * e->rx, n1 = 2 * e->ry;
+    // the transform, n1 = 2ry the fast one; in 3D fftwf_plan_dft_r2c_3d(dim_x, dim_y, dim_z)
+    // over [(i*dim_y + j)*dim_x + k] (:68-70, 349-360): n0 = 2rx, n1 = 2ry, n2 = 2rz (fastest).
+    // rocFFT takes lengths fastest-first.
+    const int n0 = 2 * e->rx, n1 = 2 * e->ry, n2 = e->is3d() ? 2 * e->rz : 0;
     FftPlans& f = e->fft;
-    if (f.fwd && f.n0 == n0 && f.n1 == n1 && f.chunk == chunk) return OC_HIP_OK;
+    if (f.fwd && f.n0 == n0 && f.n1 == n1 && f.n2 == n2 && f.chunk == chunk) return OC_HIP_OK;
     rocfft_init_once();
     f.destroy();
-    const size_t lengths[2] = {(size_t)n1, (size_t)n0};
+    const size_t lengths2[2] = {(size_t)n1, (size_t)n0};
+    const size_t lengths3[3] = {(size_t)n2, (size_t)n1, (size_t)n0};
+    const size_t* lengths = n2 ? lengths3 : lengths2;
+    const size_t dims = n2 ? 3 : 2;
     OC_FFT_TRY(rocfft_plan_create(&f.fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                                  rocfft_precision_single, 2, lengths, 2 * chunk, nullptr));
+                                  rocfft_precision_single, dims, lengths, 2 * chunk, nullptr));
     OC_FFT_TRY(rocfft_plan_create(&f.inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                                  rocfft_precision_single, 2, lengths, chunk, nullptr));
+                                  rocfft_precision_single, dims, lengths, chunk, nullptr));
     OC_FFT_TRY(rocfft_execution_info_create(&f.info_fwd));
     OC_FFT_TRY(rocfft_execution_info_create(&f.info_inv));
     size_t wf = 0, wi = 0;
@@ -243,7 +248,7 @@ int ensure_fft2d(oc_hip_engine* e, size_t chunk) {
     }
     f.n0 = n0;
     f.n1 = n1;
-    f.n2 = 0;
+    f.n2 = n2;
     f.chunk = chunk;
     return OC_HIP_OK;
 }
@@ -253,7 +258,7 @@ int run_fftcc2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     const ImagePair& im = *e->img;
     const size_t chunk = count < fftcc_chunk_limit() ? count : fftcc_chunk_limit();
     if (chunk == 0) return OC_HIP_OK;
-    OC_TRY(ensure_fft2d(e, chunk));
+    OC_TRY(ensure_fft(e, chunk));
     const size_t M = (size_t)4 * e->rx * e->ry;                   // 2rx * 2ry
     const size_t F = (size_t)(2 * e->rx) * (size_t)(e->ry + 1);   // n0 * (n1/2 + 1)
     OC_TRY(e->win.reserve(2 * chunk * M * sizeof(float)));
@@ -320,11 +325,81 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     return OC_HIP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// FFTCC3D pipeline / ICGN3D1
+// ---------------------------------------------------------------------------
+size_t fftcc3d_chunk_limit() {
+    const char* s = getenv("OC_HIP_FFTCC3D_CHUNK");
+    if (s && *s) {
+        long v = atol(s);
+        if (v > 0) return (size_t)v;
+    }
+    return 1024;
+}
+
+int run_fftcc3d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
+    if (!e->img || e->img->ndim != 3) return fail(OC_HIP_ERR_INVALID, "FFTCC3D: set_images3d has not been called");
+    const ImagePair& im = *e->img;
+    const size_t chunk = count < fftcc3d_chunk_limit() ? count : fftcc3d_chunk_limit();
+    if (chunk == 0) return OC_HIP_OK;
+    OC_TRY(ensure_fft(e, chunk));
+    const size_t M = (size_t)8 * e->rx * e->ry * e->rz;
+    const size_t F = (size_t)(2 * e->rx) * (size_t)(2 * e->ry) * (size_t)(e->rz + 1);
+    OC_TRY(e->win.reserve(2 * chunk * M * sizeof(float)));
+    OC_TRY(e->freq.reserve(2 * chunk * F * sizeof(float2)));
+    OC_TRY(e->norms.reserve(2 * chunk * sizeof(float)));
+    OC_FFT_TRY(rocfft_execution_info_set_stream(e->fft.info_fwd, e->stream));
+    OC_FFT_TRY(rocfft_execution_info_set_stream(e->fft.info_inv, e->stream));
+    ochip::Fftcc3dParams P = {im.ref_ptr(), im.tar_ptr(), im.dz, im.dy, im.dx, e->rx, e->ry, e->rz};
+    float* ref_win = e->win.as<float>();
+    float* tar_win = ref_win + chunk * M;
+    float2* ref_freq = e->freq.as<float2>();
+    float2* tar_freq = ref_freq + chunk * F;
+    ProfScope prof(e);
+    for (size_t first = 0; first < count; first += chunk) {
+        const size_t n = (count - first) < chunk ? (count - first) : chunk;
+        float* pois = d_pois + first * (size_t)stride_f;
+        if (n < chunk) {
+            OC_HIP_TRY(hipMemsetAsync(ref_win + n * M, 0, (chunk - n) * M * sizeof(float), e->stream));
+            OC_HIP_TRY(hipMemsetAsync(tar_win + n * M, 0, (chunk - n) * M * sizeof(float), e->stream));
+        }
+        OC_HIP_TRY(ochip::launch_fftcc3d_gather(P, pois, stride_f, n, ref_win, tar_win, e->norms.as<float>(), e->stream));
+        void* in_fwd[1] = {ref_win};
+        void* out_fwd[1] = {ref_freq};
+        OC_FFT_TRY(rocfft_execute(e->fft.fwd, in_fwd, out_fwd, e->fft.info_fwd));
+        OC_HIP_TRY(ochip::launch_fftcc_conjmul(ref_freq, tar_freq, ref_freq, n * F, e->stream));
+        void* in_inv[1] = {ref_freq};
+        void* out_inv[1] = {ref_win};
+        OC_FFT_TRY(rocfft_execute(e->fft.inv, in_inv, out_inv, e->fft.info_inv));
+        OC_HIP_TRY(ochip::launch_fftcc3d_argmax(P, ref_win, e->norms.as<float>(), pois, stride_f, n, e->stream));
+    }
+    return OC_HIP_OK;
+}
+
+int run_icgn3d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
+    if (!e->img || e->img->ndim != 3) return fail(OC_HIP_ERR_INVALID, "ICGN3D1: set_images3d has not been called");
+    if (!e->ref_ready || !e->tar_ready)
+        return fail(OC_HIP_ERR_INVALID, "ICGN3D1: prepare() has not been called since the last set_images");
+    const ImagePair& im = *e->img;
+    int blocks = 0;
+    const size_t scratch = ochip::icgn3d1_scratch_floats(e->rx, e->ry, e->rz, &blocks);
+    if (scratch) OC_TRY(e->tmp.reserve(scratch * sizeof(float)));
+    ochip::Icgn3dParams P = {im.ref_ptr(), e->gx.as<float>(), e->gy.as<float>(), e->gz.as<float>(), e->coef.as<float>(),
+                             im.dz, im.dy, im.dx, e->rx, e->ry, e->rz, e->conv, e->stop,
+                             scratch ? e->tmp.as<float>() : nullptr};
+    ProfScope prof(e);
+    hipError_t err = ochip::launch_icgn3d1(P, d_pois, stride_f, count, e->stream);
+    if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "ICGN3D1 kernel launch failed: %s", hipGetErrorString(err));
+    return OC_HIP_OK;
+}
+
 int run_compute_device(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     switch (e->kind) {
         case OC_HIP_FFTCC2D: return run_fftcc2d(e, d_pois, stride_f, count);
         case OC_HIP_ICGN2D1:
         case OC_HIP_ICGN2D2: return run_icgn2d(e, d_pois, stride_f, count);
+        case OC_HIP_FFTCC3D: return run_fftcc3d(e, d_pois, stride_f, count);
+        case OC_HIP_ICGN3D1: return run_icgn3d1(e, d_pois, stride_f, count);
         default: return fail(OC_HIP_ERR_UNSUPPORTED, "engine kind %d has no device path yet", e->kind);
     }
 }
@@ -506,7 +581,11 @@ int oc_hip_prepare_ref(oc_hip_engine* e) {
         OC_TRY(e->gy.reserve(bytes));
         OC_HIP_TRY(ochip::launch_grad2d(im.ref_ptr(), im.dy, im.dx, e->gx.as<float>(), e->gy.as<float>(), e->stream));
     } else {
-        return fail(OC_HIP_ERR_UNSUPPORTED, "3D prepare is not implemented yet");
+        OC_TRY(e->gx.reserve(bytes));
+        OC_TRY(e->gy.reserve(bytes));
+        OC_TRY(e->gz.reserve(bytes));
+        OC_HIP_TRY(ochip::launch_grad3d(im.ref_ptr(), im.dz, im.dy, im.dx, e->gx.as<float>(), e->gy.as<float>(),
+                                        e->gz.as<float>(), e->stream));
     }
     e->ref_ready = true;
     return OC_HIP_OK;
@@ -522,7 +601,13 @@ int oc_hip_prepare_tar(oc_hip_engine* e) {
         OC_TRY(e->coef.reserve(im.count() * 16 * sizeof(float)));
         OC_HIP_TRY(ochip::launch_bspline2d_lut(im.tar_ptr(), im.dy, im.dx, e->coef.as<float>(), e->stream));
     } else {
-        return fail(OC_HIP_ERR_UNSUPPORTED, "3D prepare is not implemented yet");
+        OC_TRY(e->coef.reserve(im.count() * sizeof(float)));
+        // the y pass needs a second volume; it is dead once prepare returns, so it lives in a local buffer
+        DevBuf pass;
+        OC_TRY(pass.reserve(im.count() * sizeof(float)));
+        OC_HIP_TRY(ochip::launch_bspline3d_prefilter(im.tar_ptr(), im.dz, im.dy, im.dx, e->coef.as<float>(),
+                                                     pass.as<float>(), e->stream));
+        OC_HIP_TRY(hipStreamSynchronize(e->stream));  // before `pass` is freed
     }
     e->tar_ready = true;
     return OC_HIP_OK;

@@ -344,7 +344,6 @@ __global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __res
     // ---- IC-GN loop (src/oc_icgn.cpp:216-307; 2D2: 762-858)
     // 2D1: 3x3 warp matrix, wave-uniform in SGPRs.  2D2: 6x6 warp matrix, column j in lane j;
     // rows 3 and 4 (the ones Deformation2D2::warp needs) are broadcast once per iteration.
-    constexpr int WN = (DOF == 6) ? 3 : 6;
     float Wm[9];      // 2D1
     float Wcol[6];    // 2D2
     float row3[6], row4[6];

