@@ -117,6 +117,7 @@ __global__ __launch_bounds__(64) void fftcc2d_argmax_kernel(Fftcc2dParams P, con
 hipError_t launch_fftcc2d_gather(const Fftcc2dParams& p, const float* pois, int stride_f, size_t count, float* ref_win,
                                  float* tar_win, float* norms, int* flags, hipStream_t stream) {
     if (count == 0) return hipSuccess;
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(fftcc2d_gather_kernel, dim3((unsigned)count), dim3(64), 0, stream, p, pois, stride_f,
                        (unsigned long long)count, ref_win, tar_win, norms, flags);
     return hipGetLastError();
@@ -125,6 +126,7 @@ hipError_t launch_fftcc2d_gather(const Fftcc2dParams& p, const float* pois, int 
 hipError_t launch_fftcc_conjmul(const float2* rf, const float2* tf, float2* zf, size_t bins, hipStream_t stream) {
     if (bins == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((bins + 255) / 256);
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(fftcc_conjmul_kernel, dim3(blocks), dim3(256), 0, stream, rf, tf, zf, (unsigned long long)bins);
     return hipGetLastError();
 }
@@ -132,6 +134,7 @@ hipError_t launch_fftcc_conjmul(const float2* rf, const float2* tf, float2* zf, 
 hipError_t launch_fftcc2d_argmax(const Fftcc2dParams& p, const float* surf, const float* norms, const int* flags,
                                  float* pois, int stride_f, size_t count, hipStream_t stream) {
     if (count == 0) return hipSuccess;
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(fftcc2d_argmax_kernel, dim3((unsigned)count), dim3(64), 0, stream, p, surf, norms, flags, pois,
                        stride_f, (unsigned long long)count);
     return hipGetLastError();

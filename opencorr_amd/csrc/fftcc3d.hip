@@ -122,6 +122,7 @@ __global__ __launch_bounds__(kBlockF3) void fftcc3d_argmax_kernel(Fftcc3dParams 
 hipError_t launch_fftcc3d_gather(const Fftcc3dParams& p, const float* pois, int stride_f, size_t count, float* ref_win,
                                  float* tar_win, float* norms, hipStream_t stream) {
     if (count == 0) return hipSuccess;
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(fftcc3d_gather_kernel, dim3((unsigned)count), dim3(kBlockF3), 0, stream, p, pois, stride_f,
                        (unsigned long long)count, ref_win, tar_win, norms);
     return hipGetLastError();
@@ -130,6 +131,7 @@ hipError_t launch_fftcc3d_gather(const Fftcc3dParams& p, const float* pois, int 
 hipError_t launch_fftcc3d_argmax(const Fftcc3dParams& p, const float* surf, const float* norms, float* pois,
                                  int stride_f, size_t count, hipStream_t stream) {
     if (count == 0) return hipSuccess;
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(fftcc3d_argmax_kernel, dim3((unsigned)count), dim3(kBlockF3), 0, stream, p, surf, norms, pois,
                        stride_f, (unsigned long long)count);
     return hipGetLastError();

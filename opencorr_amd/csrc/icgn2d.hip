@@ -586,6 +586,7 @@ static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, siz
         if (err != hipSuccess) return err;
         attr_set = true;
     }
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL((icgn2d_kernel<DOF, G>), dim3((unsigned)count), dim3(64), lds, stream, p, pois, stride_f,
                        (unsigned long long)count, nt);
     return hipGetLastError();

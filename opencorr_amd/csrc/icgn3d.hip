@@ -13,6 +13,7 @@
 // Reductions: per-thread partial sums in increasing s, xor butterfly inside each wave
 // (offsets 1..32), then a balanced tree over the 16 wave sums in wave order -- the same
 // association as the oracle's OC_ORDER_LANES with lanes = 1024.
+#include <cstdio>
 #include <cstdlib>
 
 #include "oc_device.h"
@@ -472,19 +473,25 @@ hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_f, size
     (void)icgn3d1_scratch_floats(p.rx, p.ry, p.rz, &blocks);
     if (blocks == 0) {
         const size_t lds = red_bytes + n * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static size_t attr_lds = 64 * 1024;  // default dynamic-LDS limit
+        if (lds > attr_lds) {
             hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(icgn3d1_kernel<true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit3d);
-            if (err != hipSuccess) return err;
-            attr_set = true;
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (err != hipSuccess) {
+                fprintf(stderr, "opencorr_hip: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed: %s\n", lds,
+                        hipGetErrorString(err));
+                return err;
+            }
+            attr_lds = lds;
         }
         const unsigned grid = (unsigned)(count < (1u << 30) ? count : (1u << 30));
+        (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
         hipLaunchKernelGGL(icgn3d1_kernel<true>, dim3(grid), dim3(kBlock3d), lds, stream, p, pois, stride_f,
                            (unsigned long long)count);
     } else {
         if (!p.scratch) return hipErrorInvalidValue;
         const unsigned grid = (unsigned)(count < (size_t)blocks ? count : (size_t)blocks);
+        (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
         hipLaunchKernelGGL(icgn3d1_kernel<false>, dim3(grid), dim3(kBlock3d), red_bytes, stream, p, pois, stride_f,
                            (unsigned long long)count);
     }

@@ -106,18 +106,21 @@ __global__ __launch_bounds__(256) void colmajor_to_rowmajor_kernel(const float* 
 
 hipError_t launch_grad2d(const float* img, int height, int width, float* gx, float* gy, hipStream_t stream) {
     dim3 block(256), grid((width + 255) / 256, height);
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(grad2d_kernel, grid, block, 0, stream, img, height, width, gx, gy);
     return hipGetLastError();
 }
 
 hipError_t launch_bspline2d_lut(const float* img, int height, int width, float* lut, hipStream_t stream) {
     dim3 block(256), grid((width + 255) / 256, height);
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(bspline2d_lut_kernel, grid, block, 0, stream, img, height, width, lut);
     return hipGetLastError();
 }
 
 hipError_t launch_colmajor_to_rowmajor(const float* src, int height, int width, float* dst, hipStream_t stream) {
     dim3 block(256), grid((width + 31) / 32, (height + 31) / 32);
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(colmajor_to_rowmajor_kernel, grid, block, 0, stream, src, height, width, dst);
     return hipGetLastError();
 }

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void bspline3d_prefilter_axis_kernel(const flo
 hipError_t launch_grad3d(const float* vol, int dz, int dy, int dx, float* gx, float* gy, float* gz,
                          hipStream_t stream) {
     dim3 block(256), grid((dx + 255) / 256, dy, dz);
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(grad3d_kernel, grid, block, 0, stream, vol, dz, dy, dx, gx, gy, gz);
     return hipGetLastError();
 }
@@ -90,8 +91,11 @@ hipError_t launch_grad3d(const float* vol, int dz, int dy, int dx, float* gx, fl
 hipError_t launch_bspline3d_prefilter(const float* vol, int dz, int dy, int dx, float* coef, float* tmp,
                                       hipStream_t stream) {
     dim3 block(256), grid((dx + 255) / 256, dy, dz);
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(bspline3d_prefilter_axis_kernel, grid, block, 0, stream, vol, coef, dz, dy, dx, 2);
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(bspline3d_prefilter_axis_kernel, grid, block, 0, stream, (const float*)coef, tmp, dz, dy, dx, 1);
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(bspline3d_prefilter_axis_kernel, grid, block, 0, stream, (const float*)tmp, coef, dz, dy, dx, 0);
     return hipGetLastError();
 }
