@@ -112,6 +112,12 @@ int oc_hip_set_stream(oc_hip_engine* engine, void* hip_stream);
 /* Go back to the engine's own (non-blocking) stream. */
 int oc_hip_reset_stream(oc_hip_engine* engine);
 
+/* Performance knobs; every setting computes bit-identical results.
+ *   "icgn2d_variant"  index into the ICGN2D kernel-variant table (gather depth, LDS footprint,
+ *                     software pipelining, waves per workgroup)
+ *   "icgn2d_xcd"      1: workgroups of one XCD serve a contiguous range of the POI queue */
+int oc_hip_set_tuning(oc_hip_engine* engine, const char* key, int value);
+
 /* ---- precompute ----------------------------------------------------------- */
 /* ICGN2D1::prepare()  src/oc_icgn.cpp:138-142 (prepareRef + prepareTar); FFTCC::prepare() is a no-op
  * in the reference (src/oc_fftcc.cpp:175) and here. */

@@ -24,7 +24,7 @@ SYMBOLS = [
     "oc_hip_fftcc2d_create", "oc_hip_icgn2d1_create", "oc_hip_icgn2d2_create",
     "oc_hip_fftcc3d_create", "oc_hip_icgn3d1_create", "oc_hip_destroy",
     "oc_hip_set_images2d", "oc_hip_set_images3d", "oc_hip_share_images", "oc_hip_set_subset",
-    "oc_hip_set_iteration", "oc_hip_set_stream", "oc_hip_reset_stream",
+    "oc_hip_set_iteration", "oc_hip_set_stream", "oc_hip_reset_stream", "oc_hip_set_tuning",
     "oc_hip_prepare", "oc_hip_prepare_ref", "oc_hip_prepare_tar",
     "oc_hip_compute", "oc_hip_compute_one", "oc_hip_synchronize",
     "oc_hip_get_kind", "oc_hip_get_field", "oc_hip_read_field",
@@ -70,6 +70,7 @@ def lib():
     L.oc_hip_set_iteration.argtypes = [vp, f, f]
     L.oc_hip_set_stream.argtypes = [vp, vp]
     L.oc_hip_reset_stream.argtypes = [vp]
+    L.oc_hip_set_tuning.argtypes = [vp, ctypes.c_char_p, i]
     L.oc_hip_prepare.argtypes = [vp]
     L.oc_hip_prepare_ref.argtypes = [vp]
     L.oc_hip_prepare_tar.argtypes = [vp]

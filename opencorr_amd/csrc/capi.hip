@@ -130,6 +130,9 @@ struct oc_hip_engine {
     // FFTCC working set
     FftPlans fft;
     DevBuf win, freq, norms, flags;
+    // kernel selection (oc_hip_set_tuning); every choice computes the same bits
+    int icgn2d_variant = 0;
+    int icgn2d_xcd = 0;
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -309,17 +312,20 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
                              e->conv,      e->stop};
     const int dof = e->kind == OC_HIP_ICGN2D1 ? 6 : 12;
     const int N = (2 * e->rx + 1) * (2 * e->ry + 1);
-    if (N > ochip::icgn2d_max_samples(dof))
+    // fall back to the LDS-light single-wave variant when the tuned one cannot hold the subset
+    int variant = e->icgn2d_variant;
+    if (N > ochip::icgn2d_max_samples(variant)) variant = 4;
+    if (N > ochip::icgn2d_max_samples(variant))
         return fail(OC_HIP_ERR_UNSUPPORTED, "ICGN2D%d: subset %dx%d (%d samples) exceeds the on-chip limit of %d samples",
-                    dof == 6 ? 1 : 2, 2 * e->rx + 1, 2 * e->ry + 1, N, ochip::icgn2d_max_samples(dof));
+                    dof == 6 ? 1 : 2, 2 * e->rx + 1, 2 * e->ry + 1, N, ochip::icgn2d_max_samples(variant));
     ProfScope prof(e);
     // one wave-sized workgroup per POI; grid.x is limited to 2^31-1
     const size_t kMaxGrid = 1u << 30;
     for (size_t first = 0; first < count; first += kMaxGrid) {
         const size_t n = (count - first) < kMaxGrid ? (count - first) : kMaxGrid;
         float* pois = d_pois + first * (size_t)stride_f;
-        hipError_t err = dof == 6 ? ochip::launch_icgn2d1(P, pois, stride_f, n, e->stream)
-                                  : ochip::launch_icgn2d2(P, pois, stride_f, n, e->stream);
+        hipError_t err = dof == 6 ? ochip::launch_icgn2d1(P, pois, stride_f, n, variant, e->icgn2d_xcd != 0, e->stream)
+                                  : ochip::launch_icgn2d2(P, pois, stride_f, n, variant, e->icgn2d_xcd != 0, e->stream);
         if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "ICGN2D kernel launch failed: %s", hipGetErrorString(err));
     }
     return OC_HIP_OK;
@@ -566,6 +572,23 @@ int oc_hip_reset_stream(oc_hip_engine* e) {
     OC_TRY(check_engine(e));
     std::lock_guard<std::mutex> lock(e->mu);
     e->stream = e->own_stream;
+    return OC_HIP_OK;
+}
+
+int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
+    OC_TRY(check_engine(e));
+    if (!key) return fail(OC_HIP_ERR_INVALID, "null tuning key");
+    std::lock_guard<std::mutex> lock(e->mu);
+    const std::string k(key);
+    if (k == "icgn2d_variant") {
+        if (value < 0 || value >= ochip::icgn2d_variant_count())
+            return fail(OC_HIP_ERR_INVALID, "icgn2d_variant %d out of range [0,%d)", value, ochip::icgn2d_variant_count());
+        e->icgn2d_variant = value;
+    } else if (k == "icgn2d_xcd") {
+        e->icgn2d_xcd = value != 0;
+    } else {
+        return fail(OC_HIP_ERR_INVALID, "unknown tuning key '%s'", key);
+    }
     return OC_HIP_OK;
 }
 

@@ -142,24 +142,24 @@ struct SampleWalk {
 
 // One LUT entry in flight: address generation and the four 16-byte loads are issued for a
 // whole group of G samples before any polynomial is evaluated, so each lane keeps G*64 B
-// of gathers outstanding (the interpolation sweep is latency/L1-bandwidth bound).
+// of gathers outstanding (the interpolation sweep is latency/L1-bandwidth bound).  Only the
+// fractional offsets travel with the coefficients; dy = -1 marks an out-of-range sample
+// (a valid dy lies in [0, 1)).
 struct LutFetch {
     float4 c0, c1, c2, c3;
-    float x, y;
-    int xi, yi;
-    bool out;
+    float dx, dy;
 };
 
 // range rule of BicubicBspline::compute (src/oc_cubic_bspline.cpp:137-142); out-of-range
 // samples fetch entry (0,0), which is always mapped, and are replaced by -1.f afterwards
 __device__ __forceinline__ void lut_fetch(LutFetch& f, const float* __restrict__ lut, int height, int width, float x,
                                           float y) {
-    f.out = (x < 1 || y < 1 || x >= width - 2 || y >= height - 2 || isnan(x) || isnan(y));
-    f.x = x;
-    f.y = y;
-    f.xi = f.out ? 0 : (int)floorf(x);
-    f.yi = f.out ? 0 : (int)floorf(y);
-    const float4* __restrict__ e = reinterpret_cast<const float4*>(lut) + ((size_t)f.yi * width + f.xi) * 4;
+    const bool out = (x < 1 || y < 1 || x >= width - 2 || y >= height - 2 || isnan(x) || isnan(y));
+    const int xi = out ? 0 : (int)floorf(x);
+    const int yi = out ? 0 : (int)floorf(y);
+    f.dx = x - (float)xi;
+    f.dy = out ? -1.f : y - (float)yi;
+    const float4* __restrict__ e = reinterpret_cast<const float4*>(lut) + ((size_t)yi * width + xi) * 4;
     f.c0 = e[0];
     f.c1 = e[1];
     f.c2 = e[2];
@@ -168,7 +168,7 @@ __device__ __forceinline__ void lut_fetch(LutFetch& f, const float* __restrict__
 
 // explicit 16-term left-to-right polynomial of src/oc_cubic_bspline.cpp:144-177
 __device__ __forceinline__ float lut_eval(const LutFetch& f) {
-    const float dx = f.x - (float)f.xi, dy = f.y - (float)f.yi;
+    const float dx = f.dx, dy = f.dy;
     const float dx2 = dx * dx, dy2 = dy * dy;
     const float dx3 = dx2 * dx, dy3 = dy2 * dy;
     float v = f.c0.x;
@@ -187,7 +187,7 @@ __device__ __forceinline__ float lut_eval(const LutFetch& f) {
     v = v + f.c3.y * dy3 * dx;
     v = v + f.c3.z * dy3 * dx2;
     v = v + f.c3.w * dy3 * dx3;
-    return f.out ? -1.f : v;
+    return dy < 0.f ? -1.f : v;
 }
 
 // Deformation2D2::setWarp, src/oc_deformation.cpp:301-350; q = u ux uy uxx uxy uyy v vx vy vxx vxy vyy
@@ -232,28 +232,50 @@ __device__ __forceinline__ void sd_row(float g_x, float g_y, int xl, int yl, flo
 }
 
 // ---------------------------------------------------------------------------
-// ICGN2D1 (DOF = 6, 3x3 warp) and ICGN2D2 (DOF = 12, 6x6 warp).  One wave per POI;
-// per-sample state lives in LDS as [t][lane] arrays (conflict-free ds_read/write_b32),
-// NT = ceil(N/64) at run time.
-//   LDS layout (floats): rs[NT*64] | gx[NT*64] | gy[NT*64] | ts[NT*64]
-// G = samples whose LUT gathers are issued back to back (template).
+// ICGN2D1 (DOF = 6, 3x3 warp) and ICGN2D2 (DOF = 12, 6x6 warp).  One wave per POI, WPB
+// independent waves (consecutive POIs) per workgroup -- no barriers anywhere.
+// Per-sample state lives in LDS as [t][lane] arrays (conflict-free ds_read/write_b32),
+// NT = ceil(N/64) at run time:
+//   MODE 0 (floats per wave): rs[NT*64] | ts[NT*64] | gx[NT*64] | gy[NT*64]
+//   MODE 1:                   rs[NT*64] | ts[NT*64]       (gx, gy re-read from the gradient
+//                             images in the numerator pass: half the LDS, twice the waves)
+// G    = samples whose LUT gathers are issued back to back.
+// PIPE = software-pipelined sweep: the gathers of group g+1 are in flight while the
+//        polynomials of group g are evaluated (two register buffers).
+// OCC  = minimum waves per SIMD the register allocation must allow.
 // Wave-uniform small matrices are kept one COLUMN per lane (lane j < n holds column j):
 // the inverse Hessian, and for 2D2 also the 6x6 warp matrix.
+// Every variant performs the same floating-point operations in the same order, so all
+// of them are bit-identical to the oracle in OC_ORDER_LANES.
 // ---------------------------------------------------------------------------
-template <int DOF, int G>
-__global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __restrict__ pois, int stride_f,
-                                                    unsigned long long count, int NT) {
+struct Icgn2dLaunch {
+    int stride_f;              // floats between POI records
+    int nt;                    // ceil(N / 64)
+    int xcd_chunk;             // > 0: workgroup b serves POI group (b % 8) * xcd_chunk + b / 8
+    unsigned long long count;  // POIs
+};
+
+template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC>
+__global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, float* __restrict__ pois,
+                                                               Icgn2dLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NH = DOF * (DOF + 1) / 2;
-    const unsigned long long idx = blockIdx.x;
-    if (idx >= count) return;
-    const int lane = threadIdx.x;
-    float* __restrict__ l_rs = lds + lane;
-    float* __restrict__ l_gx = l_rs + NT * kWave;
+    constexpr int ARRAYS = MODE == 0 ? 4 : 2;
+    const int NT = L.nt;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD a
+    // contiguous range of the queue so POIs that share LUT lines meet in the same L2.
+    unsigned long long grp = blockIdx.x;
+    if (L.xcd_chunk > 0) grp = (unsigned long long)(blockIdx.x & 7u) * L.xcd_chunk + (blockIdx.x >> 3);
+    const unsigned long long idx = grp * WPB + wave;
+    if (idx >= L.count) return;
+    float* __restrict__ l_rs = lds + (size_t)wave * ARRAYS * NT * kWave + lane;
+    float* __restrict__ l_ts = l_rs + NT * kWave;
+    float* __restrict__ l_gx = l_ts + NT * kWave;  // MODE 0 only
     float* __restrict__ l_gy = l_gx + NT * kWave;
-    float* __restrict__ l_ts = l_gy + NT * kWave;
 
-    float* poi = pois + idx * (unsigned long long)stride_f;
+    float* poi = pois + idx * (unsigned long long)L.stride_f;
     const float rec = lane < poi2d::FLOATS ? poi[lane] : 0.f;
     const float px = wave_bcast(rec, poi2d::X), py = wave_bcast(rec, poi2d::Y);
     const float u_in = wave_bcast(rec, poi2d::U), ux_in = wave_bcast(rec, poi2d::UX), uy_in = wave_bcast(rec, poi2d::UY);
@@ -269,9 +291,13 @@ __global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __res
     }
     const int W = 2 * rx + 1, N = W * (2 * ry + 1);
     const float fN = (float)N;
+    const int NF = N / kWave;  // passes in which every lane owns a sample; pass NF (if any) is partial
     const int q64 = kWave / W, r64 = kWave - q64 * W;
     const int r0 = lane / W;
     const int c0 = lane - r0 * W;
+    const size_t goff = (size_t)((int)py - ry) * width + ((int)px - rx);
+    const float* __restrict__ bgx = P.gx + goff;
+    const float* __restrict__ bgy = P.gy + goff;
 
     // ---- reference subset, zero-mean + norm (src/oc_icgn.cpp:174-176, src/oc_subset.cpp:39-53)
     float ref_norm;
@@ -280,21 +306,30 @@ __global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __res
         const float* __restrict__ base = P.ref + (size_t)y0 * width + x0;
         float acc = 0.f;
         SampleWalk w(lane, r0, c0, W, q64, r64);
-#pragma unroll 2
-        for (int t = 0; t < NT; t++, w.next()) {
+#pragma unroll 3
+        for (int t = 0; t < NF; t++, w.next()) {
+            const float v = base[w.r * width + w.c];
+            acc = acc + v;
+            l_rs[t * kWave] = v;
+        }
+        if (NF < NT) {
             const bool valid = w.s < N;
             const float v = valid ? base[w.r * width + w.c] : 0.f;
             acc = valid ? acc + v : acc;
-            l_rs[t * kWave] = v;
+            l_rs[NF * kWave] = v;
         }
         const float mean = wave_allreduce_sum(acc) / fN;
         acc = 0.f;
-        int s = lane;
-#pragma unroll 2
-        for (int t = 0; t < NT; t++, s += kWave) {
+#pragma unroll 3
+        for (int t = 0; t < NF; t++) {
             const float d = l_rs[t * kWave] - mean;
             l_rs[t * kWave] = d;
-            acc = s < N ? acc + d * d : acc;
+            acc = acc + d * d;
+        }
+        if (NF < NT) {
+            const float d = l_rs[NF * kWave] - mean;
+            l_rs[NF * kWave] = d;
+            acc = (NF * kWave + lane) < N ? acc + d * d : acc;
         }
         ref_norm = uni(sqrtf(wave_allreduce_sum(acc)));
     }
@@ -305,9 +340,6 @@ __global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __res
         float h[NH];
 #pragma unroll
         for (int i = 0; i < NH; i++) h[i] = 0.f;
-        const size_t goff = (size_t)((int)py - ry) * width + ((int)px - rx);
-        const float* __restrict__ bgx = P.gx + goff;
-        const float* __restrict__ bgy = P.gy + goff;
         SampleWalk w(lane, r0, c0, W, q64, r64);
 #pragma unroll 1
         for (int t = 0; t < NT; t++, w.next()) {
@@ -315,8 +347,10 @@ __global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __res
             const int off = w.r * width + w.c;
             const float g_x = valid ? bgx[off] : 0.f;
             const float g_y = valid ? bgy[off] : 0.f;
-            l_gx[t * kWave] = g_x;
-            l_gy[t * kWave] = g_y;
+            if constexpr (MODE == 0) {
+                l_gx[t * kWave] = g_x;
+                l_gy[t * kWave] = g_y;
+            }
             float sd[DOF];
             sd_row<DOF>(g_x, g_y, w.c - rx, w.r - ry, sd);
             int k = 0;
@@ -383,10 +417,8 @@ __global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __res
         float acc = 0.f;
         {
             SampleWalk w(lane, r0, c0, W, q64, r64);
-#pragma nounroll
-            for (int t0 = 0; t0 < NT; t0 += G) {
-                LutFetch f[G];
-                bool valid[G];
+            // warp the next G samples of this lane and issue their LUT gathers
+            auto issue = [&](LutFetch(&f)[G], bool(&valid)[G]) {
 #pragma unroll
                 for (int g = 0; g < G; g++, w.next()) {
                     valid[g] = w.s < N;
@@ -410,12 +442,35 @@ __global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __res
                     // a lane past the end of the subset fetches a harmless in-range point
                     lut_fetch(f[g], P.lut, height, width, valid[g] ? px + wx : 1.f, valid[g] ? py + wy : 1.f);
                 }
+            };
+            auto consume = [&](const LutFetch(&f)[G], const bool(&valid)[G], int t0) {
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     const float v = lut_eval(f[g]);
                     negative = negative || (valid[g] && v < 0.f);
                     acc = valid[g] ? acc + v : acc;
                     if (t0 + g < NT) l_ts[(t0 + g) * kWave] = v;
+                }
+            };
+            if constexpr (PIPE == 0) {
+#pragma nounroll
+                for (int t0 = 0; t0 < NT; t0 += G) {
+                    LutFetch f[G];
+                    bool valid[G];
+                    issue(f, valid);
+                    consume(f, valid, t0);
+                }
+            } else {
+                LutFetch fa[G], fb[G];
+                bool va[G], vb[G];
+                issue(fa, va);
+#pragma nounroll
+                for (int t0 = 0; t0 < NT; t0 += 2 * G) {
+                    const bool more_b = t0 + G < NT, more_a = t0 + 2 * G < NT;
+                    if (more_b) issue(fb, vb);
+                    consume(fa, va, t0);
+                    if (more_a) issue(fa, va);
+                    if (more_b) consume(fb, vb, t0 + G);
                 }
             }
         }
@@ -427,13 +482,14 @@ __global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __res
         // zeroMeanNorm of the target subset (src/oc_icgn.cpp:257)
         const float tmean = wave_allreduce_sum(acc) / fN;
         acc = 0.f;
-        {
-            int s = lane;
-#pragma unroll 4
-            for (int t = 0; t < NT; t++, s += kWave) {
-                const float d = l_ts[t * kWave] - tmean;
-                acc = s < N ? acc + d * d : acc;
-            }
+#pragma unroll 6
+        for (int t = 0; t < NF; t++) {
+            const float d = l_ts[t * kWave] - tmean;
+            acc = acc + d * d;
+        }
+        if (NF < NT) {
+            const float d = l_ts[NF * kWave] - tmean;
+            acc = (NF * kWave + lane) < N ? acc + d * d : acc;
         }
         const float tar_norm = uni(sqrtf(wave_allreduce_sum(acc)));
         // error image, ZNSSD, numerator (src/oc_icgn.cpp:260-276)
@@ -444,13 +500,20 @@ __global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __res
         float ssd = 0.f;
         {
             SampleWalk w(lane, r0, c0, W, q64, r64);
-#pragma unroll 2
-            for (int t = 0; t < NT; t++, w.next()) {
-                const bool valid = w.s < N;
+            auto sample = [&](int t, bool valid) {
+                float g_x, g_y;
+                if constexpr (MODE == 0) {
+                    g_x = l_gx[t * kWave];
+                    g_y = l_gy[t * kWave];
+                } else {
+                    const int off = w.r * width + w.c;
+                    g_x = valid ? bgx[off] : 0.f;
+                    g_y = valid ? bgy[off] : 0.f;
+                }
                 const float tz = l_ts[t * kWave] - tmean;  // same bits as in the norm pass
                 const float e = tz * factor - l_rs[t * kWave];
                 float sd[DOF];
-                sd_row<DOF>(l_gx[t * kWave], l_gy[t * kWave], w.c - rx, w.r - ry, sd);
+                sd_row<DOF>(g_x, g_y, w.c - rx, w.r - ry, sd);
                 const float e2 = e * e;
                 ssd = valid ? ssd + e2 : ssd;
 #pragma unroll
@@ -458,7 +521,10 @@ __global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __res
                     const float n = sd[i] * e;
                     num[i] = valid ? num[i] + n : num[i];
                 }
-            }
+            };
+#pragma unroll 3
+            for (int t = 0; t < NF; t++, w.next()) sample(t, true);
+            if (NF < NT) sample(NF, w.s < N);
         }
         znssd = uni(wave_allreduce_sum(ssd)) / (ref_norm * ref_norm);
         // dp = H^-1 * numerator (src/oc_icgn.cpp:279-286): lane j forms H^-1(i,j) * num[j], the
@@ -528,11 +594,12 @@ __global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __res
             // src/oc_icgn.cpp:837-857 (integer-truncated weights are reference behaviour)
             const int rxy2 = rx2 * ry2;
             const int rx4 = (int)(rx2 * rx2 * 0.25f), ry4 = (int)(ry2 * ry2 * 0.25f);
-            const float d = dp[0] * dp[0] + dp[1] * dp[1] * rx2 + dp[2] * dp[2] * ry2 + dp[3 % DOF] * dp[3 % DOF] * rx4 +
-                            dp[5 % DOF] * dp[5 % DOF] * ry4 + dp[4 % DOF] * dp[4 % DOF] * rxy2 + dp[6 % DOF] * dp[6 % DOF] +
-                            dp[7 % DOF] * dp[7 % DOF] * rx2 + dp[8 % DOF] * dp[8 % DOF] * ry2 +
-                            dp[9 % DOF] * dp[9 % DOF] * rx4 + dp[11 % DOF] * dp[11 % DOF] * ry4 +
-                            dp[10 % DOF] * dp[10 % DOF] * rxy2;
+            constexpr int D = DOF;  // keeps the dp[] indices in range when this branch is discarded
+            const float d = dp[0] * dp[0] + dp[1] * dp[1] * rx2 + dp[2] * dp[2] * ry2 + dp[3 % D] * dp[3 % D] * rx4 +
+                            dp[5 % D] * dp[5 % D] * ry4 + dp[4 % D] * dp[4 % D] * rxy2 + dp[6 % D] * dp[6 % D] +
+                            dp[7 % D] * dp[7 % D] * rx2 + dp[8 % D] * dp[8 % D] * ry2 +
+                            dp[9 % D] * dp[9 % D] * rx4 + dp[11 % D] * dp[11 % D] * ry4 +
+                            dp[10 % D] * dp[10 % D] * rxy2;
             dp_norm = uni(sqrtf(d));
         }
     } while (iter < P.stop && dp_norm >= P.conv);
@@ -572,60 +639,102 @@ __global__ __launch_bounds__(64) void icgn2d_kernel(Icgn2dParams P, float* __res
     }
 }
 
-// LDS bytes per one-wave workgroup: 4 per-sample arrays
-static size_t icgn2d_lds_bytes(int nt) { return (size_t)4 * nt * kWave * sizeof(float); }
-constexpr int kIcgn2dMaxNT = 128;  // 4 * 128 * 256 B = 128 KiB of the 160 KiB LDS
+// ---------------------------------------------------------------------------
+// launch: a table of kernel variants (all bit-identical), selected per engine through
+// oc_hip_set_tuning("icgn2d_variant", i) / ("icgn2d_xcd", 0|1); defaults chosen from the
+// MI355X sweep in DESIGN.md section 4.
+// ---------------------------------------------------------------------------
+constexpr int kLdsBudget = 160 * 1024;
 
-template <int DOF, int G>
-static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int nt, hipStream_t stream) {
-    const size_t lds = icgn2d_lds_bytes(nt);
+struct VariantInfo {
+    int g, mode, pipe, wpb, occ;
+};
+
+template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC>
+static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int nt, bool xcd,
+                           hipStream_t stream) {
+    constexpr int arrays = MODE == 0 ? 4 : 2;
+    const size_t lds = (size_t)arrays * nt * kWave * sizeof(float) * WPB;
+    if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
+    auto kern = icgn2d_kernel<DOF, G, MODE, PIPE, WPB, OCC>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(icgn2d_kernel<DOF, G>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, kIcgn2dMaxNT * 4 * kWave * 4);
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
         if (err != hipSuccess) return err;
         attr_set = true;
     }
+    const size_t groups = (count + WPB - 1) / WPB;
+    Icgn2dLaunch L;
+    L.stride_f = stride_f;
+    L.nt = nt;
+    L.count = count;
+    L.xcd_chunk = xcd ? (int)((groups + 7) / 8) : 0;
+    const size_t grid = xcd ? (size_t)L.xcd_chunk * 8 : groups;
     (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
-    hipLaunchKernelGGL((icgn2d_kernel<DOF, G>), dim3((unsigned)count), dim3(64), lds, stream, p, pois, stride_f,
-                       (unsigned long long)count, nt);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), lds, stream, p, pois, L);
     return hipGetLastError();
 }
 
-int icgn2d_max_samples(int) { return kIcgn2dMaxNT * kWave; }
+#define OC_ICGN2D_VARIANTS(X) \
+    X(0, 3, 0, 0, 1, 1)       \
+    X(1, 4, 0, 0, 1, 1)       \
+    X(2, 2, 0, 1, 1, 1)       \
+    X(3, 2, 1, 1, 1, 4)       \
+    X(4, 3, 1, 0, 1, 4)       \
+    X(5, 2, 1, 1, 4, 4)       \
+    X(6, 3, 1, 0, 4, 4)       \
+    X(7, 4, 1, 0, 1, 3)       \
+    X(8, 2, 0, 1, 4, 1)       \
+    X(9, 3, 1, 1, 1, 3)       \
+    X(10, 2, 1, 0, 1, 4)      \
+    X(11, 2, 1, 0, 4, 4)
 
-// gather depth G (LUT entries in flight per lane).  OC_HIP_ICGN_GATHER overrides the default,
-// which prefers a group size that divides the per-lane sample count.
-static int pick_gather(int nt) {
-    static const int forced = [] {
-        const char* e = getenv("OC_HIP_ICGN_GATHER");
-        return e ? atoi(e) : 0;
-    }();
-    if (forced == 2 || forced == 3 || forced == 4 || forced == 6 || forced == 8) return forced;
-    return (nt % 4 == 0) ? 4 : ((nt % 3 == 0) ? 3 : 4);
-}
+constexpr int kIcgn2dVariants = 12;
 
-template <int DOF>
-static hipError_t launch_dof(const Icgn2dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
-    if (count == 0) return hipSuccess;
-    const int N = (2 * p.rx + 1) * (2 * p.ry + 1);
-    const int nt = (N + 63) / 64;
-    if (nt > kIcgn2dMaxNT) return hipErrorInvalidValue;
-    switch (pick_gather(nt)) {
-        case 2: return launch_t<DOF, 2>(p, pois, stride_f, count, nt, stream);
-        case 3: return launch_t<DOF, 3>(p, pois, stride_f, count, nt, stream);
-        case 6: return launch_t<DOF, 6>(p, pois, stride_f, count, nt, stream);
-        case 8: return launch_t<DOF, 8>(p, pois, stride_f, count, nt, stream);
-        default: return launch_t<DOF, 4>(p, pois, stride_f, count, nt, stream);
+int icgn2d_variant_count() { return kIcgn2dVariants; }
+
+int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int* occ) {
+    switch (variant) {
+#define X(ID, GG, MM, PP, WW, OO) \
+    case ID: *g = GG; *mode = MM; *pipe = PP; *wpb = WW; *occ = OO; return 0;
+        OC_ICGN2D_VARIANTS(X)
+#undef X
+        default: return -1;
     }
 }
 
-hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
-    return launch_dof<6>(p, pois, stride_f, count, stream);
+// largest sample count a variant can hold in LDS
+int icgn2d_max_samples(int variant) {
+    int g, mode, pipe, wpb, occ;
+    if (icgn2d_variant_info(variant, &g, &mode, &pipe, &wpb, &occ)) return 0;
+    const int arrays = mode == 0 ? 4 : 2;
+    return kLdsBudget / (arrays * wpb * (int)sizeof(float) * kWave) * kWave;
 }
 
-hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
-    return launch_dof<12>(p, pois, stride_f, count, stream);
+template <int DOF>
+static hipError_t launch_dof(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
+                             hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    const int N = (2 * p.rx + 1) * (2 * p.ry + 1);
+    const int nt = (N + 63) / 64;
+    switch (variant) {
+#define X(ID, GG, MM, PP, WW, OO) \
+    case ID: return launch_t<DOF, GG, MM, PP, WW, OO>(p, pois, stride_f, count, nt, xcd, stream);
+        OC_ICGN2D_VARIANTS(X)
+#undef X
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
+                          hipStream_t stream) {
+    return launch_dof<6>(p, pois, stride_f, count, variant, xcd, stream);
+}
+
+hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
+                          hipStream_t stream) {
+    return launch_dof<12>(p, pois, stride_f, count, variant, xcd, stream);
 }
 
 }  // namespace ochip

@@ -28,18 +28,32 @@ constexpr int X = 0, Y = 1, Z = 2, P = 3, U = 3, V = 7, W = 11, U0 = 15, V0 = 16
 constexpr int FLOATS = 31;
 }  // namespace poi3d
 
-// xor-butterfly all-reduce over the 64 lanes of a wave, ascending offsets.
-// a + b is commutative in IEEE arithmetic, so both partners compute the same
-// bits and every lane ends with the same value.
-__device__ __forceinline__ float wave_allreduce_sum(float v) {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) v = v + __shfl_xor(v, off, kWave);
-    return v;
-}
-
 // broadcast lane `src`'s value as a wave-uniform value
 __device__ __forceinline__ float wave_bcast(float v, int src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+
+// DPP lane permutation inside a row of 16 lanes (no LDS crossbar, unlike ds_bpermute)
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// xor-butterfly all-reduce over the 64 lanes of a wave, ascending offsets 1, 2, 4, ... 32.
+// a + b is commutative in IEEE arithmetic, so both partners compute the same bits and
+// every lane ends with the same value.  Levels 1 and 2 are quad permutes; after them
+// the value is uniform inside each quad, so pairing lane i with 7-i (row_half_mirror)
+// adds the same two quad sums as pairing it with i^4, and likewise row_mirror for i^8.
+// The four 16-lane row sums are then combined as (r0 + r1) + (r2 + r3), which is what
+// offsets 16 and 32 compute.  Bit-identical to the __shfl_xor butterfly, 4 DPP adds +
+// 4 v_readlane instead of 6 ds_bpermute round trips.
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+    v = v + dpp_perm<0xB1>(v);   // quad_perm [1,0,3,2]  == xor 1
+    v = v + dpp_perm<0x4E>(v);   // quad_perm [2,3,0,1]  == xor 2
+    v = v + dpp_perm<0x141>(v);  // row_half_mirror       ~= xor 4
+    v = v + dpp_perm<0x140>(v);  // row_mirror            ~= xor 8
+    const float r0 = wave_bcast(v, 0), r1 = wave_bcast(v, 16), r2 = wave_bcast(v, 32), r3 = wave_bcast(v, 48);
+    return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }

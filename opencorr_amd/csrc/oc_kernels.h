@@ -21,11 +21,18 @@ struct Icgn2dParams {
     int rx, ry;
     float conv, stop;
 };
-// returns hipErrorInvalidValue if the subset does not fit the register-resident kernels
-hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);
-hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);
-// largest (2rx+1)*(2ry+1) the ICGN2D kernels accept
-int icgn2d_max_samples(int dof);
+// The ICGN2D kernels exist in several bit-identical variants (gather depth, LDS footprint,
+// software pipelining, waves per workgroup; icgn2d.hip).  `variant` indexes that table,
+// `xcd` turns on the XCD-contiguous mapping of workgroups to the POI queue.
+// Returns hipErrorInvalidValue if the subset does not fit the variant's LDS budget.
+hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, int variant, bool xcd,
+                          hipStream_t stream);
+hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, int variant, bool xcd,
+                          hipStream_t stream);
+int icgn2d_variant_count();
+int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int* occ);
+// largest (2rx+1)*(2ry+1) a variant accepts
+int icgn2d_max_samples(int variant);
 
 // ---- prepare3d.hip ---------------------------------------------------------
 hipError_t launch_grad3d(const float* vol, int dz, int dy, int dx, float* gx, float* gy, float* gz, hipStream_t stream);

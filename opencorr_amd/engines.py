@@ -93,6 +93,10 @@ class _Engine:
         """Run on a caller-owned hipStream_t (0 / None = HIP's default stream, as torch reports it)."""
         capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(stream_handle or None)))
 
+    def set_tuning(self, key, value):
+        """Performance knob of the C-ABI (``oc_hip_set_tuning``); results never change."""
+        capi.check(capi.lib().oc_hip_set_tuning(self._h, key.encode(), int(value)))
+
     def reset_stream(self):
         capi.check(capi.lib().oc_hip_reset_stream(self._h))
 

@@ -1,0 +1,111 @@
+#!/usr/bin/env python
+"""Times every ICGN2D kernel variant (x XCD mapping on/off) on one workload and checks that
+all of them produce the same bits (against variant 0 on the GPU, and against the CPU oracle
+on a strided sample of the queue).
+
+    python tools/icgn_sweep.py [--size 4096 --pois 500 --radius 16 --engine 1 --launches 3]
+                               [--variants 0,3,4] [--out gpurun_out/sweep.json]
+
+Test/bench infrastructure only: the oracle import is the checker.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--pois", type=int, default=500)
+    ap.add_argument("--radius", type=int, default=16)
+    ap.add_argument("--engine", type=int, default=1, help="1 = ICGN2D1, 2 = ICGN2D2")
+    ap.add_argument("--launches", type=int, default=3)
+    ap.add_argument("--variants", default="")
+    ap.add_argument("--xcd", default="0,1")
+    ap.add_argument("--oracle-sample", type=int, default=4000)
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+
+    import torch
+    import opencorr_amd
+    from opencorr_amd import synth
+
+    dev = torch.device("cuda", 0)
+    r = args.radius
+    so = dict(uxx=2e-6, vyy=-1e-6) if args.engine == 2 else None
+    ref, tar = synth.speckle_pair_2d(args.size, args.size, seed=20260925, device=dev, second_order=so)
+    xs, ys = synth.poi_grid_2d(args.size, args.size, args.pois, args.pois, r + 8)
+    stream = torch.cuda.current_stream().cuda_stream
+    fftcc = opencorr_amd.FFTCC2D(r, r)
+    fftcc.set_stream(stream)
+    fftcc.set_images(ref, tar)
+    Icgn = opencorr_amd.ICGN2D1 if args.engine == 1 else opencorr_amd.ICGN2D2
+    icgn = Icgn(r, r, 0.001, 10.0)
+    icgn.set_stream(stream)
+    icgn.share_images(fftcc)
+    icgn.prepare()
+    start = torch.from_numpy(opencorr_amd.make_pois2d(xs, ys)).to(dev)
+    fftcc.compute(start)
+    torch.cuda.synchronize()
+    pois = start.clone()
+
+    nvar = 12
+    variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(nvar))
+    xcds = [int(v) for v in args.xcd.split(",")]
+    base = None
+    rows = []
+    for v in variants:
+        for x in xcds:
+            icgn.set_tuning("icgn2d_variant", v)
+            icgn.set_tuning("icgn2d_xcd", x)
+            try:
+                pois.copy_(start)
+                icgn.compute(pois)  # warm-up (code object load, LDS attribute)
+                torch.cuda.synchronize()
+            except opencorr_amd.capi.OpenCorrHipError as e:
+                rows.append(dict(variant=v, xcd=x, error=str(e)))
+                print(rows[-1], flush=True)
+                continue
+            icgn.profile_reset()
+            icgn.profile_enable(True)
+            for _ in range(args.launches):
+                pois.copy_(start)
+                icgn.compute(pois)
+            ms, n = icgn.profile_read()
+            icgn.profile_enable(False)
+            got = pois.cpu().numpy()
+            if base is None:
+                base = got
+            same = bool(np.array_equal(got.view(np.uint32), base.view(np.uint32)))
+            rows.append(dict(variant=v, xcd=x, ms=ms / max(n, 1), launches=n, same_bits_as_first=same,
+                             converged=int((got[:, 16] >= 0).sum()), mean_iter=float(got[:, 17].mean())))
+            print(rows[-1], flush=True)
+
+    # oracle check of the common result on a strided sample
+    import oracle
+    step = max(1, len(xs) // args.oracle_sample)
+    sample = start.cpu().numpy()[::step].copy()
+    prep = oracle.Prepared2D(ref.cpu().numpy(), tar.cpu().numpy())
+    fn = oracle.icgn2d1 if args.engine == 1 else oracle.icgn2d2
+    fn(prep, r, r, 0.001, 10.0, sample, order=oracle.ORDER_LANES, lanes=64)
+    ok = bool(np.array_equal(sample.view(np.uint32), base[::step].view(np.uint32)))
+    summary = dict(workload="%dx%d r=%d %dx%d POIs engine ICGN2D%d" % (args.size, args.size, r, args.pois, args.pois,
+                                                                        args.engine),
+                   oracle_sample=len(sample), oracle_bit_exact=ok, rows=rows)
+    print(json.dumps(summary), flush=True)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, "w") as f:
+            json.dump(summary, f, indent=1)
+    if not ok or not all(r_.get("same_bits_as_first", True) for r_ in rows):
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
