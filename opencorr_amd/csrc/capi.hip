@@ -131,8 +131,8 @@ struct oc_hip_engine {
     FftPlans fft;
     DevBuf win, freq, norms, flags;
     // kernel selection (oc_hip_set_tuning); every choice computes the same bits
-    int icgn2d_variant = 0;
-    int icgn2d_xcd = 0;
+    int icgn2d_variant = 11;  // G = 2, LDS-light, 4 waves per workgroup (MI355X sweep)
+    int icgn2d_xcd = 1;
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
