@@ -133,6 +133,7 @@ struct oc_hip_engine {
     // kernel selection (oc_hip_set_tuning); every choice computes the same bits
     int icgn2d_variant = 11;  // G = 2, LDS-light, 4 waves per workgroup (MI355X sweep)
     int icgn2d_xcd = 1;
+    int fftcc2d_fused = 1;    // single-kernel FFTCC2D when the window is 32 x 32
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -175,6 +176,9 @@ int create_engine(int kind, int rx, int ry, int rz, float conv, float stop, int 
     e->rz = rz;
     e->conv = conv;
     e->stop = stop;
+    // MI355X sweep (profiles/r01b_icgn2d*_variant_sweep.json): 12 DoF keeps more registers live, so
+    // the single-wave G = 4 variant wins there
+    if (kind == OC_HIP_ICGN2D2) e->icgn2d_variant = 7;
     OC_HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     *out = e.release();
@@ -259,6 +263,18 @@ int ensure_fft(oc_hip_engine* e, size_t chunk) {
 int run_fftcc2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     if (!e->img || e->img->ndim != 2) return fail(OC_HIP_ERR_INVALID, "FFTCC2D: set_images2d has not been called");
     const ImagePair& im = *e->img;
+    if (e->fftcc2d_fused && ochip::fftcc2d_fused_supported(e->rx, e->ry)) {
+        ochip::Fftcc2dParams P = {im.ref_ptr(), im.tar_ptr(), im.dy, im.dx, e->rx, e->ry};
+        ProfScope prof(e);
+        const size_t kMaxBatch = 1u << 30;
+        for (size_t first = 0; first < count; first += kMaxBatch) {
+            const size_t n = (count - first) < kMaxBatch ? (count - first) : kMaxBatch;
+            hipError_t err = ochip::launch_fftcc2d_fused(P, d_pois + first * (size_t)stride_f, stride_f, n,
+                                                         e->icgn2d_xcd != 0, e->stream);
+            if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "fused FFTCC2D launch failed: %s", hipGetErrorString(err));
+        }
+        return OC_HIP_OK;
+    }
     const size_t chunk = count < fftcc_chunk_limit() ? count : fftcc_chunk_limit();
     if (chunk == 0) return OC_HIP_OK;
     OC_TRY(ensure_fft(e, chunk));
@@ -584,8 +600,10 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
         if (value < 0 || value >= ochip::icgn2d_variant_count())
             return fail(OC_HIP_ERR_INVALID, "icgn2d_variant %d out of range [0,%d)", value, ochip::icgn2d_variant_count());
         e->icgn2d_variant = value;
-    } else if (k == "icgn2d_xcd") {
+    } else if (k == "icgn2d_xcd" || k == "xcd") {
         e->icgn2d_xcd = value != 0;
+    } else if (k == "fftcc2d_fused") {
+        e->fftcc2d_fused = value != 0;
     } else {
         return fail(OC_HIP_ERR_INVALID, "unknown tuning key '%s'", key);
     }

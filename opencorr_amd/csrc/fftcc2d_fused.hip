@@ -1,0 +1,230 @@
+// fftcc2d_fused.hip -- FFTCC2D for 32 x 32 windows (subset radius 16) in ONE kernel.
+//
+// FFTCC2D::compute(POI2D*) (src/oc_fftcc.cpp:177-275) needs, per POI, two 2-D real FFTs, a
+// spectrum product and one inverse FFT of a 4 KB window.  The rocFFT pipeline of fftcc2d.hip
+// moves ~50 KB per POI through HBM between five kernels; here one wavefront keeps the whole
+// POI on chip:
+//   gather (coalesced rows, same arithmetic as fftcc2d_gather_kernel: bit-identical means
+//   and norms)  ->  z = ref + i*tar  ->  ONE complex 32x32 FFT in LDS/registers  ->
+//   R(k) = (Z(k) + conj Z(-k))/2, T(k) = (Z(k) - conj Z(-k))/(2i), C = conj(R) T  ->
+//   inverse complex FFT (unnormalised, like FFTW's c2r)  ->  arg-max with the first-max
+//   rule, wrap, ZNCC.
+// A length-32 transform is one decimation-in-frequency radix-2 step (done while reading the
+// row/column from LDS, each of the two lanes that share a row taking the even or the odd
+// outputs) followed by a 16-point FFT held in registers.  LDS: 32 rows x 33 complex (pitch
+// 33 keeps both the row and the column accesses conflict-free), 8448 B per wave.
+// Integer outputs (u, v) are what the reference computes; the float ZNCC differs from
+// FFTW's in the last bits like any other FFT implementation (tested to 1e-5 against the
+// oracle's double-precision DFT).
+#include "oc_device.h"
+#include "oc_kernels.h"
+
+namespace ochip {
+
+namespace {
+
+constexpr int FN = 32;               // window side (2 * radius)
+constexpr int FP = FN + 1;           // LDS row pitch in complex elements
+constexpr int FWAVE_LDS = FN * FP;   // float2 elements per wave
+constexpr int kFusedWaves = 4;       // POIs (waves) per workgroup
+
+__device__ constexpr float kCos16[8] = {1.000000000e+00f, 9.238795325e-01f, 7.071067812e-01f, 3.826834324e-01f, 6.123233996e-17f, -3.826834324e-01f, -7.071067812e-01f, -9.238795325e-01f};
+__device__ constexpr float kSin16[8] = {0.000000000e+00f, 3.826834324e-01f, 7.071067812e-01f, 9.238795325e-01f, 1.000000000e+00f, 9.238795325e-01f, 7.071067812e-01f, 3.826834324e-01f};
+__device__ constexpr float kCos32[16] = {1.000000000e+00f, 9.807852804e-01f, 9.238795325e-01f, 8.314696123e-01f, 7.071067812e-01f, 5.555702330e-01f, 3.826834324e-01f, 1.950903220e-01f, 6.123233996e-17f, -1.950903220e-01f, -3.826834324e-01f, -5.555702330e-01f, -7.071067812e-01f, -8.314696123e-01f, -9.238795325e-01f, -9.807852804e-01f};
+__device__ constexpr float kSin32[16] = {0.000000000e+00f, 1.950903220e-01f, 3.826834324e-01f, 5.555702330e-01f, 7.071067812e-01f, 8.314696123e-01f, 9.238795325e-01f, 9.807852804e-01f, 1.000000000e+00f, 9.807852804e-01f, 9.238795325e-01f, 8.314696123e-01f, 7.071067812e-01f, 5.555702330e-01f, 3.826834324e-01f, 1.950903220e-01f};
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// d * exp(-/+ i*angle) with (c, s) = (cos, sin) of the angle; INV selects the + sign
+template <bool INV>
+__device__ __forceinline__ float2 cmul_tw(float2 d, float c, float s) {
+#pragma clang fp contract(fast)
+    if (INV) return make_float2(d.x * c - d.y * s, d.y * c + d.x * s);
+    return make_float2(d.x * c + d.y * s, d.y * c - d.x * s);
+}
+
+// 16-point FFT in registers: radix-2 decimation in frequency, X[k] ends in v[bitrev4(k)]
+template <bool INV>
+__device__ __forceinline__ void fft16(float2 (&v)[16]) {
+#pragma unroll
+    for (int span = 8; span >= 1; span >>= 1) {
+#pragma unroll
+        for (int i0 = 0; i0 < 16; i0++) {
+            if (i0 & span) continue;
+            const int i1 = i0 + span;
+            const int m = (i0 & (span - 1)) * (8 / span);  // twiddle W16^m
+            const float2 a = v[i0], b = v[i1];
+            v[i0] = cadd(a, b);
+            const float2 d = csub(a, b);
+            if (m == 0) v[i1] = d;
+            else if (m == 4) v[i1] = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+            else v[i1] = cmul_tw<INV>(d, kCos16[m], kSin16[m]);
+        }
+    }
+}
+
+__device__ constexpr int bitrev4(int k) { return ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3); }
+
+// One length-32 transform along a line of the LDS tile.  The lane reads elements n and n+16
+// (n = 0..15) at `line + n*step`, forms its half of the first radix-2 stage (h = 0: sums ->
+// even outputs, h = 1: twiddled differences -> odd outputs) and finishes with fft16; output
+// k of the lane is X[2k + h], left in v[bitrev4(k)].
+template <bool INV>
+__device__ __forceinline__ void fft32_line(const float2* line, int step, int h, float2 (&v)[16]) {
+    const float sgn = h ? -1.f : 1.f;
+#pragma unroll
+    for (int n = 0; n < 16; n++) {
+        const float2 x0 = line[n * step], x1 = line[(n + 16) * step];
+        const float2 d = make_float2(x0.x + sgn * x1.x, x0.y + sgn * x1.y);
+        const float c = h ? kCos32[n] : 1.f, s = h ? kSin32[n] : 0.f;
+        v[n] = (n == 0) ? d : cmul_tw<INV>(d, c, s);
+    }
+    fft16<INV>(v);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64 * kFusedWaves) void fftcc2d_fused32_kernel(Fftcc2dParams P, float* __restrict__ pois,
+                                                                           int stride_f, unsigned long long count,
+                                                                           int xcd_chunk) {
+    __shared__ float2 lds[kFusedWaves * FWAVE_LDS];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned long long grp = blockIdx.x;
+    if (xcd_chunk > 0) grp = (unsigned long long)(blockIdx.x & 7u) * xcd_chunk + (blockIdx.x >> 3);
+    const unsigned long long idx = grp * kFusedWaves + wave;
+    if (idx >= count) return;
+    float2* buf = lds + wave * FWAVE_LDS;
+    float* poi = pois + idx * (unsigned long long)stride_f;
+    const float px = poi[poi2d::X], py = poi[poi2d::Y];
+    const float gu = poi[poi2d::U], gv = poi[poi2d::V];
+    const int rx = FN / 2, ry = FN / 2, width = P.width, height = P.height;
+    constexpr int M = FN * FN;
+
+    // bounds guard: the reference returns silently and leaves the POI untouched (src/oc_fftcc.cpp:190-196)
+    if ((int)px < rx || (int)px >= width - rx || (int)py < ry || (int)py >= height - ry || (int)(px + gu) < rx ||
+        (int)(px + gu) >= width - rx || (int)(py + gv) < ry || (int)(py + gv) >= height - ry)
+        return;
+
+    // ---- window fill, means, zero-mean, sums of squares (src/oc_fftcc.cpp:198-231); sample
+    // s = r*32 + c is owned by lane (s mod 64), exactly like fftcc2d_gather_kernel
+    float rn, tn;
+    {
+        float a[16], b[16];
+        float rsum = 0.f, tsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int s = lane + kWave * k;
+            const int r = s >> 5, c = s & 31;
+            const float rxp = px + c - rx, ryp = py + r - ry;
+            a[k] = P.ref[(size_t)(int)ryp * width + (int)rxp];
+            const float txp = rxp + gu, typ = ryp + gv;
+            b[k] = P.tar[(size_t)(int)typ * width + (int)txp];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            rsum += a[k];
+            tsum += b[k];
+        }
+        const float rmean = wave_allreduce_sum(rsum) / M;
+        const float tmean = wave_allreduce_sum(tsum) / M;
+        rn = 0.f;
+        tn = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int s = lane + kWave * k;
+            const float x = a[k] - rmean, y = b[k] - tmean;
+            rn += x * x;
+            tn += y * y;
+            buf[(s >> 5) * FP + (s & 31)] = make_float2(x, y);
+        }
+        rn = wave_allreduce_sum(rn);
+        tn = wave_allreduce_sum(tn);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int line = lane & 31, h = lane >> 5;
+    float2 v[16];
+    // ---- forward rows: lane (y, h) -> Z1[y][2k + h]
+    fft32_line<false>(buf + line * FP, 1, h, v);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 16; k++) buf[line * FP + 2 * k + h] = v[bitrev4(k)];
+    __builtin_amdgcn_wave_barrier();
+    // ---- forward columns: lane (x, h) -> Z[2k + h][x]
+    fft32_line<false>(buf + line, FP, h, v);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 16; k++) buf[(2 * k + h) * FP + line] = v[bitrev4(k)];
+    __builtin_amdgcn_wave_barrier();
+    // ---- spectra of the two real windows and their product conj(R) * T (src/oc_fftcc.cpp:236-241)
+    {
+        const int mx = (FN - line) & (FN - 1);
+        float2 zm[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) zm[k] = buf[((FN - (2 * k + h)) & (FN - 1)) * FP + mx];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float2 z = v[bitrev4(k)];
+            const float rr = 0.5f * (z.x + zm[k].x), ri = 0.5f * (z.y - zm[k].y);
+            const float tr = 0.5f * (z.y + zm[k].y), ti = -0.5f * (z.x - zm[k].x);
+            float2 cc;
+            cc.x = (rr * tr) + (ri * ti);
+            cc.y = (rr * ti) - (ri * tr);
+            buf[(2 * k + h) * FP + line] = cc;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- inverse rows, inverse columns (unnormalised)
+    fft32_line<true>(buf + line * FP, 1, h, v);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 16; k++) buf[line * FP + 2 * k + h] = v[bitrev4(k)];
+    __builtin_amdgcn_wave_barrier();
+    fft32_line<true>(buf + line, FP, h, v);
+
+    // ---- arg-max with "strict >, scanning from index 0" (src/oc_fftcc.cpp:246-255): the lane's
+    // 16 surface values sit at linear indices (2k + h)*32 + x, ascending in k
+    float best = -2.f;
+    int bidx = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const float val = v[bitrev4(k)].x;
+        if (val > best) { best = val; bidx = (2 * k + h) * FN + line; }
+    }
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const float ov = __shfl_xor(best, off, kWave);
+        const int oi = __shfl_xor(bidx, off, kWave);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (lane == 0) {
+        int du = bidx % FN, dv = bidx / FN;
+        if (du > rx) du -= FN;
+        if (dv > ry) dv -= FN;
+        poi[poi2d::U] = (float)du + gu;
+        poi[poi2d::V] = (float)dv + gv;
+        poi[poi2d::U0] = gu;
+        poi[poi2d::V0] = gv;
+        poi[poi2d::ZNCC] = best / (sqrtf(rn * tn) * M);
+    }
+}
+
+bool fftcc2d_fused_supported(int rx, int ry) { return rx == FN / 2 && ry == FN / 2; }
+
+hipError_t launch_fftcc2d_fused(const Fftcc2dParams& p, float* pois, int stride_f, size_t count, bool xcd,
+                                hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    if (!fftcc2d_fused_supported(p.rx, p.ry)) return hipErrorInvalidValue;
+    const size_t groups = (count + kFusedWaves - 1) / kFusedWaves;
+    const int chunk = xcd ? (int)((groups + 7) / 8) : 0;
+    const size_t grid = xcd ? (size_t)chunk * 8 : groups;
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
+    hipLaunchKernelGGL(fftcc2d_fused32_kernel, dim3((unsigned)grid), dim3(64 * kFusedWaves), 0, stream, p, pois, stride_f,
+                       (unsigned long long)count, chunk);
+    return hipGetLastError();
+}
+
+}  // namespace ochip

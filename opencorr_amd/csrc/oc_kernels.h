@@ -74,6 +74,12 @@ hipError_t launch_fftcc_conjmul(const float2* rf, const float2* tf, float2* zf, 
 hipError_t launch_fftcc2d_argmax(const Fftcc2dParams& p, const float* surf, const float* norms, const int* flags,
                                  float* pois, int stride_floats, size_t count, hipStream_t stream);
 
+// ---- fftcc2d_fused.hip -----------------------------------------------------
+// whole FFTCC2D::compute for 32 x 32 windows (rx == ry == 16) in one kernel, no rocFFT, no scratch
+bool fftcc2d_fused_supported(int rx, int ry);
+hipError_t launch_fftcc2d_fused(const Fftcc2dParams& p, float* pois, int stride_floats, size_t count, bool xcd,
+                                hipStream_t stream);
+
 // ---- fftcc3d.hip -----------------------------------------------------------
 struct Fftcc3dParams {
     const float* ref;

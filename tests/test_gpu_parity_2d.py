@@ -76,6 +76,53 @@ def test_fftcc2d_matches_oracle(eng, speckle_small, rx, ry):
     assert np.array_equal(_bits(got[:, untouched]), _bits(want[:, untouched]))
 
 
+def test_fftcc2d_fused_kernel_matches_rocfft_pipeline(eng, speckle_small):
+    """rx = ry = 16 runs the single-kernel LDS FFT by default; the rocFFT pipeline must agree:
+    identical integer results, ZNCC to float rounding, guarded POIs untouched."""
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    xs, ys = synth.poi_grid_2d(h, w, 31, 29, 24)
+    xs = np.concatenate([xs, [3, w - 2, 150]]).astype(np.float32)
+    ys = np.concatenate([ys, [100, 100, 2]]).astype(np.float32)
+    base = eng.make_pois2d(xs, ys)
+    base[::7, 2] = 1.0   # non-zero initial guesses shift the target window (src/oc_fftcc.cpp:215-216)
+    base[::5, 8] = -2.0
+    f = eng.FFTCC2D(16, 16)
+    f.set_images(ref, tar)
+    fused = f.compute(base.copy())
+    f.set_tuning("fftcc2d_fused", 0)
+    piped = f.compute(base.copy())
+    for col in (2, 8, 14, 15):
+        assert np.array_equal(fused[:, col], piped[:, col]), col
+    assert np.abs(fused[:, 16] - piped[:, 16]).max() <= 2e-6
+    other = [c for c in range(25) if c not in (2, 8, 14, 15, 16)]
+    assert np.array_equal(_bits(fused[:, other]), _bits(base[:, other]))
+    assert np.array_equal(_bits(fused[-3:]), _bits(base[-3:]))
+    assert (fused[:-3, 16] > 0.5).mean() > 0.9
+
+
+@pytest.mark.parametrize("variant,xcd", [(0, 0), (4, 1), (6, 1), (11, 0), (2, 1)])
+def test_icgn2d1_variants_identical_bits(eng, speckle_small, variant, xcd):
+    """Every kernel variant / workgroup mapping of oc_hip_set_tuning computes the same bits."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 19, 23, 26)
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, 16, 16, pois)
+    want = pois.copy()
+    prep = oracle.Prepared2D(ref, tar)
+    oracle.icgn2d1(prep, 16, 16, 0.001, 10, want, order=oracle.ORDER_LANES, lanes=64)
+    icgn = eng.ICGN2D1(16, 16, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    icgn.set_tuning("icgn2d_variant", variant)
+    icgn.set_tuning("icgn2d_xcd", xcd)
+    got = icgn.compute(pois.copy())
+    assert np.array_equal(_bits(got), _bits(want))
+
+
 @pytest.mark.parametrize("rx,ry", [(16, 16), (15, 15), (7, 9), (20, 20)])
 def test_icgn2d1_bit_exact_vs_oracle(eng, speckle_small, rx, ry):
     import oracle

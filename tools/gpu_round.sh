@@ -1,0 +1,18 @@
+#!/bin/bash
+# GPU-box session: parity tests, bench line, rocprofv3 kernel-trace summary of the bench.
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r01c}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+export TMPDIR=/tmp
+echo "== pytest -m gpu"
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/pytest.log
+echo "== bench"
+timeout 900 python bench.py --steps 10 --warmup 2 2>&1 | tail -3 | tee $OUT/bench.log
+cd /tmp
+echo "== rocprofv3 kernel trace of the bench"
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+tail -2 $OUT/bench_under_rocprof.log
+ls $OUT/prof | head
+python $ROOT/tools/rocpd_summary.py $(ls $OUT/prof/*.db | head -1) $OUT/kernel_stats.csv 2>&1 | head -14
