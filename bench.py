@@ -37,6 +37,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# HBM bytes per ICGN2D1 launch of THIS workload from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in their
+# own runs, corrected as the guide prescribes); written by tools/pmc_traffic.py, see tools/gpu_round.sh
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "icgn2d1_hbm_traffic_configB.json")
 RX = RY = 16
 CONV, STOP = 0.001, 10.0
 POIS_PER_GPU_SIDE = 500
@@ -186,7 +189,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(world),
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE; compare with algorithmic_bytes_per_launch)",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": icgn_avg_ms,
                 "launches_timed": icgn_launches,
@@ -203,6 +207,14 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(world):
+    """HBM bytes per ICGN launch from the committed PMC record (collected on the N = 1 workload)."""
+    if world != 1 or not os.path.exists(TRAFFIC_JSON):
+        return None
+    with open(TRAFFIC_JSON) as f:
+        return float(json.load(f)["hbm_bytes_per_launch"])
 
 
 def cpu_baseline(ref, tar, xs, ys, sample):
