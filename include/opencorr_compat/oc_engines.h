@@ -15,7 +15,8 @@
 //   * images are snapshotted to HBM when needed (first prepare()/compute() after setImages);
 //     editing the host image afterwards requires setImages() again, as with the reference's CUDA
 //     module (examples/test_2d_dic_gpu_icgn.cpp:99-136);
-//   * self_adaptive subsets are not supported by the GPU engines yet.
+//   * setSelfAdaptive(true) is honoured by ICGN2D1/ICGN2D2; a POI whose radius is negative is rejected
+//     with zncc = -3 (the reference would try to allocate a negative-sized subset).
 #pragma once
 
 #include <cstdlib>
@@ -60,10 +61,9 @@ public:
         subset_radius_y = radius_y;
         if (engine_) hipdetail::check(oc_hip_set_subset(engine_, radius_x, radius_y, 0));
     }
-    void setSelfAdaptive(bool is_self_adaptive) {
-        if (is_self_adaptive) throw std::string("self-adaptive subsets are not supported by the HIP engines");
-        self_adaptive = false;
-    }
+    // DIC::setSelfAdaptive (src/oc_dic.cpp:34-37).  Honoured by ICGN2D1/ICGN2D2 (per-POI radius from
+    // poi->subset_radius); FFTCC2D ignores it, as in the reference (src/oc_fftcc.cpp:177-275 never reads it).
+    virtual void setSelfAdaptive(bool is_self_adaptive) { self_adaptive = is_self_adaptive; }
     void setDevice(int device) { device_ = device; }
 
     virtual void prepare() = 0;
@@ -204,7 +204,30 @@ protected:
     float stop_condition = 10.f;
 };
 
-class ICGN2D1 : public IcgnShim<DIC, POI2D> {
+// the 2D extras of src/oc_icgn.h:75-76,130-131: centre-offset overloads and self-adaptive subsets
+class Icgn2DShim : public IcgnShim<DIC, POI2D> {
+public:
+    using IcgnShim<DIC, POI2D>::compute;
+    void setSelfAdaptive(bool is_self_adaptive) override {
+        hipdetail::check(oc_hip_set_self_adaptive(engine_, is_self_adaptive ? 1 : 0));
+        self_adaptive = is_self_adaptive;
+    }
+    void compute(POI2D* poi, Point2D& center_offset) {
+        uploadIfNeeded();
+        const float off[2] = {center_offset.x, center_offset.y};
+        hipdetail::check(oc_hip_compute_one_with_offset(engine_, poi, off));
+    }
+    void compute(std::vector<POI2D>& poi_queue, std::vector<Point2D>& center_offset_queue) {
+        if (center_offset_queue.size() < poi_queue.size()) throw std::string("center_offset_queue is shorter than poi_queue");
+        uploadIfNeeded();
+        static_assert(sizeof(Point2D) == 2 * sizeof(float), "Point2D must be two packed floats");
+        hipdetail::check(oc_hip_compute_with_offsets(engine_, poi_queue.data(),
+                                                     reinterpret_cast<const float*>(center_offset_queue.data()),
+                                                     poi_queue.size(), sizeof(POI2D), OC_HIP_HOST));
+    }
+};
+
+class ICGN2D1 : public Icgn2DShim {
 public:
     ICGN2D1(int rx, int ry, float conv_criterion_, float stop_condition_, int thread_number_) {
         subset_radius_x = rx;
@@ -216,7 +239,7 @@ public:
     }
 };
 
-class ICGN2D2 : public IcgnShim<DIC, POI2D> {
+class ICGN2D2 : public Icgn2DShim {
 public:
     ICGN2D2(int rx, int ry, float conv_criterion_, float stop_condition_, int thread_number_) {
         subset_radius_x = rx;

@@ -139,6 +139,17 @@ int oc_hip_compute(oc_hip_engine* engine, void* pois, size_t count, size_t strid
  * a mutex-guarded batch of one, safe to call from the caller's own OpenMP region
  * (src/oc_epipolar_search.cpp:184-188). */
 int oc_hip_compute_one(oc_hip_engine* engine, void* poi);
+/* ICGN2D1::compute(std::vector<POI2D>&, std::vector<Point2D>& center_offset_queue)  src/oc_icgn.cpp:549-557
+ * (ICGN2D2 :1128-1136): local subset coordinates are shifted by center_offsets[i] = {x, y} (two floats per POI,
+ * the reference's Point2D) and the target subset is centred at POI + offset.  The offsets live in the same
+ * memory space as the POIs. */
+int oc_hip_compute_with_offsets(oc_hip_engine* engine, void* pois, const float* center_offsets, size_t count,
+                                size_t stride_bytes, int memory);
+/* ICGN2D1::compute(POI2D*, Point2D& center_offset)  src/oc_icgn.cpp:353 (ICGN2D2 :910) */
+int oc_hip_compute_one_with_offset(oc_hip_engine* engine, void* poi, const float* center_offset);
+/* DIC::setSelfAdaptive(bool)  src/oc_dic.cpp:34-37: when on, ICGN2D1/2D2 take the subset radius of every POI from
+ * poi->subset_radius instead of the engine's (src/oc_icgn.cpp:152-158, 697-703) */
+int oc_hip_set_self_adaptive(oc_hip_engine* engine, int enable);
 /* wait for everything enqueued on the engine's stream */
 int oc_hip_synchronize(oc_hip_engine* engine);
 

@@ -126,12 +126,14 @@ struct oc_hip_engine {
     DevBuf gx, gy, gz, coef;  // coef: 2D LUT (16 floats / px) or 3D coefficient volume
     DevBuf tmp;               // scratch for layout conversion / 3D prefilter passes
     bool ref_ready = false, tar_ready = false;
-    DevBuf poi_stage;
+    DevBuf poi_stage, off_stage;
+    DevBuf cursors;  // small device scratch (batch maxima)
     // FFTCC working set
     FftPlans fft;
     DevBuf win, freq, norms, flags;
     // kernel selection (oc_hip_set_tuning); every choice computes the same bits
-    int icgn2d_variant = 11;  // G = 2, LDS-light, 4 waves per workgroup (MI355X sweep)
+    int icgn2d_variant = 5;   // G = 2, LDS-light, 4 waves per workgroup (MI355X sweep)
+    bool self_adaptive = false;  // DIC::setSelfAdaptive
     int icgn2d_xcd = 1;
     int fftcc2d_fused = 1;    // single-kernel FFTCC2D when the window is 32 x 32
     // profiling
@@ -178,7 +180,7 @@ int create_engine(int kind, int rx, int ry, int rz, float conv, float stop, int 
     e->stop = stop;
     // MI355X sweep (profiles/r01b_icgn2d*_variant_sweep.json): 12 DoF keeps more registers live, so
     // the single-wave G = 4 variant wins there
-    if (kind == OC_HIP_ICGN2D2) e->icgn2d_variant = 7;
+    if (kind == OC_HIP_ICGN2D2) e->icgn2d_variant = 3;
     OC_HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     *out = e.release();
@@ -318,28 +320,41 @@ int run_fftcc2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
 // ---------------------------------------------------------------------------
 // ICGN2D
 // ---------------------------------------------------------------------------
-int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
+int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, const float* d_offsets) {
     if (!e->img || e->img->ndim != 2) return fail(OC_HIP_ERR_INVALID, "ICGN2D: set_images2d has not been called");
     if (!e->ref_ready || !e->tar_ready)
         return fail(OC_HIP_ERR_INVALID, "ICGN2D: prepare() has not been called since the last set_images");
     const ImagePair& im = *e->img;
-    ochip::Icgn2dParams P = {im.ref_ptr(), e->gx.as<float>(), e->gy.as<float>(), e->coef.as<float>(),
-                             im.dy,        im.dx,              e->rx,             e->ry,
-                             e->conv,      e->stop};
     const int dof = e->kind == OC_HIP_ICGN2D1 ? 6 : 12;
-    const int N = (2 * e->rx + 1) * (2 * e->ry + 1);
+    int rx = e->rx, ry = e->ry;
+    if (e->self_adaptive) {
+        // every POI brings its own radius (src/oc_icgn.cpp:152-158): size the on-chip arrays for the largest
+        OC_TRY(e->cursors.reserve(2 * sizeof(int)));
+        OC_HIP_TRY(ochip::launch_poi2d_max_radius(d_pois, stride_f, count, e->cursors.as<int>(), e->stream));
+        int mx[2] = {0, 0};
+        OC_HIP_TRY(hipMemcpyAsync(mx, e->cursors.p, sizeof(mx), hipMemcpyDeviceToHost, e->stream));
+        OC_HIP_TRY(hipStreamSynchronize(e->stream));
+        rx = mx[0] > 0 ? mx[0] : 1;
+        ry = mx[1] > 0 ? mx[1] : 1;
+        if (rx > 4096 || ry > 4096) return fail(OC_HIP_ERR_UNSUPPORTED, "ICGN2D: self-adaptive subset radius %d x %d is not plausible", rx, ry);
+    }
+    ochip::Icgn2dParams P = {im.ref_ptr(), e->gx.as<float>(), e->gy.as<float>(), e->coef.as<float>(),
+                             im.dy,        im.dx,              rx,                ry,
+                             e->conv,      e->stop,            d_offsets,         e->self_adaptive ? 1 : 0};
+    const long long N = (2LL * rx + 1) * (2LL * ry + 1);
     // fall back to the LDS-light single-wave variant when the tuned one cannot hold the subset
     int variant = e->icgn2d_variant;
-    if (N > ochip::icgn2d_max_samples(variant)) variant = 4;
+    if (N > ochip::icgn2d_max_samples(variant)) variant = 1;
     if (N > ochip::icgn2d_max_samples(variant))
-        return fail(OC_HIP_ERR_UNSUPPORTED, "ICGN2D%d: subset %dx%d (%d samples) exceeds the on-chip limit of %d samples",
-                    dof == 6 ? 1 : 2, 2 * e->rx + 1, 2 * e->ry + 1, N, ochip::icgn2d_max_samples(variant));
+        return fail(OC_HIP_ERR_UNSUPPORTED, "ICGN2D%d: subset %dx%d (%lld samples) exceeds the on-chip limit of %d samples",
+                    dof == 6 ? 1 : 2, 2 * rx + 1, 2 * ry + 1, N, ochip::icgn2d_max_samples(variant));
     ProfScope prof(e);
-    // one wave-sized workgroup per POI; grid.x is limited to 2^31-1
+    // one wave per POI; grid.x is limited to 2^31-1
     const size_t kMaxGrid = 1u << 30;
     for (size_t first = 0; first < count; first += kMaxGrid) {
         const size_t n = (count - first) < kMaxGrid ? (count - first) : kMaxGrid;
         float* pois = d_pois + first * (size_t)stride_f;
+        if (d_offsets) P.offsets = d_offsets + 2 * first;
         hipError_t err = dof == 6 ? ochip::launch_icgn2d1(P, pois, stride_f, n, variant, e->icgn2d_xcd != 0, e->stream)
                                   : ochip::launch_icgn2d2(P, pois, stride_f, n, variant, e->icgn2d_xcd != 0, e->stream);
         if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "ICGN2D kernel launch failed: %s", hipGetErrorString(err));
@@ -415,11 +430,13 @@ int run_icgn3d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     return OC_HIP_OK;
 }
 
-int run_compute_device(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
+int run_compute_device(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, const float* d_offsets = nullptr) {
+    if (d_offsets && e->kind != OC_HIP_ICGN2D1 && e->kind != OC_HIP_ICGN2D2)
+        return fail(OC_HIP_ERR_INVALID, "center offsets are an ICGN2D1/ICGN2D2 feature (src/oc_icgn.h:75-76,130-131)");
     switch (e->kind) {
         case OC_HIP_FFTCC2D: return run_fftcc2d(e, d_pois, stride_f, count);
         case OC_HIP_ICGN2D1:
-        case OC_HIP_ICGN2D2: return run_icgn2d(e, d_pois, stride_f, count);
+        case OC_HIP_ICGN2D2: return run_icgn2d(e, d_pois, stride_f, count, d_offsets);
         case OC_HIP_FFTCC3D: return run_fftcc3d(e, d_pois, stride_f, count);
         case OC_HIP_ICGN3D1: return run_icgn3d1(e, d_pois, stride_f, count);
         default: return fail(OC_HIP_ERR_UNSUPPORTED, "engine kind %d has no device path yet", e->kind);
@@ -659,7 +676,7 @@ int oc_hip_prepare(oc_hip_engine* e) {
     return oc_hip_prepare_tar(e);
 }
 
-int oc_hip_compute(oc_hip_engine* e, void* pois, size_t count, size_t stride_bytes, int memory) {
+static int compute_impl(oc_hip_engine* e, void* pois, const float* offsets, size_t count, size_t stride_bytes, int memory) {
     OC_TRY(activate(e));
     if (count == 0) return OC_HIP_OK;
     if (!pois) return fail(OC_HIP_ERR_INVALID, "null POI buffer");
@@ -668,21 +685,54 @@ int oc_hip_compute(oc_hip_engine* e, void* pois, size_t count, size_t stride_byt
                     stride_bytes, e->poi_bytes());
     std::lock_guard<std::mutex> lock(e->mu);
     const int stride_f = (int)(stride_bytes / 4);
-    if (memory == OC_HIP_DEVICE) return run_compute_device(e, static_cast<float*>(pois), stride_f, count);
+    if (memory == OC_HIP_DEVICE) return run_compute_device(e, static_cast<float*>(pois), stride_f, count, offsets);
     // host queue: H2D of the AoS, kernels, D2H (the reference's CUDA module does the same,
     // examples/test_2d_dic_gpu_icgn.cpp:136-149)
     const size_t bytes = count * stride_bytes;
     OC_TRY(e->poi_stage.reserve(bytes));
     OC_HIP_TRY(hipMemcpyAsync(e->poi_stage.p, pois, bytes, hipMemcpyHostToDevice, e->stream));
-    OC_TRY(run_compute_device(e, e->poi_stage.as<float>(), stride_f, count));
+    const float* d_off = nullptr;
+    if (offsets) {
+        OC_TRY(e->off_stage.reserve(count * 2 * sizeof(float)));
+        OC_HIP_TRY(hipMemcpyAsync(e->off_stage.p, offsets, count * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        d_off = e->off_stage.as<float>();
+    }
+    OC_TRY(run_compute_device(e, e->poi_stage.as<float>(), stride_f, count, d_off));
     OC_HIP_TRY(hipMemcpyAsync(pois, e->poi_stage.p, bytes, hipMemcpyDeviceToHost, e->stream));
     OC_HIP_TRY(hipStreamSynchronize(e->stream));
     return OC_HIP_OK;
 }
 
+int oc_hip_compute(oc_hip_engine* e, void* pois, size_t count, size_t stride_bytes, int memory) {
+    OC_TRY(check_engine(e));
+    return compute_impl(e, pois, nullptr, count, stride_bytes, memory);
+}
+
+int oc_hip_compute_with_offsets(oc_hip_engine* e, void* pois, const float* center_offsets, size_t count,
+                                size_t stride_bytes, int memory) {
+    OC_TRY(check_engine(e));
+    if (!center_offsets) return fail(OC_HIP_ERR_INVALID, "null center-offset buffer");
+    return compute_impl(e, pois, center_offsets, count, stride_bytes, memory);
+}
+
 int oc_hip_compute_one(oc_hip_engine* e, void* poi) {
     OC_TRY(check_engine(e));
-    return oc_hip_compute(e, poi, 1, e->poi_bytes(), OC_HIP_HOST);
+    return compute_impl(e, poi, nullptr, 1, e->poi_bytes(), OC_HIP_HOST);
+}
+
+int oc_hip_compute_one_with_offset(oc_hip_engine* e, void* poi, const float* center_offset) {
+    OC_TRY(check_engine(e));
+    if (!center_offset) return fail(OC_HIP_ERR_INVALID, "null center offset");
+    return compute_impl(e, poi, center_offset, 1, e->poi_bytes(), OC_HIP_HOST);
+}
+
+int oc_hip_set_self_adaptive(oc_hip_engine* e, int enable) {
+    OC_TRY(check_engine(e));
+    if (e->kind != OC_HIP_ICGN2D1 && e->kind != OC_HIP_ICGN2D2)
+        return fail(OC_HIP_ERR_UNSUPPORTED, "self-adaptive subsets are implemented for ICGN2D1/ICGN2D2");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->self_adaptive = enable != 0;
+    return OC_HIP_OK;
 }
 
 int oc_hip_synchronize(oc_hip_engine* e) {

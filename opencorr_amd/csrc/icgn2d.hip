@@ -217,15 +217,17 @@ __device__ __forceinline__ void set_warp_2d2(float (&w)[36], const float (&q)[12
     w[30] = 0.f; w[31] = 0.f; w[32] = 0.f; w[33] = 0.f; w[34] = 0.f; w[35] = 1.f;
 }
 
-// steepest-descent row of one sample (src/oc_icgn.cpp:191-196; 2D2: 725-745)
+// steepest-descent row of one sample (src/oc_icgn.cpp:191-196; 2D2: 725-745; center-offset
+// overloads :390-398 / :953-972).  The local coordinates arrive as floats: without a centre
+// offset they are small integers, so the reference's integer products (xl*xl, :733-738) are
+// exact in float as well.
 template <int DOF>
-__device__ __forceinline__ void sd_row(float g_x, float g_y, int xl, int yl, float (&sd)[DOF]) {
-    const float fxl = (float)xl, fyl = (float)yl;
+__device__ __forceinline__ void sd_row(float g_x, float g_y, float fxl, float fyl, float (&sd)[DOF]) {
     if constexpr (DOF == 6) {
         sd[0] = g_x; sd[1] = g_x * fxl; sd[2] = g_x * fyl;
         sd[3] = g_y; sd[4] = g_y * fxl; sd[5] = g_y * fyl;
     } else {
-        const float xx = (float)(xl * xl) * 0.5f, xy = (float)(xl * yl), yy = (float)(yl * yl) * 0.5f;
+        const float xx = (fxl * fxl) * 0.5f, xy = fxl * fyl, yy = (fyl * fyl) * 0.5f;
         sd[0] = g_x; sd[1] = g_x * fxl; sd[2] = g_x * fyl; sd[3] = g_x * xx; sd[4] = g_x * xy; sd[5] = g_x * yy;
         sd[6] = g_y; sd[7] = g_y * fxl; sd[8] = g_y * fyl; sd[9] = g_y * xx; sd[10] = g_y * xy; sd[11] = g_y * yy;
     }
@@ -245,6 +247,12 @@ __device__ __forceinline__ void sd_row(float g_x, float g_y, int xl, int yl, flo
 // OCC  = minimum waves per SIMD the register allocation must allow.
 // Wave-uniform small matrices are kept one COLUMN per lane (lane j < n holds column j):
 // the inverse Hessian, and for 2D2 also the 6x6 warp matrix.
+// OFFS = the compute(poi_queue, center_offset_queue) overloads (src/oc_icgn.cpp:353-557,
+//        910-1136): local coordinates are shifted by a per-POI offset and the target subset is
+//        centred at POI + offset.
+// P.self_adaptive = DIC::setSelfAdaptive(true): every POI brings its own subset radius
+//        (poi->subset_radius, src/oc_icgn.cpp:152-158); L.nt then sizes the LDS arrays for the
+//        largest subset of the batch.
 // Every variant performs the same floating-point operations in the same order, so all
 // of them are bit-identical to the oracle in OC_ORDER_LANES.
 // ---------------------------------------------------------------------------
@@ -255,13 +263,13 @@ struct Icgn2dLaunch {
     unsigned long long count;  // POIs
 };
 
-template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC>
+template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC, int OFFS>
 __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, float* __restrict__ pois,
                                                                Icgn2dLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NH = DOF * (DOF + 1) / 2;
     constexpr int ARRAYS = MODE == 0 ? 4 : 2;
-    const int NT = L.nt;
+    const int NTA = L.nt;  // passes the LDS arrays are sized for (>= the passes of any POI)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD a
@@ -270,10 +278,10 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     if (L.xcd_chunk > 0) grp = (unsigned long long)(blockIdx.x & 7u) * L.xcd_chunk + (blockIdx.x >> 3);
     const unsigned long long idx = grp * WPB + wave;
     if (idx >= L.count) return;
-    float* __restrict__ l_rs = lds + (size_t)wave * ARRAYS * NT * kWave + lane;
-    float* __restrict__ l_ts = l_rs + NT * kWave;
-    float* __restrict__ l_gx = l_ts + NT * kWave;  // MODE 0 only
-    float* __restrict__ l_gy = l_gx + NT * kWave;
+    float* __restrict__ l_rs = lds + (size_t)wave * ARRAYS * NTA * kWave + lane;
+    float* __restrict__ l_ts = l_rs + NTA * kWave;
+    float* __restrict__ l_gx = l_ts + NTA * kWave;  // MODE 0 only
+    float* __restrict__ l_gy = l_gx + NTA * kWave;
 
     float* poi = pois + idx * (unsigned long long)L.stride_f;
     const float rec = lane < poi2d::FLOATS ? poi[lane] : 0.f;
@@ -281,7 +289,24 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     const float u_in = wave_bcast(rec, poi2d::U), ux_in = wave_bcast(rec, poi2d::UX), uy_in = wave_bcast(rec, poi2d::UY);
     const float v_in = wave_bcast(rec, poi2d::V), vx_in = wave_bcast(rec, poi2d::VX), vy_in = wave_bcast(rec, poi2d::VY);
     const float zncc_in = wave_bcast(rec, poi2d::ZNCC);
-    const int rx = P.rx, ry = P.ry, height = P.height, width = P.width;
+    const int height = P.height, width = P.width;
+    int rx = P.rx, ry = P.ry;
+    if (P.self_adaptive) {
+        // poi->subset_radius is a Point2D of floats; the reference passes it to int parameters
+        rx = (int)wave_bcast(rec, poi2d::SRX);
+        ry = (int)wave_bcast(rec, poi2d::SRY);
+        // a radius the batch was not sized for (negative, or changed behind the engine's back): the
+        // reference would reallocate; here the POI is rejected like any other unusable POI
+        if (rx < 0 || ry < 0 || (2 * rx + 1) * (2 * ry + 1) > NTA * kWave) {
+            if (lane == 0) poi[poi2d::ZNCC] = zncc_in >= 0 ? -3.f : zncc_in;
+            return;
+        }
+    }
+    float offx = 0.f, offy = 0.f;
+    if constexpr (OFFS) {
+        offx = uni(P.offsets[2 * idx]);
+        offy = uni(P.offsets[2 * idx + 1]);
+    }
 
     // guard, src/oc_icgn.cpp:160-167 (2D2: 705-712)
     if (py - ry < 0 || px - rx < 0 || py + ry > height - 1 || px + rx > width - 1 || fabsf(u_in) >= width ||
@@ -291,6 +316,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     }
     const int W = 2 * rx + 1, N = W * (2 * ry + 1);
     const float fN = (float)N;
+    const int NT = (N + kWave - 1) / kWave;
     const int NF = N / kWave;  // passes in which every lane owns a sample; pass NF (if any) is partial
     const int q64 = kWave / W, r64 = kWave - q64 * W;
     const int r0 = lane / W;
@@ -352,7 +378,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 l_gy[t * kWave] = g_y;
             }
             float sd[DOF];
-            sd_row<DOF>(g_x, g_y, w.c - rx, w.r - ry, sd);
+            sd_row<DOF>(g_x, g_y, (float)(w.c - rx) - offx, (float)(w.r - ry) - offy, sd);
             int k = 0;
 #pragma unroll
             for (int i = 0; i < DOF; i++)
@@ -397,6 +423,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             Wcol[i] = c;
         }
     }
+    const float tcx = px + offx, tcy = py + offy;  // centre of the target subset
     int iter = 0;
     float dp_norm = 0.f, znssd = 0.f;
     float cur[12];
@@ -422,7 +449,8 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
 #pragma unroll
                 for (int g = 0; g < G; g++, w.next()) {
                     valid[g] = w.s < N;
-                    const float xl = (float)(w.c - rx), yl = (float)(w.r - ry);
+                    // local_coor = (c - rx) - center_offset (src/oc_icgn.cpp:447-450); "- 0.f" is exact
+                    const float xl = (float)(w.c - rx) - offx, yl = (float)(w.r - ry) - offy;
                     float wx, wy;
                     if constexpr (DOF == 6) {
                         // Deformation2D1::warp, src/oc_deformation.cpp:94-105
@@ -440,7 +468,8 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                         }
                     }
                     // a lane past the end of the subset fetches a harmless in-range point
-                    lut_fetch(f[g], P.lut, height, width, valid[g] ? px + wx : 1.f, valid[g] ? py + wy : 1.f);
+                    // tar_subset->center = POI + center_offset, then + warped_coor (src/oc_icgn.cpp:425-426,452)
+                    lut_fetch(f[g], P.lut, height, width, valid[g] ? tcx + wx : 1.f, valid[g] ? tcy + wy : 1.f);
                 }
             };
             auto consume = [&](const LutFetch(&f)[G], const bool(&valid)[G], int t0) {
@@ -513,7 +542,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 const float tz = l_ts[t * kWave] - tmean;  // same bits as in the norm pass
                 const float e = tz * factor - l_rs[t * kWave];
                 float sd[DOF];
-                sd_row<DOF>(g_x, g_y, w.c - rx, w.r - ry, sd);
+                sd_row<DOF>(g_x, g_y, (float)(w.c - rx) - offx, (float)(w.r - ry) - offy, sd);
                 const float e2 = e * e;
                 ssd = valid ? ssd + e2 : ssd;
 #pragma unroll
@@ -650,13 +679,13 @@ struct VariantInfo {
     int g, mode, pipe, wpb, occ;
 };
 
-template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC>
+template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC, int OFFS>
 static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int nt, bool xcd,
                            hipStream_t stream) {
     constexpr int arrays = MODE == 0 ? 4 : 2;
     const size_t lds = (size_t)arrays * nt * kWave * sizeof(float) * WPB;
     if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
-    auto kern = icgn2d_kernel<DOF, G, MODE, PIPE, WPB, OCC>;
+    auto kern = icgn2d_kernel<DOF, G, MODE, PIPE, WPB, OCC, OFFS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -676,21 +705,17 @@ static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, siz
     return hipGetLastError();
 }
 
+//        id  G mode pipe wpb occ
 #define OC_ICGN2D_VARIANTS(X) \
     X(0, 3, 0, 0, 1, 1)       \
-    X(1, 4, 0, 0, 1, 1)       \
-    X(2, 2, 0, 1, 1, 1)       \
-    X(3, 2, 1, 1, 1, 4)       \
-    X(4, 3, 1, 0, 1, 4)       \
-    X(5, 2, 1, 1, 4, 4)       \
-    X(6, 3, 1, 0, 4, 4)       \
-    X(7, 4, 1, 0, 1, 3)       \
-    X(8, 2, 0, 1, 4, 1)       \
-    X(9, 3, 1, 1, 1, 3)       \
-    X(10, 2, 1, 0, 1, 4)      \
-    X(11, 2, 1, 0, 4, 4)
+    X(1, 3, 1, 0, 1, 4)       \
+    X(2, 3, 1, 0, 4, 4)       \
+    X(3, 4, 1, 0, 1, 3)       \
+    X(4, 2, 1, 0, 1, 4)       \
+    X(5, 2, 1, 0, 4, 4)       \
+    X(6, 2, 0, 1, 1, 1)
 
-constexpr int kIcgn2dVariants = 12;
+constexpr int kIcgn2dVariants = 7;
 
 int icgn2d_variant_count() { return kIcgn2dVariants; }
 
@@ -716,11 +741,14 @@ template <int DOF>
 static hipError_t launch_dof(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
                              hipStream_t stream) {
     if (count == 0) return hipSuccess;
+    // p.rx, p.ry: the engine's radius, or in self-adaptive mode the largest radii of the batch
     const int N = (2 * p.rx + 1) * (2 * p.ry + 1);
     const int nt = (N + 63) / 64;
     switch (variant) {
-#define X(ID, GG, MM, PP, WW, OO) \
-    case ID: return launch_t<DOF, GG, MM, PP, WW, OO>(p, pois, stride_f, count, nt, xcd, stream);
+#define X(ID, GG, MM, PP, WW, OO)                                                                           \
+    case ID:                                                                                                \
+        return p.offsets ? launch_t<DOF, GG, MM, PP, WW, OO, 1>(p, pois, stride_f, count, nt, xcd, stream)  \
+                         : launch_t<DOF, GG, MM, PP, WW, OO, 0>(p, pois, stride_f, count, nt, xcd, stream);
         OC_ICGN2D_VARIANTS(X)
 #undef X
         default: return hipErrorInvalidValue;
@@ -735,6 +763,29 @@ hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_f, size
 hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
                           hipStream_t stream) {
     return launch_dof<12>(p, pois, stride_f, count, variant, xcd, stream);
+}
+
+// largest subset radii of a POI queue (self-adaptive mode sizes the LDS arrays from them)
+__global__ __launch_bounds__(256) void poi2d_max_radius_kernel(const float* __restrict__ pois, int stride_f,
+                                                               unsigned long long count, int* __restrict__ out) {
+    int mx = 0, my = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        mx = max(mx, (int)pois[i * stride_f + poi2d::SRX]);
+        my = max(my, (int)pois[i * stride_f + poi2d::SRY]);
+    }
+    atomicMax(out, mx);
+    atomicMax(out + 1, my);
+}
+
+hipError_t launch_poi2d_max_radius(const float* pois, int stride_f, size_t count, int* out2, hipStream_t stream) {
+    hipError_t err = hipMemsetAsync(out2, 0, 2 * sizeof(int), stream);
+    if (err != hipSuccess || count == 0) return err;
+    const unsigned blocks = (unsigned)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(poi2d_max_radius_kernel, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned long long)count,
+                       out2);
+    return hipGetLastError();
 }
 
 }  // namespace ochip

@@ -18,9 +18,13 @@ struct Icgn2dParams {
     const float* gy;
     const float* lut;  // target bicubic coefficient LUT, 16 floats per pixel
     int height, width;
-    int rx, ry;
+    int rx, ry;        // subset radius (self_adaptive: the largest radii of the batch)
     float conv, stop;
+    const float* offsets;  // per-POI centre offsets (x, y), or nullptr: compute(poi_queue, center_offset_queue)
+    int self_adaptive;     // DIC::setSelfAdaptive: every POI carries its own subset radius
 };
+// writes max over the queue of (int)subset_radius.x / .y to out2[0], out2[1]
+hipError_t launch_poi2d_max_radius(const float* pois, int stride_floats, size_t count, int* out2, hipStream_t stream);
 // The ICGN2D kernels exist in several bit-identical variants (gather depth, LDS footprint,
 // software pipelining, waves per workgroup; icgn2d.hip).  `variant` indexes that table,
 // `xcd` turns on the XCD-contiguous mapping of workgroups to the POI queue.

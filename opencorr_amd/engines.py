@@ -125,6 +125,28 @@ class _Engine:
         capi.check(capi.lib().oc_hip_compute(self._h, p, n, stride, mem))
         return pois
 
+    def compute_with_offsets(self, pois, center_offsets):
+        """compute(poi_queue, center_offset_queue) of ICGN2D1/2D2 (src/oc_icgn.h:76,131);
+        ``center_offsets`` is (n, 2) float32 (Point2D x, y) in the same memory space as ``pois``."""
+        floats = capi.POI2D_FLOATS
+        if _is_torch(pois):
+            p, mem, _ = _buf(pois)
+            o, omem, _ = _buf(center_offsets)
+            if omem != mem:
+                raise ValueError("POIs and center offsets must live in the same memory space")
+            n, stride = pois.shape[0], pois.stride(0) * 4
+        else:
+            if pois.dtype != np.float32 or not pois.flags.c_contiguous or pois.ndim != 2 or pois.shape[1] < floats:
+                raise ValueError("pois must be a C-contiguous float32 array of shape (n, >=%d)" % floats)
+            off = np.ascontiguousarray(center_offsets, dtype=np.float32)
+            p, mem = ctypes.c_void_p(pois.ctypes.data), capi.HOST
+            o = ctypes.c_void_p(off.ctypes.data)
+            n, stride = pois.shape[0], pois.strides[0]
+        if tuple(center_offsets.shape) != (n, 2):
+            raise ValueError("center_offsets must have shape (n, 2)")
+        capi.check(capi.lib().oc_hip_compute_with_offsets(self._h, p, o, n, stride, mem))
+        return pois
+
     def compute_one(self, poi):
         assert poi.dtype == np.float32 and poi.flags.c_contiguous
         capi.check(capi.lib().oc_hip_compute_one(self._h, ctypes.c_void_p(poi.ctypes.data)))
@@ -160,6 +182,10 @@ class _Engine:
 class _IcgnMixin:
     def set_iteration(self, conv_criterion, stop_condition):
         capi.check(capi.lib().oc_hip_set_iteration(self._h, conv_criterion, stop_condition))
+
+    def set_self_adaptive(self, is_self_adaptive):
+        """DIC::setSelfAdaptive (src/oc_dic.cpp:34-37): per-POI subset radius from poi.subset_radius."""
+        capi.check(capi.lib().oc_hip_set_self_adaptive(self._h, 1 if is_self_adaptive else 0))
 
 
 class FFTCC2D(_Engine):

@@ -58,6 +58,10 @@ def lib():
         L.oc_oracle_fftcc2d.argtypes = [fp, fp, i, i, i, i, fp, l, i, fp]
         L.oc_oracle_icgn2d1.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i]
         L.oc_oracle_icgn2d2.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i]
+        L.oc_oracle_icgn2d1_ex.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i, fp, i]
+        L.oc_oracle_icgn2d2_ex.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i, fp, i]
+        L.oc_oracle_icgn2d1_ex.restype = None
+        L.oc_oracle_icgn2d2_ex.restype = None
         L.oc_oracle_gradient3d.argtypes = [fp, i, i, i, fp, fp, fp, i]
         L.oc_oracle_bspline3d_prefilter.argtypes = [fp, i, i, i, fp, i]
         L.oc_oracle_bspline3d_eval.argtypes = [fp, i, i, i, f, f, f]
@@ -148,18 +152,28 @@ class Prepared2D:
         self.lut = bspline2d_lut(self.tar, threads)
 
 
-def icgn2d1(prep, rx, ry, conv, stop, pois, order=ORDER_SEQ, lanes=64, threads=0):
+def _icgn2d(fn, prep, rx, ry, conv, stop, pois, order, lanes, threads, center_offsets, self_adaptive):
     assert pois.dtype == np.float32 and pois.flags.c_contiguous and pois.shape[1] == POI2D_FLOATS
     h, w = prep.ref.shape
-    lib().oc_oracle_icgn2d1(_fp(prep.ref), _fp(prep.gx), _fp(prep.gy), _fp(prep.lut), h, w, rx, ry,
-                            float(conv), float(stop), _fp(pois), pois.shape[0], order, lanes, threads)
+    off = None
+    if center_offsets is not None:
+        off = np.ascontiguousarray(center_offsets, dtype=np.float32)
+        assert off.shape == (pois.shape[0], 2)
+    fn(_fp(prep.ref), _fp(prep.gx), _fp(prep.gy), _fp(prep.lut), h, w, rx, ry, float(conv), float(stop), _fp(pois),
+       pois.shape[0], order, lanes, threads, _fp(off) if off is not None else None, 1 if self_adaptive else 0)
 
 
-def icgn2d2(prep, rx, ry, conv, stop, pois, order=ORDER_SEQ, lanes=64, threads=0):
-    assert pois.dtype == np.float32 and pois.flags.c_contiguous and pois.shape[1] == POI2D_FLOATS
-    h, w = prep.ref.shape
-    lib().oc_oracle_icgn2d2(_fp(prep.ref), _fp(prep.gx), _fp(prep.gy), _fp(prep.lut), h, w, rx, ry,
-                            float(conv), float(stop), _fp(pois), pois.shape[0], order, lanes, threads)
+def icgn2d1(prep, rx, ry, conv, stop, pois, order=ORDER_SEQ, lanes=64, threads=0, center_offsets=None,
+            self_adaptive=False):
+    """ICGN2D1::compute(poi_queue[, center_offset_queue]); ``self_adaptive`` = DIC::setSelfAdaptive(true)."""
+    _icgn2d(lib().oc_oracle_icgn2d1_ex, prep, rx, ry, conv, stop, pois, order, lanes, threads, center_offsets,
+            self_adaptive)
+
+
+def icgn2d2(prep, rx, ry, conv, stop, pois, order=ORDER_SEQ, lanes=64, threads=0, center_offsets=None,
+            self_adaptive=False):
+    _icgn2d(lib().oc_oracle_icgn2d2_ex, prep, rx, ry, conv, stop, pois, order, lanes, threads, center_offsets,
+            self_adaptive)
 
 
 def gradient3d(vol, threads=0):

@@ -389,6 +389,20 @@ static inline void sd_row(float g_x, float g_y, int xl, int yl, float* sd) {
     }
 }
 
+// steepest-descent row of the center-offset overloads: float local coordinates
+// (src/oc_icgn.cpp:390-398; 2D2: 953-972)
+template <int DOF>
+static inline void sd_row_f(float g_x, float g_y, float xl, float yl, float* sd) {
+    if constexpr (DOF == 6) {
+        sd[0] = g_x; sd[1] = g_x * xl; sd[2] = g_x * yl;
+        sd[3] = g_y; sd[4] = g_y * xl; sd[5] = g_y * yl;
+    } else {
+        float xx = (xl * xl) * 0.5f, xy = xl * yl, yy = (yl * yl) * 0.5f;
+        sd[0] = g_x; sd[1] = g_x * xl; sd[2] = g_x * yl; sd[3] = g_x * xx; sd[4] = g_x * xy; sd[5] = g_x * yy;
+        sd[6] = g_y; sd[7] = g_y * xl; sd[8] = g_y * yl; sd[9] = g_y * xx; sd[10] = g_y * xy; sd[11] = g_y * yy;
+    }
+}
+
 // src/oc_deformation.cpp:117-128
 static inline void set_warp_2d1(float* w, float u, float ux, float uy, float v, float vx, float vy) {
     w[0] = 1.f + ux; w[1] = uy; w[2] = u;
@@ -424,9 +438,20 @@ static inline void set_warp_2d2(float* w, const float* q) {
 }
 
 // DOF = 6 -> ICGN2D1, DOF = 12 -> ICGN2D2
+// off: centre offset {x, y} of the compute(POI2D*, Point2D&) overloads (src/oc_icgn.cpp:353-547,
+// 910-1126), or nullptr for the plain compute(POI2D*).  self_adaptive: DIC::setSelfAdaptive, the
+// subset radius comes from poi->subset_radius (:152-158).
 template <int DOF, template <int> class Acc>
 static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float stop, float* poi, int lanes,
-                       std::vector<float>& scratch) {
+                       std::vector<float>& scratch, const float* off = nullptr, int self_adaptive = 0) {
+    if (self_adaptive) {
+        rx = (int)poi[23];  // Point2D (float) passed to int parameters of ICGN2D1_::update
+        ry = (int)poi[24];
+        if (rx < 0 || ry < 0) {  // the reference would allocate a negative-sized subset; rejected like the GPU engine does
+            poi[16] = poi[16] >= 0 ? -3.f : poi[16];
+            return;
+        }
+    }
     const float px = poi[0], py = poi[1];
     float* p = poi + 2;        // deformation.p[12]: u ux uy uxx uxy uyy v vx vy vxx vxy vyy
     float* res = poi + 14;     // u0 v0 zncc iteration convergence feature
@@ -485,7 +510,10 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
                 sgx[s] = g_x;
                 sgy[s] = g_y;
                 float sd[DOF];
-                sd_row<DOF>(g_x, g_y, xl, yl, sd);
+                if (off)
+                    sd_row_f<DOF>(g_x, g_y, xl - off[0], yl - off[1], sd);
+                else
+                    sd_row<DOF>(g_x, g_y, xl, yl, sd);
                 int t = 0;
                 for (int i = 0; i < DOF; i++)
                     for (int j = 0; j <= i; j++) a.add(s, t++, sd[i] * sd[j]);
@@ -525,6 +553,10 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
             for (int c = 0; c < W; c++) {
                 int s = r * W + c;
                 float xl = (float)(c - rx), yl = (float)(r - ry);
+                if (off) {  // local_coor = x_local - center_offset (src/oc_icgn.cpp:447-450)
+                    xl = xl - off[0];
+                    yl = yl - off[1];
+                }
                 float wx, wy;
                 if constexpr (DOF == 6) {
                     // src/oc_deformation.cpp:94-105
@@ -542,7 +574,9 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
                         wy = wy + r4[k] * pv[k];
                     }
                 }
-                float v = bspline2d_eval(im.lut, height, width, px + wx, py + wy);
+                // tar_subset->center = POI (+ center_offset, src/oc_icgn.cpp:425-426), then + warped_coor
+                float cx = off ? px + off[0] : px, cy = off ? py + off[1] : py;
+                float v = bspline2d_eval(im.lut, height, width, cx + wx, cy + wy);
                 if (v < 0.f) negative = true;
                 ts[s] = v;
                 am.add(s, 0, v);
@@ -570,7 +604,10 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
                 float e = ts[s] * factor - rs[s];
                 ae.add(s, DOF, e * e);
                 float sd[DOF];
-                sd_row<DOF>(sgx[s], sgy[s], c - rx, r - ry, sd);
+                if (off)
+                    sd_row_f<DOF>(sgx[s], sgy[s], (float)(c - rx) - off[0], (float)(r - ry) - off[1], sd);
+                else
+                    sd_row<DOF>(sgx[s], sgy[s], c - rx, r - ry, sd);
                 for (int i = 0; i < DOF; i++) ae.add(s, i, sd[i] * e);
             }
         ae.finish();
@@ -951,6 +988,25 @@ void oc_oracle_fftcc2d(const float* ref, const float* tar, int height, int width
     }
 }
 
+void oc_oracle_icgn2d1_ex(const float* ref, const float* gx, const float* gy, const float* tar_lut, int height, int width,
+                          int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes, int threads,
+                          const float* center_offsets, int self_adaptive) {
+    threads = resolve_threads(threads);
+    Images2D im = {ref, gx, gy, tar_lut, height, width};
+#pragma omp parallel num_threads(threads)
+    {
+        std::vector<float> scratch;
+#pragma omp for schedule(static)
+        for (long i = 0; i < n; i++) {
+            const float* off = center_offsets ? center_offsets + 2 * i : nullptr;
+            if (order == OC_ORDER_SEQ)
+                icgn2d_poi<6, AccSeq>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch, off, self_adaptive);
+            else
+                icgn2d_poi<6, AccLanes>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch, off, self_adaptive);
+        }
+    }
+}
+
 void oc_oracle_icgn2d1(const float* ref, const float* gx, const float* gy, const float* tar_lut, int height, int width,
                        int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes, int threads) {
     threads = resolve_threads(threads);
@@ -964,6 +1020,25 @@ void oc_oracle_icgn2d1(const float* ref, const float* gx, const float* gy, const
                 icgn2d_poi<6, AccSeq>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch);
             else
                 icgn2d_poi<6, AccLanes>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch);
+        }
+    }
+}
+
+void oc_oracle_icgn2d2_ex(const float* ref, const float* gx, const float* gy, const float* tar_lut, int height, int width,
+                          int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes, int threads,
+                          const float* center_offsets, int self_adaptive) {
+    threads = resolve_threads(threads);
+    Images2D im = {ref, gx, gy, tar_lut, height, width};
+#pragma omp parallel num_threads(threads)
+    {
+        std::vector<float> scratch;
+#pragma omp for schedule(static)
+        for (long i = 0; i < n; i++) {
+            const float* off = center_offsets ? center_offsets + 2 * i : nullptr;
+            if (order == OC_ORDER_SEQ)
+                icgn2d_poi<12, AccSeq>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch, off, self_adaptive);
+            else
+                icgn2d_poi<12, AccLanes>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch, off, self_adaptive);
         }
     }
 }

@@ -70,6 +70,15 @@ void oc_oracle_icgn2d1(const float* ref, const float* gx, const float* gy, const
 void oc_oracle_icgn2d2(const float* ref, const float* gx, const float* gy, const float* tar_lut,
                        int height, int width, int rx, int ry, float conv, float stop,
                        float* pois, long n, int order, int lanes, int threads);
+/* The same with the per-POI centre offsets of compute(poi_queue, center_offset_queue)
+ * (src/oc_icgn.cpp:353-557, 910-1136; center_offsets = n x {x, y} or NULL) and/or
+ * DIC::setSelfAdaptive (subset radius from poi->subset_radius, src/oc_icgn.cpp:152-158). */
+void oc_oracle_icgn2d1_ex(const float* ref, const float* gx, const float* gy, const float* tar_lut, int height,
+                          int width, int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes,
+                          int threads, const float* center_offsets, int self_adaptive);
+void oc_oracle_icgn2d2_ex(const float* ref, const float* gx, const float* gy, const float* tar_lut, int height,
+                          int width, int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes,
+                          int threads, const float* center_offsets, int self_adaptive);
 
 /* src/oc_gradient.cpp:143-231 */
 void oc_oracle_gradient3d(const float* vol, int dz, int dy, int dx, float* gx, float* gy, float* gz, int threads);

@@ -6,6 +6,7 @@
 // out.bin: n POI2D records (100 bytes each) after FFTCC2D::compute + ICGN2D1::prepare/compute
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <vector>
 
@@ -41,7 +42,41 @@ int main(int argc, char** argv) {
         ICGN2D1* icgn1 = new ICGN2D1(rx, ry, it[0], it[1], cpu_thread_number);
         icgn1->setImages(ref_img, tar_img);
         icgn1->prepare();
+        const std::vector<POI2D> after_fftcc = poi_queue;
         icgn1->compute(poi_queue);
+        // compute(poi_queue, center_offset_queue) with zero offsets and setSelfAdaptive(true) with every
+        // POI carrying the engine's own radius must both reproduce the plain run bit for bit
+        {
+            std::vector<POI2D> q = after_fftcc;
+            std::vector<Point2D> offsets(q.size(), Point2D(0.f, 0.f));
+            icgn1->compute(q, offsets);
+            if (std::memcmp(q.data(), poi_queue.data(), q.size() * sizeof(POI2D)) != 0) {
+                std::cerr << "zero center offsets change the result" << std::endl;
+                return 9;
+            }
+            q = after_fftcc;
+            for (POI2D& p : q) p.subset_radius = Point2D((float)rx, (float)ry);
+            icgn1->setSelfAdaptive(true);
+            icgn1->compute(q);
+            icgn1->setSelfAdaptive(false);
+            for (size_t i = 0; i < q.size(); i++) {
+                // guarded POIs keep the radius they came with; everything else must agree
+                if (q[i].result.zncc != poi_queue[i].result.zncc || q[i].deformation.u != poi_queue[i].deformation.u ||
+                    q[i].deformation.vy != poi_queue[i].deformation.vy) {
+                    std::cerr << "self-adaptive run with the engine's radius differs at POI " << i << std::endl;
+                    return 10;
+                }
+            }
+            if (n > 0) {
+                POI2D one = after_fftcc[0];
+                Point2D off(0.f, 0.f);
+                icgn1->compute(&one, off);
+                if (one.deformation.u != poi_queue[0].deformation.u) {
+                    std::cerr << "compute(POI2D*, Point2D&) disagrees" << std::endl;
+                    return 11;
+                }
+            }
+        }
         // single-POI entry point: recompute the first POI from its FFTCC state and check it agrees
         if (n > 0) {
             POI2D one(Point2D(xs[0], ys[0]));

@@ -102,7 +102,7 @@ def test_fftcc2d_fused_kernel_matches_rocfft_pipeline(eng, speckle_small):
     assert (fused[:-3, 16] > 0.5).mean() > 0.9
 
 
-@pytest.mark.parametrize("variant,xcd", [(0, 0), (4, 1), (6, 1), (11, 0), (2, 1)])
+@pytest.mark.parametrize("variant,xcd", [(0, 0), (1, 1), (2, 1), (5, 0), (6, 1), (3, 0), (4, 1)])
 def test_icgn2d1_variants_identical_bits(eng, speckle_small, variant, xcd):
     """Every kernel variant / workgroup mapping of oc_hip_set_tuning computes the same bits."""
     import oracle
@@ -272,3 +272,77 @@ def test_icgn2d2_bit_exact_vs_oracle(eng, rx, ry):
     assert np.abs(np.median(want[m, P["uxx"]]) - so["uxx"]) < 2e-5
     assert np.abs(np.median(want[m, P["vyy"]]) - so["vyy"]) < 2e-5
     assert want[-3, P["zncc"]] == -3.0 and want[-2, P["zncc"]] == -3.0 and want[-1, P["zncc"]] == -2.0
+
+
+@pytest.mark.parametrize("dof", [6, 12])
+def test_icgn2d_center_offsets_bit_exact(eng, dof):
+    """compute(poi_queue, center_offset_queue) (src/oc_icgn.cpp:353-557, 910-1136): float local
+    coordinates shifted by a per-POI offset, target subset centred at POI + offset."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = synth.speckle_pair_2d(320, 340, seed=5)
+    xs, ys = synth.poi_grid_2d(320, 340, 14, 12, 36)
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, 16, 16, pois)
+    rng = np.random.default_rng(9)
+    off = rng.uniform(-3.0, 3.0, (len(pois), 2)).astype(np.float32)
+    off[:5] = 0.0                      # zero offsets must reproduce the plain overload
+    off[5] = [0.5, -0.25]
+    prep = oracle.Prepared2D(ref, tar)
+    want = pois.copy()
+    (oracle.icgn2d1 if dof == 6 else oracle.icgn2d2)(prep, 16, 16, 0.001, 10, want, order=oracle.ORDER_LANES,
+                                                     lanes=64, center_offsets=off)
+    icgn = (eng.ICGN2D1 if dof == 6 else eng.ICGN2D2)(16, 16, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    got = icgn.compute_with_offsets(pois.copy(), off)
+    assert np.array_equal(_bits(got), _bits(want))
+    plain = icgn.compute(pois.copy())
+    assert np.array_equal(_bits(got[:5]), _bits(plain[:5]))
+    assert not np.array_equal(got[5:, 2], plain[5:, 2])
+    assert (want[:, oracle.P2["zncc"]] > 0.9).mean() > 0.95
+    # device-resident queue + offsets
+    import torch
+    dp, do = torch.from_numpy(pois.copy()).cuda(), torch.from_numpy(off).cuda()
+    icgn.compute_with_offsets(dp, do)
+    icgn.synchronize()
+    assert np.array_equal(_bits(dp.cpu().numpy()), _bits(want))
+
+
+@pytest.mark.parametrize("dof", [6, 12])
+def test_icgn2d_self_adaptive_radius_bit_exact(eng, dof):
+    """DIC::setSelfAdaptive(true): every POI brings its own subset radius (src/oc_icgn.cpp:152-158)."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = synth.speckle_pair_2d(330, 350, seed=6)
+    xs, ys = synth.poi_grid_2d(330, 350, 13, 11, 40)
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, 16, 16, pois)
+    rng = np.random.default_rng(10)
+    pois[:, 23] = rng.integers(9, 25, len(pois)).astype(np.float32)
+    pois[:, 24] = rng.integers(9, 25, len(pois)).astype(np.float32)
+    pois[0, 23:25] = [24.9, 9.9]   # fractional radii truncate like the reference's float -> int argument
+    pois[1, 23] = -3.0             # unusable radius: rejected in-band
+    prep = oracle.Prepared2D(ref, tar)
+    want = pois.copy()
+    fn = oracle.icgn2d1 if dof == 6 else oracle.icgn2d2
+    fn(prep, 5, 5, 0.001, 10, want, order=oracle.ORDER_LANES, lanes=64, self_adaptive=True)
+    icgn = (eng.ICGN2D1 if dof == 6 else eng.ICGN2D2)(5, 5, 0.001, 10)   # the engine's own radius is ignored
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    icgn.set_self_adaptive(True)
+    got = icgn.compute(pois.copy())
+    assert np.array_equal(_bits(got), _bits(want))
+    P = oracle.P2
+    assert got[1, P["zncc"]] == -3.0
+    ok = np.ones(len(pois), bool)
+    ok[1] = False
+    assert np.array_equal(got[ok, P["srx"]], np.trunc(pois[ok, 23])) and np.array_equal(got[ok, P["sry"]], np.trunc(pois[ok, 24]))
+    assert (got[ok, P["zncc"]] > 0.9).mean() > 0.9
+    # and switched off again the engine's radius applies
+    icgn.set_self_adaptive(False)
+    icgn.set_subset(16, 16)
+    base = pois.copy()
+    want2 = base.copy()
+    fn(prep, 16, 16, 0.001, 10, want2, order=oracle.ORDER_LANES, lanes=64)
+    assert np.array_equal(_bits(icgn.compute(base)), _bits(want2))

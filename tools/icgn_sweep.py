@@ -55,7 +55,7 @@ def main():
     torch.cuda.synchronize()
     pois = start.clone()
 
-    nvar = 12
+    nvar = 7
     variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(nvar))
     xcds = [int(v) for v in args.xcd.split(",")]
     base = None
