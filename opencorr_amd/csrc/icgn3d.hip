@@ -258,7 +258,8 @@ __global__ __launch_bounds__(kBlock3d) void icgn3d1_kernel(Icgn3dParams P, float
                                                            unsigned long long count) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* red = lds;                               // kRedChunk * 16 floats
-    float* lds_ts = lds + kRedChunk * kWaves3d;     // N floats when TS_LDS
+    float* lds_hinv = lds + kRedChunk * kWaves3d;   // 12 x 64 floats: column j of H^-1 in lane j (parked between solves)
+    float* lds_ts = lds_hinv + 12 * kWave;          // N floats when TS_LDS
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
     const int rx = P.rx, ry = P.ry, rz = P.rz, DX = P.dx, DY = P.dy, DZ = P.dz;
@@ -269,11 +270,12 @@ __global__ __launch_bounds__(kBlock3d) void icgn3d1_kernel(Icgn3dParams P, float
 
     for (unsigned long long idx = blockIdx.x; idx < count; idx += gridDim.x) {
         float* poi = pois + idx * (unsigned long long)stride_f;
-        const float px = poi[poi3d::X], py = poi[poi3d::Y], pz = poi[poi3d::Z];
+        // every thread reads the same record: keep it in SGPRs (the hot loops need the VGPRs)
+        const float px = uni3(poi[poi3d::X]), py = uni3(poi[poi3d::Y]), pz = uni3(poi[poi3d::Z]);
         float init[12];
 #pragma unroll
-        for (int i = 0; i < 12; i++) init[i] = poi[poi3d::P + i];
-        const float zncc_in = poi[poi3d::ZNCC];
+        for (int i = 0; i < 12; i++) init[i] = uni3(poi[poi3d::P + i]);
+        const float zncc_in = uni3(poi[poi3d::ZNCC]);
         __syncthreads();  // everyone has read the record before anyone may overwrite it
 
         // guard, src/oc_icgn.cpp:1279-1286
@@ -306,8 +308,8 @@ __global__ __launch_bounds__(kBlock3d) void icgn3d1_kernel(Icgn3dParams P, float
 
         // ---- SD image + Hessian (src/oc_icgn.cpp:1299-1337) and its inverse (:1339)
         const int cx = (int)px, cy = (int)py, cz = (int)pz;
-        float hinv_col[12];
         {
+            float hinv_col[12];
             // lane j < 12 assembles column j of the symmetric Hessian.  The 78 unique sums are
             // accumulated in three sweeps over the samples (rows 0-5, 6-8, 9-11: 21 + 24 + 33
             // running sums) to stay inside the 128-VGPR budget of a 1024-thread workgroup.
@@ -318,14 +320,16 @@ __global__ __launch_bounds__(kBlock3d) void icgn3d1_kernel(Icgn3dParams P, float
             hessian_rows<6, 9>(P, tid, wave, lane, SX, SY, N, rx, ry, rz, cx, cy, cz, DX, DY, red, col);
             hessian_rows<9, 12>(P, tid, wave, lane, SX, SY, N, rx, ry, rz, cx, cy, cz, DX, DY, red, col);
             lu_inverse_lanes3<12>(col, hinv_col, lane);  // every wave redundantly, identical results
+            if (wave == 0) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) lds_hinv[i * kWave + lane] = hinv_col[i];
+            }
+            // visible to every wave after the barriers of the first block_allreduce below
         }
 
         // ---- IC-GN loop (src/oc_icgn.cpp:1344-1447)
         float Wm[16];
         set_warp_3d1(Wm, init);
-        float cur[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) cur[i] = 0.f;
         int iter = 0;
         float dp_norm = 0.f, znssd = 0.f;
         bool failed = false;
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(kBlock3d) void icgn3d1_kernel(Icgn3dParams P, float
             float dp[12];
 #pragma unroll
             for (int i = 0; i < 12; i++) {
-                const float prod = hinv_col[i] * numj;
+                const float prod = lds_hinv[i * kWave + lane] * numj;
                 float v = 0.f;
 #pragma unroll
                 for (int j = 0; j < 12; j++) v += wave_bcast(prod, j);
@@ -412,10 +416,6 @@ __global__ __launch_bounds__(kBlock3d) void icgn3d1_kernel(Icgn3dParams P, float
                 }
 #pragma unroll
             for (int i = 0; i < 16; i++) Wm[i] = uni3(Wn[i]);
-            // Deformation3D1::setDeformation(), src/oc_deformation.cpp:416-432
-            cur[0] = Wm[3]; cur[1] = Wm[0] - 1.f; cur[2] = Wm[1]; cur[3] = Wm[2];
-            cur[4] = Wm[7]; cur[5] = Wm[4]; cur[6] = Wm[5] - 1.f; cur[7] = Wm[6];
-            cur[8] = Wm[11]; cur[9] = Wm[8]; cur[10] = Wm[9]; cur[11] = Wm[10] - 1.f;
             // src/oc_icgn.cpp:1445
             dp_norm = uni3(sqrtf(dp[0] * dp[0] + dp[4] * dp[4] + dp[8] * dp[8]));
         } while (iter < P.stop && dp_norm >= P.conv);
@@ -426,6 +426,9 @@ __global__ __launch_bounds__(kBlock3d) void icgn3d1_kernel(Icgn3dParams P, float
         }
         // ---- outputs (src/oc_icgn.cpp:1449-1489)
         if (tid == 0) {
+            // Deformation3D1::setDeformation(), src/oc_deformation.cpp:416-432: p <- W after the last update
+            const float cur[12] = {Wm[3], Wm[0] - 1.f, Wm[1], Wm[2], Wm[7],  Wm[4],
+                                   Wm[5] - 1.f, Wm[6], Wm[11], Wm[8], Wm[9], Wm[10] - 1.f};
             float zncc = 0.5f * (2 - znssd);
             const float fiter = (float)iter;
             if (dp_norm >= P.conv && fiter >= P.stop) zncc = -4.f;
@@ -456,7 +459,7 @@ constexpr size_t kLdsLimit3d = 160 * 1024;
 
 size_t icgn3d1_scratch_floats(int rx, int ry, int rz, int* blocks) {
     const size_t n = (size_t)(2 * rx + 1) * (2 * ry + 1) * (2 * rz + 1);
-    const size_t lds = (kRedChunk * kWaves3d + n) * sizeof(float);
+    const size_t lds = (kRedChunk * kWaves3d + 12 * kWave + n) * sizeof(float);
     if (lds <= kLdsLimit3d) {
         *blocks = 0;  // LDS mode: one workgroup per POI, no scratch
         return 0;
@@ -468,7 +471,7 @@ size_t icgn3d1_scratch_floats(int rx, int ry, int rz, int* blocks) {
 hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
     if (count == 0) return hipSuccess;
     const size_t n = (size_t)(2 * p.rx + 1) * (2 * p.ry + 1) * (2 * p.rz + 1);
-    const size_t red_bytes = kRedChunk * kWaves3d * sizeof(float);
+    const size_t red_bytes = (kRedChunk * kWaves3d + 12 * kWave) * sizeof(float);
     int blocks = 0;
     (void)icgn3d1_scratch_floats(p.rx, p.ry, p.rz, &blocks);
     if (blocks == 0) {

@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""Runs the BASELINE.json configurations that are not the bench line (A, C, D on one GPU, E) at
+their full sizes on one MI355X and checks them through size-independent properties plus a strided
+oracle sample.  One JSON line per configuration.
+
+    python tools/run_configs.py [--configs A,C,D1,E] [--out gpurun_out/configs.json]
+
+Checks per configuration
+  * converged fraction and recovery of the analytic displacement field the synthetic pair was
+    rendered with (median / max error over converged POIs),
+  * GPU == oracle, bit for bit, on a strided sample of the queue (the oracle is the checker;
+    test/bench infrastructure only),
+  * idempotence of the sharding: the first and second half of the queue computed separately
+    give the same bits as the whole queue.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(fn, sync, reps=3):
+    fn()
+    sync()
+    best = 1e30
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        sync()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def run_2d(name, side, r, nside, engine, oracle_sample, so=None):
+    import torch
+    import opencorr_amd as oc
+    import oracle
+    from opencorr_amd import synth
+    dev = torch.device("cuda", 0)
+    ref, tar = synth.speckle_pair_2d(side, side, seed=20260925, device=dev, second_order=so)
+    xs, ys = synth.poi_grid_2d(side, side, nside, nside, r + 8)
+    n = len(xs)
+    stream = torch.cuda.current_stream().cuda_stream
+    f = oc.FFTCC2D(r, r)
+    f.set_stream(stream)
+    f.set_images(ref, tar)
+    Icgn = oc.ICGN2D1 if engine == 1 else oc.ICGN2D2
+    g = Icgn(r, r, 0.001, 10.0)
+    g.set_stream(stream)
+    g.share_images(f)
+    t0 = time.perf_counter()
+    g.prepare()
+    torch.cuda.synchronize()
+    prepare_s = time.perf_counter() - t0
+    pristine = torch.from_numpy(oc.make_pois2d(xs, ys)).to(dev)
+    pois = pristine.clone()
+
+    def step():
+        pois.copy_(pristine)
+        f.compute(pois)
+        g.compute(pois)
+
+    secs = timed(step, torch.cuda.synchronize)
+    after = pois.cpu().numpy()
+    # sharding idempotence
+    halves = pristine.clone()
+    h = n // 2
+    f.compute(halves[:h]); g.compute(halves[:h]); f.compute(halves[h:]); g.compute(halves[h:])
+    torch.cuda.synchronize()
+    same_split = bool(np.array_equal(halves.cpu().numpy().view(np.uint32), after.view(np.uint32)))
+    # analytic field
+    eu, ev = synth.expected_deformation_2d(xs, ys, side, side, second_order=so)
+    conv = after[:, 16] >= 0
+    du, dv = np.abs(after[conv, 2] - eu[conv]), np.abs(after[conv, 8] - ev[conv])
+    # oracle sample (FFTCC by the GPU, ICGN by the oracle)
+    step_s = max(1, n // oracle_sample)
+    fin = pristine.clone()
+    f.compute(fin)
+    torch.cuda.synchronize()
+    sample = fin.cpu().numpy()[::step_s].copy()
+    prep = oracle.Prepared2D(ref.cpu().numpy(), tar.cpu().numpy())
+    (oracle.icgn2d1 if engine == 1 else oracle.icgn2d2)(prep, r, r, 0.001, 10.0, sample, order=oracle.ORDER_LANES, lanes=64)
+    bit_exact = bool(np.array_equal(sample.view(np.uint32), after[::step_s].view(np.uint32)))
+    return dict(config=name, engine="FFTCC2D+ICGN2D%d" % engine, image="%dx%d" % (side, side), radius=r, pois=n,
+                seconds=secs, pois_per_s=float(conv.sum() / secs), converged=int(conv.sum()),
+                mean_iterations=float(after[conv, 17].mean()), prepare_s=prepare_s,
+                median_abs_err_u=float(np.median(du)), max_abs_err_u=float(du.max()), max_abs_err_v=float(dv.max()),
+                oracle_sample=len(sample), oracle_bit_exact=bit_exact, split_queue_same_bits=same_split)
+
+
+def run_3d(name, dim, r, nside, oracle_sample):
+    import torch
+    import opencorr_amd as oc
+    import oracle
+    from opencorr_amd import synth
+    dev = torch.device("cuda", 0)
+    t0 = time.perf_counter()
+    ref, tar = synth.speckle_pair_3d(dim, dim, dim, seed=20260927, device=dev)
+    gen_s = time.perf_counter() - t0
+    xs, ys, zs = synth.poi_grid_3d(dim, dim, dim, nside, nside, nside, r + 8)
+    n = len(xs)
+    stream = torch.cuda.current_stream().cuda_stream
+    f = oc.FFTCC3D(r, r, r)
+    f.set_stream(stream)
+    f.set_images(ref, tar)
+    g = oc.ICGN3D1(r, r, r, 0.001, 20.0)
+    g.set_stream(stream)
+    g.share_images(f)
+    t0 = time.perf_counter()
+    g.prepare()
+    torch.cuda.synchronize()
+    prepare_s = time.perf_counter() - t0
+    pristine = torch.from_numpy(oc.make_pois3d(xs, ys, zs)).to(dev)
+    pois = pristine.clone()
+    t_f = timed(lambda: (pois.copy_(pristine), f.compute(pois)), torch.cuda.synchronize, reps=1)
+    guess = pois.clone()
+    t_g = timed(lambda: (pois.copy_(guess), g.compute(pois)), torch.cuda.synchronize, reps=1)
+    after = pois.cpu().numpy()
+    P = oracle.P3
+    conv = after[:, P["zncc"]] >= 0
+    w = synth.DEFAULT_WARP_3D
+    xp, yp, zp = xs - (dim - 1) * 0.5, ys - (dim - 1) * 0.5, zs - (dim - 1) * 0.5
+    eu = w["u"] + w["ux"] * xp + w["uy"] * yp + w["uz"] * zp
+    ev = w["v"] + w["vx"] * xp + w["vy"] * yp + w["vz"] * zp
+    ew = w["w"] + w["wx"] * xp + w["wy"] * yp + w["wz"] * zp
+    err = np.maximum.reduce([np.abs(after[conv, P["u"]] - eu[conv]), np.abs(after[conv, P["v"]] - ev[conv]),
+                             np.abs(after[conv, P["w"]] - ew[conv])])
+    step_s = max(1, n // oracle_sample)
+    sample = guess.cpu().numpy()[::step_s].copy()
+    prep = oracle.Prepared3D(ref.cpu().numpy(), tar.cpu().numpy())
+    t0 = time.perf_counter()
+    oracle.icgn3d1(prep, r, r, r, 0.001, 20.0, sample, order=oracle.ORDER_LANES, lanes=1024)
+    oracle_s = time.perf_counter() - t0
+    bit_exact = bool(np.array_equal(sample.view(np.uint32), after[::step_s].view(np.uint32)))
+    return dict(config=name, engine="FFTCC3D+ICGN3D1", volume="%d^3" % dim, radius=r, pois=n, fftcc_seconds=t_f,
+                icgn_seconds=t_g, pois_per_s=float(conv.sum() / (t_f + t_g)), converged=int(conv.sum()),
+                mean_iterations=float(after[conv, P["iteration"]].mean()), prepare_s=prepare_s, generate_s=gen_s,
+                median_abs_err=float(np.median(err)), max_abs_err=float(err.max()), oracle_sample=len(sample),
+                oracle_seconds=oracle_s, oracle_pois_per_s=len(sample) / oracle_s, oracle_cores=oracle.max_threads(),
+                oracle_bit_exact=bit_exact)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="A,C,D1,E")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    out = []
+    for c in a.configs.split(","):
+        if c == "A":
+            rec = run_2d("A (2048^2, r=15, 100x100 POIs)", 2048, 15, 100, 1, 10000)
+        elif c == "C":
+            rec = run_2d("C (4096^2, r=20, ICGN2D2, 316x316 POIs)", 4096, 20, 316, 2, 4000, so=dict(uxx=2e-6, vyy=-1e-6))
+        elif c == "D1":
+            rec = run_2d("D on ONE GPU (8192^2, r=16, 1414x1414 POIs)", 8192, 16, 1414, 1, 4000)
+        elif c == "E":
+            rec = run_3d("E on ONE GPU (512^3, r=16, 37^3 POIs)", 512, 16, 37, 96)
+        elif c == "Es":
+            rec = run_3d("E-small (256^3, r=16, 12^3 POIs)", 256, 16, 12, 48)
+        else:
+            continue
+        print(json.dumps(rec), flush=True)
+        out.append(rec)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
