@@ -423,7 +423,7 @@ int run_icgn3d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     if (scratch) OC_TRY(e->tmp.reserve(scratch * sizeof(float)));
     ochip::Icgn3dParams P = {im.ref_ptr(), e->gx.as<float>(), e->gy.as<float>(), e->gz.as<float>(), e->coef.as<float>(),
                              im.dz, im.dy, im.dx, e->rx, e->ry, e->rz, e->conv, e->stop,
-                             scratch ? e->tmp.as<float>() : nullptr};
+                             scratch ? e->tmp.as<float>() : nullptr, 1};
     ProfScope prof(e);
     hipError_t err = ochip::launch_icgn3d1(P, d_pois, stride_f, count, e->stream);
     if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "ICGN3D1 kernel launch failed: %s", hipGetErrorString(err));

@@ -2,17 +2,26 @@
 //
 // Replaces ICGN3D1::compute(POI3D*) (src/oc_icgn.cpp:1270-1490) for a whole POI queue (:1492-1500).
 //
-// Mapping: ONE 1024-thread workgroup (16 wavefronts = a whole CU's worth of waves) per POI.
-// Sample s = (i*SY + j)*SX + k of the (2rz+1)(2ry+1)(2rx+1) subvolume is owned by thread
-// s % 1024.  The warped-target subvolume (the only per-sample state that is produced inside
-// the Gauss-Newton loop) lives in LDS when it fits (33^3 floats = 144 KB of the 160 KB) and in
-// a per-workgroup global scratch slot otherwise; the zero-mean reference subvolume and the
-// three gradients are re-read from the (L2-resident) volumes each iteration -- x-contiguous,
-// coalesced loads.  The 64-tap tricubic gather (16 rows of 4 x-contiguous coefficients,
-// src/oc_cubic_bspline.cpp:353-405) dominates.
+// Mapping: ONE 512-thread workgroup (8 wavefronts) per POI, two workgroups per CU, persistent over
+// the queue.  Sample s = (i*SY + j)*SX + k of the (2rz+1)(2ry+1)(2rx+1) subvolume is owned by
+// thread s % 512.
+//
+// The 64-tap tricubic gather (src/oc_cubic_bspline.cpp:353-405) is what bounds the kernel.  As
+// 16 unaligned 16-byte loads per sample it keeps the texture path busy while neighbouring lanes
+// re-fetch three quarters of each other's taps.  Instead the workgroup sweeps the subvolume in
+// passes of 512 consecutive samples and, per pass, stages the box of B-spline coefficients those
+// samples can touch into LDS with coalesced row loads (the box is the image of the pass's index
+// box under the affine warp -- monotone in every index even in floating point, so evaluating the
+// 8 corners with the samples' own expression bounds it exactly); the 64 taps are then LDS reads.
+// A pass whose box does not fit (large rotations / strains) falls back to global loads.
+//
+// The warped-target subvolume (the only per-sample state produced inside the Gauss-Newton loop)
+// goes to a per-workgroup global scratch slot (written once, read twice per iteration, coalesced;
+// L2 resident); the zero-mean reference subvolume and the three gradients are re-read from the
+// volumes each iteration (x-contiguous, coalesced).
 // Reductions: per-thread partial sums in increasing s, xor butterfly inside each wave
-// (offsets 1..32), then a balanced tree over the 16 wave sums in wave order -- the same
-// association as the oracle's OC_ORDER_LANES with lanes = 1024.
+// (offsets 1..32), then a balanced tree over the 8 wave sums in wave order -- the same
+// association as the oracle's OC_ORDER_LANES with lanes = 512.
 #include <cstdio>
 #include <cstdlib>
 
@@ -21,8 +30,10 @@
 
 namespace ochip {
 
-constexpr int kBlock3d = 1024;
-constexpr int kWaves3d = kBlock3d / kWave;  // 16
+constexpr int kBlock3d = 512;
+constexpr int kWaves3d = kBlock3d / kWave;  // 8
+constexpr int kWinCap = 14080;              // floats of LDS for the staged coefficient box (55 KB)
+constexpr int kBoxSlots = 512;              // passes whose boxes are precomputed together
 constexpr int kRedChunk = 13;               // values reduced per LDS round trip
 
 __device__ __forceinline__ float uni3(float v) {
@@ -181,14 +192,43 @@ __device__ __forceinline__ float bspline3d_eval(const float* __restrict__ coef, 
     return out ? -1.f : v;
 }
 
+// The same evaluation with the 64 coefficients taken from the staged box: `win` is the box in
+// LDS, (ox, oy, oz) its origin in the volume, nx / nxy its row and plane pitches.  Same range
+// rule, same weights, same order of operations as bspline3d_eval: identical bits.
+__device__ __forceinline__ float bspline3d_eval_lds(const float* __restrict__ win, int ox, int oy, int oz, int nx, int nxy,
+                                                    int dz, int dy, int dx, float x, float y, float z) {
+    const bool out = (x < 1 || y < 1 || z < 1 || x >= dx - 2 || y >= dy - 2 || z >= dz - 2 || isnan(x) || isnan(y) ||
+                      isnan(z));
+    const int xi = out ? ox + 1 : (int)floorf(x), yi = out ? oy + 1 : (int)floorf(y), zi = out ? oz + 1 : (int)floorf(z);
+    const float fx = x - (float)xi, fy = y - (float)yi, fz = z - (float)zi;
+    const float bx0 = basis0(fx), bx1 = basis1(fx), bx2 = basis2(fx), bx3 = basis3(fx);
+    const float by[4] = {basis0(fy), basis1(fy), basis2(fy), basis3(fy)};
+    const float bz[4] = {basis0(fz), basis1(fz), basis2(fz), basis3(fz)};
+    const float* __restrict__ base = win + ((zi - 1 - oz) * nxy + (yi - 1 - oy) * nx + (xi - 1 - ox));
+    float sum_y[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float sum_x[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float* __restrict__ row = base + i * nxy + j * nx;
+            sum_x[j] = ((bx0 * row[0] + bx1 * row[1]) + bx2 * row[2]) + bx3 * row[3];
+        }
+        sum_y[i] = ((by[0] * sum_x[0] + by[1] * sum_x[1]) + by[2] * sum_x[2]) + by[3] * sum_x[3];
+    }
+    const float v = ((bz[0] * sum_y[0] + bz[1] * sum_y[1]) + bz[2] * sum_y[2]) + bz[3] * sum_y[3];
+    return out ? -1.f : v;
+}
+
 // walks the samples owned by one thread: s = tid, tid+1024, ... as (i = z, j = y, k = x) indices
 struct Walk3 {
     int i, j, k, s;
     int SX, SY, di, dj, dk;
-    __device__ __forceinline__ Walk3(int tid, int SX_, int SY_) : s(tid), SX(SX_), SY(SY_) {
+    __device__ __forceinline__ Walk3(int tid, int SX_, int SY_, int first_pass = 0)
+        : s(tid + first_pass * kBlock3d), SX(SX_), SY(SY_) {
         const int plane = SX_ * SY_;
-        i = tid / plane;
-        int rem = tid - i * plane;
+        i = s / plane;
+        int rem = s - i * plane;
         j = rem / SX_;
         k = rem - j * SX_;
         di = kBlock3d / plane;
@@ -253,22 +293,28 @@ __device__ __forceinline__ void hessian_rows(const Icgn3dParams& P, int tid, int
         }
 }
 
-template <bool TS_LDS>
-__global__ __launch_bounds__(kBlock3d) void icgn3d1_kernel(Icgn3dParams P, float* __restrict__ pois, int stride_f,
+__global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, float* __restrict__ pois, int stride_f,
                                                            unsigned long long count) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* red = lds;                               // kRedChunk * 16 floats
+    __shared__ __attribute__((aligned(16))) float lds[kRedChunk * kWaves3d + 12 * kWave + kWinCap + 6 * kBoxSlots];
+    float* red = lds;                               // kRedChunk * 8 floats
     float* lds_hinv = lds + kRedChunk * kWaves3d;   // 12 x 64 floats: column j of H^-1 in lane j (parked between solves)
-    float* lds_ts = lds_hinv + 12 * kWave;          // N floats when TS_LDS
+    float* win = lds_hinv + 12 * kWave;             // staged coefficient box of the current pass
+    int* boxes = reinterpret_cast<int*>(win + kWinCap);  // origin + extent of the box of each pass (kBoxSlots x 6)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
     const int rx = P.rx, ry = P.ry, rz = P.rz, DX = P.dx, DY = P.dy, DZ = P.dz;
     const int SX = 2 * rx + 1, SY = 2 * ry + 1, SZ = 2 * rz + 1;
     const int N = SX * SY * SZ;
     const float fN = (float)N;
-    float* __restrict__ ts = TS_LDS ? lds_ts : P.scratch + (size_t)blockIdx.x * N;
+    float* __restrict__ ts = P.scratch + (size_t)blockIdx.x * N;
+    const int plane = SX * SY;
 
-    for (unsigned long long idx = blockIdx.x; idx < count; idx += gridDim.x) {
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): every XCD walks a
+    // contiguous eighth of the queue, its workgroups interleaved over it, so that subvolumes in
+    // flight behind one L2 overlap (neighbouring POIs share most of their voxels).
+    const unsigned long long xcd_chunk = (count + 7) / 8, xcd_lo = (blockIdx.x & 7u) * xcd_chunk;
+    const unsigned long long xcd_hi = min(count, xcd_lo + xcd_chunk);
+    for (unsigned long long idx = xcd_lo + (blockIdx.x >> 3); idx < xcd_hi; idx += gridDim.x >> 3) {
         float* poi = pois + idx * (unsigned long long)stride_f;
         // every thread reads the same record: keep it in SGPRs (the hot loops need the VGPRs)
         const float px = uni3(poi[poi3d::X]), py = uni3(poi[poi3d::Y]), pz = uni3(poi[poi3d::Z]);
@@ -339,17 +385,101 @@ __global__ __launch_bounds__(kBlock3d) void icgn3d1_kernel(Icgn3dParams P, float
             bool out_of_range = false;
             float acc[1] = {0.f};
             {
-                Walk3 w(tid, SX, SY);
-                for (; w.s < N; w.next()) {
-                    const float xl = (float)(w.k - rx), yl = (float)(w.j - ry), zl = (float)(w.i - rz);
-                    // Deformation3D1::warp, src/oc_deformation.cpp:518-530
-                    const float wx = ((Wm[0] * xl + Wm[1] * yl) + Wm[2] * zl) + Wm[3] * 1.f;
-                    const float wy = ((Wm[4] * xl + Wm[5] * yl) + Wm[6] * zl) + Wm[7] * 1.f;
-                    const float wz = ((Wm[8] * xl + Wm[9] * yl) + Wm[10] * zl) + Wm[11] * 1.f;
-                    const float v = bspline3d_eval(P.coef, DZ, DY, DX, px + wx, py + wy, pz + wz);
-                    out_of_range = out_of_range || (v < 0.f);
-                    ts[w.s] = v;
-                    acc[0] += v;
+                // Deformation3D1::warp (src/oc_deformation.cpp:518-530) + subvolume centre, as every sample evaluates it
+                auto warp_x = [&](float xl, float yl, float zl) { return px + (((Wm[0] * xl + Wm[1] * yl) + Wm[2] * zl) + Wm[3] * 1.f); };
+                auto warp_y = [&](float xl, float yl, float zl) { return py + (((Wm[4] * xl + Wm[5] * yl) + Wm[6] * zl) + Wm[7] * 1.f); };
+                auto warp_z = [&](float xl, float yl, float zl) { return pz + (((Wm[8] * xl + Wm[9] * yl) + Wm[10] * zl) + Wm[11] * 1.f); };
+                // ---- coefficient boxes of all passes of this sweep, one pass per thread (the box of a pass
+                // costs more arithmetic than a sample does, so it is not recomputed by every wave in every pass).
+                // A pass = M * 512 consecutive samples: thread tid owns s = tid + 512 * (M * pass + m), m < M.
+                const int M = P.samples_per_pass;
+                const int pass_len = M * kBlock3d;
+                const int npass = (N + pass_len - 1) / pass_len;
+                for (int round0 = 0; round0 < npass; round0 += kBoxSlots) {
+                    __syncthreads();  // the previous round's boxes are no longer needed
+                    for (int pass = round0 + tid; pass < min(npass, round0 + kBoxSlots); pass += kBlock3d) {
+                        // index box of the pass's samples [s0, s1]: whole rows and (when several planes are
+                        // touched) whole planes -- conservative, still a box
+                        const int s0 = pass * pass_len, s1 = min(s0 + pass_len - 1, N - 1);
+                        const int i0 = s0 / plane, i1 = s1 / plane;
+                        const int ra = (s0 - i0 * plane) / SX, rb = (s1 - i1 * plane) / SX;
+                        const int j0 = i0 == i1 ? ra : 0, j1 = i0 == i1 ? rb : SY - 1;
+                        const bool one_row = i0 == i1 && j0 == j1;
+                        const int k0 = one_row ? s0 - i0 * plane - ra * SX : 0, k1 = one_row ? s1 - i1 * plane - rb * SX : SX - 1;
+                        // its image under the warp: every coordinate is monotone in each index (also in floating
+                        // point), so the 8 corners bound what any sample of the pass computes
+                        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+                        for (int c = 0; c < 8; c++) {
+                            const float xl = (float)(((c & 1) ? k1 : k0) - rx), yl = (float)(((c & 2) ? j1 : j0) - ry),
+                                        zl = (float)(((c & 4) ? i1 : i0) - rz);
+                            const float q[3] = {warp_x(xl, yl, zl), warp_y(xl, yl, zl), warp_z(xl, yl, zl)};
+#pragma unroll
+                            for (int a = 0; a < 3; a++) {
+                                lo[a] = fminf(lo[a], q[a]);
+                                hi[a] = fmaxf(hi[a], q[a]);
+                            }
+                        }
+                        // taps of an in-range sample lie in [floor - 1, floor + 2]; in-range means [1, D - 2)
+                        const int D[3] = {DX, DY, DZ};
+                        int o[3], n[3];
+                        bool usable = true;
+#pragma unroll
+                        for (int a = 0; a < 3; a++) {
+                            usable = usable && lo[a] == lo[a] && hi[a] == hi[a] && fabsf(lo[a]) < 1.0e9f && fabsf(hi[a]) < 1.0e9f;
+                            const int fl = (int)floorf(fmaxf(lo[a], 1.f)) - 1, fh = (int)floorf(fminf(hi[a], (float)(D[a] - 3))) + 2;
+                            o[a] = max(fl, 0);
+                            n[a] = min(fh, D[a] - 1) - o[a] + 1;
+                        }
+                        // n[0] = 0 marks "do not stage": nothing of the pass is in range (every sample evaluates
+                        // to -1), or the box does not fit -> global taps
+                        const bool stage = usable && n[0] >= 4 && n[1] >= 4 && n[2] >= 4 && (long long)n[0] * n[1] * n[2] <= kWinCap;
+                        int* slot = boxes + (pass - round0) * 6;
+                        slot[0] = o[0]; slot[1] = o[1]; slot[2] = o[2];
+                        slot[3] = stage ? n[0] : 0; slot[4] = n[1]; slot[5] = n[2];
+                    }
+                    __syncthreads();
+                    Walk3 w(tid, SX, SY, round0 * M);
+                    for (int pass = round0; pass < min(npass, round0 + kBoxSlots); pass++) {
+                        const int* slot = boxes + (pass - round0) * 6;
+                        int o[3], n[3];
+#pragma unroll
+                        for (int a = 0; a < 3; a++) {
+                            o[a] = __builtin_amdgcn_readfirstlane(slot[a]);
+                            n[a] = __builtin_amdgcn_readfirstlane(slot[3 + a]);
+                        }
+                        const bool staged = n[0] > 0;
+                        const int nx = n[0], nxy = n[0] * n[1];
+                        if (staged) {
+                            __syncthreads();  // the previous pass has finished reading the box
+                            // rows of the box, round-robin over the waves; (zr, yr) advance without a division
+                            const int rows = n[1] * n[2];
+                            int zr = wave / n[1], yr = wave - zr * n[1];
+                            const int dzr = kWaves3d / n[1], dyr = kWaves3d - dzr * n[1];
+                            for (int row = wave; row < rows; row += kWaves3d) {
+                                const float* __restrict__ src = P.coef + ((size_t)(o[2] + zr) * DY + (o[1] + yr)) * DX + o[0];
+                                for (int x = lane; x < nx; x += kWave) win[row * nx + x] = src[x];
+                                yr += dyr;
+                                zr += dzr;
+                                if (yr >= n[1]) {
+                                    yr -= n[1];
+                                    zr++;
+                                }
+                            }
+                            __syncthreads();
+                        }
+                        for (int m = 0; m < M; m++, w.next()) {
+                            if (w.s < N) {
+                                const float xl = (float)(w.k - rx), yl = (float)(w.j - ry), zl = (float)(w.i - rz);
+                                const float x = warp_x(xl, yl, zl), y = warp_y(xl, yl, zl), z = warp_z(xl, yl, zl);
+                                const float v = staged ? bspline3d_eval_lds(win, o[0], o[1], o[2], nx, nxy, DZ, DY, DX, x, y, z)
+                                                       : bspline3d_eval(P.coef, DZ, DY, DX, x, y, z);
+                                out_of_range = out_of_range || (v < 0.f);
+                                ts[w.s] = v;
+                                acc[0] += v;
+                            }
+                        }
+                    }
                 }
             }
             // src/oc_icgn.cpp:1396-1400
@@ -455,49 +585,37 @@ __global__ __launch_bounds__(kBlock3d) void icgn3d1_kernel(Icgn3dParams P, float
     }
 }
 
-constexpr size_t kLdsLimit3d = 160 * 1024;
-
+// persistent workgroups (two per CU), each with one scratch slot for the warped subvolume
 size_t icgn3d1_scratch_floats(int rx, int ry, int rz, int* blocks) {
     const size_t n = (size_t)(2 * rx + 1) * (2 * ry + 1) * (2 * rz + 1);
-    const size_t lds = (kRedChunk * kWaves3d + 12 * kWave + n) * sizeof(float);
-    if (lds <= kLdsLimit3d) {
-        *blocks = 0;  // LDS mode: one workgroup per POI, no scratch
-        return 0;
-    }
-    *blocks = 512;  // persistent workgroups, one scratch slot each
+    *blocks = 512;
     return n * (size_t)*blocks;
 }
 
 hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
     if (count == 0) return hipSuccess;
-    const size_t n = (size_t)(2 * p.rx + 1) * (2 * p.ry + 1) * (2 * p.rz + 1);
-    const size_t red_bytes = (kRedChunk * kWaves3d + 12 * kWave) * sizeof(float);
+    if (!p.scratch) return hipErrorInvalidValue;
     int blocks = 0;
     (void)icgn3d1_scratch_floats(p.rx, p.ry, p.rz, &blocks);
-    if (blocks == 0) {
-        const size_t lds = red_bytes + n * sizeof(float);
-        static size_t attr_lds = 64 * 1024;  // default dynamic-LDS limit
-        if (lds > attr_lds) {
-            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(icgn3d1_kernel<true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (err != hipSuccess) {
-                fprintf(stderr, "opencorr_hip: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed: %s\n", lds,
-                        hipGetErrorString(err));
-                return err;
-            }
-            attr_lds = lds;
+    unsigned grid = (unsigned)(count < (size_t)blocks ? count : (size_t)blocks);
+    grid = (grid + 7) / 8 * 8;  // whole XCD rounds (idle workgroups exit at once); never more than `blocks` slots
+    // samples per thread and pass: as many as keep the nominal coefficient box (small deformation
+    // gradients) inside the LDS window; passes that still overflow fall back to global taps
+    Icgn3dParams q = p;
+    q.samples_per_pass = 1;
+    for (int m = 4; m >= 1; m >>= 1) {
+        const long long sx = 2 * p.rx + 1, sy = 2 * p.ry + 1, sz = 2 * p.rz + 1, len = (long long)m * kBlock3d;
+        const long long planes = (len + sx * sy - 1) / (sx * sy) + 1;
+        const long long nz = (planes < sz ? planes : sz) + 3 + 1;
+        const long long rows = planes > 1 ? sy : (len + sx - 1) / sx + 1;
+        const long long ny = (rows < sy ? rows : sy) + 3 + 2, nx = sx + 3 + 2;
+        if (nx * ny * nz <= kWinCap) {
+            q.samples_per_pass = m;
+            break;
         }
-        const unsigned grid = (unsigned)(count < (1u << 30) ? count : (1u << 30));
-        (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
-        hipLaunchKernelGGL(icgn3d1_kernel<true>, dim3(grid), dim3(kBlock3d), lds, stream, p, pois, stride_f,
-                           (unsigned long long)count);
-    } else {
-        if (!p.scratch) return hipErrorInvalidValue;
-        const unsigned grid = (unsigned)(count < (size_t)blocks ? count : (size_t)blocks);
-        (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
-        hipLaunchKernelGGL(icgn3d1_kernel<false>, dim3(grid), dim3(kBlock3d), red_bytes, stream, p, pois, stride_f,
-                           (unsigned long long)count);
     }
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
+    hipLaunchKernelGGL(icgn3d1_kernel, dim3(grid), dim3(kBlock3d), 0, stream, q, pois, stride_f, (unsigned long long)count);
     return hipGetLastError();
 }
 

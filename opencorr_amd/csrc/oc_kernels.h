@@ -54,7 +54,8 @@ struct Icgn3dParams {
     int dz, dy, dx;
     int rx, ry, rz;
     float conv, stop;
-    float* scratch;  // per-workgroup warped-subvolume slots, only when the subvolume exceeds LDS
+    float* scratch;  // per-workgroup slots for the warped subvolume
+    int samples_per_pass;  // samples per thread between two coefficient-box stagings (set by launch_icgn3d1)
 };
 // floats of global scratch the kernel needs for this radius (0 when the subvolume fits LDS);
 // *blocks receives the number of persistent workgroups in scratch mode (0 in LDS mode)

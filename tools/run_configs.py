@@ -135,7 +135,7 @@ def run_3d(name, dim, r, nside, oracle_sample):
     sample = guess.cpu().numpy()[::step_s].copy()
     prep = oracle.Prepared3D(ref.cpu().numpy(), tar.cpu().numpy())
     t0 = time.perf_counter()
-    oracle.icgn3d1(prep, r, r, r, 0.001, 20.0, sample, order=oracle.ORDER_LANES, lanes=1024)
+    oracle.icgn3d1(prep, r, r, r, 0.001, 20.0, sample, order=oracle.ORDER_LANES, lanes=512)
     oracle_s = time.perf_counter() - t0
     bit_exact = bool(np.array_equal(sample.view(np.uint32), after[::step_s].view(np.uint32)))
     return dict(config=name, engine="FFTCC3D+ICGN3D1", volume="%d^3" % dim, radius=r, pois=n, fftcc_seconds=t_f,
