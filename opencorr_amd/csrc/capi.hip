@@ -452,7 +452,7 @@ extern "C" {
 
 const char* oc_hip_last_error(void) { return g_last_error.c_str(); }
 
-int oc_hip_abi_version(void) { return 1; }
+int oc_hip_abi_version(void) { return 2; }
 
 int oc_hip_device_count(int* count) {
     if (!count) return fail(OC_HIP_ERR_INVALID, "null count");
