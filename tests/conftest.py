@@ -23,6 +23,12 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_icgn2():
+    """x y u v u0 v0 zncc iteration convergence of the reference authors' CUDA ICGN2D2 run on the OHT pair."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "oht_cfrp_sift_icgn2_gpu_r16.npz"))["table"]
+
+
+@pytest.fixture(scope="session")
 def speckle_small():
     """320 x 300 synthetic speckle pair with the SURVEY 8(d) displacement field."""
     from opencorr_amd import synth

@@ -11,6 +11,14 @@ Inputs (all under /root/reference/examples/2d_dic/):
 produced by examples/test_2d_dic_fftcc_icgn1.cpp (r=16, conv 1e-3, stop 10,
 POI grid 100 x 300, step 2, origin (30,30)).  Only data is stored -- no
 reference source code.
+
+A second, weaker anchor for the second-order engine:
+  oht_cfrp_4_sift_icgn2(gpu)_r16.csv        x,y,u,v,u0,v0,ZNCC,iteration,convergence,feature
+written by the reference authors' CUDA ICGN2D2 (examples/test_2d_dic_gpu_icgn.cpp) from SIFT +
+FeatureAffine initial guesses.  The CSV keeps only the translation part (u0, v0) of those
+guesses, so a re-run starts from a slightly different point; IC-GN is path independent enough
+that the converged u, v, ZNCC still agree to ~1e-5 px / 1e-7 (see tests/test_oracle_golden.py).
+Stored as oht_cfrp_sift_icgn2_gpu_r16.npz.
 """
 import os
 
@@ -40,6 +48,13 @@ def main():
         deformation=deform.astype(np.float32),
         params=np.array([16, 16, 10], dtype=np.int32), conv=np.float32(0.001))
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    t2 = np.genfromtxt(os.path.join(REF, "oht_cfrp_4_sift_icgn2(gpu)_r16.csv"), delimiter=",", skip_header=1,
+                       usecols=range(9))
+    assert t2.shape == (30000, 9) and np.array_equal(t2[:, :2], table[:, :2])
+    out2 = os.path.join(os.path.dirname(OUT), "oht_cfrp_sift_icgn2_gpu_r16.npz")
+    # x y u v u0 v0 zncc iteration convergence
+    np.savez_compressed(out2, table=t2.astype(np.float32))
+    print("wrote", out2, os.path.getsize(out2), "bytes")
 
 
 if __name__ == "__main__":

@@ -346,3 +346,22 @@ def test_icgn2d_self_adaptive_radius_bit_exact(eng, dof):
     want2 = base.copy()
     fn(prep, 16, 16, 0.001, 10, want2, order=oracle.ORDER_LANES, lanes=64)
     assert np.array_equal(_bits(icgn.compute(base)), _bits(want2))
+
+
+def test_icgn2d2_golden_soft_anchor_on_gpu(eng, golden, golden_icgn2):
+    """ICGN2D2 on the GPU against the reference authors' CUDA ICGN2D2 CSV (soft anchor: same (u0, v0),
+    converged values only) and bit-exact against the oracle."""
+    import oracle
+    from test_oracle_golden import icgn2_soft_anchor_check
+    tab = golden_icgn2
+    pois = oracle.make_pois2d(tab[:, 0], tab[:, 1])
+    pois[:, oracle.P2["u"]], pois[:, oracle.P2["v"]] = tab[:, 4], tab[:, 5]
+    icgn = eng.ICGN2D2(16, 16, golden["conv"], golden["stop"])
+    icgn.set_images(golden["ref"], golden["tar"])
+    icgn.prepare()
+    got = icgn.compute(pois.copy())
+    icgn2_soft_anchor_check(got, tab)
+    want = pois.copy()
+    oracle.icgn2d2(oracle.Prepared2D(golden["ref"], golden["tar"]), 16, 16, golden["conv"], golden["stop"], want,
+                   order=oracle.ORDER_LANES, lanes=64)
+    assert np.array_equal(_bits(got), _bits(want))

@@ -68,3 +68,27 @@ def test_lanes_order_close_to_sequential(oracle_run):
     same_it = conv & (a[:, P2["iteration"]] == b[:, P2["iteration"]])
     assert np.abs(a[same_it, P2["u"]] - b[same_it, P2["u"]]).max() <= 1e-4
     assert np.abs(a[same_it, P2["v"]] - b[same_it, P2["v"]]).max() <= 1e-4
+
+
+def icgn2_soft_anchor_check(p, tab):
+    """Shared by the oracle and the GPU test: converged ICGN2D2 results vs the reference's CUDA ICGN2D2 CSV,
+    both started from the CSV's (u0, v0) -- the CSV does not keep the gradient part of the SIFT/affine guess,
+    so trajectories differ and only the converged values are compared."""
+    m = (tab[:, 6] > 0.9) & (p[:, P2["zncc"]] > 0.9) & (tab[:, 7] < 10)
+    assert m.sum() > 28000
+    du, dv = np.abs(p[m, P2["u"]] - tab[m, 2]), np.abs(p[m, P2["v"]] - tab[m, 3])
+    assert np.median(du) <= 2e-5 and np.median(dv) <= 2e-5
+    assert np.percentile(du, 99) <= 3e-4 and np.percentile(dv, 99) <= 3e-4
+    assert du.max() <= 2e-3 and dv.max() <= 2e-3
+    dz = np.abs(p[m, P2["zncc"]] - tab[m, 6])
+    assert np.median(dz) <= 1e-6 and np.percentile(dz, 99) <= 1e-5
+
+
+def test_icgn2d2_converges_to_the_reference_cuda_results(golden, golden_icgn2):
+    """Soft external anchor for the 12-DoF engine."""
+    tab = golden_icgn2
+    p = oracle.make_pois2d(tab[:, 0], tab[:, 1])
+    p[:, P2["u"]], p[:, P2["v"]] = tab[:, 4], tab[:, 5]
+    prep = oracle.Prepared2D(golden["ref"], golden["tar"])
+    oracle.icgn2d2(prep, 16, 16, golden["conv"], golden["stop"], p)
+    icgn2_soft_anchor_check(p, tab)
