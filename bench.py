@@ -14,8 +14,16 @@ timed region and reported separately.
 Workload (BASELINE.json configs[1], SURVEY.md 8d "B"): 4096 x 4096 synthetic speckle
 pair, r = 16 (33 x 33 subset, 32 x 32 FFTCC window), 500 x 500 = 250 000 POIs,
 conv 1e-3, stop 10.  N > 1 is weak scaling: 250 000 POIs per GPU cut from one
-N*250 000-POI queue over an 8192 x 8192 pair replicated on every GPU (N = 8 is
-BASELINE config "D").
+N*250 000-POI queue over a pair replicated on every GPU.  The image grows with N so that
+the POI pitch -- i.e. how much neighbouring subsets overlap, which sets the cache behaviour
+of the kernel -- stays what it is at N = 1: 4096 x 8192 with 1000 x 500 POIs at N = 2,
+8192 x 8192 with 1000 x 1000 at N = 4; N = 8 is BASELINE config "D" as written (8192 x 8192,
+1414 x 1414 POIs; a denser grid, 8192^2 being the largest image the 32-bit LUT offsets address).
+
+For N > 1 the all-gather of step k overlaps the correlation of step k+1 (double-buffered
+queues, `async_op=True`): a production pipeline streams image pairs, and xGMI moving one
+pair's records while the next pair is being correlated is how it would run.  All K gathers
+complete inside the timed region.
 
 Besides the contract fields the JSON line carries
   roofline     -- ICGN2D1 kernel: algorithmic bytes (3*N2*4 + k*N2*64 + 200 per
@@ -87,22 +95,37 @@ def main():
     from opencorr_amd.dist import allgather_pois, shard_bounds
 
     # ---- workload ---------------------------------------------------------------------
-    side = args.size or (4096 if world == 1 else 8192)
     per_side = args.pois or POIS_PER_GPU_SIDE
     n_total = world * per_side * per_side
-    if world == 1:
-        nx = ny = per_side
+    # image (height, width) and POI grid (nx, ny) per world size: constant POI pitch up to N = 4
+    if args.size:
+        height = width = args.size
+        nx = int(np.floor(np.sqrt(n_total)))
+        ny = -(-n_total // nx)
+    elif world == 1:
+        height, width, nx, ny = 4096, 4096, per_side, per_side
+    elif world == 2:
+        height, width, nx, ny = 4096, 8192, 2 * per_side, per_side
+    elif world == 4:
+        height, width, nx, ny = 8192, 8192, 2 * per_side, 2 * per_side
     else:
+        height = width = 8192
         nx = int(np.floor(np.sqrt(n_total)))
         ny = -(-n_total // nx)
     t0 = time.time()
-    ref, tar = synth.speckle_pair_2d(side, side, seed=20260925, device=dev)
-    xs, ys = synth.poi_grid_2d(side, side, nx, ny, RX + 8)
+    ref, tar = synth.speckle_pair_2d(height, width, seed=20260925, device=dev)
+    xs, ys = synth.poi_grid_2d(height, width, nx, ny, RX + 8)
     xs, ys = xs[:n_total], ys[:n_total]
     n_total = len(xs)
     lo, hi = shard_bounds(n_total, world, rank)
     pristine = torch.from_numpy(opencorr_amd.make_pois2d(xs[lo:hi], ys[lo:hi])).to(dev)
-    pois = pristine.clone()
+    # two queues (and two gather buffers): step k+1 fills one while the all-gather of step k reads the other
+    queues = [pristine.clone(), pristine.clone()] if world > 1 else [pristine.clone()]
+    per_rank = -(-n_total // world)
+    gather_bufs = [torch.empty((world * per_rank, pristine.shape[1]), dtype=pristine.dtype, device=dev)
+                   for _ in queues] if world > 1 else []
+    pending = [None] * len(queues)
+    pois = queues[0]
     gen_s = time.time() - t0
 
     stream = torch.cuda.current_stream().cuda_stream
@@ -119,17 +142,31 @@ def main():
     prepare_ms = (time.time() - t0) * 1e3
 
     gathered = None
+    step_no = 0
 
     def step():
-        nonlocal gathered
+        nonlocal gathered, pois, step_no
+        b = step_no % len(queues)
+        step_no += 1
+        if pending[b] is not None:
+            pending[b].wait()  # the gather that last read this queue / wrote this buffer has finished
+            pending[b] = None
+        pois = queues[b]
         pois.copy_(pristine)
         fftcc.compute(pois)
         icgn.compute(pois)
         if world > 1:
-            gathered = allgather_pois(pois, n_total)
+            gathered, pending[b] = allgather_pois(pois, n_total, out=gather_bufs[b], async_op=True)
+
+    def drain():
+        for b in range(len(pending)):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     icgn.profile_enable(True)
     fftcc.profile_enable(True)
@@ -139,6 +176,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -176,11 +214,12 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": ("B: %dx%d speckle pair, r=16 (33x33 subset, 32x32 FFTCC window), %d POIs/GPU, "
-                             "FFTCC2D init -> ICGN2D1 conv=1e-3 stop=10" % (side, side, hi - lo)),
+                             "FFTCC2D init -> ICGN2D1 conv=1e-3 stop=10" % (width, height, hi - lo)),
                 "total_pois": n_total,
                 "converged_pois": converged,
                 "mean_iterations": mean_iter,
-                "collective": "RCCL all_gather of POI records" if world > 1 else "none",
+                "collective": ("RCCL all_gather of POI records, overlapped with the next step's kernels"
+                               if world > 1 else "none"),
             },
             "roofline": {
                 "kernel": "icgn2d1_kernel",

@@ -15,6 +15,7 @@
 // in increasing s followed by the xor butterfly of oc_device.h; the CPU oracle
 // uses the same association (OC_ORDER_LANES) and the results are bit-identical.
 // Wave-uniform state (warp matrix, inverse Hessian, norms) is held in SGPRs.
+#include <atomic>
 #include <cstdlib>
 
 #include "oc_device.h"
@@ -686,12 +687,18 @@ static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, siz
     const size_t lds = (size_t)arrays * nt * kWave * sizeof(float) * WPB;
     if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
     auto kern = icgn2d_kernel<DOF, G, MODE, PIPE, WPB, OCC, OFFS>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the dynamic-LDS limit is a per-device property of the loaded function: raise it once on every
+    // device this process launches on (one engine per device is a supported host layout)
+    static std::atomic<unsigned long long> attr_devices{0};
+    int dev = 0;
+    hipError_t derr = hipGetDevice(&dev);
+    if (derr != hipSuccess) return derr;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
         if (err != hipSuccess) return err;
-        attr_set = true;
+        attr_devices.fetch_or(bit, std::memory_order_release);
     }
     const size_t groups = (count + WPB - 1) / WPB;
     Icgn2dLaunch L;

@@ -18,11 +18,17 @@ def shard_bounds(n_total, world_size, rank):
     return lo, hi
 
 
-def allgather_pois(local, n_total, group=None):
+def allgather_pois(local, n_total, group=None, out=None, async_op=False):
     """Gathers the per-rank POI blocks (n_local x F float32) into the full (n_total x F) queue.
 
     Blocks are padded to ceil(n_total / G) records so a single fixed-size
     ``all_gather_into_tensor`` suffices; the padding is dropped on return.
+
+    ``out``: optional preallocated (G * ceil(n_total / G), F) buffer to gather into (a steady-state
+    pipeline reuses it).  ``async_op=True`` returns ``(queue, work)``: the collective then runs on the
+    backend's own stream behind the work already enqueued on the current stream, and the caller's
+    later kernels do not wait for it -- the next image pair is correlated while xGMI moves this
+    one's records.  Call ``work.wait()`` before reading the queue or reusing the buffers.
     """
     world = dist.get_world_size(group)
     per = -(-n_total // world)
@@ -30,6 +36,11 @@ def allgather_pois(local, n_total, group=None):
     if local.shape[0] < per:
         pad = torch.zeros((per - local.shape[0], floats), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
-    out = torch.empty((world * per, floats), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    if out is None:
+        out = torch.empty((world * per, floats), dtype=local.dtype, device=local.device)
+    elif tuple(out.shape) != (world * per, floats) or out.dtype != local.dtype or not out.is_contiguous():
+        raise ValueError("out must be a contiguous (%d, %d) %s tensor" % (world * per, floats, local.dtype))
+    work = dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=async_op)
+    if async_op:
+        return out[:n_total], work
     return out[:n_total]

@@ -41,6 +41,12 @@ def _worker(rank, world, port, n_total, out_dir):
         prep = oracle.Prepared2D(ref, tar, threads=1)
         oracle.icgn2d1(prep, 12, 12, 0.001, 10, pois, order=oracle.ORDER_LANES, threads=1)
     full = allgather_pois(torch.from_numpy(pois), n_total)
+    # the pipelined form bench.py uses: preallocated buffer, async handle
+    per = -(-n_total // world)
+    buf = torch.empty((world * per, pois.shape[1]), dtype=torch.float32)
+    full2, work = allgather_pois(torch.from_numpy(pois), n_total, out=buf, async_op=True)
+    work.wait()
+    assert torch.equal(full, full2) and full2.data_ptr() == buf.data_ptr()
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), full.numpy())
     dist.destroy_process_group()
 
