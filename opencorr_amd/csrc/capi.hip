@@ -132,7 +132,7 @@ struct oc_hip_engine {
     FftPlans fft;
     DevBuf win, freq, norms, flags;
     // kernel selection (oc_hip_set_tuning); every choice computes the same bits
-    int icgn2d_variant = 5;   // G = 2, LDS-light, 4 waves per workgroup (MI355X sweep)
+    int icgn2d_variant = 2;   // G = 3, LDS-light, 4 waves per workgroup (MI355X sweep)
     bool self_adaptive = false;  // DIC::setSelfAdaptive
     int icgn2d_xcd = 1;
     int fftcc2d_fused = 1;    // single-kernel FFTCC2D when the window is 32 x 32

@@ -151,20 +151,40 @@ struct LutFetch {
     float dx, dy;
 };
 
-// range rule of BicubicBspline::compute (src/oc_cubic_bspline.cpp:137-142); out-of-range
-// samples fetch entry (0,0), which is always mapped, and are replaced by -1.f afterwards
-__device__ __forceinline__ void lut_fetch(LutFetch& f, const float* __restrict__ lut, int height, int width, float x,
+// All image-sized arrays are read through buffer resources (V#): a 32-bit per-lane byte offset plus a
+// wave-uniform SGPR offset replace the 64-bit per-lane address arithmetic of flat loads -- in these loops
+// the address math used to cost as many VALU slots as the arithmetic it fed.  Raw buffer, stride 0,
+// num_records = 2^32 - 1 bytes: the images (<= 268 MB) and the LUT (<= 4 GiB) both fit.
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+}
+
+// range rule of BicubicBspline::compute (src/oc_cubic_bspline.cpp:137-142): x < 1 || y < 1 ||
+// x >= width-2 || y >= height-2 || NaN -> -1.  With xi = (int)floor(x) that is
+// (unsigned)(xi - 1) > width - 4; the median clamp keeps the float -> int conversion defined for wild
+// values and sends NaN to -2 (v_med3_f32 returns the minimum of the other two for a NaN input), i.e.
+// outside.  floor(x) is exactly (float)xi for in-range x, so dx = x - floor(x) has the reference's bits.
+// Out-of-range samples fetch entry (0,0), which is always mapped, and are replaced by -1.f afterwards.
+__device__ __forceinline__ void lut_fetch(LutFetch& f, __amdgpu_buffer_rsrc_t lut, int height, int width, float x,
                                           float y) {
-    const bool out = (x < 1 || y < 1 || x >= width - 2 || y >= height - 2 || isnan(x) || isnan(y));
-    const int xi = out ? 0 : (int)floorf(x);
-    const int yi = out ? 0 : (int)floorf(y);
-    f.dx = x - (float)xi;
-    f.dy = out ? -1.f : y - (float)yi;
-    const float4* __restrict__ e = reinterpret_cast<const float4*>(lut) + ((size_t)yi * width + xi) * 4;
-    f.c0 = e[0];
-    f.c1 = e[1];
-    f.c2 = e[2];
-    f.c3 = e[3];
+    const float fx = floorf(x), fy = floorf(y);
+    const int xi = (int)__builtin_amdgcn_fmed3f(fx, -2.f, 2.0e9f), yi = (int)__builtin_amdgcn_fmed3f(fy, -2.f, 2.0e9f);
+    const bool out = (unsigned)(xi - 1) > (unsigned)(width - 4) || (unsigned)(yi - 1) > (unsigned)(height - 4);
+    f.dx = x - fx;
+    f.dy = out ? -1.f : y - fy;
+    // 24-bit multiply: full rate, and exact because in-range yi and the width are below 2^24
+    const unsigned e = out ? 0u : (__umul24((unsigned)yi, (unsigned)width) + (unsigned)xi) << 6;
+    f.c0 = buf_f32x4(lut, e);
+    f.c1 = buf_f32x4(lut, e + 16);
+    f.c2 = buf_f32x4(lut, e + 32);
+    f.c3 = buf_f32x4(lut, e + 48);
 }
 
 // explicit 16-term left-to-right polynomial of src/oc_cubic_bspline.cpp:144-177
@@ -216,6 +236,12 @@ __device__ __forceinline__ void set_warp_2d2(float (&w)[36], const float (&q)[12
     w[18] = 0.5f * uxx; w[19] = uxy; w[20] = 0.5f * uyy; w[21] = 1.f + ux; w[22] = uy; w[23] = u;
     w[24] = 0.5f * vxx; w[25] = vxy; w[26] = 0.5f * vyy; w[27] = vx; w[28] = 1.f + vy; w[29] = v;
     w[30] = 0.f; w[31] = 0.f; w[32] = 0.f; w[33] = 0.f; w[34] = 0.f; w[35] = 1.f;
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) {
+    f2 r = {a, b};
+    return r;
 }
 
 // steepest-descent row of one sample (src/oc_icgn.cpp:191-196; 2D2: 725-745; center-offset
@@ -322,26 +348,30 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     const int q64 = kWave / W, r64 = kWave - q64 * W;
     const int r0 = lane / W;
     const int c0 = lane - r0 * W;
-    const size_t goff = (size_t)((int)py - ry) * width + ((int)px - rx);
-    const float* __restrict__ bgx = P.gx + goff;
-    const float* __restrict__ bgy = P.gy + goff;
+    // subset origin as a wave-uniform byte offset (images are <= 2^28 bytes)
+    const unsigned goff = (unsigned)__builtin_amdgcn_readfirstlane((((int)py - ry) * width + ((int)px - rx)) * 4);
+    const __amdgpu_buffer_rsrc_t r_gx = make_rsrc(P.gx), r_gy = make_rsrc(P.gy), r_ref = make_rsrc(P.ref),
+                                 r_lut = make_rsrc(P.lut);
+    const unsigned w4 = (unsigned)width * 4u;
+    // byte offset of sample (r, c) from the subset origin
+    auto soff = [&](const SampleWalk& w) { return __umul24((unsigned)w.r, w4) + ((unsigned)w.c << 2); };
 
     // ---- reference subset, zero-mean + norm (src/oc_icgn.cpp:174-176, src/oc_subset.cpp:39-53)
     float ref_norm;
     {
         const int x0 = (int)(px - rx), y0 = (int)(py - ry);
-        const float* __restrict__ base = P.ref + (size_t)y0 * width + x0;
+        const unsigned roff = (unsigned)__builtin_amdgcn_readfirstlane((y0 * width + x0) * 4);
         float acc = 0.f;
         SampleWalk w(lane, r0, c0, W, q64, r64);
 #pragma unroll 3
         for (int t = 0; t < NF; t++, w.next()) {
-            const float v = base[w.r * width + w.c];
+            const float v = buf_f32(r_ref, soff(w), roff);
             acc = acc + v;
             l_rs[t * kWave] = v;
         }
         if (NF < NT) {
             const bool valid = w.s < N;
-            const float v = valid ? base[w.r * width + w.c] : 0.f;
+            const float v = valid ? buf_f32(r_ref, soff(w), roff) : 0.f;
             acc = valid ? acc + v : acc;
             l_rs[NF * kWave] = v;
         }
@@ -368,23 +398,61 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
 #pragma unroll
         for (int i = 0; i < NH; i++) h[i] = 0.f;
         SampleWalk w(lane, r0, c0, W, q64, r64);
+        if constexpr (DOF == 6) {
+            // The 21 running sums H(i,j) += sd[i]*sd[j] as packed-fp32 pairs (v_pk_mul_f32 / v_pk_add_f32: two
+            // IEEE operations per issue slot, each rounded on its own -- every H(i,j) still receives the same
+            // products in the same order).  With A = (sd1, sd2) = g_x*(x, y), B = (sd4, sd5) = g_y*(x, y):
+            f2 hAA = mk2(0.f, 0.f), hBB = hAA, hAB = hAA, hAs = hAA, hxA = hAA, hyA = hAA, hxB = hAA, hyB = hAA;
+            float h00 = 0.f, h33 = 0.f, h30 = 0.f, h21 = 0.f, h54 = 0.f;
+            auto sample = [&](int t, bool valid) {
+                const unsigned off = soff(w);
+                const float g_x = valid ? buf_f32(r_gx, off, goff) : 0.f;
+                const float g_y = valid ? buf_f32(r_gy, off, goff) : 0.f;
+                if constexpr (MODE == 0) {
+                    l_gx[t * kWave] = g_x;
+                    l_gy[t * kWave] = g_y;
+                }
+                const f2 xy = mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
+                const f2 A = g_x * xy, B = g_y * xy;
+                const f2 nAA = hAA + A * A, nBB = hBB + B * B, nAB = hAB + A * B, nAs = hAs + A * B.yx;
+                const f2 nxA = hxA + g_x * A, nyA = hyA + g_y * A, nxB = hxB + g_x * B, nyB = hyB + g_y * B;
+                const float n00 = h00 + g_x * g_x, n33 = h33 + g_y * g_y, n30 = h30 + g_y * g_x;
+                const float n21 = h21 + A.y * A.x, n54 = h54 + B.y * B.x;
+                if (valid) {
+                    hAA = nAA; hBB = nBB; hAB = nAB; hAs = nAs; hxA = nxA; hyA = nyA; hxB = nxB; hyB = nyB;
+                    h00 = n00; h33 = n33; h30 = n30; h21 = n21; h54 = n54;
+                }
+            };
 #pragma unroll 1
-        for (int t = 0; t < NT; t++, w.next()) {
-            const bool valid = w.s < N;
-            const int off = w.r * width + w.c;
-            const float g_x = valid ? bgx[off] : 0.f;
-            const float g_y = valid ? bgy[off] : 0.f;
-            if constexpr (MODE == 0) {
-                l_gx[t * kWave] = g_x;
-                l_gy[t * kWave] = g_y;
-            }
-            float sd[DOF];
-            sd_row<DOF>(g_x, g_y, (float)(w.c - rx) - offx, (float)(w.r - ry) - offy, sd);
-            int k = 0;
+            for (int t = 0; t < NF; t++, w.next()) sample(t, true);
+            if (NF < NT) sample(NF, w.s < N);
+            // back to the row-major lower triangle h[i*(i+1)/2 + j]
+            h[0] = h00;                                                           // (0,0)
+            h[1] = hxA.x; h[2] = hAA.x;                                           // (1,0) (1,1)
+            h[3] = hxA.y; h[4] = h21; h[5] = hAA.y;                               // (2,0) (2,1) (2,2)
+            h[6] = h30; h[7] = hyA.x; h[8] = hyA.y; h[9] = h33;                   // (3,0) (3,1) (3,2) (3,3)
+            h[10] = hxB.x; h[11] = hAB.x; h[12] = hAs.y; h[13] = hyB.x; h[14] = hBB.x;                // (4,0..4)
+            h[15] = hxB.y; h[16] = hAs.x; h[17] = hAB.y; h[18] = hyB.y; h[19] = h54; h[20] = hBB.y;   // (5,0..5)
+        } else {
+            auto sample = [&](int t, bool valid) {
+                const unsigned off = soff(w);
+                const float g_x = valid ? buf_f32(r_gx, off, goff) : 0.f;
+                const float g_y = valid ? buf_f32(r_gy, off, goff) : 0.f;
+                if constexpr (MODE == 0) {
+                    l_gx[t * kWave] = g_x;
+                    l_gy[t * kWave] = g_y;
+                }
+                float sd[DOF];
+                sd_row<DOF>(g_x, g_y, (float)(w.c - rx) - offx, (float)(w.r - ry) - offy, sd);
+                int k = 0;
 #pragma unroll
-            for (int i = 0; i < DOF; i++)
+                for (int i = 0; i < DOF; i++)
 #pragma unroll
-                for (int j = 0; j <= i; j++, k++) h[k] = valid ? h[k] + sd[i] * sd[j] : h[k];
+                    for (int j = 0; j <= i; j++, k++) h[k] = valid ? h[k] + sd[i] * sd[j] : h[k];
+            };
+#pragma unroll 1
+            for (int t = 0; t < NF; t++, w.next()) sample(t, true);
+            if (NF < NT) sample(NF, w.s < N);
         }
         // lane j < DOF assembles column j of the symmetric Hessian
         float col[DOF];
@@ -470,7 +538,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     }
                     // a lane past the end of the subset fetches a harmless in-range point
                     // tar_subset->center = POI + center_offset, then + warped_coor (src/oc_icgn.cpp:425-426,452)
-                    lut_fetch(f[g], P.lut, height, width, valid[g] ? tcx + wx : 1.f, valid[g] ? tcy + wy : 1.f);
+                    lut_fetch(f[g], r_lut, height, width, valid[g] ? tcx + wx : 1.f, valid[g] ? tcy + wy : 1.f);
                 }
             };
             auto consume = [&](const LutFetch(&f)[G], const bool(&valid)[G], int t0) {
@@ -530,31 +598,45 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         float ssd = 0.f;
         {
             SampleWalk w(lane, r0, c0, W, q64, r64);
+            f2 nA = mk2(0.f, 0.f), nB = nA;  // DOF 6: (num1, num2) and (num4, num5) as packed pairs
             auto sample = [&](int t, bool valid) {
                 float g_x, g_y;
                 if constexpr (MODE == 0) {
                     g_x = l_gx[t * kWave];
                     g_y = l_gy[t * kWave];
                 } else {
-                    const int off = w.r * width + w.c;
-                    g_x = valid ? bgx[off] : 0.f;
-                    g_y = valid ? bgy[off] : 0.f;
+                    const unsigned off = soff(w);
+                    g_x = valid ? buf_f32(r_gx, off, goff) : 0.f;
+                    g_y = valid ? buf_f32(r_gy, off, goff) : 0.f;
                 }
                 const float tz = l_ts[t * kWave] - tmean;  // same bits as in the norm pass
                 const float e = tz * factor - l_rs[t * kWave];
-                float sd[DOF];
-                sd_row<DOF>(g_x, g_y, (float)(w.c - rx) - offx, (float)(w.r - ry) - offy, sd);
                 const float e2 = e * e;
                 ssd = valid ? ssd + e2 : ssd;
+                if constexpr (DOF == 6) {
+                    const f2 xy = mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
+                    const f2 A = g_x * xy, B = g_y * xy;  // (sd1, sd2), (sd4, sd5)
+                    const f2 mA = nA + A * e, mB = nB + B * e;
+                    const float m0 = num[0] + g_x * e, m3 = num[3] + g_y * e;
+                    if (valid) {
+                        nA = mA; nB = mB; num[0] = m0; num[3] = m3;
+                    }
+                } else {
+                    float sd[DOF];
+                    sd_row<DOF>(g_x, g_y, (float)(w.c - rx) - offx, (float)(w.r - ry) - offy, sd);
 #pragma unroll
-                for (int i = 0; i < DOF; i++) {
-                    const float n = sd[i] * e;
-                    num[i] = valid ? num[i] + n : num[i];
+                    for (int i = 0; i < DOF; i++) {
+                        const float n = sd[i] * e;
+                        num[i] = valid ? num[i] + n : num[i];
+                    }
                 }
             };
 #pragma unroll 3
             for (int t = 0; t < NF; t++, w.next()) sample(t, true);
             if (NF < NT) sample(NF, w.s < N);
+            if constexpr (DOF == 6) {
+                num[1] = nA.x; num[2] = nA.y; num[4] = nB.x; num[5] = nB.y;
+            }
         }
         znssd = uni(wave_allreduce_sum(ssd)) / (ref_norm * ref_norm);
         // dp = H^-1 * numerator (src/oc_icgn.cpp:279-286): lane j forms H^-1(i,j) * num[j], the

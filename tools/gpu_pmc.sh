@@ -11,7 +11,7 @@ cd /tmp
 pmc() {
   name=$1; shift
   timeout 300 rocprofv3 --pmc "$@" --kernel-include-regex "icgn2d_kernel" --output-format csv -d $OUT/pmc_$name -o $name -- \
-      python $ROOT/tools/icgn_sweep.py --launches 1 --oracle-sample 200 --variants $VARS $EXTRA > $OUT/pmc_$name.log 2>&1
+      python $ROOT/tools/icgn_sweep.py --launches 1 --oracle-sample 200 --variants $VARS --xcd 1 $EXTRA > $OUT/pmc_$name.log 2>&1
   echo "pmc $name rc=$?"
 }
 EXTRA="$@"
