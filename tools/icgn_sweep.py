@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--xcd", default="0,1")
     ap.add_argument("--oracle-sample", type=int, default=4000)
     ap.add_argument("--out", default="")
+    ap.add_argument("--tile", type=int, default=0, help="reorder the POI queue into T x T tiles of the grid (locality experiment)")
     args = ap.parse_args()
 
     import torch
@@ -41,6 +42,12 @@ def main():
     so = dict(uxx=2e-6, vyy=-1e-6) if args.engine == 2 else None
     ref, tar = synth.speckle_pair_2d(args.size, args.size, seed=20260925, device=dev, second_order=so)
     xs, ys = synth.poi_grid_2d(args.size, args.size, args.pois, args.pois, r + 8)
+    if args.tile:
+        gi, gj = np.divmod(np.arange(len(xs)), args.pois)  # grid row, column of each POI
+        key = ((gi // args.tile) * (-(-args.pois // args.tile)) + gj // args.tile) * (args.tile * args.tile) + \
+              (gi % args.tile) * args.tile + gj % args.tile
+        order = np.argsort(key, kind="stable")
+        xs, ys = xs[order], ys[order]
     stream = torch.cuda.current_stream().cuda_stream
     fftcc = opencorr_amd.FFTCC2D(r, r)
     fftcc.set_stream(stream)
