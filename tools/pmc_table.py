@@ -19,10 +19,10 @@ def main(root, out=None):
         tag = os.path.basename(os.path.dirname(path))
         seq = collections.defaultdict(list)
         for r in csv.DictReader(open(path)):
-            m = re.search(r"icgn2d_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", r["Kernel_Name"])
+            m = re.search(r"icgn2d_kernel<([\d, ]+)>", r["Kernel_Name"])
             if not m:
                 continue
-            key = tuple(int(x) for x in m.groups())
+            key = tuple(int(x) for x in m.group(1).split(","))
             d = int(r["Dispatch_Id"])
             if d not in seq[key]:
                 seq[key].append(d)
@@ -33,12 +33,11 @@ def main(root, out=None):
     counters = sorted({c for k in per for o in per[k] for c in per[k][o]})
     rows = []
     for key in sorted(per):
-        for ordinal, xcd in ((1, 0), (3, 1)):
-            if ordinal not in per[key]:
-                continue
+        # every (variant, mapping) is dispatched twice by tools/icgn_sweep.py --launches 1: warm-up, then the timed one
+        for n, ordinal in enumerate(sorted(per[key])[1::2]):
             c = per[key][ordinal]
             ms = [v for (t, o), v in dur[key].items() if o == ordinal]
-            row = dict(dof=key[0], G=key[1], mode=key[2], pipe=key[3], wpb=key[4], occ=key[5], xcd=xcd,
+            row = dict(dof=key[0], G=key[1], mode=key[2], pipe=key[3], wpb=key[4], occ=key[5], xcd=n,
                        ms_under_pmc=sum(ms) / len(ms))
             row.update({n: c.get(n, float("nan")) for n in counters})
             rows.append(row)
