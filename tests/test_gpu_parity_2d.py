@@ -365,3 +365,64 @@ def test_icgn2d2_golden_soft_anchor_on_gpu(eng, golden, golden_icgn2):
     oracle.icgn2d2(oracle.Prepared2D(golden["ref"], golden["tar"]), 16, 16, golden["conv"], golden["stop"], want,
                    order=oracle.ORDER_LANES, lanes=64)
     assert np.array_equal(_bits(got), _bits(want))
+
+
+def test_edge_cases_of_the_boundary(eng, speckle_small):
+    """Empty queue, a queue embedded in wider records (stride_bytes), API misuse reported as errors."""
+    import torch
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    f = eng.FFTCC2D(16, 16)
+    f.set_images(ref, tar)
+    icgn = eng.ICGN2D1(16, 16, 0.001, 10)
+    # compute before set_images / prepare is an error, not a crash or a silent no-op
+    with pytest.raises(eng.capi.OpenCorrHipError):
+        icgn.compute(eng.make_pois2d([100.0], [100.0]))
+    icgn.share_images(f)
+    with pytest.raises(eng.capi.OpenCorrHipError):
+        icgn.compute(eng.make_pois2d([100.0], [100.0]))
+    icgn.prepare()
+    # empty queue
+    empty = np.zeros((0, 25), np.float32)
+    assert f.compute(empty).shape == (0, 25) and icgn.compute(empty).shape == (0, 25)
+    # POI records embedded in 32-float rows: only the first 25 floats of every row are touched
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 7, 5, 40)
+    plain = eng.make_pois2d(xs, ys)
+    wide = torch.full((len(xs), 32), 7.5, dtype=torch.float32, device="cuda")
+    wide[:, :25] = torch.from_numpy(plain).cuda()
+    f.compute(wide)
+    icgn.compute(wide)
+    f.synchronize(); icgn.synchronize()
+    got = wide.cpu().numpy()
+    want = icgn.compute(f.compute(plain.copy()))
+    assert np.array_equal(_bits(got[:, :25]), _bits(want)) and (got[:, 25:] == 7.5).all()
+    # bad stride
+    with pytest.raises(eng.capi.OpenCorrHipError):
+        eng.capi.check(eng.capi.lib().oc_hip_compute(icgn._h, wide.data_ptr(), 3, 99, eng.capi.DEVICE))
+
+
+def test_large_subsets_and_the_on_chip_limit(eng):
+    """r = 36 (73 x 73 = 5329 samples, 84 passes) still runs -- through the variant with the LDS share it needs --
+    and stays bit-exact; a subset beyond the on-chip capacity is refused with OC_HIP_ERR_UNSUPPORTED."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = synth.speckle_pair_2d(260, 280, seed=12)
+    xs, ys = synth.poi_grid_2d(260, 280, 4, 3, 60)
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, 16, 16, pois)
+    want = pois.copy()
+    prep = oracle.Prepared2D(ref, tar)
+    oracle.icgn2d1(prep, 36, 36, 0.001, 10, want, order=oracle.ORDER_LANES, lanes=64)
+    icgn = eng.ICGN2D1(36, 36, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    got = icgn.compute(pois.copy())
+    assert np.array_equal(_bits(got), _bits(want))
+    assert (want[:, oracle.P2["zncc"]] > 0.9).all()
+    big = eng.ICGN2D1(72, 72, 0.001, 10)   # 145 x 145 = 21 025 samples > 20 480 (160 KB of LDS / 2 arrays)
+    big.set_images(ref, tar)
+    big.prepare()
+    with pytest.raises(eng.capi.OpenCorrHipError) as err:
+        big.compute(pois.copy())
+    assert err.value.status == eng.capi.ERR_UNSUPPORTED
