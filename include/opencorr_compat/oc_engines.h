@@ -251,6 +251,24 @@ public:
     }
 };
 
+// NR2D1(int rx, int ry, float conv_criterion, float stop_condition, int thread_number)  src/oc_nr.h / src/oc_nr.cpp:75-91.
+// prepare() builds the target gradients and the three interpolation tables (src/oc_nr.cpp:119-158).
+class NR2D1 : public IcgnShim<DIC, POI2D> {
+public:
+    NR2D1(int rx, int ry, float conv_criterion_, float stop_condition_, int thread_number_) {
+        subset_radius_x = rx;
+        subset_radius_y = ry;
+        conv_criterion = conv_criterion_;
+        stop_condition = stop_condition_;
+        thread_number = thread_number_;
+        hipdetail::check(oc_hip_nr2d1_create(rx, ry, conv_criterion_, stop_condition_, device_, &engine_));
+    }
+    void prepare() override {
+        uploadIfNeeded();
+        hipdetail::check(oc_hip_prepare(engine_));
+    }
+};
+
 class ICGN3D1 : public IcgnShim<DVC, POI3D> {
 public:
     ICGN3D1(int rx, int ry, int rz, float conv_criterion_, float stop_condition_, int thread_number_) {

@@ -57,7 +57,8 @@ typedef enum oc_hip_kind {
     OC_HIP_ICGN2D1 = 2,
     OC_HIP_ICGN2D2 = 3,
     OC_HIP_FFTCC3D = 4,
-    OC_HIP_ICGN3D1 = 5
+    OC_HIP_ICGN3D1 = 5,
+    OC_HIP_NR2D1 = 6
 } oc_hip_kind;
 
 #define OC_HIP_POI2D_BYTES 100
@@ -81,6 +82,11 @@ int oc_hip_icgn2d1_create(int radius_x, int radius_y, float conv_criterion, floa
 /* ICGN2D2(int rx, int ry, float conv, float stop, int thread_number)  src/oc_icgn.cpp:612-629 */
 int oc_hip_icgn2d2_create(int radius_x, int radius_y, float conv_criterion, float stop_condition, int device,
                           oc_hip_engine** out);
+/* NR2D1(int rx, int ry, float conv_criterion, float stop_condition, int thread_number)  src/oc_nr.cpp:75-91
+ * (forward-additive Newton-Raphson).  prepare() = NR2D1::prepare (:119-158): target gradients and
+ * three bicubic tables; compute() = NR2D1::compute(poi_queue) (:324-332).  Per-POI codes: -1 (guard), -4, -5. */
+int oc_hip_nr2d1_create(int radius_x, int radius_y, float conv_criterion, float stop_condition, int device,
+                        oc_hip_engine** out);
 /* FFTCC3D(int rx, int ry, int rz, int thread_number)  src/oc_fftcc.cpp:300-313 */
 int oc_hip_fftcc3d_create(int radius_x, int radius_y, int radius_z, int device, oc_hip_engine** out);
 /* ICGN3D1(int rx, int ry, int rz, float conv, float stop, int thread_number)  src/oc_icgn.cpp:1197-1213 */
@@ -158,7 +164,8 @@ int oc_hip_get_kind(const oc_hip_engine* engine, int* kind);
 /* Device pointers of the precomputed fields (row-major float32):
  *   "ref","tar"           height*width            (3D: dz*dy*dx)
  *   "gx","gy"[,"gz"]      same shape              ICGN engines after prepare_ref
- *   "lut"                 height*width*16         ICGN2D* after prepare_tar  (3D: "coef", dz*dy*dx)
+ *   "lut"                 height*width*16         ICGN2D* / NR2D1 after prepare_tar  (3D: "coef", dz*dy*dx)
+ *   "lut_gx","lut_gy"     height*width*16         NR2D1 after prepare: tables of the target gradients
  * Returns OC_HIP_ERR_INVALID for an unknown name or a field not built yet. */
 int oc_hip_get_field(const oc_hip_engine* engine, const char* name, const float** device_ptr, size_t* count);
 /* Copy a field to host memory (test helper). */

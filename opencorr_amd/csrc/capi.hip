@@ -124,6 +124,7 @@ struct oc_hip_engine {
     hipStream_t stream = nullptr;
     std::shared_ptr<ImagePair> img;
     DevBuf gx, gy, gz, coef;  // coef: 2D LUT (16 floats / px) or 3D coefficient volume
+    DevBuf coef_gx, coef_gy;  // NR2D1: LUTs of the target gradients
     DevBuf tmp;               // scratch for layout conversion / 3D prefilter passes
     bool ref_ready = false, tar_ready = false;
     DevBuf poi_stage, off_stage;
@@ -142,7 +143,7 @@ struct oc_hip_engine {
     std::mutex mu;
 
     bool is3d() const { return kind == OC_HIP_FFTCC3D || kind == OC_HIP_ICGN3D1; }
-    bool is_icgn() const { return kind == OC_HIP_ICGN2D1 || kind == OC_HIP_ICGN2D2 || kind == OC_HIP_ICGN3D1; }
+    bool is_icgn() const { return kind == OC_HIP_ICGN2D1 || kind == OC_HIP_ICGN2D2 || kind == OC_HIP_ICGN3D1 || kind == OC_HIP_NR2D1; }
     size_t poi_bytes() const { return is3d() ? OC_HIP_POI3D_BYTES : OC_HIP_POI2D_BYTES; }
 };
 
@@ -363,6 +364,32 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
 }
 
 // ---------------------------------------------------------------------------
+// NR2D1
+// ---------------------------------------------------------------------------
+int run_nr2d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
+    if (!e->img || e->img->ndim != 2) return fail(OC_HIP_ERR_INVALID, "NR2D1: set_images2d has not been called");
+    if (!e->tar_ready) return fail(OC_HIP_ERR_INVALID, "NR2D1: prepare() has not been called since the last set_images");
+    const ImagePair& im = *e->img;
+    if ((unsigned long long)im.dy * im.dx * 64ull > (1ull << 32))
+        return fail(OC_HIP_ERR_UNSUPPORTED, "NR2D1: image %d x %d exceeds the 4 GiB coefficient-table limit (max 8192 x 8192)", im.dx, im.dy);
+    const long long N = (2LL * e->rx + 1) * (2LL * e->ry + 1);
+    if (N > ochip::nr2d1_max_samples())
+        return fail(OC_HIP_ERR_UNSUPPORTED, "NR2D1: subset %dx%d (%lld samples) exceeds the on-chip limit of %d samples",
+                    2 * e->rx + 1, 2 * e->ry + 1, N, ochip::nr2d1_max_samples());
+    ochip::Nr2dParams P = {im.ref_ptr(), e->coef.as<float>(), e->coef_gx.as<float>(), e->coef_gy.as<float>(),
+                           im.dy,        im.dx,               e->rx,                  e->ry,
+                           e->conv,      e->stop};
+    ProfScope prof(e);
+    const size_t kMaxGrid = 1u << 30;
+    for (size_t first = 0; first < count; first += kMaxGrid) {
+        const size_t n = (count - first) < kMaxGrid ? (count - first) : kMaxGrid;
+        hipError_t err = ochip::launch_nr2d1(P, d_pois + first * (size_t)stride_f, stride_f, n, e->stream);
+        if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "NR2D1 kernel launch failed: %s", hipGetErrorString(err));
+    }
+    return OC_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
 // FFTCC3D pipeline / ICGN3D1
 // ---------------------------------------------------------------------------
 size_t fftcc3d_chunk_limit() {
@@ -437,6 +464,7 @@ int run_compute_device(oc_hip_engine* e, float* d_pois, int stride_f, size_t cou
         case OC_HIP_FFTCC2D: return run_fftcc2d(e, d_pois, stride_f, count);
         case OC_HIP_ICGN2D1:
         case OC_HIP_ICGN2D2: return run_icgn2d(e, d_pois, stride_f, count, d_offsets);
+        case OC_HIP_NR2D1: return run_nr2d1(e, d_pois, stride_f, count);
         case OC_HIP_FFTCC3D: return run_fftcc3d(e, d_pois, stride_f, count);
         case OC_HIP_ICGN3D1: return run_icgn3d1(e, d_pois, stride_f, count);
         default: return fail(OC_HIP_ERR_UNSUPPORTED, "engine kind %d has no device path yet", e->kind);
@@ -472,6 +500,9 @@ int oc_hip_icgn2d1_create(int rx, int ry, float conv, float stop, int device, oc
 }
 int oc_hip_icgn2d2_create(int rx, int ry, float conv, float stop, int device, oc_hip_engine** out) {
     return create_engine(OC_HIP_ICGN2D2, rx, ry, 0, conv, stop, device, out);
+}
+int oc_hip_nr2d1_create(int rx, int ry, float conv, float stop, int device, oc_hip_engine** out) {
+    return create_engine(OC_HIP_NR2D1, rx, ry, 0, conv, stop, device, out);
 }
 int oc_hip_fftcc3d_create(int rx, int ry, int rz, int device, oc_hip_engine** out) {
     return create_engine(OC_HIP_FFTCC3D, rx, ry, rz, 0.f, 0.f, device, out);
@@ -634,6 +665,10 @@ int oc_hip_prepare_ref(oc_hip_engine* e) {
     std::lock_guard<std::mutex> lock(e->mu);
     const ImagePair& im = *e->img;
     const size_t bytes = im.count() * sizeof(float);
+    if (e->kind == OC_HIP_NR2D1) {
+        e->ref_ready = true;  // NR2D1::prepare builds target-side tables only (src/oc_nr.cpp:119-158)
+        return OC_HIP_OK;
+    }
     if (im.ndim == 2) {
         OC_TRY(e->gx.reserve(bytes));
         OC_TRY(e->gy.reserve(bytes));
@@ -658,6 +693,16 @@ int oc_hip_prepare_tar(oc_hip_engine* e) {
     if (im.ndim == 2) {
         OC_TRY(e->coef.reserve(im.count() * 16 * sizeof(float)));
         OC_HIP_TRY(ochip::launch_bspline2d_lut(im.tar_ptr(), im.dy, im.dx, e->coef.as<float>(), e->stream));
+        if (e->kind == OC_HIP_NR2D1) {
+            // gradients of the TARGET and their interpolation tables (src/oc_nr.cpp:121-157)
+            OC_TRY(e->gx.reserve(im.count() * sizeof(float)));
+            OC_TRY(e->gy.reserve(im.count() * sizeof(float)));
+            OC_TRY(e->coef_gx.reserve(im.count() * 16 * sizeof(float)));
+            OC_TRY(e->coef_gy.reserve(im.count() * 16 * sizeof(float)));
+            OC_HIP_TRY(ochip::launch_grad2d(im.tar_ptr(), im.dy, im.dx, e->gx.as<float>(), e->gy.as<float>(), e->stream));
+            OC_HIP_TRY(ochip::launch_bspline2d_lut(e->gx.as<float>(), im.dy, im.dx, e->coef_gx.as<float>(), e->stream));
+            OC_HIP_TRY(ochip::launch_bspline2d_lut(e->gy.as<float>(), im.dy, im.dx, e->coef_gy.as<float>(), e->stream));
+        }
     } else {
         OC_TRY(e->coef.reserve(im.count() * sizeof(float)));
         // the y pass needs a second volume; it is dead once prepare returns, so it lives in a local buffer
@@ -729,7 +774,7 @@ int oc_hip_compute_one_with_offset(oc_hip_engine* e, void* poi, const float* cen
 int oc_hip_set_self_adaptive(oc_hip_engine* e, int enable) {
     OC_TRY(check_engine(e));
     if (e->kind != OC_HIP_ICGN2D1 && e->kind != OC_HIP_ICGN2D2)
-        return fail(OC_HIP_ERR_UNSUPPORTED, "self-adaptive subsets are implemented for ICGN2D1/ICGN2D2");
+        return fail(OC_HIP_ERR_UNSUPPORTED, "self-adaptive subsets are implemented for ICGN2D1/ICGN2D2 (NR2D1 has none in the reference)");
     std::lock_guard<std::mutex> lock(e->mu);
     e->self_adaptive = enable != 0;
     return OC_HIP_OK;
@@ -762,6 +807,8 @@ int oc_hip_get_field(const oc_hip_engine* e, const char* name, const float** ptr
     else if (s == "gy" && e->ref_ready) { *ptr = e->gy.as<float>(); *count = n; }
     else if (s == "gz" && e->ref_ready && e->is3d()) { *ptr = e->gz.as<float>(); *count = n; }
     else if (s == "lut" && e->tar_ready && !e->is3d()) { *ptr = e->coef.as<float>(); *count = n * 16; }
+    else if (s == "lut_gx" && e->tar_ready && e->kind == OC_HIP_NR2D1) { *ptr = e->coef_gx.as<float>(); *count = n * 16; }
+    else if (s == "lut_gy" && e->tar_ready && e->kind == OC_HIP_NR2D1) { *ptr = e->coef_gy.as<float>(); *count = n * 16; }
     else if (s == "coef" && e->tar_ready && e->is3d()) { *ptr = e->coef.as<float>(); *count = n; }
     else return fail(OC_HIP_ERR_INVALID, "get_field: '%s' is unknown or not built yet", name);
     return OC_HIP_OK;

@@ -1,0 +1,247 @@
+// dic2d_device.h -- device helpers shared by the 2D correlation kernels (icgn2d.hip, nr2d.hip):
+// wave-uniform small dense algebra in the oracle's operation order, the sample walk of a
+// one-wave-per-POI kernel, buffer-resource loads and the bicubic LUT fetch / evaluation.
+#pragma once
+
+#include "oc_device.h"
+
+namespace ochip {
+
+__device__ __forceinline__ float uni(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// ---------------------------------------------------------------------------
+// small dense algebra on wave-uniform values (every lane computes the same
+// thing).  Same operation order as the oracle (oracle/oc_oracle.cpp lu_inverse,
+// inverse3, mat_mul), which restates Eigen's PartialPivLU / cofactor inverse /
+// lazy product used at src/oc_icgn.cpp:210,290,759,831.
+// ---------------------------------------------------------------------------
+// Inverse of an n x n matrix by LU with partial pivoting + solve against the identity,
+// distributed over the wave: lane j (j < n) holds COLUMN j of the matrix in col[0..n-1]
+// and receives column j of the inverse in inv[0..n-1].  Every scalar operation (pivot
+// choice, multipliers f = a_rk / a_kk, eliminations a_rc -= f * a_kc, the two
+// triangular solves) is the one the sequential algorithm performs on that element, so
+// the result is bit-identical to oracle lu_inverse(); only the element -> lane
+// placement differs.  Multipliers and pivots are broadcast with v_readlane (SGPRs).
+template <int n>
+__device__ __forceinline__ void lu_inverse_lanes(float (&col)[n], float (&inv)[n], int lane) {
+    int perm[n];  // wave-uniform row permutation
+#pragma unroll
+    for (int i = 0; i < n; i++) perm[i] = i;
+#pragma unroll
+    for (int k = 0; k < n; k++) {
+        int piv = k;
+        float best = fabsf(wave_bcast(col[k], k));
+#pragma unroll
+        for (int r = k + 1; r < n; r++) {
+            const float v = fabsf(wave_bcast(col[r], k));
+            if (v > best) { best = v; piv = r; }
+        }
+#pragma unroll
+        for (int r = k + 1; r < n; r++) {  // swap rows k <-> piv (at most one r matches)
+            const bool sw = (piv == r);
+            const float a = col[k], b = col[r];
+            col[k] = sw ? b : a;
+            col[r] = sw ? a : b;
+            const int pa = perm[k], pb = perm[r];
+            perm[k] = sw ? pb : pa;
+            perm[r] = sw ? pa : pb;
+        }
+        const float d = wave_bcast(col[k], k);
+#pragma unroll
+        for (int r = k + 1; r < n; r++) {
+            const float f = wave_bcast(col[r], k) / d;
+            const float upd = col[r] - f * col[k];
+            col[r] = lane == k ? f : (lane > k ? upd : col[r]);
+        }
+    }
+    // lane c solves L U x = P e_c
+    float y[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        float v = (perm[i] == lane) ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < i; j++) v = v - wave_bcast(col[i], j) * y[j];
+        y[i] = v;
+    }
+#pragma unroll
+    for (int i = n - 1; i >= 0; i--) {
+        float v = y[i];
+#pragma unroll
+        for (int j = i + 1; j < n; j++) v = v - wave_bcast(col[i], j) * y[j];
+        y[i] = v / wave_bcast(col[i], i);
+    }
+#pragma unroll
+    for (int i = 0; i < n; i++) inv[i] = y[i];
+}
+
+template <int n>
+__device__ __forceinline__ void mat_mul(const float (&a)[n * n], const float (&b)[n * n], float (&c)[n * n]) {
+#pragma unroll
+    for (int i = 0; i < n; i++)
+#pragma unroll
+        for (int j = 0; j < n; j++) {
+            float v = a[i * n + 0] * b[0 * n + j];
+#pragma unroll
+            for (int k = 1; k < n; k++) v = v + a[i * n + k] * b[k * n + j];
+            c[i * n + j] = v;
+        }
+}
+
+__device__ __forceinline__ float cof3(const float (&m)[9], int i, int j) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];
+}
+__device__ __forceinline__ void inverse3(const float (&m)[9], float (&r)[9]) {
+    const float c0 = cof3(m, 0, 0), c1 = cof3(m, 1, 0), c2 = cof3(m, 2, 0);
+    const float det = (c0 * m[0] + c1 * m[3]) + c2 * m[6];
+    const float invdet = 1.f / det;
+    r[0] = c0 * invdet; r[1] = c1 * invdet; r[2] = c2 * invdet;
+    r[3] = cof3(m, 0, 1) * invdet; r[4] = cof3(m, 1, 1) * invdet; r[5] = cof3(m, 2, 1) * invdet;
+    r[6] = cof3(m, 0, 2) * invdet; r[7] = cof3(m, 1, 2) * invdet; r[8] = cof3(m, 2, 2) * invdet;
+}
+
+// Deformation2D1::setWarp, src/oc_deformation.cpp:117-128
+__device__ __forceinline__ void set_warp_2d1(float (&w)[9], float u, float ux, float uy, float v, float vx, float vy) {
+    w[0] = 1.f + ux; w[1] = uy; w[2] = u;
+    w[3] = vx; w[4] = 1.f + vy; w[5] = v;
+    w[6] = 0.f; w[7] = 0.f; w[8] = 1.f;
+}
+
+// walks the samples owned by one lane: s = lane, lane+64, ... as (row r, column c)
+struct SampleWalk {
+    int r, c, s;
+    int W, q64, r64;
+    __device__ __forceinline__ SampleWalk(int lane, int r0, int c0, int W_, int q64_, int r64_)
+        : r(r0), c(c0), s(lane), W(W_), q64(q64_), r64(r64_) {}
+    __device__ __forceinline__ void next() {
+        s += kWave;
+        c += r64;
+        r += q64;
+        const bool wrap = c >= W;
+        c = wrap ? c - W : c;
+        r = wrap ? r + 1 : r;
+    }
+};
+
+// One LUT entry in flight: address generation and the four 16-byte loads are issued for a
+// whole group of G samples before any polynomial is evaluated, so each lane keeps G*64 B
+// of gathers outstanding (the interpolation sweep is latency/L1-bandwidth bound).  Only the
+// fractional offsets travel with the coefficients; dy = -1 marks an out-of-range sample
+// (a valid dy lies in [0, 1)).
+struct LutFetch {
+    float4 c0, c1, c2, c3;
+    float dx, dy;
+};
+
+// All image-sized arrays are read through buffer resources (V#): a 32-bit per-lane byte offset plus a
+// wave-uniform SGPR offset replace the 64-bit per-lane address arithmetic of flat loads -- in these loops
+// the address math used to cost as many VALU slots as the arithmetic it fed.  Raw buffer, stride 0,
+// num_records = 2^32 - 1 bytes: the images (<= 268 MB) and the LUT (<= 4 GiB) both fit.
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+}
+
+// range rule of BicubicBspline::compute (src/oc_cubic_bspline.cpp:137-142): x < 1 || y < 1 ||
+// x >= width-2 || y >= height-2 || NaN -> -1.  With xi = (int)floor(x) that is
+// (unsigned)(xi - 1) > width - 4; the median clamp keeps the float -> int conversion defined for wild
+// values and sends NaN to -2 (v_med3_f32 returns the minimum of the other two for a NaN input), i.e.
+// outside.  floor(x) is exactly (float)xi for in-range x, so dx = x - floor(x) has the reference's bits.
+// Out-of-range samples fetch entry (0,0), which is always mapped, and are replaced by -1.f afterwards.
+__device__ __forceinline__ void lut_fetch(LutFetch& f, __amdgpu_buffer_rsrc_t lut, int height, int width, float x,
+                                          float y) {
+    const float fx = floorf(x), fy = floorf(y);
+    const int xi = (int)__builtin_amdgcn_fmed3f(fx, -2.f, 2.0e9f), yi = (int)__builtin_amdgcn_fmed3f(fy, -2.f, 2.0e9f);
+    const bool out = (unsigned)(xi - 1) > (unsigned)(width - 4) || (unsigned)(yi - 1) > (unsigned)(height - 4);
+    f.dx = x - fx;
+    f.dy = out ? -1.f : y - fy;
+    // 24-bit multiply: full rate, and exact because in-range yi and the width are below 2^24
+    const unsigned e = out ? 0u : (__umul24((unsigned)yi, (unsigned)width) + (unsigned)xi) << 6;
+    f.c0 = buf_f32x4(lut, e);
+    f.c1 = buf_f32x4(lut, e + 16);
+    f.c2 = buf_f32x4(lut, e + 32);
+    f.c3 = buf_f32x4(lut, e + 48);
+}
+
+// explicit 16-term left-to-right polynomial of src/oc_cubic_bspline.cpp:144-177
+__device__ __forceinline__ float lut_eval(const LutFetch& f) {
+    const float dx = f.dx, dy = f.dy;
+    const float dx2 = dx * dx, dy2 = dy * dy;
+    const float dx3 = dx2 * dx, dy3 = dy2 * dy;
+    float v = f.c0.x;
+    v = v + f.c0.y * dx;
+    v = v + f.c0.z * dx2;
+    v = v + f.c0.w * dx3;
+    v = v + f.c1.x * dy;
+    v = v + f.c1.y * dy * dx;
+    v = v + f.c1.z * dy * dx2;
+    v = v + f.c1.w * dy * dx3;
+    v = v + f.c2.x * dy2;
+    v = v + f.c2.y * dy2 * dx;
+    v = v + f.c2.z * dy2 * dx2;
+    v = v + f.c2.w * dy2 * dx3;
+    v = v + f.c3.x * dy3;
+    v = v + f.c3.y * dy3 * dx;
+    v = v + f.c3.z * dy3 * dx2;
+    v = v + f.c3.w * dy3 * dx3;
+    return dy < 0.f ? -1.f : v;
+}
+
+// Deformation2D2::setWarp, src/oc_deformation.cpp:301-350; q = u ux uy uxx uxy uyy v vx vy vxx vxy vyy
+__device__ __forceinline__ void set_warp_2d2(float (&w)[36], const float (&q)[12]) {
+    const float u = q[0], ux = q[1], uy = q[2], uxx = q[3], uxy = q[4], uyy = q[5];
+    const float v = q[6], vx = q[7], vy = q[8], vxx = q[9], vxy = q[10], vyy = q[11];
+    w[0] = 1.f + 2.f * ux + ux * ux + u * uxx;
+    w[1] = 2.f * u * uxy + 2.f * (1.f + ux) * uy;
+    w[2] = uy * uy + u * uyy;
+    w[3] = 2.f * u * (1 + ux);
+    w[4] = 2.f * u * uy;
+    w[5] = u * u;
+    w[6] = 0.5f * (v * uxx + 2.f * (1.f + ux) * vx + u * vxx);
+    w[7] = 1.f + uy * vx + ux * vy + v * uxy + u * vxy + vy + ux;
+    w[8] = 0.5f * (v * uyy + 2.f * uy * (1.f + vy) + u * vyy);
+    w[9] = v + v * ux + u * vx;
+    w[10] = u + v * uy + u * vy;
+    w[11] = u * v;
+    w[12] = vx * vx + v * vxx;
+    w[13] = 2.f * v * vxy + 2.f * vx * (1.f + vy);
+    w[14] = 1.f + 2.f * vy + vy * vy + v * vyy;
+    w[15] = 2.f * v * vx;
+    w[16] = 2.f * v * (1.f + vy);
+    w[17] = v * v;
+    w[18] = 0.5f * uxx; w[19] = uxy; w[20] = 0.5f * uyy; w[21] = 1.f + ux; w[22] = uy; w[23] = u;
+    w[24] = 0.5f * vxx; w[25] = vxy; w[26] = 0.5f * vyy; w[27] = vx; w[28] = 1.f + vy; w[29] = v;
+    w[30] = 0.f; w[31] = 0.f; w[32] = 0.f; w[33] = 0.f; w[34] = 0.f; w[35] = 1.f;
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) {
+    f2 r = {a, b};
+    return r;
+}
+
+// steepest-descent row of one sample (src/oc_icgn.cpp:191-196; 2D2: 725-745; center-offset
+// overloads :390-398 / :953-972).  The local coordinates arrive as floats: without a centre
+// offset they are small integers, so the reference's integer products (xl*xl, :733-738) are
+// exact in float as well.
+template <int DOF>
+__device__ __forceinline__ void sd_row(float g_x, float g_y, float fxl, float fyl, float (&sd)[DOF]) {
+    if constexpr (DOF == 6) {
+        sd[0] = g_x; sd[1] = g_x * fxl; sd[2] = g_x * fyl;
+        sd[3] = g_y; sd[4] = g_y * fxl; sd[5] = g_y * fyl;
+    } else {
+        const float xx = (fxl * fxl) * 0.5f, xy = fxl * fyl, yy = (fyl * fyl) * 0.5f;
+        sd[0] = g_x; sd[1] = g_x * fxl; sd[2] = g_x * fyl; sd[3] = g_x * xx; sd[4] = g_x * xy; sd[5] = g_x * yy;
+        sd[6] = g_y; sd[7] = g_y * fxl; sd[8] = g_y * fyl; sd[9] = g_y * xx; sd[10] = g_y * xy; sd[11] = g_y * yy;
+    }
+}
+
+}  // namespace ochip

@@ -38,6 +38,19 @@ int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int
 // largest (2rx+1)*(2ry+1) a variant accepts
 int icgn2d_max_samples(int variant);
 
+// ---- nr2d.hip --------------------------------------------------------------
+struct Nr2dParams {
+    const float* ref;     // reference image, row-major
+    const float* lut;     // bicubic LUT of the target image
+    const float* lut_gx;  // bicubic LUT of d/dx target
+    const float* lut_gy;  // bicubic LUT of d/dy target
+    int height, width;
+    int rx, ry;
+    float conv, stop;
+};
+hipError_t launch_nr2d1(const Nr2dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);
+int nr2d1_max_samples();
+
 // ---- prepare3d.hip ---------------------------------------------------------
 hipError_t launch_grad3d(const float* vol, int dz, int dy, int dx, float* gx, float* gy, float* gz, hipStream_t stream);
 // coef <- prefilter_z(prefilter_y(prefilter_x(vol))); tmp is a scratch volume of the same size

@@ -162,7 +162,7 @@ class _Engine:
         capi.check(capi.lib().oc_hip_get_field(self._h, name.encode(), ctypes.byref(ptr), ctypes.byref(count)))
         out = np.empty(count.value, dtype=np.float32)
         capi.check(capi.lib().oc_hip_read_field(self._h, name.encode(), ctypes.c_void_p(out.ctypes.data), count.value))
-        if name == "lut":
+        if name in ("lut", "lut_gx", "lut_gy"):
             return out.reshape(self.shape + (16,))
         return out.reshape(self.shape)
 
@@ -215,6 +215,16 @@ class ICGN2D2(_Engine, _IcgnMixin):
         self.thread_number = thread_number
         capi.check(capi.lib().oc_hip_icgn2d2_create(subset_radius_x, subset_radius_y, conv_criterion, stop_condition,
                                                     device, ctypes.byref(self._h)))
+
+
+class NR2D1(_Engine, _IcgnMixin):
+    """NR2D1(rx, ry, conv_criterion, stop_condition, thread_number) -- src/oc_nr.h, src/oc_nr.cpp:75-91."""
+
+    def __init__(self, subset_radius_x, subset_radius_y, conv_criterion, stop_condition, thread_number=1, device=0):
+        super().__init__()
+        self.thread_number = thread_number
+        capi.check(capi.lib().oc_hip_nr2d1_create(subset_radius_x, subset_radius_y, conv_criterion, stop_condition,
+                                                  device, ctypes.byref(self._h)))
 
 
 class FFTCC3D(_Engine):

@@ -60,6 +60,8 @@ def lib():
         L.oc_oracle_icgn2d2.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i]
         L.oc_oracle_icgn2d1_ex.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i, fp, i]
         L.oc_oracle_icgn2d2_ex.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i, fp, i]
+        L.oc_oracle_nr2d1.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i]
+        L.oc_oracle_nr2d1.restype = None
         L.oc_oracle_icgn2d1_ex.restype = None
         L.oc_oracle_icgn2d2_ex.restype = None
         L.oc_oracle_gradient3d.argtypes = [fp, i, i, i, fp, fp, fp, i]
@@ -174,6 +176,26 @@ def icgn2d2(prep, rx, ry, conv, stop, pois, order=ORDER_SEQ, lanes=64, threads=0
             self_adaptive=False):
     _icgn2d(lib().oc_oracle_icgn2d2_ex, prep, rx, ry, conv, stop, pois, order, lanes, threads, center_offsets,
             self_adaptive)
+
+
+class PreparedNR2D:
+    """What NR2D1::prepare() builds (src/oc_nr.cpp:119-158): the target's gradients and three LUTs."""
+
+    def __init__(self, ref, tar, threads=0):
+        self.ref = _img(ref)
+        self.tar = _img(tar)
+        gx, gy = gradient2d(self.tar, threads)
+        self.lut = bspline2d_lut(self.tar, threads)
+        self.lut_gx = bspline2d_lut(gx, threads)
+        self.lut_gy = bspline2d_lut(gy, threads)
+
+
+def nr2d1(prep, rx, ry, conv, stop, pois, order=ORDER_SEQ, lanes=64, threads=0):
+    """NR2D1::compute(poi_queue), in place on ``pois`` (n x 25 float32)."""
+    assert pois.dtype == np.float32 and pois.flags.c_contiguous and pois.shape[1] == POI2D_FLOATS
+    h, w = prep.ref.shape
+    lib().oc_oracle_nr2d1(_fp(prep.ref), _fp(prep.lut), _fp(prep.lut_gx), _fp(prep.lut_gy), h, w, rx, ry, float(conv),
+                          float(stop), _fp(pois), pois.shape[0], order, lanes, threads)
 
 
 def gradient3d(vol, threads=0):

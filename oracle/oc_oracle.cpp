@@ -678,6 +678,146 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
 }
 
 // ---------------------------------------------------------------------------
+// NR2D1 -- forward-additive Newton-Raphson, src/oc_nr.cpp:160-322
+// ---------------------------------------------------------------------------
+// lut / lut_gx / lut_gy: bicubic coefficient tables of the TARGET image and of its two
+// gradient images (NR2D1::prepare, src/oc_nr.cpp:119-158).
+template <template <int> class Acc>
+static void nr2d1_poi(const float* ref, const float* lut, const float* lut_gx, const float* lut_gy, int height,
+                      int width, int rx, int ry, float conv, float stop, float* poi, int lanes,
+                      std::vector<float>& scratch) {
+    const float px = poi[0], py = poi[1];
+    float* p = poi + 2;     // u ux uy uxx uxy uyy v vx vy ...
+    float* res = poi + 14;  // u0 v0 zncc iteration convergence feature
+    // guard, src/oc_nr.cpp:165-171: failure is -1 here (not -3), and the two checks after the
+    // else-branch (:304-316) run for guarded POIs as well
+    if (py - ry < 0 || px - rx < 0 || py + ry > height - 1 || px + rx > width - 1 || std::fabs(p[0]) >= width ||
+        std::fabs(p[6]) >= height || res[2] < 0 || std::isnan(p[0]) || std::isnan(p[6])) {
+        res[2] = res[2] < -1 ? res[2] : -1.f;
+    } else {
+        const int W = 2 * rx + 1, H = 2 * ry + 1, N = W * H;
+        scratch.resize((size_t)N * 4);
+        float* rs = scratch.data();
+        float* ts = rs + N;
+        float* tgx = ts + N;
+        float* tgy = tgx + N;
+        const int x0 = (int)(px - rx), y0 = (int)(py - ry);
+        float ref_norm;
+        {
+            Acc<1> a(lanes);
+            for (int r = 0; r < H; r++)
+                for (int c = 0; c < W; c++) {
+                    int s = r * W + c;
+                    rs[s] = ref[(size_t)(y0 + r) * width + (x0 + c)];
+                    a.add(s, 0, rs[s]);
+                }
+            a.finish();
+            float mean = a.get(0) / (float)N;
+            Acc<1> b(lanes);
+            for (int s = 0; s < N; s++) {
+                rs[s] = rs[s] - mean;
+                b.add(s, 0, rs[s] * rs[s]);
+            }
+            b.finish();
+            ref_norm = std::sqrt(b.get(0));
+        }
+        const float u0 = p[0], v0 = p[6];
+        float cur[6] = {p[0], p[1], p[2], p[6], p[7], p[8]};  // u ux uy v vx vy
+        int iter = 0;
+        float dp_norm = 0.f, znssd = 0.f;
+        do {
+            iter++;
+            float Wm[9];
+            set_warp_2d1(Wm, cur[0], cur[1], cur[2], cur[3], cur[4], cur[5]);
+            // warped target subset and its gradients (:195-209), Hessian from the target gradients (:213-238)
+            Acc<1> am(lanes);
+            Acc<21> ah(lanes);
+            for (int r = 0; r < H; r++)
+                for (int c = 0; c < W; c++) {
+                    int s = r * W + c;
+                    float xl = (float)(c - rx), yl = (float)(r - ry);
+                    float wx = (Wm[0] * xl + Wm[1] * yl) + Wm[2] * 1.f;
+                    float wy = (Wm[3] * xl + Wm[4] * yl) + Wm[5] * 1.f;
+                    float gxp = px + wx, gyp = py + wy;
+                    ts[s] = bspline2d_eval(lut, height, width, gxp, gyp);
+                    tgx[s] = bspline2d_eval(lut_gx, height, width, gxp, gyp);
+                    tgy[s] = bspline2d_eval(lut_gy, height, width, gxp, gyp);
+                    am.add(s, 0, ts[s]);
+                    float sd[6];
+                    sd_row<6>(tgx[s], tgy[s], c - rx, r - ry, sd);
+                    int t = 0;
+                    for (int i = 0; i < 6; i++)
+                        for (int j = 0; j <= i; j++) ah.add(s, t++, sd[i] * sd[j]);  // H(i,j) and H(j,i) get the same products
+                }
+            am.finish();
+            ah.finish();
+            float tmean = am.get(0) / (float)N;
+            Acc<1> an(lanes);
+            for (int s = 0; s < N; s++) {
+                ts[s] = ts[s] - tmean;
+                an.add(s, 0, ts[s] * ts[s]);
+            }
+            an.finish();
+            float tar_norm = std::sqrt(an.get(0));
+            float hess[36], hinv[36];
+            {
+                int t = 0;
+                for (int i = 0; i < 6; i++)
+                    for (int j = 0; j <= i; j++) {
+                        hess[i * 6 + j] = ah.get(t);
+                        hess[j * 6 + i] = ah.get(t);
+                        t++;
+                    }
+            }
+            lu_inverse(hess, hinv, 6);
+            // error image, ZNSSD, numerator (:244-262)
+            float factor = tar_norm / ref_norm;
+            Acc<7> ae(lanes);
+            for (int r = 0; r < H; r++)
+                for (int c = 0; c < W; c++) {
+                    int s = r * W + c;
+                    float e = rs[s] * factor - ts[s];
+                    ae.add(s, 6, e * e);
+                    float sd[6];
+                    sd_row<6>(tgx[s], tgy[s], c - rx, r - ry, sd);
+                    for (int i = 0; i < 6; i++) ae.add(s, i, sd[i] * e);
+                }
+            ae.finish();
+            znssd = ae.get(6) / (tar_norm * tar_norm);
+            float dp[6];
+            for (int i = 0; i < 6; i++) {
+                float v = 0.f;
+                for (int j = 0; j < 6; j++) v += hinv[i * 6 + j] * ae.get(j);
+                dp[i] = v;
+            }
+            for (int i = 0; i < 6; i++) cur[i] = cur[i] + dp[i];  // :277-279
+            const int rx2 = rx * rx, ry2 = ry * ry;
+            float d = 0.f;  // :285-291, one += per term
+            d += dp[0] * dp[0];
+            d += dp[1] * dp[1] * rx2;
+            d += dp[2] * dp[2] * ry2;
+            d += dp[3] * dp[3];
+            d += dp[4] * dp[4] * rx2;
+            d += dp[5] * dp[5] * ry2;
+            dp_norm = std::sqrt(d);
+        } while (iter < stop && dp_norm >= conv);
+        p[0] = cur[0]; p[1] = cur[1]; p[2] = cur[2];
+        p[6] = cur[3]; p[7] = cur[4]; p[8] = cur[5];
+        res[0] = u0;
+        res[1] = v0;
+        res[2] = 0.5f * (2 - znssd);
+        res[3] = (float)iter;
+        res[4] = dp_norm;
+    }
+    if (res[4] >= conv && res[3] >= stop) res[2] = -4.f;
+    if (std::isnan(res[2]) || std::isnan(p[0]) || std::isnan(p[6])) {
+        p[0] = res[0];
+        p[6] = res[1];
+        res[2] = -5.f;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // ICGN3D1 -- src/oc_icgn.cpp:1270-1490
 // ---------------------------------------------------------------------------
 struct Images3D {
@@ -1056,6 +1196,25 @@ void oc_oracle_icgn2d2(const float* ref, const float* gx, const float* gy, const
                 icgn2d_poi<12, AccSeq>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch);
             else
                 icgn2d_poi<12, AccLanes>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch);
+        }
+    }
+}
+
+void oc_oracle_nr2d1(const float* ref, const float* tar_lut, const float* tar_lut_gx, const float* tar_lut_gy, int height,
+                     int width, int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes,
+                     int threads) {
+    threads = resolve_threads(threads);
+#pragma omp parallel num_threads(threads)
+    {
+        std::vector<float> scratch;
+#pragma omp for schedule(static)
+        for (long i = 0; i < n; i++) {
+            if (order == OC_ORDER_SEQ)
+                nr2d1_poi<AccSeq>(ref, tar_lut, tar_lut_gx, tar_lut_gy, height, width, rx, ry, conv, stop,
+                                  pois + i * OC_POI2D_FLOATS, lanes, scratch);
+            else
+                nr2d1_poi<AccLanes>(ref, tar_lut, tar_lut_gx, tar_lut_gy, height, width, rx, ry, conv, stop,
+                                    pois + i * OC_POI2D_FLOATS, lanes, scratch);
         }
     }
 }

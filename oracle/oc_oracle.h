@@ -79,6 +79,12 @@ void oc_oracle_icgn2d1_ex(const float* ref, const float* gx, const float* gy, co
 void oc_oracle_icgn2d2_ex(const float* ref, const float* gx, const float* gy, const float* tar_lut, int height,
                           int width, int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes,
                           int threads, const float* center_offsets, int self_adaptive);
+/* NR2D1::compute(poi_queue), src/oc_nr.cpp:160-332 (forward-additive Newton-Raphson).
+ * tar_lut, tar_lut_gx, tar_lut_gy: oc_oracle_bspline2d_lut of the target image and of
+ * oc_oracle_gradient2d(target) -- what NR2D1::prepare builds (src/oc_nr.cpp:119-158). */
+void oc_oracle_nr2d1(const float* ref, const float* tar_lut, const float* tar_lut_gx, const float* tar_lut_gy, int height,
+                     int width, int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes,
+                     int threads);
 
 /* src/oc_gradient.cpp:143-231 */
 void oc_oracle_gradient3d(const float* vol, int dz, int dy, int dx, float* gx, float* gy, float* gz, int threads);

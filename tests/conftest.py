@@ -29,6 +29,12 @@ def golden_icgn2():
 
 
 @pytest.fixture(scope="session")
+def golden_nr1():
+    """x y u v u0 v0 zncc iteration convergence of the reference's FFTCC2D -> NR2D1 example on the OHT pair."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "oht_cfrp_fftcc_nr1_r16.npz"))["table"]
+
+
+@pytest.fixture(scope="session")
 def speckle_small():
     """320 x 300 synthetic speckle pair with the SURVEY 8(d) displacement field."""
     from opencorr_amd import synth

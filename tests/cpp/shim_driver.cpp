@@ -4,6 +4,7 @@
 //   shim_driver <in.bin> <out.bin>
 // in.bin : int32 height, width, rx, ry, n; float32 conv, stop; ref[h*w], tar[h*w] (row-major); x[n], y[n]
 // out.bin: n POI2D records (100 bytes each) after FFTCC2D::compute + ICGN2D1::prepare/compute
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -85,6 +86,23 @@ int main(int argc, char** argv) {
             if (one.deformation.u != poi_queue[0].deformation.u || one.result.iteration != poi_queue[0].result.iteration) {
                 std::cerr << "compute(POI2D*) disagrees with compute(vector&)" << std::endl;
                 return 7;
+            }
+        }
+        // the Newton-Raphson engine through the same interface: must agree with ICGN2D1 to well below the
+        // convergence criterion on POIs both solved (they minimise the same ZNSSD)
+        {
+            NR2D1 nr1(rx, ry, it[0], it[1], cpu_thread_number);
+            nr1.setImages(ref_img, tar_img);
+            nr1.prepare();
+            std::vector<POI2D> q = after_fftcc;
+            nr1.compute(q);
+            for (size_t i = 0; i < q.size(); i++) {
+                if (q[i].result.zncc > 0.9f && poi_queue[i].result.zncc > 0.9f &&
+                    (std::fabs(q[i].deformation.u - poi_queue[i].deformation.u) > 5e-3f ||
+                     std::fabs(q[i].deformation.v - poi_queue[i].deformation.v) > 5e-3f)) {
+                    std::cerr << "NR2D1 and ICGN2D1 disagree at POI " << i << std::endl;
+                    return 12;
+                }
             }
         }
         // error path: compute before prepare must throw std::string

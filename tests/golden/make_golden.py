@@ -19,6 +19,11 @@ FeatureAffine initial guesses.  The CSV keeps only the translation part (u0, v0)
 guesses, so a re-run starts from a slightly different point; IC-GN is path independent enough
 that the converged u, v, ZNCC still agree to ~1e-5 px / 1e-7 (see tests/test_oracle_golden.py).
 Stored as oht_cfrp_sift_icgn2_gpu_r16.npz.
+
+And the golden vectors of the Newton-Raphson engine:
+  oht_cfrp_4_fftcc_nr1_r16.csv              x,y,u,v,u0,v0,ZNCC,iteration,convergence,feature,exx,eyy,exy
+produced by examples/test_2d_dic_fftcc_nr1.cpp (FFTCC2D -> NR2D1, r=16, conv 1e-3, stop 10, same grid).
+Stored as oht_cfrp_fftcc_nr1_r16.npz (first nine columns).
 """
 import os
 
@@ -55,6 +60,11 @@ def main():
     # x y u v u0 v0 zncc iteration convergence
     np.savez_compressed(out2, table=t2.astype(np.float32))
     print("wrote", out2, os.path.getsize(out2), "bytes")
+    t3 = np.genfromtxt(os.path.join(REF, "oht_cfrp_4_fftcc_nr1_r16.csv"), delimiter=",", skip_header=1, usecols=range(9))
+    assert t3.shape == (30000, 9) and np.array_equal(t3[:, :2], table[:, :2])
+    out3 = os.path.join(os.path.dirname(OUT), "oht_cfrp_fftcc_nr1_r16.npz")
+    np.savez_compressed(out3, table=t3.astype(np.float32))
+    print("wrote", out3, os.path.getsize(out3), "bytes")
 
 
 if __name__ == "__main__":

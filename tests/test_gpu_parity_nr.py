@@ -1,0 +1,111 @@
+"""GPU parity of NR2D1 (forward-additive Newton-Raphson) against the oracle and the
+reference's golden CSV.  Bars: prepare tables bit-exact; results bit-exact vs the oracle in
+OC_ORDER_LANES; the golden example within the tolerances of the oracle's own golden test."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_nr2d1_prepare_tables_bit_exact(speckle_small):
+    import opencorr_amd as eng
+    import oracle
+    ref, tar = speckle_small
+    nr = eng.NR2D1(16, 16, 0.001, 10)
+    nr.set_images(ref, tar)
+    nr.prepare()
+    prep = oracle.PreparedNR2D(ref, tar)
+    assert np.array_equal(_bits(nr.read_field("lut")), _bits(prep.lut))
+    assert np.array_equal(_bits(nr.read_field("lut_gx")), _bits(prep.lut_gx))
+    assert np.array_equal(_bits(nr.read_field("lut_gy")), _bits(prep.lut_gy))
+
+
+@pytest.mark.parametrize("rx,ry", [(16, 16), (15, 15), (9, 12)])
+def test_nr2d1_bit_exact_vs_oracle(speckle_small, rx, ry):
+    import opencorr_amd as eng
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    xs, ys = synth.poi_grid_2d(h, w, 19, 15, 28)
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, rx, ry, pois)
+    # edge cases: outside the guard (-1), a wild guess (NR keeps iterating on -1 samples: no abort in the reference),
+    # a negative ZNCC on entry (< -1 is kept), a NaN guess (-> -5 with u, v restored from u0, v0)
+    extra = oracle.make_pois2d([5, 160, 160, 160, 160], [150, 150, 150, 150, 150])
+    P = oracle.P2
+    extra[1, P["u"]] = 200.0
+    extra[2, P["zncc"]] = -2.5
+    extra[3, P["u"]] = np.nan
+    extra[3, P["u0"]], extra[3, P["v0"]] = 3.0, -4.0
+    extra[4, P["zncc"]] = -0.5
+    pois = np.concatenate([pois, extra]).astype(np.float32)
+    want = pois.copy()
+    prep = oracle.PreparedNR2D(ref, tar)
+    oracle.nr2d1(prep, rx, ry, 0.001, 10, want, order=oracle.ORDER_LANES, lanes=64)
+    nr = eng.NR2D1(rx, ry, 0.001, 10)
+    nr.set_images(ref, tar)
+    nr.prepare()
+    got = nr.compute(pois.copy())
+    # the wild guess drives every sample out of range: a constant subset, zero norm, a singular Hessian -- the
+    # reference then carries NaNs in ux..vy / convergence (zncc = -5); NaN payload bits are not part of the contract
+    both_nan = np.isnan(got) & np.isnan(want)
+    mism = np.argwhere((_bits(got) != _bits(want)) & ~both_nan)
+    assert mism.size == 0, "first mismatches (poi, field): %s" % mism[:10].tolist()
+    assert want[-4, P["zncc"]] == -5.0 and np.isnan(want[-4, P["ux"]])
+    assert want[-5, P["zncc"]] == -1.0 and want[-3, P["zncc"]] == -2.5 and want[-1, P["zncc"]] == -1.0
+    assert want[-2, P["zncc"]] == -5.0 and want[-2, P["u"]] == 3.0 and want[-2, P["v"]] == -4.0
+    if min(rx, ry) >= 15:
+        assert (want[:-5, P["zncc"]] > 0.9).all()
+    # subset_radius is not touched by NR2D1 (src/oc_nr.cpp:296-303)
+    assert (got[:, [23, 24]] == 0).all()
+
+
+def test_nr2d1_golden_on_gpu(golden, golden_nr1):
+    """FFTCC2D -> NR2D1 of examples/test_2d_dic_fftcc_nr1.cpp end to end on the GPU."""
+    import opencorr_amd as eng
+    import oracle
+    from test_oracle_golden import nr1_golden_check
+    tab = golden_nr1
+    pois = oracle.make_pois2d(tab[:, 0], tab[:, 1])
+    f = eng.FFTCC2D(golden["rx"], golden["ry"])
+    f.set_images(golden["ref"], golden["tar"])
+    f.compute(pois)
+    after = pois.copy()
+    nr = eng.NR2D1(golden["rx"], golden["ry"], golden["conv"], golden["stop"])
+    nr.share_images(f)
+    nr.prepare()
+    nr.compute(pois)
+    nr1_golden_check(pois, after, tab, golden["stop"])
+    want = after.copy()
+    oracle.nr2d1(oracle.PreparedNR2D(golden["ref"], golden["tar"]), golden["rx"], golden["ry"], golden["conv"],
+                 golden["stop"], want, order=oracle.ORDER_LANES, lanes=64)
+    assert np.array_equal(_bits(pois), _bits(want))
+
+
+def test_nr2d1_throughput_config_b_shape():
+    """Config-B-sized run (4096^2, 250 000 POIs): property checks only (converged fraction, analytic field)."""
+    import torch
+    import opencorr_amd as eng
+    from opencorr_amd import synth
+    dev = torch.device("cuda", 0)
+    ref, tar = synth.speckle_pair_2d(4096, 4096, seed=20260925, device=dev)
+    xs, ys = synth.poi_grid_2d(4096, 4096, 500, 500, 24)
+    f = eng.FFTCC2D(16, 16)
+    f.set_images(ref, tar)
+    nr = eng.NR2D1(16, 16, 0.001, 10)
+    nr.share_images(f)
+    nr.prepare()
+    pois = torch.from_numpy(eng.make_pois2d(xs, ys)).to(dev)
+    f.compute(pois)
+    nr.compute(pois)
+    nr.synchronize()
+    p = pois.cpu().numpy()
+    conv = p[:, 16] > 0
+    assert conv.mean() > 0.999
+    eu, ev = synth.expected_deformation_2d(xs, ys, 4096, 4096)
+    assert np.abs(p[conv, 2] - eu[conv]).max() < 0.03 and np.abs(p[conv, 8] - ev[conv]).max() < 0.03

@@ -92,3 +92,29 @@ def test_icgn2d2_converges_to_the_reference_cuda_results(golden, golden_icgn2):
     prep = oracle.Prepared2D(golden["ref"], golden["tar"])
     oracle.icgn2d2(prep, 16, 16, golden["conv"], golden["stop"], p)
     icgn2_soft_anchor_check(p, tab)
+
+
+def nr1_golden_check(p, after_fftcc, tab, stop):
+    """Shared by the oracle and the GPU test: NR2D1 results vs the reference's own CSV
+    (examples/2d_dic/oht_cfrp_4_fftcc_nr1_r16.csv)."""
+    same_init = (after_fftcc[:, P2["u"]] == tab[:, 4]) & (after_fftcc[:, P2["v"]] == tab[:, 5])
+    assert same_init.mean() >= 0.999
+    m = (tab[:, 7] < stop) & same_init & (tab[:, 6] > 0)  # converged in the reference's run
+    assert m.sum() > 28000
+    assert np.abs(p[m, P2["u"]] - tab[m, 2]).max() <= 2e-4 and np.abs(p[m, P2["v"]] - tab[m, 3]).max() <= 2e-4
+    assert np.median(np.abs(p[m, P2["u"]] - tab[m, 2])) <= 1e-6
+    assert np.abs(p[m, P2["zncc"]] - tab[m, 6]).max() <= 1e-5
+    assert (p[m, P2["iteration"]] == tab[m, 7]).mean() >= 0.99
+    assert np.array_equal(p[m, P2["u0"]], tab[m, 4]) and np.array_equal(p[m, P2["v0"]], tab[m, 5])
+
+
+@pytest.mark.parametrize("order", [oracle.ORDER_SEQ, oracle.ORDER_LANES])
+def test_nr2d1_matches_golden(golden, golden_nr1, order):
+    """The Newton-Raphson engine is pinned on the reference's golden CSV like ICGN2D1 is."""
+    tab = golden_nr1
+    pois = oracle.make_pois2d(tab[:, 0], tab[:, 1])
+    oracle.fftcc2d(golden["ref"], golden["tar"], golden["rx"], golden["ry"], pois)
+    after = pois.copy()
+    prep = oracle.PreparedNR2D(golden["ref"], golden["tar"])
+    oracle.nr2d1(prep, golden["rx"], golden["ry"], golden["conv"], golden["stop"], pois, order=order)
+    nr1_golden_check(pois, after, tab, golden["stop"])

@@ -50,7 +50,7 @@ def run_2d(name, side, r, nside, engine, oracle_sample, so=None):
     f = oc.FFTCC2D(r, r)
     f.set_stream(stream)
     f.set_images(ref, tar)
-    Icgn = oc.ICGN2D1 if engine == 1 else oc.ICGN2D2
+    Icgn = {1: oc.ICGN2D1, 2: oc.ICGN2D2, 3: oc.NR2D1}[engine]
     g = Icgn(r, r, 0.001, 10.0)
     g.set_stream(stream)
     g.share_images(f)
@@ -84,10 +84,14 @@ def run_2d(name, side, r, nside, engine, oracle_sample, so=None):
     f.compute(fin)
     torch.cuda.synchronize()
     sample = fin.cpu().numpy()[::step_s].copy()
-    prep = oracle.Prepared2D(ref.cpu().numpy(), tar.cpu().numpy())
-    (oracle.icgn2d1 if engine == 1 else oracle.icgn2d2)(prep, r, r, 0.001, 10.0, sample, order=oracle.ORDER_LANES, lanes=64)
+    if engine == 3:
+        oracle.nr2d1(oracle.PreparedNR2D(ref.cpu().numpy(), tar.cpu().numpy()), r, r, 0.001, 10.0, sample,
+                     order=oracle.ORDER_LANES, lanes=64)
+    else:
+        prep = oracle.Prepared2D(ref.cpu().numpy(), tar.cpu().numpy())
+        (oracle.icgn2d1 if engine == 1 else oracle.icgn2d2)(prep, r, r, 0.001, 10.0, sample, order=oracle.ORDER_LANES, lanes=64)
     bit_exact = bool(np.array_equal(sample.view(np.uint32), after[::step_s].view(np.uint32)))
-    return dict(config=name, engine="FFTCC2D+ICGN2D%d" % engine, image="%dx%d" % (side, side), radius=r, pois=n,
+    return dict(config=name, engine="FFTCC2D+" + {1: "ICGN2D1", 2: "ICGN2D2", 3: "NR2D1"}[engine], image="%dx%d" % (side, side), radius=r, pois=n,
                 seconds=secs, pois_per_s=float(conv.sum() / secs), converged=int(conv.sum()),
                 mean_iterations=float(after[conv, 17].mean()), prepare_s=prepare_s,
                 median_abs_err_u=float(np.median(du)), max_abs_err_u=float(du.max()), max_abs_err_v=float(dv.max()),
@@ -159,6 +163,8 @@ def main():
             rec = run_2d("C (4096^2, r=20, ICGN2D2, 316x316 POIs)", 4096, 20, 316, 2, 4000, so=dict(uxx=2e-6, vyy=-1e-6))
         elif c == "D1":
             rec = run_2d("D on ONE GPU (8192^2, r=16, 1414x1414 POIs)", 8192, 16, 1414, 1, 4000)
+        elif c == "BNR":
+            rec = run_2d("B with NR2D1 (4096^2, r=16, 500x500 POIs)", 4096, 16, 500, 3, 4000)
         elif c == "E":
             rec = run_3d("E on ONE GPU (512^3, r=16, 37^3 POIs)", 512, 16, 37, 96)
         elif c == "Es":
