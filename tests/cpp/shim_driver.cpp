@@ -105,6 +105,19 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        // the reference's CUDA-module shape (gpu_lib/opencorr_gpu.h:31-101): ICGN2D1GPU fed with row-major Img2D
+        {
+            Img2D ref2{w, h, ref.data()}, tar2{w, h, tar.data()};
+            ICGN2D1GPU gpu(rx, ry, it[0], (int)it[1]);
+            gpu.setImages(ref2, tar2);
+            gpu.prepare();
+            std::vector<POI2D> q = after_fftcc;
+            gpu.compute(q);
+            if (std::memcmp(q.data(), poi_queue.data(), q.size() * sizeof(POI2D)) != 0) {
+                std::cerr << "ICGN2D1GPU (Img2D) differs from ICGN2D1 (Image2D)" << std::endl;
+                return 13;
+            }
+        }
         // error path: compute before prepare must throw std::string
         bool threw = false;
         try {
