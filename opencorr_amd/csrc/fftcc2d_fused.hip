@@ -16,7 +16,7 @@
 // Integer outputs (u, v) are what the reference computes; the float ZNCC differs from
 // FFTW's in the last bits like any other FFT implementation (tested to 1e-5 against the
 // oracle's double-precision DFT).
-#include "oc_device.h"
+#include "dic2d_device.h"
 #include "oc_kernels.h"
 
 namespace ochip {
@@ -33,20 +33,25 @@ __device__ constexpr float kSin16[8] = {0.000000000e+00f, 3.826834324e-01f, 7.07
 __device__ constexpr float kCos32[16] = {1.000000000e+00f, 9.807852804e-01f, 9.238795325e-01f, 8.314696123e-01f, 7.071067812e-01f, 5.555702330e-01f, 3.826834324e-01f, 1.950903220e-01f, 6.123233996e-17f, -1.950903220e-01f, -3.826834324e-01f, -5.555702330e-01f, -7.071067812e-01f, -8.314696123e-01f, -9.238795325e-01f, -9.807852804e-01f};
 __device__ constexpr float kSin32[16] = {0.000000000e+00f, 1.950903220e-01f, 3.826834324e-01f, 5.555702330e-01f, 7.071067812e-01f, 8.314696123e-01f, 9.238795325e-01f, 9.807852804e-01f, 1.000000000e+00f, 9.807852804e-01f, 9.238795325e-01f, 8.314696123e-01f, 7.071067812e-01f, 5.555702330e-01f, 3.826834324e-01f, 1.950903220e-01f};
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// complex numbers as 2-wide vectors (re, im): additions and the twiddle products then run on the packed-fp32
+// pipe (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), one instruction per complex operation
+typedef float c2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ c2 mkc(float re, float im) {
+    c2 r = {re, im};
+    return r;
+}
 
-// d * exp(-/+ i*angle) with (c, s) = (cos, sin) of the angle; INV selects the + sign
+// d * exp(-/+ i*angle) with (c, s) = (cos, sin) of the angle; INV selects the + sign:
+// forward (d.x c + d.y s, d.y c - d.x s), inverse (d.x c - d.y s, d.y c + d.x s)
 template <bool INV>
-__device__ __forceinline__ float2 cmul_tw(float2 d, float c, float s) {
+__device__ __forceinline__ c2 cmul_tw(c2 d, float c, float s) {
 #pragma clang fp contract(fast)
-    if (INV) return make_float2(d.x * c - d.y * s, d.y * c + d.x * s);
-    return make_float2(d.x * c + d.y * s, d.y * c - d.x * s);
+    return d * c + d.yx * (INV ? mkc(-s, s) : mkc(s, -s));
 }
 
 // 16-point FFT in registers: radix-2 decimation in frequency, X[k] ends in v[bitrev4(k)]
 template <bool INV>
-__device__ __forceinline__ void fft16(float2 (&v)[16]) {
+__device__ __forceinline__ void fft16(c2 (&v)[16]) {
 #pragma unroll
     for (int span = 8; span >= 1; span >>= 1) {
 #pragma unroll
@@ -54,11 +59,11 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
             if (i0 & span) continue;
             const int i1 = i0 + span;
             const int m = (i0 & (span - 1)) * (8 / span);  // twiddle W16^m
-            const float2 a = v[i0], b = v[i1];
-            v[i0] = cadd(a, b);
-            const float2 d = csub(a, b);
+            const c2 a = v[i0], b = v[i1];
+            v[i0] = a + b;
+            const c2 d = a - b;
             if (m == 0) v[i1] = d;
-            else if (m == 4) v[i1] = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+            else if (m == 4) v[i1] = INV ? mkc(-d.y, d.x) : mkc(d.y, -d.x);
             else v[i1] = cmul_tw<INV>(d, kCos16[m], kSin16[m]);
         }
     }
@@ -71,12 +76,13 @@ __device__ constexpr int bitrev4(int k) { return ((k & 1) << 3) | ((k & 2) << 1)
 // even outputs, h = 1: twiddled differences -> odd outputs) and finishes with fft16; output
 // k of the lane is X[2k + h], left in v[bitrev4(k)].
 template <bool INV>
-__device__ __forceinline__ void fft32_line(const float2* line, int step, int h, float2 (&v)[16]) {
+__device__ __forceinline__ void fft32_line(const c2* line, int step, int h, c2 (&v)[16]) {
+#pragma clang fp contract(fast)
     const float sgn = h ? -1.f : 1.f;
 #pragma unroll
     for (int n = 0; n < 16; n++) {
-        const float2 x0 = line[n * step], x1 = line[(n + 16) * step];
-        const float2 d = make_float2(x0.x + sgn * x1.x, x0.y + sgn * x1.y);
+        const c2 x0 = line[n * step], x1 = line[(n + 16) * step];
+        const c2 d = x0 + sgn * x1;
         const float c = h ? kCos32[n] : 1.f, s = h ? kSin32[n] : 0.f;
         v[n] = (n == 0) ? d : cmul_tw<INV>(d, c, s);
     }
@@ -88,14 +94,14 @@ __device__ __forceinline__ void fft32_line(const float2* line, int step, int h, 
 __global__ __launch_bounds__(64 * kFusedWaves) void fftcc2d_fused32_kernel(Fftcc2dParams P, float* __restrict__ pois,
                                                                            int stride_f, unsigned long long count,
                                                                            int xcd_chunk) {
-    __shared__ float2 lds[kFusedWaves * FWAVE_LDS];
+    __shared__ c2 lds[kFusedWaves * FWAVE_LDS];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned long long grp = blockIdx.x;
     if (xcd_chunk > 0) grp = (unsigned long long)(blockIdx.x & 7u) * xcd_chunk + (blockIdx.x >> 3);
     const unsigned long long idx = grp * kFusedWaves + wave;
     if (idx >= count) return;
-    float2* buf = lds + wave * FWAVE_LDS;
+    c2* buf = lds + wave * FWAVE_LDS;
     float* poi = pois + idx * (unsigned long long)stride_f;
     const float px = poi[poi2d::X], py = poi[poi2d::Y];
     const float gu = poi[poi2d::U], gv = poi[poi2d::V];
@@ -111,6 +117,8 @@ __global__ __launch_bounds__(64 * kFusedWaves) void fftcc2d_fused32_kernel(Fftcc
     // s = r*32 + c is owned by lane (s mod 64), exactly like fftcc2d_gather_kernel
     float rn, tn;
     {
+        // buffer-resource loads: 32-bit offsets (the guard above keeps both windows inside the images)
+        const __amdgpu_buffer_rsrc_t r_ref = make_rsrc(P.ref), r_tar = make_rsrc(P.tar);
         float a[16], b[16];
         float rsum = 0.f, tsum = 0.f;
 #pragma unroll
@@ -118,9 +126,9 @@ __global__ __launch_bounds__(64 * kFusedWaves) void fftcc2d_fused32_kernel(Fftcc
             const int s = lane + kWave * k;
             const int r = s >> 5, c = s & 31;
             const float rxp = px + c - rx, ryp = py + r - ry;
-            a[k] = P.ref[(size_t)(int)ryp * width + (int)rxp];
+            a[k] = buf_f32(r_ref, (__umul24((unsigned)(int)ryp, (unsigned)width) + (unsigned)(int)rxp) << 2, 0);
             const float txp = rxp + gu, typ = ryp + gv;
-            b[k] = P.tar[(size_t)(int)typ * width + (int)txp];
+            b[k] = buf_f32(r_tar, (__umul24((unsigned)(int)typ, (unsigned)width) + (unsigned)(int)txp) << 2, 0);
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void fftcc2d_fused32_kernel(Fftcc
             const float x = a[k] - rmean, y = b[k] - tmean;
             rn += x * x;
             tn += y * y;
-            buf[(s >> 5) * FP + (s & 31)] = make_float2(x, y);
+            buf[(s >> 5) * FP + (s & 31)] = mkc(x, y);
         }
         rn = wave_allreduce_sum(rn);
         tn = wave_allreduce_sum(tn);
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void fftcc2d_fused32_kernel(Fftcc
     __builtin_amdgcn_wave_barrier();
 
     const int line = lane & 31, h = lane >> 5;
-    float2 v[16];
+    c2 v[16];
     // ---- forward rows: lane (y, h) -> Z1[y][2k + h]
     fft32_line<false>(buf + line * FP, 1, h, v);
     __builtin_amdgcn_wave_barrier();
@@ -161,19 +169,16 @@ __global__ __launch_bounds__(64 * kFusedWaves) void fftcc2d_fused32_kernel(Fftcc
     // ---- spectra of the two real windows and their product conj(R) * T (src/oc_fftcc.cpp:236-241)
     {
         const int mx = (FN - line) & (FN - 1);
-        float2 zm[16];
+        c2 zm[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) zm[k] = buf[((FN - (2 * k + h)) & (FN - 1)) * FP + mx];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const float2 z = v[bitrev4(k)];
+            const c2 z = v[bitrev4(k)];
             const float rr = 0.5f * (z.x + zm[k].x), ri = 0.5f * (z.y - zm[k].y);
             const float tr = 0.5f * (z.y + zm[k].y), ti = -0.5f * (z.x - zm[k].x);
-            float2 cc;
-            cc.x = (rr * tr) + (ri * ti);
-            cc.y = (rr * ti) - (ri * tr);
-            buf[(2 * k + h) * FP + line] = cc;
+            buf[(2 * k + h) * FP + line] = mkc((rr * tr) + (ri * ti), (rr * ti) - (ri * tr));
         }
     }
     __builtin_amdgcn_wave_barrier();
