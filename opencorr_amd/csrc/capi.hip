@@ -129,6 +129,8 @@ struct oc_hip_engine {
     bool ref_ready = false, tar_ready = false;
     DevBuf poi_stage, off_stage;
     DevBuf cursors;  // small device scratch (batch maxima)
+    DevBuf perm, tiles;  // locality schedule of the ICGN2D queue (poi_order.hip)
+    int icgn2d_tile_px = 64;   // 0 = visit the queue in its own order
     // FFTCC working set
     FftPlans fft;
     DevBuf win, freq, norms, flags;
@@ -341,7 +343,8 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
     }
     ochip::Icgn2dParams P = {im.ref_ptr(), e->gx.as<float>(), e->gy.as<float>(), e->coef.as<float>(),
                              im.dy,        im.dx,              rx,                ry,
-                             e->conv,      e->stop,            d_offsets,         e->self_adaptive ? 1 : 0};
+                             e->conv,      e->stop,            d_offsets,         nullptr,
+                             e->self_adaptive ? 1 : 0};
     const long long N = (2LL * rx + 1) * (2LL * ry + 1);
     // fall back to the LDS-light single-wave variant when the tuned one cannot hold the subset
     int variant = e->icgn2d_variant;
@@ -349,13 +352,22 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
     if (N > ochip::icgn2d_max_samples(variant))
         return fail(OC_HIP_ERR_UNSUPPORTED, "ICGN2D%d: subset %dx%d (%lld samples) exceeds the on-chip limit of %d samples",
                     dof == 6 ? 1 : 2, 2 * rx + 1, 2 * ry + 1, N, ochip::icgn2d_max_samples(variant));
-    ProfScope prof(e);
     // one wave per POI; grid.x is limited to 2^31-1
     const size_t kMaxGrid = 1u << 30;
     for (size_t first = 0; first < count; first += kMaxGrid) {
         const size_t n = (count - first) < kMaxGrid ? (count - first) : kMaxGrid;
         float* pois = d_pois + first * (size_t)stride_f;
         if (d_offsets) P.offsets = d_offsets + 2 * first;
+        // locality schedule: worth three tiny kernels once the queue is much larger than what is in flight
+        P.perm = nullptr;
+        if (e->icgn2d_tile_px > 0 && n >= 16384) {
+            OC_TRY(e->perm.reserve(n * sizeof(unsigned)));
+            OC_TRY(e->tiles.reserve(ochip::poi2d_tile_count(im.dy, im.dx, e->icgn2d_tile_px) * sizeof(unsigned)));
+            OC_HIP_TRY(ochip::launch_poi2d_tile_order(pois, stride_f, n, im.dy, im.dx, e->icgn2d_tile_px, e->tiles.as<unsigned>(),
+                                                      e->perm.as<unsigned>(), e->stream));
+            P.perm = e->perm.as<unsigned>();
+        }
+        ProfScope prof(e);  // the solver kernel alone (what rocprofv3 reports for it)
         hipError_t err = dof == 6 ? ochip::launch_icgn2d1(P, pois, stride_f, n, variant, e->icgn2d_xcd != 0, e->stream)
                                   : ochip::launch_icgn2d2(P, pois, stride_f, n, variant, e->icgn2d_xcd != 0, e->stream);
         if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "ICGN2D kernel launch failed: %s", hipGetErrorString(err));
@@ -650,6 +662,9 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
         e->icgn2d_variant = value;
     } else if (k == "icgn2d_xcd" || k == "xcd") {
         e->icgn2d_xcd = value != 0;
+    } else if (k == "icgn2d_tile_px") {
+        if (value < 0 || (value > 0 && value < 16)) return fail(OC_HIP_ERR_INVALID, "icgn2d_tile_px must be 0 (off) or >= 16");
+        e->icgn2d_tile_px = value;
     } else if (k == "fftcc2d_fused") {
         e->fftcc2d_fused = value != 0;
     } else {

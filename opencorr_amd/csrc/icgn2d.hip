@@ -65,8 +65,10 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     // contiguous range of the queue so POIs that share LUT lines meet in the same L2.
     unsigned long long grp = blockIdx.x;
     if (L.xcd_chunk > 0) grp = (unsigned long long)(blockIdx.x & 7u) * L.xcd_chunk + (blockIdx.x >> 3);
-    const unsigned long long idx = grp * WPB + wave;
-    if (idx >= L.count) return;
+    const unsigned long long slot = grp * WPB + wave;
+    if (slot >= L.count) return;
+    // the k-th wave of the launch solves POI perm[k] (a locality schedule) or simply POI k
+    const unsigned long long idx = P.perm ? (unsigned long long)__builtin_amdgcn_readfirstlane((int)P.perm[slot]) : slot;
     float* __restrict__ l_rs = lds + (size_t)wave * ARRAYS * NTA * kWave + lane;
     float* __restrict__ l_ts = l_rs + NTA * kWave;
     float* __restrict__ l_gx = l_ts + NTA * kWave;  // MODE 0 only

@@ -21,6 +21,7 @@ struct Icgn2dParams {
     int rx, ry;        // subset radius (self_adaptive: the largest radii of the batch)
     float conv, stop;
     const float* offsets;  // per-POI centre offsets (x, y), or nullptr: compute(poi_queue, center_offset_queue)
+    const unsigned* perm;  // visiting order of the queue (poi_order.hip), or nullptr: queue order
     int self_adaptive;     // DIC::setSelfAdaptive: every POI carries its own subset radius
 };
 // writes max over the queue of (int)subset_radius.x / .y to out2[0], out2[1]
@@ -37,6 +38,13 @@ int icgn2d_variant_count();
 int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int* occ);
 // largest (2rx+1)*(2ry+1) a variant accepts
 int icgn2d_max_samples(int variant);
+
+// ---- poi_order.hip ---------------------------------------------------------
+// locality schedule: perm[k] = index of the k-th POI to visit (tile by tile); tiles = scratch of
+// poi2d_tile_count(height, width, tile_px) unsigned ints
+size_t poi2d_tile_count(int height, int width, int tile_px);
+hipError_t launch_poi2d_tile_order(const float* pois, int stride_floats, size_t count, int height, int width, int tile_px,
+                                   unsigned* tiles, unsigned* perm, hipStream_t stream);
 
 // ---- nr2d.hip --------------------------------------------------------------
 struct Nr2dParams {

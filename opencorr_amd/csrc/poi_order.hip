@@ -1,0 +1,92 @@
+// poi_order.hip -- locality schedule for a POI queue: a permutation that visits the queue tile by tile.
+//
+// The ICGN2D kernels are served by per-XCD L2 caches (4 MB each); POIs that are neighbours in the image
+// share most of their coefficient-table lines.  A caller's queue is usually row-major over the whole
+// image, so a workgroup batch covers one long thin strip whose table footprint (33 rows x image width
+// x 64 B) overflows the L2.  Visiting the POIs tile by tile (square tiles of `tile_px` pixels, tiles in
+// row-major order, any order inside a tile) keeps the footprint of the POIs in flight near 2 MB.
+// Every POI is computed exactly as before -- only the order of the independent per-POI solves changes.
+//
+// Counting sort in three small kernels: histogram of tile ids, exclusive scan (one workgroup), scatter.
+#include "oc_device.h"
+#include "oc_kernels.h"
+
+namespace ochip {
+
+namespace {
+
+__device__ __forceinline__ unsigned tile_of(const float* poi, int height, int width, int tile_px, int ntx) {
+    // NaN / out-of-image coordinates land in an edge tile; such POIs are rejected by the guards later anyway
+    const float x = poi[poi2d::X], y = poi[poi2d::Y];
+    const int xi = x >= 0.f ? (x < (float)width ? (int)x : width - 1) : 0;
+    const int yi = y >= 0.f ? (y < (float)height ? (int)y : height - 1) : 0;
+    return (unsigned)(yi / tile_px) * (unsigned)ntx + (unsigned)(xi / tile_px);
+}
+
+__global__ __launch_bounds__(256) void tile_histogram_kernel(const float* __restrict__ pois, int stride_f, unsigned count,
+                                                             int height, int width, int tile_px, int ntx,
+                                                             unsigned* __restrict__ counts) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    atomicAdd(counts + tile_of(pois + (size_t)i * stride_f, height, width, tile_px, ntx), 1u);
+}
+
+// counts[0..n) -> exclusive prefix sums in place, one 1024-thread workgroup
+__global__ __launch_bounds__(1024) void tile_scan_kernel(unsigned* __restrict__ counts, int n) {
+    __shared__ unsigned part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = tid * per, hi = min(n, lo + per);
+    unsigned sum = 0;
+    for (int i = lo; i < hi; i++) sum += counts[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
+        const unsigned v = tid >= off ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = part[tid] - sum;
+    for (int i = lo; i < hi; i++) {
+        const unsigned c = counts[i];
+        counts[i] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_scatter_kernel(const float* __restrict__ pois, int stride_f, unsigned count,
+                                                           int height, int width, int tile_px, int ntx,
+                                                           unsigned* __restrict__ cursors, unsigned* __restrict__ perm) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const unsigned slot = atomicAdd(cursors + tile_of(pois + (size_t)i * stride_f, height, width, tile_px, ntx), 1u);
+    perm[slot] = i;
+}
+
+}  // namespace
+
+size_t poi2d_tile_count(int height, int width, int tile_px) {
+    return (size_t)((width + tile_px - 1) / tile_px) * (size_t)((height + tile_px - 1) / tile_px);
+}
+
+// perm[k] = index of the k-th POI to visit.  `tiles` is scratch for poi2d_tile_count() unsigned ints.
+hipError_t launch_poi2d_tile_order(const float* pois, int stride_f, size_t count, int height, int width, int tile_px,
+                                   unsigned* tiles, unsigned* perm, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    if (count > 0xffffffffull) return hipErrorInvalidValue;
+    const int ntx = (width + tile_px - 1) / tile_px;
+    const int ntiles = (int)poi2d_tile_count(height, width, tile_px);
+    hipError_t err = hipMemsetAsync(tiles, 0, (size_t)ntiles * sizeof(unsigned), stream);
+    if (err != hipSuccess) return err;
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(tile_histogram_kernel, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, height, width,
+                       tile_px, ntx, tiles);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, tiles, ntiles);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, height, width,
+                       tile_px, ntx, tiles, perm);
+    return hipGetLastError();
+}
+
+}  // namespace ochip

@@ -123,6 +123,39 @@ def test_icgn2d1_variants_identical_bits(eng, speckle_small, variant, xcd):
     assert np.array_equal(_bits(got), _bits(want))
 
 
+def test_icgn2d_tile_schedule_changes_no_bits(eng, speckle_small):
+    """The locality schedule (poi_order.hip) only reorders the independent per-POI solves: a queue long
+    enough to engage it gives the same bits as queue order, and the same bits as the oracle."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    xs, ys = synth.poi_grid_2d(h, w, 150, 120, 24)  # 18000 POIs >= the 16384 threshold
+    rng = np.random.default_rng(3)
+    shuffle = rng.permutation(len(xs))  # an arbitrary (not row-major) caller order
+    xs, ys = xs[shuffle], ys[shuffle]
+    xs = np.concatenate([xs, [2.0, np.float32(w + 50), 100.0]]).astype(np.float32)  # guard trippers
+    ys = np.concatenate([ys, [100.0, 60.0, np.float32(-7)]]).astype(np.float32)
+    fftcc = eng.FFTCC2D(16, 16)
+    fftcc.set_images(ref, tar)
+    start = eng.make_pois2d(xs, ys)
+    fftcc.compute(start)
+    icgn = eng.ICGN2D1(16, 16, 0.001, 10)
+    icgn.share_images(fftcc)
+    icgn.prepare()
+    outs = []
+    for px in (0, 64, 160):
+        icgn.set_tuning("icgn2d_tile_px", px)
+        pois = start.copy()
+        icgn.compute(pois)
+        outs.append(pois)
+    assert np.array_equal(_bits(outs[0]), _bits(outs[1]))
+    assert np.array_equal(_bits(outs[0]), _bits(outs[2]))
+    sample = start[::9].copy()
+    oracle.icgn2d1(oracle.Prepared2D(ref, tar), 16, 16, 0.001, 10, sample, order=oracle.ORDER_LANES, lanes=64)
+    assert np.array_equal(_bits(sample), _bits(outs[1][::9]))
+
+
 @pytest.mark.parametrize("rx,ry", [(16, 16), (15, 15), (7, 9), (20, 20)])
 def test_icgn2d1_bit_exact_vs_oracle(eng, speckle_small, rx, ry):
     import oracle

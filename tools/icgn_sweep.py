@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--xcd", default="0,1")
     ap.add_argument("--oracle-sample", type=int, default=4000)
     ap.add_argument("--out", default="")
+    ap.add_argument("--tile-px", default="", help="comma list of engine-side tile schedules to time (icgn2d_tile_px)")
     ap.add_argument("--tile", type=int, default=0, help="reorder the POI queue into T x T tiles of the grid (locality experiment)")
     args = ap.parse_args()
 
@@ -65,12 +66,15 @@ def main():
     nvar = 7
     variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(nvar))
     xcds = [int(v) for v in args.xcd.split(",")]
+    tiles = [int(v) for v in args.tile_px.split(",")] if args.tile_px else [None]
     base = None
     rows = []
-    for v in variants:
+    for v, tpx in [(v_, t_) for v_ in variants for t_ in tiles]:
         for x in xcds:
             icgn.set_tuning("icgn2d_variant", v)
             icgn.set_tuning("icgn2d_xcd", x)
+            if tpx is not None:
+                icgn.set_tuning("icgn2d_tile_px", tpx)
             try:
                 pois.copy_(start)
                 icgn.compute(pois)  # warm-up (code object load, LDS attribute)
@@ -90,7 +94,7 @@ def main():
             if base is None:
                 base = got
             same = bool(np.array_equal(got.view(np.uint32), base.view(np.uint32)))
-            rows.append(dict(variant=v, xcd=x, ms=ms / max(n, 1), launches=n, same_bits_as_first=same,
+            rows.append(dict(variant=v, xcd=x, tile_px=tpx, ms=ms / max(n, 1), launches=n, same_bits_as_first=same,
                              converged=int((got[:, 16] >= 0).sum()), mean_iter=float(got[:, 17].mean())))
             print(rows[-1], flush=True)
 
