@@ -269,6 +269,29 @@ public:
     }
 };
 
+// ICLM2D1 / ICLM2D2(int rx, int ry, float conv_criterion, float stop_condition, int thread_number)
+// src/oc_iclm.h:56-85, 104-133: prepare()/compute() as ICGN2D*, plus setDamping and self-adaptive subsets.
+template <int KIND>
+class Iclm2DShim : public IcgnShim<DIC, POI2D> {
+public:
+    Iclm2DShim(int rx, int ry, float conv_criterion_, float stop_condition_, int thread_number_) {
+        subset_radius_x = rx;
+        subset_radius_y = ry;
+        conv_criterion = conv_criterion_;
+        stop_condition = stop_condition_;
+        thread_number = thread_number_;
+        hipdetail::check(KIND == OC_HIP_ICLM2D1 ? oc_hip_iclm2d1_create(rx, ry, conv_criterion_, stop_condition_, device_, &engine_)
+                                                : oc_hip_iclm2d2_create(rx, ry, conv_criterion_, stop_condition_, device_, &engine_));
+    }
+    void setDamping(float lambda, float alpha, float beta) { hipdetail::check(oc_hip_set_damping(engine_, lambda, alpha, beta)); }
+    void setSelfAdaptive(bool is_self_adaptive) override {
+        hipdetail::check(oc_hip_set_self_adaptive(engine_, is_self_adaptive ? 1 : 0));
+        self_adaptive = is_self_adaptive;
+    }
+};
+using ICLM2D1 = Iclm2DShim<OC_HIP_ICLM2D1>;
+using ICLM2D2 = Iclm2DShim<OC_HIP_ICLM2D2>;
+
 class ICGN3D1 : public IcgnShim<DVC, POI3D> {
 public:
     ICGN3D1(int rx, int ry, int rz, float conv_criterion_, float stop_condition_, int thread_number_) {

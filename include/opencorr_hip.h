@@ -58,7 +58,9 @@ typedef enum oc_hip_kind {
     OC_HIP_ICGN2D2 = 3,
     OC_HIP_FFTCC3D = 4,
     OC_HIP_ICGN3D1 = 5,
-    OC_HIP_NR2D1 = 6
+    OC_HIP_NR2D1 = 6,
+    OC_HIP_ICLM2D1 = 7,
+    OC_HIP_ICLM2D2 = 8
 } oc_hip_kind;
 
 #define OC_HIP_POI2D_BYTES 100
@@ -87,6 +89,18 @@ int oc_hip_icgn2d2_create(int radius_x, int radius_y, float conv_criterion, floa
  * three bicubic tables; compute() = NR2D1::compute(poi_queue) (:324-332).  Per-POI codes: -1 (guard), -4, -5. */
 int oc_hip_nr2d1_create(int radius_x, int radius_y, float conv_criterion, float stop_condition, int device,
                         oc_hip_engine** out);
+/* ICLM2D1 / ICLM2D2(int rx, int ry, float conv_criterion, float stop_condition, int thread_number)
+ * src/oc_iclm.cpp:70-87, 422-439 (inverse-compositional Levenberg-Marquardt).  prepare() as for
+ * ICGN2D*; compute() = ICLM2D1::compute(poi_queue) (:360-368) / ICLM2D2::compute(poi_queue) (:733-741); both honour
+ * oc_hip_set_self_adaptive.  Per-POI codes: -3 (guard), -4, -5; unlike ICGN there is no abort when the warped subset
+ * leaves the image (out-of-range samples take the interpolator's -1.f, src/oc_iclm.cpp:230-243). */
+int oc_hip_iclm2d1_create(int radius_x, int radius_y, float conv_criterion, float stop_condition, int device,
+                          oc_hip_engine** out);
+int oc_hip_iclm2d2_create(int radius_x, int radius_y, float conv_criterion, float stop_condition, int device,
+                          oc_hip_engine** out);
+/* ICLM2D1::setDamping / ICLM2D2::setDamping(float lambda, float alpha, float beta)  src/oc_iclm.cpp:114-119, 466-471;
+ * defaults 100, 0.1, 10 (struct DampingParameter, src/oc_iclm.h:33-38).  lambda must be > 0. */
+int oc_hip_set_damping(oc_hip_engine* engine, float lambda, float alpha, float beta);
 /* FFTCC3D(int rx, int ry, int rz, int thread_number)  src/oc_fftcc.cpp:300-313 */
 int oc_hip_fftcc3d_create(int radius_x, int radius_y, int radius_z, int device, oc_hip_engine** out);
 /* ICGN3D1(int rx, int ry, int rz, float conv, float stop, int thread_number)  src/oc_icgn.cpp:1197-1213 */

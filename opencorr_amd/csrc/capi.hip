@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -130,6 +131,7 @@ struct oc_hip_engine {
     DevBuf poi_stage, off_stage;
     DevBuf cursors;  // small device scratch (batch maxima)
     DevBuf perm, tiles;  // locality schedule of the ICGN2D queue (poi_order.hip)
+    float lm_lambda = 100.f, lm_alpha = 0.1f, lm_beta = 10.f;  // DampingParameter defaults, src/oc_iclm.h:33-38
     int icgn2d_tile_px = 64;   // 0 = visit the queue in its own order
     // FFTCC working set
     FftPlans fft;
@@ -145,7 +147,9 @@ struct oc_hip_engine {
     std::mutex mu;
 
     bool is3d() const { return kind == OC_HIP_FFTCC3D || kind == OC_HIP_ICGN3D1; }
-    bool is_icgn() const { return kind == OC_HIP_ICGN2D1 || kind == OC_HIP_ICGN2D2 || kind == OC_HIP_ICGN3D1 || kind == OC_HIP_NR2D1; }
+    bool is_iclm() const { return kind == OC_HIP_ICLM2D1 || kind == OC_HIP_ICLM2D2; }
+    bool is_icgn2d() const { return kind == OC_HIP_ICGN2D1 || kind == OC_HIP_ICGN2D2 || is_iclm(); }
+    bool is_icgn() const { return is_icgn2d() || kind == OC_HIP_ICGN3D1 || kind == OC_HIP_NR2D1; }
     size_t poi_bytes() const { return is3d() ? OC_HIP_POI3D_BYTES : OC_HIP_POI2D_BYTES; }
 };
 
@@ -328,7 +332,8 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
     if (!e->ref_ready || !e->tar_ready)
         return fail(OC_HIP_ERR_INVALID, "ICGN2D: prepare() has not been called since the last set_images");
     const ImagePair& im = *e->img;
-    const int dof = e->kind == OC_HIP_ICGN2D1 ? 6 : 12;
+    const int dof = (e->kind == OC_HIP_ICGN2D1 || e->kind == OC_HIP_ICLM2D1) ? 6 : 12;
+    const bool lm = e->is_iclm();
     int rx = e->rx, ry = e->ry;
     if (e->self_adaptive) {
         // every POI brings its own radius (src/oc_icgn.cpp:152-158): size the on-chip arrays for the largest
@@ -344,10 +349,13 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
     ochip::Icgn2dParams P = {im.ref_ptr(), e->gx.as<float>(), e->gy.as<float>(), e->coef.as<float>(),
                              im.dy,        im.dx,              rx,                ry,
                              e->conv,      e->stop,            d_offsets,         nullptr,
-                             e->self_adaptive ? 1 : 0};
+                             e->self_adaptive ? 1 : 0,
+                             lm ? std::log((double)e->lm_lambda) : 0.0,
+                             e->lm_alpha,  e->lm_beta};
     const long long N = (2LL * rx + 1) * (2LL * ry + 1);
     // fall back to the LDS-light single-wave variant when the tuned one cannot hold the subset
     int variant = e->icgn2d_variant;
+    if (lm) variant = 1;  // the IC-LM launch shape has the LDS footprint of variant 1
     if (N > ochip::icgn2d_max_samples(variant)) variant = 1;
     if (N > ochip::icgn2d_max_samples(variant))
         return fail(OC_HIP_ERR_UNSUPPORTED, "ICGN2D%d: subset %dx%d (%lld samples) exceeds the on-chip limit of %d samples",
@@ -368,8 +376,13 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
             P.perm = e->perm.as<unsigned>();
         }
         ProfScope prof(e);  // the solver kernel alone (what rocprofv3 reports for it)
-        hipError_t err = dof == 6 ? ochip::launch_icgn2d1(P, pois, stride_f, n, variant, e->icgn2d_xcd != 0, e->stream)
-                                  : ochip::launch_icgn2d2(P, pois, stride_f, n, variant, e->icgn2d_xcd != 0, e->stream);
+        hipError_t err;
+        if (lm)
+            err = dof == 6 ? ochip::launch_iclm2d1(P, pois, stride_f, n, e->icgn2d_xcd != 0, e->stream)
+                           : ochip::launch_iclm2d2(P, pois, stride_f, n, e->icgn2d_xcd != 0, e->stream);
+        else
+            err = dof == 6 ? ochip::launch_icgn2d1(P, pois, stride_f, n, variant, e->icgn2d_xcd != 0, e->stream)
+                           : ochip::launch_icgn2d2(P, pois, stride_f, n, variant, e->icgn2d_xcd != 0, e->stream);
         if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "ICGN2D kernel launch failed: %s", hipGetErrorString(err));
     }
     return OC_HIP_OK;
@@ -475,7 +488,9 @@ int run_compute_device(oc_hip_engine* e, float* d_pois, int stride_f, size_t cou
     switch (e->kind) {
         case OC_HIP_FFTCC2D: return run_fftcc2d(e, d_pois, stride_f, count);
         case OC_HIP_ICGN2D1:
-        case OC_HIP_ICGN2D2: return run_icgn2d(e, d_pois, stride_f, count, d_offsets);
+        case OC_HIP_ICGN2D2:
+        case OC_HIP_ICLM2D1:
+        case OC_HIP_ICLM2D2: return run_icgn2d(e, d_pois, stride_f, count, d_offsets);
         case OC_HIP_NR2D1: return run_nr2d1(e, d_pois, stride_f, count);
         case OC_HIP_FFTCC3D: return run_fftcc3d(e, d_pois, stride_f, count);
         case OC_HIP_ICGN3D1: return run_icgn3d1(e, d_pois, stride_f, count);
@@ -513,6 +528,26 @@ int oc_hip_icgn2d1_create(int rx, int ry, float conv, float stop, int device, oc
 int oc_hip_icgn2d2_create(int rx, int ry, float conv, float stop, int device, oc_hip_engine** out) {
     return create_engine(OC_HIP_ICGN2D2, rx, ry, 0, conv, stop, device, out);
 }
+int oc_hip_iclm2d1_create(int rx, int ry, float conv, float stop, int device, oc_hip_engine** out) {
+    return create_engine(OC_HIP_ICLM2D1, rx, ry, 0, conv, stop, device, out);
+}
+
+int oc_hip_iclm2d2_create(int rx, int ry, float conv, float stop, int device, oc_hip_engine** out) {
+    return create_engine(OC_HIP_ICLM2D2, rx, ry, 0, conv, stop, device, out);
+}
+
+int oc_hip_set_damping(oc_hip_engine* e, float lambda, float alpha, float beta) {
+    OC_TRY(check_engine(e));
+    if (!e->is_iclm()) return fail(OC_HIP_ERR_INVALID, "set_damping: not an ICLM2D1/ICLM2D2 engine");
+    // powf(lambda, q) with a non-integer q is NaN for lambda < 0 and the reference would then reject every step
+    if (!(lambda > 0.f)) return fail(OC_HIP_ERR_INVALID, "set_damping: lambda must be > 0 (got %g)", (double)lambda);
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->lm_lambda = lambda;
+    e->lm_alpha = alpha;
+    e->lm_beta = beta;
+    return OC_HIP_OK;
+}
+
 int oc_hip_nr2d1_create(int rx, int ry, float conv, float stop, int device, oc_hip_engine** out) {
     return create_engine(OC_HIP_NR2D1, rx, ry, 0, conv, stop, device, out);
 }
@@ -788,8 +823,8 @@ int oc_hip_compute_one_with_offset(oc_hip_engine* e, void* poi, const float* cen
 
 int oc_hip_set_self_adaptive(oc_hip_engine* e, int enable) {
     OC_TRY(check_engine(e));
-    if (e->kind != OC_HIP_ICGN2D1 && e->kind != OC_HIP_ICGN2D2)
-        return fail(OC_HIP_ERR_UNSUPPORTED, "self-adaptive subsets are implemented for ICGN2D1/ICGN2D2 (NR2D1 has none in the reference)");
+    if (!e->is_icgn2d())
+        return fail(OC_HIP_ERR_UNSUPPORTED, "self-adaptive subsets are implemented for ICGN2D1/2D2 and ICLM2D1/2D2 (NR2D1 has none in the reference)");
     std::lock_guard<std::mutex> lock(e->mu);
     e->self_adaptive = enable != 0;
     return OC_HIP_OK;

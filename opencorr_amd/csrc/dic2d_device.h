@@ -222,6 +222,36 @@ __device__ __forceinline__ void set_warp_2d2(float (&w)[36], const float (&q)[12
     w[30] = 0.f; w[31] = 0.f; w[32] = 0.f; w[33] = 0.f; w[34] = 0.f; w[35] = 1.f;
 }
 
+// First damping value of IC-LM: powf(damping.lambda, znssd / znssd0) (src/oc_iclm.cpp:253, :628) as a fixed sequence
+// of IEEE double operations -- exp(q * ln(lambda)), ln(lambda) taken once on the host, argument reduction by ln 2
+// (hi/lo split), degree-14 Taylor polynomial, one rounding to float.  libm powf implementations differ in the
+// last bit between platforms (glibc's is off by one ulp from the correctly rounded value in ~0.05% of cases); this
+// form is reproducible, and the oracle restates the identical sequence.
+__device__ __forceinline__ float pow_lambda(double log_lambda, float q) {
+    const double t = (double)q * log_lambda;
+    if (!(t == t)) return __builtin_nanf("");
+    if (t > 700.0) return __builtin_inff();
+    if (t < -700.0) return 0.f;
+    const double kf = floor(t * 1.44269504088896338700e+00 + 0.5);
+    const double r = (t - kf * 6.93147180369123816490e-01) - kf * 1.90821492927058770002e-10;
+    double e = 1.0 / 87178291200.0;
+    e = e * r + 1.0 / 6227020800.0;
+    e = e * r + 1.0 / 479001600.0;
+    e = e * r + 1.0 / 39916800.0;
+    e = e * r + 1.0 / 3628800.0;
+    e = e * r + 1.0 / 362880.0;
+    e = e * r + 1.0 / 40320.0;
+    e = e * r + 1.0 / 5040.0;
+    e = e * r + 1.0 / 720.0;
+    e = e * r + 1.0 / 120.0;
+    e = e * r + 1.0 / 24.0;
+    e = e * r + 1.0 / 6.0;
+    e = e * r + 0.5;
+    e = e * r + 1.0;
+    e = e * r + 1.0;
+    return (float)ldexp(e, (int)kf);
+}
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 mk2(float a, float b) {
     f2 r = {a, b};

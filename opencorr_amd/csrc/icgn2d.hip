@@ -42,6 +42,10 @@ namespace ochip {
 // P.self_adaptive = DIC::setSelfAdaptive(true): every POI brings its own subset radius
 //        (poi->subset_radius, src/oc_icgn.cpp:152-158); L.nt then sizes the LDS arrays for the
 //        largest subset of the batch.
+// LM   = the inverse-compositional Levenberg-Marquardt classes ICLM2D1 / ICLM2D2 (src/oc_iclm.cpp:150-358,
+//        505-731): same subset, Hessian and numerator code; the Hessian is kept (column j in lane j), damped and
+//        inverted every iteration, a step is only applied when the ZNSSD went down, out-of-range samples do not
+//        abort (they enter the subset as -1.f), and 2D2 weighs the convergence norm in float.
 // Every variant performs the same floating-point operations in the same order, so all
 // of them are bit-identical to the oracle in OC_ORDER_LANES.
 // ---------------------------------------------------------------------------
@@ -52,7 +56,7 @@ struct Icgn2dLaunch {
     unsigned long long count;  // POIs
 };
 
-template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC, int OFFS>
+template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC, int OFFS, int LM = 0>
 __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, float* __restrict__ pois,
                                                                Icgn2dLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -157,6 +161,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
 
     // ---- steepest-descent image + Hessian (src/oc_icgn.cpp:179-207; 2D2: 716-756), inverse (:210 / :759)
     float hinv_col[DOF];  // lane j < DOF: column j of H^-1
+    float hcol[LM ? DOF : 1];  // LM: column j of H itself
     {
         float h[NH];
 #pragma unroll
@@ -231,7 +236,12 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 if (lane == j) col[i] = v;  // H(i,j)
                 if (lane == i) col[j] = v;  // H(j,i)
             }
-        lu_inverse_lanes<DOF>(col, hinv_col, lane);
+        if constexpr (LM) {
+#pragma unroll
+            for (int i = 0; i < DOF; i++) hcol[i] = col[i];
+        } else {
+            lu_inverse_lanes<DOF>(col, hinv_col, lane);
+        }
     }
 
     // ---- IC-GN loop (src/oc_icgn.cpp:216-307; 2D2: 762-858)
@@ -262,6 +272,12 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     float cur[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) cur[i] = 0.f;
+    float znssd0 = 4.f, lambda = 0.f;  // IC-LM state (src/oc_iclm.cpp:226)
+    if constexpr (LM) {
+        // p_current.setDeformation(p_initial) copies the parameters themselves (src/oc_iclm.cpp:223 / :598)
+        cur[0] = u_in; cur[1] = ux_in; cur[2] = uy_in;
+        cur[6] = v_in; cur[7] = vx_in; cur[8] = vy_in;
+    }
 #pragma nounroll
     do {
         iter++;
@@ -336,10 +352,12 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 }
             }
         }
-        // src/oc_icgn.cpp:251-255
-        if (wave_any(negative)) {
-            if (lane == 0) poi[poi2d::ZNCC] = -3.f;
-            return;
+        // src/oc_icgn.cpp:251-255 (the IC-LM classes have no such check)
+        if constexpr (!LM) {
+            if (wave_any(negative)) {
+                if (lane == 0) poi[poi2d::ZNCC] = -3.f;
+                return;
+            }
         }
         // zeroMeanNorm of the target subset (src/oc_icgn.cpp:257)
         const float tmean = wave_allreduce_sum(acc) / fN;
@@ -403,6 +421,14 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             }
         }
         znssd = uni(wave_allreduce_sum(ssd)) / (ref_norm * ref_norm);
+        if constexpr (LM) {
+            // src/oc_iclm.cpp:250-257: lambda from the first ZNSSD; (H + lambda * I)^-1 every iteration
+            if (iter == 1) lambda = uni(pow_lambda(P.lm_log_lambda, znssd / znssd0) - 1.f);
+            float dcol[DOF];
+#pragma unroll
+            for (int i = 0; i < DOF; i++) dcol[i] = hcol[i] + lambda * (lane == i ? 1.f : 0.f);
+            lu_inverse_lanes<DOF>(dcol, hinv_col, lane);
+        }
         // dp = H^-1 * numerator (src/oc_icgn.cpp:279-286): lane j forms H^-1(i,j) * num[j], the
         // products of row i are then added in ascending j exactly like the reference loop
         float numj = 0.f;
@@ -420,6 +446,12 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             for (int j = 0; j < DOF; j++) v += wave_bcast(prod, j);
             dp[i] = v;
         }
+        // IC-LM applies the step only when the ZNSSD went down (src/oc_iclm.cpp:283-300); wave-uniform
+        const bool accept = !LM || znssd < znssd0;
+        if constexpr (LM) {
+            lambda = lambda * (accept ? P.lm_alpha : P.lm_beta);
+            znssd0 = accept ? znssd : znssd0;
+        }
         // W <- W * (dW)^-1 ; p <- W (src/oc_icgn.cpp:287-293 / 828-834)
         const int rx2 = rx * rx, ry2 = ry * ry;
         if constexpr (DOF == 6) {
@@ -427,11 +459,13 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             set_warp_2d1(dW, dp[0], dp[1], dp[2], dp[3], dp[4], dp[5]);
             inverse3(dW, dWi);
             mat_mul<3>(Wm, dWi, Wn);
+            if (accept) {
 #pragma unroll
-            for (int i = 0; i < 9; i++) Wm[i] = uni(Wn[i]);
-            // src/oc_deformation.cpp:107-115
-            cur[0] = Wm[2]; cur[1] = Wm[0] - 1.f; cur[2] = Wm[1];
-            cur[6] = Wm[5]; cur[7] = Wm[3]; cur[8] = Wm[4] - 1.f;
+                for (int i = 0; i < 9; i++) Wm[i] = uni(Wn[i]);
+                // src/oc_deformation.cpp:107-115
+                cur[0] = Wm[2]; cur[1] = Wm[0] - 1.f; cur[2] = Wm[1];
+                cur[6] = Wm[5]; cur[7] = Wm[3]; cur[8] = Wm[4] - 1.f;
+            }
             // convergence norm (src/oc_icgn.cpp:296-306)
             const float d = dp[0] * dp[0] + dp[1] * dp[1] * rx2 + dp[2] * dp[2] * ry2 + dp[3] * dp[3] +
                             dp[4] * dp[4] * rx2 + dp[5] * dp[5] * ry2;
@@ -458,6 +492,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 for (int k = 1; k < 6; k++) v = v + wave_bcast(Wcol[i], k) * dinv[k];
                 ncol[i] = v;
             }
+            if (accept) {
 #pragma unroll
             for (int i = 0; i < 6; i++) Wcol[i] = ncol[i];
             // Deformation2D2::setDeformation(), src/oc_deformation.cpp:284-299
@@ -467,15 +502,24 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             const float r43 = wave_bcast(Wcol[4], 3), r44 = wave_bcast(Wcol[4], 4), r45 = wave_bcast(Wcol[4], 5);
             cur[0] = r35; cur[1] = r33 - 1.f; cur[2] = r34; cur[3] = r30 * 2.f; cur[4] = r31; cur[5] = r32 * 2.f;
             cur[6] = r45; cur[7] = r43; cur[8] = r44 - 1.f; cur[9] = r40 * 2.f; cur[10] = r41; cur[11] = r42 * 2.f;
-            // src/oc_icgn.cpp:837-857 (integer-truncated weights are reference behaviour)
+            }
             const int rxy2 = rx2 * ry2;
-            const int rx4 = (int)(rx2 * rx2 * 0.25f), ry4 = (int)(ry2 * ry2 * 0.25f);
             constexpr int D = DOF;  // keeps the dp[] indices in range when this branch is discarded
-            const float d = dp[0] * dp[0] + dp[1] * dp[1] * rx2 + dp[2] * dp[2] * ry2 + dp[3 % D] * dp[3 % D] * rx4 +
-                            dp[5 % D] * dp[5 % D] * ry4 + dp[4 % D] * dp[4 % D] * rxy2 + dp[6 % D] * dp[6 % D] +
-                            dp[7 % D] * dp[7 % D] * rx2 + dp[8 % D] * dp[8 % D] * ry2 +
-                            dp[9 % D] * dp[9 % D] * rx4 + dp[11 % D] * dp[11 % D] * ry4 +
-                            dp[10 % D] * dp[10 % D] * rxy2;
+            float d;
+            if constexpr (!LM) {
+                // src/oc_icgn.cpp:837-857 (integer-truncated weights are reference behaviour)
+                const int rx4 = (int)(rx2 * rx2 * 0.25f), ry4 = (int)(ry2 * ry2 * 0.25f);
+                d = dp[0] * dp[0] + dp[1] * dp[1] * rx2 + dp[2] * dp[2] * ry2 + dp[3 % D] * dp[3 % D] * rx4 +
+                    dp[5 % D] * dp[5 % D] * ry4 + dp[4 % D] * dp[4 % D] * rxy2 + dp[6 % D] * dp[6 % D] +
+                    dp[7 % D] * dp[7 % D] * rx2 + dp[8 % D] * dp[8 % D] * ry2 + dp[9 % D] * dp[9 % D] * rx4 +
+                    dp[11 % D] * dp[11 % D] * ry4 + dp[10 % D] * dp[10 % D] * rxy2;
+            } else {
+                // src/oc_iclm.cpp:675-687: p * p * rx2 * rx2 * 0.25f, left to right in float
+                d = dp[0] * dp[0] + dp[1] * dp[1] * rx2 + dp[2] * dp[2] * ry2 + dp[3 % D] * dp[3 % D] * rx2 * rx2 * 0.25f +
+                    dp[5 % D] * dp[5 % D] * ry2 * ry2 * 0.25f + dp[4 % D] * dp[4 % D] * rxy2 + dp[6 % D] * dp[6 % D] +
+                    dp[7 % D] * dp[7 % D] * rx2 + dp[8 % D] * dp[8 % D] * ry2 + dp[9 % D] * dp[9 % D] * rx2 * rx2 * 0.25f +
+                    dp[11 % D] * dp[11 % D] * ry2 * ry2 * 0.25f + dp[10 % D] * dp[10 % D] * rxy2;
+            }
             dp_norm = uni(sqrtf(d));
         }
     } while (iter < P.stop && dp_norm >= P.conv);
@@ -526,13 +570,13 @@ struct VariantInfo {
     int g, mode, pipe, wpb, occ;
 };
 
-template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC, int OFFS>
+template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC, int OFFS, int LM = 0>
 static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int nt, bool xcd,
                            hipStream_t stream) {
     constexpr int arrays = MODE == 0 ? 4 : 2;
     const size_t lds = (size_t)arrays * nt * kWave * sizeof(float) * WPB;
     if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
-    auto kern = icgn2d_kernel<DOF, G, MODE, PIPE, WPB, OCC, OFFS>;
+    auto kern = icgn2d_kernel<DOF, G, MODE, PIPE, WPB, OCC, OFFS, LM>;
     // the dynamic-LDS limit is a per-device property of the loaded function: raise it once on every
     // device this process launches on (one engine per device is a supported host layout)
     static std::atomic<unsigned long long> attr_devices{0};
@@ -616,6 +660,22 @@ hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_f, size
 hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
                           hipStream_t stream) {
     return launch_dof<12>(p, pois, stride_f, count, variant, xcd, stream);
+}
+
+// IC-LM: one launch shape each (G = 3, gradients re-read, one wave per workgroup so the LDS limit is the
+// largest; the per-iteration LU keeps more registers live, hence occupancy 3)
+int iclm2d_max_samples() { return kLdsBudget / (2 * (int)sizeof(float) * kWave) * kWave; }
+
+hipError_t launch_iclm2d1(const Icgn2dParams& p, float* pois, int stride_f, size_t count, bool xcd, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    const int nt = ((2 * p.rx + 1) * (2 * p.ry + 1) + 63) / 64;
+    return launch_t<6, 3, 1, 0, 1, 4, 0, 1>(p, pois, stride_f, count, nt, xcd, stream);
+}
+
+hipError_t launch_iclm2d2(const Icgn2dParams& p, float* pois, int stride_f, size_t count, bool xcd, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    const int nt = ((2 * p.rx + 1) * (2 * p.ry + 1) + 63) / 64;
+    return launch_t<12, 4, 1, 0, 1, 3, 0, 1>(p, pois, stride_f, count, nt, xcd, stream);
 }
 
 // largest subset radii of a POI queue (self-adaptive mode sizes the LDS arrays from them)

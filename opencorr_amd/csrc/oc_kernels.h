@@ -23,6 +23,9 @@ struct Icgn2dParams {
     const float* offsets;  // per-POI centre offsets (x, y), or nullptr: compute(poi_queue, center_offset_queue)
     const unsigned* perm;  // visiting order of the queue (poi_order.hip), or nullptr: queue order
     int self_adaptive;     // DIC::setSelfAdaptive: every POI carries its own subset radius
+    // IC-LM only (launch_iclm2d*): DampingParameter of src/oc_iclm.h:33-38 with ln(lambda) taken on the host
+    double lm_log_lambda;
+    float lm_alpha, lm_beta;
 };
 // writes max over the queue of (int)subset_radius.x / .y to out2[0], out2[1]
 hipError_t launch_poi2d_max_radius(const float* pois, int stride_floats, size_t count, int* out2, hipStream_t stream);
@@ -32,6 +35,10 @@ hipError_t launch_poi2d_max_radius(const float* pois, int stride_floats, size_t 
 // Returns hipErrorInvalidValue if the subset does not fit the variant's LDS budget.
 hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, int variant, bool xcd,
                           hipStream_t stream);
+// ICLM2D1 / ICLM2D2 (src/oc_iclm.cpp): the same kernel with the Levenberg-Marquardt step
+hipError_t launch_iclm2d1(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
+hipError_t launch_iclm2d2(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
+int iclm2d_max_samples();
 hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, int variant, bool xcd,
                           hipStream_t stream);
 int icgn2d_variant_count();

@@ -227,6 +227,32 @@ class NR2D1(_Engine, _IcgnMixin):
                                                   device, ctypes.byref(self._h)))
 
 
+class _IclmMixin(_IcgnMixin):
+    def set_damping(self, lambda_, alpha, beta):
+        """ICLM2D*::setDamping(lambda, alpha, beta) (src/oc_iclm.cpp:114-119); defaults 100, 0.1, 10."""
+        capi.check(capi.lib().oc_hip_set_damping(self._h, lambda_, alpha, beta))
+
+
+class ICLM2D1(_Engine, _IclmMixin):
+    """ICLM2D1(rx, ry, conv_criterion, stop_condition, thread_number) -- src/oc_iclm.h:56-85."""
+
+    def __init__(self, subset_radius_x, subset_radius_y, conv_criterion, stop_condition, thread_number=1, device=0):
+        super().__init__()
+        self.thread_number = thread_number
+        capi.check(capi.lib().oc_hip_iclm2d1_create(subset_radius_x, subset_radius_y, conv_criterion, stop_condition,
+                                                    device, ctypes.byref(self._h)))
+
+
+class ICLM2D2(_Engine, _IclmMixin):
+    """ICLM2D2(rx, ry, conv_criterion, stop_condition, thread_number) -- src/oc_iclm.h:104-133."""
+
+    def __init__(self, subset_radius_x, subset_radius_y, conv_criterion, stop_condition, thread_number=1, device=0):
+        super().__init__()
+        self.thread_number = thread_number
+        capi.check(capi.lib().oc_hip_iclm2d2_create(subset_radius_x, subset_radius_y, conv_criterion, stop_condition,
+                                                    device, ctypes.byref(self._h)))
+
+
 class FFTCC3D(_Engine):
     """FFTCC3D(rx, ry, rz, thread_number) -- src/oc_fftcc.h:75-89."""
     _ndim = 3

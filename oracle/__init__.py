@@ -62,6 +62,10 @@ def lib():
         L.oc_oracle_icgn2d2_ex.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i, fp, i]
         L.oc_oracle_nr2d1.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i]
         L.oc_oracle_nr2d1.restype = None
+        L.oc_oracle_iclm2d.argtypes = [i, fp, fp, fp, fp, i, i, i, i, f, f, fp, i, fp, l, i, i, i, i]
+        L.oc_oracle_iclm2d.restype = None
+        L.oc_oracle_pow_lambda.argtypes = [f, f]
+        L.oc_oracle_pow_lambda.restype = f
         L.oc_oracle_icgn2d1_ex.restype = None
         L.oc_oracle_icgn2d2_ex.restype = None
         L.oc_oracle_gradient3d.argtypes = [fp, i, i, i, fp, fp, fp, i]
@@ -176,6 +180,35 @@ def icgn2d2(prep, rx, ry, conv, stop, pois, order=ORDER_SEQ, lanes=64, threads=0
             self_adaptive=False):
     _icgn2d(lib().oc_oracle_icgn2d2_ex, prep, rx, ry, conv, stop, pois, order, lanes, threads, center_offsets,
             self_adaptive)
+
+
+def _iclm2d(dof, prep, rx, ry, conv, stop, pois, damping, order, lanes, threads, self_adaptive):
+    assert pois.dtype == np.float32 and pois.flags.c_contiguous and pois.shape[1] == POI2D_FLOATS
+    h, w = prep.ref.shape
+    d = np.asarray(damping, dtype=np.float32)
+    assert d.shape == (3,)
+    lib().oc_oracle_iclm2d(dof, _fp(prep.ref), _fp(prep.gx), _fp(prep.gy), _fp(prep.lut), h, w, rx, ry, float(conv),
+                           float(stop), _fp(d), 1 if self_adaptive else 0, _fp(pois), pois.shape[0], POI2D_FLOATS, order,
+                           lanes, threads)
+
+
+DEFAULT_DAMPING = (100.0, 0.1, 10.0)  # struct DampingParameter, src/oc_iclm.h:33-38
+
+
+def iclm2d1(prep, rx, ry, conv, stop, pois, damping=DEFAULT_DAMPING, order=ORDER_SEQ, lanes=64, threads=0,
+            self_adaptive=False):
+    """ICLM2D1::compute(poi_queue) (src/oc_iclm.cpp:150-368), in place on ``pois``; ``prep`` as for icgn2d1."""
+    _iclm2d(6, prep, rx, ry, conv, stop, pois, damping, order, lanes, threads, self_adaptive)
+
+
+def iclm2d2(prep, rx, ry, conv, stop, pois, damping=DEFAULT_DAMPING, order=ORDER_SEQ, lanes=64, threads=0,
+            self_adaptive=False):
+    """ICLM2D2::compute(poi_queue) (src/oc_iclm.cpp:505-741)."""
+    _iclm2d(12, prep, rx, ry, conv, stop, pois, damping, order, lanes, threads, self_adaptive)
+
+
+def pow_lambda(lam, q):
+    return float(lib().oc_oracle_pow_lambda(float(lam), float(q)))
 
 
 class PreparedNR2D:

@@ -25,6 +25,7 @@
 #include <complex>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 namespace {
@@ -437,13 +438,55 @@ static inline void set_warp_2d2(float* w, const float* q) {
     w[30] = 0.f; w[31] = 0.f; w[32] = 0.f; w[33] = 0.f; w[34] = 0.f; w[35] = 1.f;
 }
 
-// DOF = 6 -> ICGN2D1, DOF = 12 -> ICGN2D2
+// First-iteration damping of IC-LM: powf(damping.lambda, znssd / znssd0) (src/oc_iclm.cpp:253, :628).  libm's powf
+// is not reproducible across platforms to the last bit, so the restatement fixes the arithmetic: exp(q * ln(lambda))
+// in double with ln(lambda) taken once on the host, exp by argument reduction and a degree-14 Taylor polynomial
+// evaluated with plain IEEE double operations, rounded once to float.  Relative error ~2e-16 before the rounding, so
+// the result is the correctly rounded float power except within ~1e-8 of a rounding tie
+// (tests/test_oracle_golden.py compares it with libm's powf over a dense sample).  The HIP engine restates the same
+// sequence (opencorr_amd/csrc/dic2d_device.h).
+static inline float pow_lambda(double log_lambda, float q) {
+    const double t = (double)q * log_lambda;
+    if (!(t == t)) return std::numeric_limits<float>::quiet_NaN();
+    if (t > 700.0) return std::numeric_limits<float>::infinity();
+    if (t < -700.0) return 0.f;
+    const double kf = std::floor(t * 1.44269504088896338700e+00 + 0.5);
+    const double r = (t - kf * 6.93147180369123816490e-01) - kf * 1.90821492927058770002e-10;
+    double e = 1.0 / 87178291200.0;
+    e = e * r + 1.0 / 6227020800.0;
+    e = e * r + 1.0 / 479001600.0;
+    e = e * r + 1.0 / 39916800.0;
+    e = e * r + 1.0 / 3628800.0;
+    e = e * r + 1.0 / 362880.0;
+    e = e * r + 1.0 / 40320.0;
+    e = e * r + 1.0 / 5040.0;
+    e = e * r + 1.0 / 720.0;
+    e = e * r + 1.0 / 120.0;
+    e = e * r + 1.0 / 24.0;
+    e = e * r + 1.0 / 6.0;
+    e = e * r + 0.5;
+    e = e * r + 1.0;
+    e = e * r + 1.0;
+    return (float)std::ldexp(e, (int)kf);
+}
+
+// IC-LM damping (struct DampingParameter, src/oc_iclm.h:33-38) with ln(lambda) precomputed
+struct LmDamping {
+    double log_lambda;
+    float alpha, beta;
+};
+
+// DOF = 6 -> ICGN2D1, DOF = 12 -> ICGN2D2; with lm != nullptr the Levenberg-Marquardt variants ICLM2D1 / ICLM2D2
+// (src/oc_iclm.cpp:150-358, 505-731): same subset, Hessian and numerator code, plus the damped inverse every
+// iteration, the accept/reject step, NO abort on out-of-range samples (they enter the subset as -1.f), and for
+// 2D2 float (not truncated-int) weights in the convergence norm.
 // off: centre offset {x, y} of the compute(POI2D*, Point2D&) overloads (src/oc_icgn.cpp:353-547,
 // 910-1126), or nullptr for the plain compute(POI2D*).  self_adaptive: DIC::setSelfAdaptive, the
 // subset radius comes from poi->subset_radius (:152-158).
 template <int DOF, template <int> class Acc>
 static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float stop, float* poi, int lanes,
-                       std::vector<float>& scratch, const float* off = nullptr, int self_adaptive = 0) {
+                       std::vector<float>& scratch, const float* off = nullptr, int self_adaptive = 0,
+                       const LmDamping* lm = nullptr) {
     if (self_adaptive) {
         rx = (int)poi[23];  // Point2D (float) passed to int parameters of ICGN2D1_::update
         ry = (int)poi[24];
@@ -528,7 +571,7 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
             }
     }
     float hinv[DOF * DOF];
-    lu_inverse(hess, hinv, DOF);
+    if (!lm) lu_inverse(hess, hinv, DOF);
 
     // initial guess: first-order terms only (src/oc_icgn.cpp:216, 2D2: 765-770 + src/oc_deformation.cpp:249-266)
     const float u0 = p[0], ux0 = p[1], uy0 = p[2], v0 = p[6], vx0 = p[7], vy0 = p[8];
@@ -544,6 +587,12 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
     int iter = 0;
     float dp_norm = 0.f, znssd = 0.f;
     float cur[12] = {0.f};
+    float znssd0 = 4.f, lambda = 0.f;  // IC-LM state (src/oc_iclm.cpp:226)
+    if (lm) {
+        // p_current.setDeformation(p_initial) (src/oc_iclm.cpp:223 / :598): the parameters themselves are copied
+        cur[0] = u0; cur[1] = ux0; cur[2] = uy0;
+        cur[6] = v0; cur[7] = vx0; cur[8] = vy0;
+    }
     do {
         iter++;
         // warped target subset, src/oc_icgn.cpp:230-242 (2D2: 784-796)
@@ -581,8 +630,8 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
                 ts[s] = v;
                 am.add(s, 0, v);
             }
-        // src/oc_icgn.cpp:251-255
-        if (negative) {
+        // src/oc_icgn.cpp:251-255 (the IC-LM classes have no such check)
+        if (negative && !lm) {
             res[2] = -3.f;
             return;
         }
@@ -612,6 +661,14 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
             }
         ae.finish();
         znssd = ae.get(DOF) / (ref_norm * ref_norm);
+        if (lm) {
+            // src/oc_iclm.cpp:250-257: lambda from the first ZNSSD, then (H + lambda * I)^-1 every iteration
+            if (iter == 1) lambda = pow_lambda(lm->log_lambda, znssd / znssd0) - 1.f;
+            float hl[DOF * DOF];
+            for (int i = 0; i < DOF; i++)
+                for (int j = 0; j < DOF; j++) hl[i * DOF + j] = hess[i * DOF + j] + lambda * (i == j ? 1.f : 0.f);
+            lu_inverse(hl, hinv, DOF);
+        }
         float dp[DOF];
         for (int i = 0; i < DOF; i++) {  // src/oc_icgn.cpp:279-286
             float v = 0.f;
@@ -627,13 +684,21 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
             set_warp_2d2(dW, dp);
             lu_inverse(dW, dWi, WN);
         }
-        mat_mul(Wm, dWi, Wn, WN);
-        for (int i = 0; i < WN * WN; i++) Wm[i] = Wn[i];
+        // IC-LM accepts the step only when the ZNSSD went down (src/oc_iclm.cpp:283-300)
+        const bool accept = !lm || znssd < znssd0;
+        if (lm) lambda = lambda * (accept ? lm->alpha : lm->beta);
+        if (accept) {
+            mat_mul(Wm, dWi, Wn, WN);
+            for (int i = 0; i < WN * WN; i++) Wm[i] = Wn[i];
+            znssd0 = znssd;
+        }
         const int rx2 = rx * rx, ry2 = ry * ry;
         if constexpr (DOF == 6) {
             // src/oc_deformation.cpp:107-115
-            cur[0] = Wm[2]; cur[1] = Wm[0] - 1.f; cur[2] = Wm[1];
-            cur[6] = Wm[5]; cur[7] = Wm[3]; cur[8] = Wm[4] - 1.f;
+            if (accept) {
+                cur[0] = Wm[2]; cur[1] = Wm[0] - 1.f; cur[2] = Wm[1];
+                cur[6] = Wm[5]; cur[7] = Wm[3]; cur[8] = Wm[4] - 1.f;
+            }
             // src/oc_icgn.cpp:296-306; dp = u ux uy v vx vy
             float d = dp[0] * dp[0] + dp[1] * dp[1] * rx2 + dp[2] * dp[2] * ry2 + dp[3] * dp[3] + dp[4] * dp[4] * rx2 +
                       dp[5] * dp[5] * ry2;
@@ -642,15 +707,26 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
             // src/oc_deformation.cpp:284-299
             const float* r3 = Wm + 3 * WN;
             const float* r4 = Wm + 4 * WN;
-            cur[0] = r3[5]; cur[1] = r3[3] - 1.f; cur[2] = r3[4]; cur[3] = r3[0] * 2.f; cur[4] = r3[1]; cur[5] = r3[2] * 2.f;
-            cur[6] = r4[5]; cur[7] = r4[3]; cur[8] = r4[4] - 1.f; cur[9] = r4[0] * 2.f; cur[10] = r4[1]; cur[11] = r4[2] * 2.f;
-            // src/oc_icgn.cpp:837-857 (the integer-truncated weights are reference behaviour)
+            if (accept) {
+                cur[0] = r3[5]; cur[1] = r3[3] - 1.f; cur[2] = r3[4]; cur[3] = r3[0] * 2.f; cur[4] = r3[1]; cur[5] = r3[2] * 2.f;
+                cur[6] = r4[5]; cur[7] = r4[3]; cur[8] = r4[4] - 1.f; cur[9] = r4[0] * 2.f; cur[10] = r4[1]; cur[11] = r4[2] * 2.f;
+            }
             const int rxy2 = rx2 * ry2;
-            const int rx4 = (int)(rx2 * rx2 * 0.25f), ry4 = (int)(ry2 * ry2 * 0.25f);
             const float* q = dp;  // u ux uy uxx uxy uyy v vx vy vxx vxy vyy
-            float d = q[0] * q[0] + q[1] * q[1] * rx2 + q[2] * q[2] * ry2 + q[3] * q[3] * rx4 + q[5] * q[5] * ry4 +
-                      q[4] * q[4] * rxy2 + q[6] * q[6] + q[7] * q[7] * rx2 + q[8] * q[8] * ry2 + q[9] * q[9] * rx4 +
-                      q[11] * q[11] * ry4 + q[10] * q[10] * rxy2;
+            float d;
+            if (!lm) {
+                // src/oc_icgn.cpp:837-857 (the integer-truncated weights are reference behaviour)
+                const int rx4 = (int)(rx2 * rx2 * 0.25f), ry4 = (int)(ry2 * ry2 * 0.25f);
+                d = q[0] * q[0] + q[1] * q[1] * rx2 + q[2] * q[2] * ry2 + q[3] * q[3] * rx4 + q[5] * q[5] * ry4 +
+                    q[4] * q[4] * rxy2 + q[6] * q[6] + q[7] * q[7] * rx2 + q[8] * q[8] * ry2 + q[9] * q[9] * rx4 +
+                    q[11] * q[11] * ry4 + q[10] * q[10] * rxy2;
+            } else {
+                // src/oc_iclm.cpp:675-687: p*p * rx2 * rx2 * 0.25f, left to right in float
+                d = q[0] * q[0] + q[1] * q[1] * rx2 + q[2] * q[2] * ry2 + q[3] * q[3] * rx2 * rx2 * 0.25f +
+                    q[5] * q[5] * ry2 * ry2 * 0.25f + q[4] * q[4] * rxy2 + q[6] * q[6] + q[7] * q[7] * rx2 +
+                    q[8] * q[8] * ry2 + q[9] * q[9] * rx2 * rx2 * 0.25f + q[11] * q[11] * ry2 * ry2 * 0.25f +
+                    q[10] * q[10] * rxy2;
+            }
             dp_norm = std::sqrt(d);
         }
     } while (iter < stop && dp_norm >= conv);
@@ -1199,6 +1275,36 @@ void oc_oracle_icgn2d2(const float* ref, const float* gx, const float* gy, const
         }
     }
 }
+
+// ICLM2D1 / ICLM2D2 (src/oc_iclm.cpp): dof = 6 or 12; damping = {lambda, alpha, beta} (src/oc_iclm.h:33-38)
+void oc_oracle_iclm2d(int dof, const float* ref, const float* gx, const float* gy, const float* tar_lut, int height, int width,
+                      int rx, int ry, float conv, float stop, const float* damping, int self_adaptive, float* pois, long n,
+                      int stride_floats, int order, int lanes, int threads) {
+    Images2D im = {ref, gx, gy, tar_lut, height, width};
+    const LmDamping lm = {std::log((double)damping[0]), damping[1], damping[2]};
+    const int nt = resolve_threads(threads);
+#pragma omp parallel num_threads(nt)
+    {
+        std::vector<float> scratch;
+#pragma omp for schedule(static)
+        for (long i = 0; i < n; i++) {
+            float* poi = pois + (size_t)i * stride_floats;
+            if (dof == 6) {
+                if (order == OC_ORDER_LANES)
+                    icgn2d_poi<6, AccLanes>(im, rx, ry, conv, stop, poi, lanes, scratch, nullptr, self_adaptive, &lm);
+                else
+                    icgn2d_poi<6, AccSeq>(im, rx, ry, conv, stop, poi, lanes, scratch, nullptr, self_adaptive, &lm);
+            } else {
+                if (order == OC_ORDER_LANES)
+                    icgn2d_poi<12, AccLanes>(im, rx, ry, conv, stop, poi, lanes, scratch, nullptr, self_adaptive, &lm);
+                else
+                    icgn2d_poi<12, AccSeq>(im, rx, ry, conv, stop, poi, lanes, scratch, nullptr, self_adaptive, &lm);
+            }
+        }
+    }
+}
+
+float oc_oracle_pow_lambda(float lambda, float q) { return pow_lambda(std::log((double)lambda), q); }
 
 void oc_oracle_nr2d1(const float* ref, const float* tar_lut, const float* tar_lut_gx, const float* tar_lut_gy, int height,
                      int width, int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes,

@@ -86,6 +86,15 @@ void oc_oracle_nr2d1(const float* ref, const float* tar_lut, const float* tar_lu
                      int width, int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes,
                      int threads);
 
+/* ICLM2D1::compute / ICLM2D2::compute(poi_queue), src/oc_iclm.cpp:150-368, 505-741 (inverse-compositional
+ * Levenberg-Marquardt).  dof = 6 or 12; damping = {lambda, alpha, beta} of
+ * ICLM2D*::setDamping (defaults 100, 0.1, 10: src/oc_iclm.h:33-38); POI stride in floats. */
+void oc_oracle_iclm2d(int dof, const float* ref, const float* gx, const float* gy, const float* tar_lut, int height, int width,
+                      int rx, int ry, float conv, float stop, const float* damping, int self_adaptive, float* pois, long n,
+                      int stride_floats, int order, int lanes, int threads);
+/* the fixed-arithmetic restatement of powf(lambda, q) used for the first damping value (src/oc_iclm.cpp:253) */
+float oc_oracle_pow_lambda(float lambda, float q);
+
 /* src/oc_gradient.cpp:143-231 */
 void oc_oracle_gradient3d(const float* vol, int dz, int dy, int dx, float* gx, float* gy, float* gz, int threads);
 /* src/oc_cubic_bspline.cpp:214-351 */

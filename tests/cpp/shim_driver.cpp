@@ -105,6 +105,30 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        // the Levenberg-Marquardt engines (examples/test_2d_dic_fftcc_iclm1.cpp usage): same minimum as ICGN2D1
+        {
+            ICLM2D1 lm1(rx, ry, it[0], it[1], cpu_thread_number);
+            lm1.setImages(ref_img, tar_img);
+            lm1.prepare();
+            lm1.setDamping(100.f, 0.1f, 10.f);
+            std::vector<POI2D> q = after_fftcc;
+            lm1.compute(q);
+            ICLM2D2 lm2(rx, ry, it[0], it[1], cpu_thread_number);
+            lm2.setImages(ref_img, tar_img);
+            lm2.prepare();
+            std::vector<POI2D> q2 = after_fftcc;
+            lm2.compute(q2);
+            for (size_t i = 0; i < q.size(); i++) {
+                if (q[i].result.zncc > 0.9f && poi_queue[i].result.zncc > 0.9f &&
+                    (std::fabs(q[i].deformation.u - poi_queue[i].deformation.u) > 5e-3f ||
+                     std::fabs(q[i].deformation.v - poi_queue[i].deformation.v) > 5e-3f ||
+                     std::fabs(q2[i].deformation.u - poi_queue[i].deformation.u) > 2e-2f ||
+                     std::fabs(q2[i].deformation.v - poi_queue[i].deformation.v) > 2e-2f)) {
+                    std::cerr << "ICLM2D1/2D2 and ICGN2D1 disagree at POI " << i << std::endl;
+                    return 14;
+                }
+            }
+        }
         // the reference's CUDA-module shape (gpu_lib/opencorr_gpu.h:31-101): ICGN2D1GPU fed with row-major Img2D
         {
             Img2D ref2{w, h, ref.data()}, tar2{w, h, tar.data()};

@@ -118,3 +118,82 @@ def test_nr2d1_matches_golden(golden, golden_nr1, order):
     prep = oracle.PreparedNR2D(golden["ref"], golden["tar"])
     oracle.nr2d1(prep, golden["rx"], golden["ry"], golden["conv"], golden["stop"], pois, order=order)
     nr1_golden_check(pois, after, tab, golden["stop"])
+
+
+# ---- IC-LM (src/oc_iclm.cpp).  The reference ships no result table for it (only a timing CSV), so the oracle is
+# ---- anchored through what the algorithm implies: with lambda = 1 the damping vanishes and the accepted steps are
+# ---- Gauss-Newton steps; with the default damping it converges to the minimum the ICGN2D1 golden CSV records.
+def test_pow_lambda_is_the_correctly_rounded_power():
+    """First damping value powf(lambda, q) (src/oc_iclm.cpp:253): the fixed-arithmetic restatement equals libm's
+    powf except for rare 1-ulp cases (glibc's powf is not correctly rounded; the restatement is)."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    libm.powf.restype = ctypes.c_float
+    rng = np.random.default_rng(5)
+    qs = np.concatenate([rng.random(20000), rng.random(2000) * 1e-3, [0.0, 1.0, 0.25, 0.5]]).astype(np.float32)
+    off = 0
+    for lam in (100.0, 10.0, 2.5):
+        for q in qs:
+            a, b = np.float32(oracle.pow_lambda(lam, q)), np.float32(libm.powf(lam, float(q)))
+            if a != b:
+                off += 1
+                assert abs(int(a.view(np.uint32)) - int(b.view(np.uint32))) == 1
+                exact = np.float32(np.exp(np.float64(q) * np.log(np.float64(lam))))
+                assert a == exact  # the restatement is the correctly rounded one
+    assert off <= 0.002 * 3 * len(qs)
+    assert oracle.pow_lambda(1.0, 0.37) == 1.0 and oracle.pow_lambda(100.0, 0.0) == 1.0
+
+
+@pytest.fixture(scope="module")
+def iclm_run(golden, oracle_run):
+    after_fftcc, _ = oracle_run
+    prep = oracle.Prepared2D(golden["ref"], golden["tar"])
+    out = {}
+    for name, fn, damping in (("lm1", oracle.iclm2d1, oracle.DEFAULT_DAMPING), ("lm1_unit", oracle.iclm2d1, (1.0, 0.1, 10.0)),
+                              ("lm2", oracle.iclm2d2, oracle.DEFAULT_DAMPING)):
+        p = after_fftcc.copy()
+        fn(prep, golden["rx"], golden["ry"], golden["conv"], golden["stop"], p, damping=damping)
+        out[name] = p
+    return out
+
+
+def iclm1_golden_check(p, tab, stop):
+    """Shared with the GPU test: ICLM2D1 against the reference's ICGN2D1 table (same ZNSSD minimum)."""
+    m = (tab[:, 7] < stop) & (p[:, P2["zncc"]] > 0)
+    assert m.sum() > 27000
+    du, dv = np.abs(p[m, P2["u"]] - tab[m, 2]), np.abs(p[m, P2["v"]] - tab[m, 3])
+    assert np.median(du) <= 2e-6 and np.median(dv) <= 2e-6
+    assert du.max() <= 2e-3 and dv.max() <= 2e-3
+    assert np.abs(p[m, P2["zncc"]] - tab[m, 6]).max() <= 5e-5
+    assert np.array_equal(p[m, P2["u0"]], tab[m, 4]) and np.array_equal(p[m, P2["v0"]], tab[m, 5])
+
+
+def test_iclm2d1_reaches_the_minimum_of_the_golden_icgn1_table(golden, iclm_run):
+    iclm1_golden_check(iclm_run["lm1"], golden["table"], golden["stop"])
+
+
+def test_iclm2d1_with_unit_lambda_takes_gauss_newton_steps(oracle_run, iclm_run):
+    """lambda = 1: powf(1, q) - 1 = 0, so (H + 0 I)^-1 = H^-1 bit for bit and every accepted step is ICGN2D1's.
+    The two differ only where a step was rejected (ZNSSD not strictly lower, typically the last one)."""
+    _, out = oracle_run
+    gn, lm = out[oracle.ORDER_SEQ], iclm_run["lm1_unit"]
+    same = (gn.view(np.uint32) == lm.view(np.uint32)).all(axis=1)
+    assert same.mean() >= 0.5
+    both = (gn[:, P2["zncc"]] > 0) & (lm[:, P2["zncc"]] > 0)
+    assert np.abs(gn[both, P2["u"]] - lm[both, P2["u"]]).max() <= 2e-3
+    # a rejected step can only cost iterations, never save them
+    assert (lm[both, P2["iteration"]] >= gn[both, P2["iteration"]]).all()
+
+
+def test_iclm2d2_agrees_with_icgn2d2(golden, oracle_run, iclm_run):
+    after_fftcc, _ = oracle_run
+    prep = oracle.Prepared2D(golden["ref"], golden["tar"])
+    gn2 = after_fftcc.copy()
+    oracle.icgn2d2(prep, golden["rx"], golden["ry"], golden["conv"], golden["stop"], gn2)
+    lm2 = iclm_run["lm2"]
+    m = (gn2[:, P2["zncc"]] > 0.9) & (lm2[:, P2["zncc"]] > 0.9)
+    assert m.sum() > 22000
+    for k in ("u", "v"):
+        d = np.abs(gn2[m, P2[k]] - lm2[m, P2[k]])
+        assert np.median(d) <= 5e-6 and d.max() <= 5e-3
