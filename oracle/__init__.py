@@ -26,7 +26,7 @@ P2 = dict(x=0, y=1, u=2, ux=3, uy=4, uxx=5, uxy=6, uyy=7, v=8, vx=9, vy=10, vxx=
 # float offsets inside a POI3D record (src/oc_poi.h:187-222)
 P3 = dict(x=0, y=1, z=2, u=3, ux=4, uy=5, uz=6, v=7, vx=8, vy=9, vz=10, w=11, wx=12, wy=13, wz=14,
           u0=15, v0=16, w0=17, zncc=18, iteration=19, convergence=20, feature=21,
-          srx=28, sry=29, srz=30)
+          exx=22, eyy=23, ezz=24, exy=25, eyz=26, ezx=27, srx=28, sry=29, srz=30)
 
 
 def build(force=False):
@@ -64,6 +64,10 @@ def lib():
         L.oc_oracle_nr2d1.restype = None
         L.oc_oracle_iclm2d.argtypes = [i, fp, fp, fp, fp, i, i, i, i, f, f, fp, i, fp, l, i, i, i, i]
         L.oc_oracle_iclm2d.restype = None
+        L.oc_oracle_strain2d.argtypes = [fp, l, i, f, i, f, i, i]
+        L.oc_oracle_strain2d.restype = None
+        L.oc_oracle_strain3d.argtypes = [fp, l, i, f, i, f, i, i]
+        L.oc_oracle_strain3d.restype = None
         L.oc_oracle_pow_lambda.argtypes = [f, f]
         L.oc_oracle_pow_lambda.restype = f
         L.oc_oracle_icgn2d1_ex.restype = None
@@ -209,6 +213,20 @@ def iclm2d2(prep, rx, ry, conv, stop, pois, damping=DEFAULT_DAMPING, order=ORDER
 
 def pow_lambda(lam, q):
     return float(lib().oc_oracle_pow_lambda(float(lam), float(q)))
+
+
+def strain2d(pois, subregion_radius, neighbor_number_min, zncc_threshold=0.9, approximation=1, threads=0):
+    """Strain::prepare + Strain::compute(std::vector<POI2D>&) (src/oc_strain.cpp:96-107, 149-247), in place."""
+    assert pois.dtype == np.float32 and pois.flags.c_contiguous and pois.shape[1] == POI2D_FLOATS
+    lib().oc_oracle_strain2d(_fp(pois), pois.shape[0], POI2D_FLOATS, float(subregion_radius), int(neighbor_number_min),
+                             float(zncc_threshold), int(approximation), threads)
+
+
+def strain3d(pois, subregion_radius, neighbor_number_min, zncc_threshold=0.9, approximation=1, threads=0):
+    """Strain::compute(std::vector<POI3D>&) (src/oc_strain.cpp:372-488), in place."""
+    assert pois.dtype == np.float32 and pois.flags.c_contiguous and pois.shape[1] == POI3D_FLOATS
+    lib().oc_oracle_strain3d(_fp(pois), pois.shape[0], POI3D_FLOATS, float(subregion_radius), int(neighbor_number_min),
+                             float(zncc_threshold), int(approximation), threads)
 
 
 class PreparedNR2D:

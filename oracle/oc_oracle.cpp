@@ -1072,6 +1072,224 @@ static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Strain (src/oc_strain.cpp:149-247 for POI2D, :372-473 for POI3D): plane fit of u, v (, w) over the neighbour POIs
+// of a subregion, SURVEY 8f row 4.
+//
+// What the reference fixes: the neighbour set (squared float distance < radius^2 -- nanoflann's L2_Simple metric and
+// RadiusResultSet, strict <; query point included), the ZNCC filter, the KNN fallback when fewer than
+// neighbor_number_min POIs lie inside the radius (:165-186), the "at least neighbor_number_min accepted POIs" rule
+// (:190), the design matrix [1, dx, dy(, dz)] with float differences (:201-209) and the Cauchy / Green formulas
+// (:220-234, :446-466).  What it leaves to third-party code that is not in the tree (nanoflann's kd-tree traversal
+// order with sorted = false, Eigen's colPivHouseholderQr in float): the ORDER of the rows and the rounding of the
+// least-squares solve.  The restatement fixes both: rows are taken cell by cell over a uniform grid (pitch a little
+// above the radius, anchored at the queue's minimum coordinates; the 3 x 3 (x 3) block around the POI in row-major
+// cell order) and by ascending queue index inside a cell; KNN rows by ascending (distance^2, index); the normal
+// equations are accumulated and solved in double (elimination without pivoting, the matrix is SPD) and rounded to
+// float once.  The result is the least-squares solution of the float data to ~1e-13, i.e. it differs from Eigen's
+// float QR by that QR's own rounding (~1e-6 relative); the reference's golden table pins it at that level
+// (tests/test_oracle_strain.py).  A pivot that vanishes (collinear neighbours) zeroes that gradient component.
+// ---------------------------------------------------------------------------
+struct StrainGrid {
+    float x0, y0, z0, inv_pitch;
+    int ncx, ncy, ncz;
+};
+
+// shared by the oracle and (restated) by the HIP engine: cell of a coordinate triple
+static inline int strain_cell_axis(float c, float c0, float inv_pitch, int nc) {
+    const float t = (c - c0) * inv_pitch;
+    int k = t >= 0.f ? (t < (float)nc ? (int)t : nc - 1) : 0;  // NaN -> 0
+    return k;
+}
+
+template <int DIM>
+static void strain_solve(const double* S, const double* B, int nrhs, double* grad) {
+    // S: (DIM+1) x (DIM+1) normal matrix (row-major, symmetric), B: nrhs right-hand sides of DIM+1 entries.
+    // grad[r*(DIM+1) + k]: solution k of right-hand side r.  Gaussian elimination in fixed order.
+    constexpr int D = DIM + 1;
+    double A[D][D + 3];
+    for (int i = 0; i < D; i++) {
+        for (int j = 0; j < D; j++) A[i][j] = S[i * D + j];
+        for (int r = 0; r < nrhs; r++) A[i][D + r] = B[r * D + i];
+    }
+    bool dead[D];
+    for (int k = 0; k < D; k++) {
+        const double piv = A[k][k];
+        // a pivot that is zero to rounding relative to the original diagonal: no information along this column
+        dead[k] = !(piv > 1e-12 * S[k * D + k]);
+        if (dead[k]) continue;
+        for (int i = k + 1; i < D; i++) {
+            const double f = A[i][k] / piv;
+            for (int j = k + 1; j < D + nrhs; j++) A[i][j] = A[i][j] - f * A[k][j];
+        }
+    }
+    for (int r = 0; r < nrhs; r++)
+        for (int k = D - 1; k >= 0; k--) {
+            double v = 0.0;
+            if (!dead[k]) {
+                v = A[k][D + r];
+                for (int j = k + 1; j < D; j++) v = v - A[k][j] * grad[r * D + j];
+                v = v / A[k][k];
+            }
+            grad[r * D + k] = v;
+        }
+}
+
+template <int DIM>
+static void strain_queue(float* pois, long n, int stride, float radius, int nmin, float thr, int approximation, int threads) {
+    constexpr int D = DIM + 1;
+    constexpr int ZNCC = DIM == 2 ? 16 : 18;
+    constexpr int U = DIM == 2 ? 2 : 3, V = DIM == 2 ? 8 : 7, Wf = 11;
+    constexpr int E0 = DIM == 2 ? 20 : 22;
+    if (n <= 0) return;
+    // grid
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (long i = 0; i < n; i++)
+        for (int a = 0; a < DIM; a++) {
+            const float c = pois[i * stride + a];
+            if (c < mn[a]) mn[a] = c;
+            if (c > mx[a]) mx[a] = c;
+        }
+    for (int a = 0; a < 3; a++)
+        if (!(mn[a] <= mx[a])) mn[a] = mx[a] = 0.f;
+    float pitch = radius * 1.001f;
+    const float span = std::fmax(std::fmax(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
+    const float cap = DIM == 2 ? 4096.f : 256.f;  // cells per axis
+    if (!(pitch > span / cap)) pitch = span / cap;
+    if (!(pitch > 0.f)) pitch = 1.f;
+    StrainGrid g;
+    g.x0 = mn[0]; g.y0 = mn[1]; g.z0 = mn[2];
+    g.inv_pitch = 1.f / pitch;
+    g.ncx = (int)((mx[0] - mn[0]) * g.inv_pitch) + 1;
+    g.ncy = (int)((mx[1] - mn[1]) * g.inv_pitch) + 1;
+    g.ncz = DIM == 3 ? (int)((mx[2] - mn[2]) * g.inv_pitch) + 1 : 1;
+    const long ncell = (long)g.ncx * g.ncy * g.ncz;
+    std::vector<int> cell(n), start(ncell + 1, 0), order(n);
+    for (long i = 0; i < n; i++) {
+        const float* p = pois + i * stride;
+        const int cx = strain_cell_axis(p[0], g.x0, g.inv_pitch, g.ncx), cy = strain_cell_axis(p[1], g.y0, g.inv_pitch, g.ncy);
+        const int cz = DIM == 3 ? strain_cell_axis(p[2], g.z0, g.inv_pitch, g.ncz) : 0;
+        cell[i] = (cz * g.ncy + cy) * g.ncx + cx;
+        start[cell[i] + 1]++;
+    }
+    for (long c = 0; c < ncell; c++) start[c + 1] += start[c];
+    {
+        std::vector<int> cur(start.begin(), start.end() - 1);
+        for (long i = 0; i < n; i++) order[cur[cell[i]]++] = (int)i;  // ascending index inside a cell
+    }
+    const float r2 = radius * radius;
+    std::vector<float> out((size_t)n * 6, 0.f);
+    std::vector<char> wrote(n, 0);
+    const int nt = threads <= 0 ? omp_get_max_threads() : threads;
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 64)
+    for (long i = 0; i < n; i++) {
+        const float* pi = pois + i * stride;
+        if (!(pi[ZNCC] >= thr)) continue;  // src/oc_strain.cpp:241 / :481
+        double S[D * D] = {0.0}, B[3 * D] = {0.0};
+        int nfit = 0;
+        auto add_row = [&](const float* pj) {
+            double row[D];
+            row[0] = 1.0;
+            for (int a = 0; a < DIM; a++) row[a + 1] = (double)(pj[a] - pi[a]);  // float difference, src/oc_strain.cpp:204-205
+            for (int a = 0; a < D; a++)
+                for (int b = 0; b < D; b++) S[a * D + b] = S[a * D + b] + row[a] * row[b];
+            const double rhs[3] = {(double)pj[U], (double)pj[V], DIM == 3 ? (double)pj[Wf] : 0.0};
+            for (int r = 0; r < DIM; r++)
+                for (int a = 0; a < D; a++) B[r * D + a] = B[r * D + a] + row[a] * rhs[r];
+            nfit++;
+        };
+        auto dist2 = [&](const float* pj) {
+            float d = 0.f;
+            for (int a = 0; a < DIM; a++) {
+                const float df = pi[a] - pj[a];
+                d = d + df * df;
+            }
+            return d;
+        };
+        // radius search
+        int inside = 0;
+        const int cx = cell[i] % g.ncx, cy = (cell[i] / g.ncx) % g.ncy, cz = cell[i] / (g.ncx * g.ncy);
+        for (int dz = (DIM == 3 ? -1 : 0); dz <= (DIM == 3 ? 1 : 0); dz++)
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    const int x = cx + dx, y = cy + dy, z = cz + dz;
+                    if (x < 0 || y < 0 || z < 0 || x >= g.ncx || y >= g.ncy || z >= g.ncz) continue;
+                    const long c = ((long)z * g.ncy + y) * g.ncx + x;
+                    for (int k = start[c]; k < start[c + 1]; k++) {
+                        const float* pj = pois + (long)order[k] * stride;
+                        if (dist2(pj) < r2) {
+                            inside++;
+                            if (pj[ZNCC] >= thr) add_row(pj);
+                        }
+                    }
+                }
+        if (inside < nmin) {
+            // KNN fallback (src/oc_strain.cpp:177-186): the nmin nearest POIs, ascending (distance^2, index)
+            for (int a = 0; a < D * D; a++) S[a] = 0.0;
+            for (int a = 0; a < 3 * D; a++) B[a] = 0.0;
+            nfit = 0;
+            float last_d = -1.f;
+            long last_j = -1;
+            for (int k = 0; k < nmin; k++) {
+                float best_d = INFINITY;
+                long best_j = -1;
+                for (long j = 0; j < n; j++) {
+                    const float d = dist2(pois + j * stride);
+                    if (!(d > last_d || (d == last_d && j > last_j))) continue;  // already taken (NaN never enters)
+                    if (d < best_d) {
+                        best_d = d;
+                        best_j = j;
+                    }
+                }
+                if (best_j < 0) break;
+                last_d = best_d;
+                last_j = best_j;
+                const float* pj = pois + best_j * stride;
+                if (pj[ZNCC] >= thr) add_row(pj);
+            }
+        }
+        if (nfit < nmin) continue;  // src/oc_strain.cpp:190
+        double grad[3 * D];
+        strain_solve<DIM>(S, B, DIM, grad);
+        float* e = out.data() + (size_t)i * 6;
+        if (DIM == 2) {
+            const float ux = (float)grad[1], uy = (float)grad[2], vx = (float)grad[D + 1], vy = (float)grad[D + 2];
+            if (approximation == 1) {
+                e[0] = ux; e[1] = vy; e[2] = 0.5f * (uy + vx);
+                wrote[i] = 1;
+            }
+            if (approximation == 2) {
+                e[0] = ux + 0.5f * (ux * ux + vx * vx);
+                e[1] = vy + 0.5f * (uy * uy + vy * vy);
+                e[2] = 0.5f * (uy + vx + uy * ux + vy * vx);
+                wrote[i] = 1;
+            }
+        } else {
+            const float ux = (float)grad[1], uy = (float)grad[2], uz = (float)grad[3];
+            const float vx = (float)grad[D + 1], vy = (float)grad[D + 2], vz = (float)grad[D + 3];
+            const float wx = (float)grad[2 * D + 1], wy = (float)grad[2 * D + 2], wz = (float)grad[2 * D + 3];
+            if (approximation == 1) {
+                e[0] = ux; e[1] = vy; e[2] = wz;
+                e[3] = 0.5f * (uy + vx); e[4] = 0.5f * (vz + wy); e[5] = 0.5f * (wx + uz);
+                wrote[i] = 1;
+            }
+            if (approximation == 2) {
+                e[0] = ux + 0.5f * (ux * ux + vx * vx + wx * wx);
+                e[1] = vy + 0.5f * (uy * uy + vy * vy + wy * wy);
+                e[2] = wz + 0.5f * (uz * uz + vz * vz + wz * wz);
+                e[3] = 0.5f * (uy + vx + uy * ux + vy * vx + wy * wx);
+                e[4] = 0.5f * (vz + wy + uz * uy + vz * vy + wz * wy);
+                e[5] = 0.5f * (wx + uz + ux * uz + vx * vz + wx * wz);
+                wrote[i] = 1;
+            }
+        }
+    }
+    // the strain fields are the only thing written, and only for POIs that were fitted (everything else untouched)
+    for (long i = 0; i < n; i++)
+        if (wrote[i])
+            for (int k = 0; k < (DIM == 2 ? 3 : 6); k++) pois[i * stride + E0 + k] = out[(size_t)i * 6 + k];
+}
+
 static int resolve_threads(int threads) {
     if (threads <= 0) return omp_get_max_threads();
     return threads;
@@ -1302,6 +1520,16 @@ void oc_oracle_iclm2d(int dof, const float* ref, const float* gx, const float* g
             }
         }
     }
+}
+
+void oc_oracle_strain2d(float* pois, long n, int stride_floats, float subregion_radius, int neighbor_number_min,
+                        float zncc_threshold, int approximation, int threads) {
+    strain_queue<2>(pois, n, stride_floats, subregion_radius, neighbor_number_min, zncc_threshold, approximation, threads);
+}
+
+void oc_oracle_strain3d(float* pois, long n, int stride_floats, float subregion_radius, int neighbor_number_min,
+                        float zncc_threshold, int approximation, int threads) {
+    strain_queue<3>(pois, n, stride_floats, subregion_radius, neighbor_number_min, zncc_threshold, approximation, threads);
 }
 
 float oc_oracle_pow_lambda(float lambda, float q) { return pow_lambda(std::log((double)lambda), q); }

@@ -95,6 +95,15 @@ void oc_oracle_iclm2d(int dof, const float* ref, const float* gx, const float* g
 /* the fixed-arithmetic restatement of powf(lambda, q) used for the first damping value (src/oc_iclm.cpp:253) */
 float oc_oracle_pow_lambda(float lambda, float q);
 
+/* Strain::compute(poi_queue) for POI2D (src/oc_strain.cpp:149-247) and POI3D (:372-488), after Strain::prepare
+ * (:96-147): subregion_radius, neighbor_number_min as in the constructor (:31-46); zncc_threshold default 0.9
+ * (:36); approximation 1 = Cauchy, 2 = Green (:220-234).  Writes strain.exx.. in place (2D: floats 20..22,
+ * 3D: floats 22..27) for every POI that was fitted; nothing else is touched. */
+void oc_oracle_strain2d(float* pois, long n, int stride_floats, float subregion_radius, int neighbor_number_min,
+                        float zncc_threshold, int approximation, int threads);
+void oc_oracle_strain3d(float* pois, long n, int stride_floats, float subregion_radius, int neighbor_number_min,
+                        float zncc_threshold, int approximation, int threads);
+
 /* src/oc_gradient.cpp:143-231 */
 void oc_oracle_gradient3d(const float* vol, int dz, int dy, int dx, float* gx, float* gy, float* gz, int threads);
 /* src/oc_cubic_bspline.cpp:214-351 */

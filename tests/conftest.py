@@ -35,6 +35,14 @@ def golden_nr1():
 
 
 @pytest.fixture(scope="session")
+def golden_strain():
+    """x y u v zncc exx eyy exy of the reference's Strain example on the OHT table (radius 20, 5 neighbours)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "oht_cfrp_strain_r20.npz"))
+    return dict(table=z["table"], radius=float(z["params"][0]), neighbors=int(z["params"][1]),
+                zncc_threshold=float(z["params"][2]), approximation=int(z["params"][3]))
+
+
+@pytest.fixture(scope="session")
 def speckle_small():
     """320 x 300 synthetic speckle pair with the SURVEY 8(d) displacement field."""
     from opencorr_amd import synth

@@ -24,6 +24,13 @@ And the golden vectors of the Newton-Raphson engine:
   oht_cfrp_4_fftcc_nr1_r16.csv              x,y,u,v,u0,v0,ZNCC,iteration,convergence,feature,exx,eyy,exy
 produced by examples/test_2d_dic_fftcc_nr1.cpp (FFTCC2D -> NR2D1, r=16, conv 1e-3, stop 10, same grid).
 Stored as oht_cfrp_fftcc_nr1_r16.npz (first nine columns).
+
+And the golden vectors of Strain: the last three columns (exx, eyy, exy) of
+  oht_cfrp_4_fftcc_icgn1_r16.csv
+were added to that table by examples/test_2d_dic_strain.cpp (Strain(20, 5), ZNCC threshold 0.9, Cauchy strain) from
+the table's own u, v, ZNCC.  Stored as oht_cfrp_strain_r20.npz: x y u v zncc exx eyy exy in float64 (the CSV's 8
+decimals) -- the table stores strains for every POI; the current source skips POIs below the ZNCC threshold
+(src/oc_strain.cpp:241), so the tests compare POIs with ZNCC >= 0.9 only.
 """
 import os
 
@@ -65,6 +72,11 @@ def main():
     out3 = os.path.join(os.path.dirname(OUT), "oht_cfrp_fftcc_nr1_r16.npz")
     np.savez_compressed(out3, table=t3.astype(np.float32))
     print("wrote", out3, os.path.getsize(out3), "bytes")
+    t4 = np.genfromtxt(os.path.join(REF, "oht_cfrp_4_fftcc_icgn1_r16.csv"), delimiter=",", skip_header=1, usecols=range(13))
+    out4 = os.path.join(os.path.dirname(OUT), "oht_cfrp_strain_r20.npz")
+    np.savez_compressed(out4, table=t4[:, [0, 1, 2, 3, 6, 10, 11, 12]],
+                        params=np.array([20.0, 5.0, 0.9, 1.0]))  # radius, min neighbours, ZNCC threshold, approximation
+    print("wrote", out4, os.path.getsize(out4), "bytes")
 
 
 if __name__ == "__main__":

@@ -16,16 +16,22 @@ def main(db_path, out_path, top=40):
         "max(vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size) from kernels group by name "
         "order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
+    # median per kernel: robust against the cold first launch when comparing with bench.py's timed launches
+    median = {}
+    for name, dur in db.execute("select name, duration from kernels"):
+        median.setdefault(name, []).append(dur)
+    median = {k: sorted(v)[len(v) // 2] for k, v in median.items()}
     with open(out_path, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "percent", "vgpr", "sgpr", "lds_bytes",
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "median_us", "min_us", "max_us", "percent", "vgpr", "sgpr", "lds_bytes",
                     "scratch_bytes"])
         for r in rows[:top]:
             name = r[0] if len(r[0]) < 160 else r[0][:157] + "..."
-            w.writerow([name, r[1], "%.3f" % (r[2] / 1e3), "%.3f" % (r[3] / 1e3), "%.3f" % (r[4] / 1e3),
+            w.writerow([name, r[1], "%.3f" % (r[2] / 1e3), "%.3f" % (r[3] / 1e3), "%.3f" % (median[r[0]] / 1e3), "%.3f" % (r[4] / 1e3),
                         "%.3f" % (r[5] / 1e3), "%.2f" % (100.0 * r[2] / total), r[6], r[7], r[8], r[9]])
     for r in rows[:12]:
-        print("%-90s calls %5d  avg %10.3f us  %5.1f%%" % (r[0][:90], r[1], r[3] / 1e3, 100.0 * r[2] / total))
+        print("%-90s calls %5d  avg %10.3f us  median %10.3f us  %5.1f%%" % (r[0][:90], r[1], r[3] / 1e3, median[r[0]] / 1e3,
+                                                                              100.0 * r[2] / total))
 
 
 if __name__ == "__main__":
