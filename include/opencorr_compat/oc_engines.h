@@ -305,6 +305,64 @@ public:
     }
 };
 
+// Strain(float subregion_radius, int neighbor_number_min, int thread_number)  src/oc_strain.h:34-73.
+// prepare(poi_queue) builds the neighbour search over the queue's coordinates, compute(poi_queue) writes
+// poi.strain of every POI that can be fitted (src/oc_strain.cpp:96-147, 236-247, 476-488).  The POI2DS (stereo)
+// overloads are not offered.
+class Strain {
+public:
+    Strain(float subregion_radius_, int neighbor_number_min_, int thread_number_)
+        : subregion_radius(subregion_radius_), neighbor_number_min(neighbor_number_min_), thread_number(thread_number_) {
+        hipdetail::check(oc_hip_strain_create(subregion_radius_, neighbor_number_min_, hipdetail::default_device(), &engine_));
+    }
+    ~Strain() { if (engine_) oc_hip_destroy(engine_); }
+    Strain(const Strain&) = delete;
+    Strain& operator=(const Strain&) = delete;
+
+    float getSubregionRadius() const { return subregion_radius; }
+    int getNeighborMin() const { return neighbor_number_min; }
+    float getZnccThreshold() const { return zncc_threshold; }
+    void setSubregionRadius(float v) { push(v, neighbor_number_min, zncc_threshold, approximation); }
+    void setNeighborMin(int v) { push(subregion_radius, v, zncc_threshold, approximation); }
+    void setZnccThreshold(float v) { push(subregion_radius, neighbor_number_min, v, approximation); }
+    void setDescription(int v) { description = v; }  // stored; the reference's compute() does not read it either
+    void setApproximation(int v) { push(subregion_radius, neighbor_number_min, zncc_threshold, v); }  // 1 Cauchy, 2 Green
+
+    void prepare(std::vector<POI2D>& q) { hipdetail::check(oc_hip_strain_prepare(engine_, q.data(), q.size(), sizeof(POI2D), 2, OC_HIP_HOST)); }
+    void prepare(std::vector<POI3D>& q) { hipdetail::check(oc_hip_strain_prepare(engine_, q.data(), q.size(), sizeof(POI3D), 3, OC_HIP_HOST)); }
+    void compute(std::vector<POI2D>& q) { hipdetail::check(oc_hip_strain_compute(engine_, q.data(), q.size(), sizeof(POI2D), 2, OC_HIP_HOST)); }
+    void compute(std::vector<POI3D>& q) { hipdetail::check(oc_hip_strain_compute(engine_, q.data(), q.size(), sizeof(POI3D), 3, OC_HIP_HOST)); }
+    // compute(POI*, poi_queue) (src/oc_strain.cpp:149, :372): `poi` must be an element of poi_queue; the whole queue is
+    // evaluated on a copy and only that POI's strain is taken over (use the queue overload for more than a few POIs)
+    void compute(POI2D* poi, std::vector<POI2D>& q) { one(poi, q, 2); }
+    void compute(POI3D* poi, std::vector<POI3D>& q) { one(poi, q, 3); }
+
+protected:
+    float subregion_radius;
+    int neighbor_number_min;
+    float zncc_threshold = 0.9f;
+    int description = 1;
+    int approximation = 1;
+    int thread_number;
+
+private:
+    oc_hip_engine* engine_ = nullptr;
+    void push(float r, int n, float z, int a) {
+        hipdetail::check(oc_hip_strain_set(engine_, r, n, z, a));
+        subregion_radius = r;
+        neighbor_number_min = n;
+        zncc_threshold = z;
+        approximation = a;
+    }
+    template <class Poi>
+    void one(Poi* poi, std::vector<Poi>& q, int ndim) {
+        if (q.empty() || poi < q.data() || poi >= q.data() + q.size()) throw std::string("Strain::compute(POI*, queue): the POI must be an element of the queue");
+        std::vector<Poi> copy(q);
+        hipdetail::check(oc_hip_strain_compute(engine_, copy.data(), copy.size(), sizeof(Poi), ndim, OC_HIP_HOST));
+        poi->strain = copy[poi - q.data()].strain;
+    }
+};
+
 // ---- the reference's CUDA-module shapes (gpu_lib/opencorr_gpu.h:31-101), so that
 // examples/test_2d_dic_gpu_icgn.cpp / test_dvc_gpu_icgn.cpp compile against this header --------------
 struct Img2D { int width, height; float* data; };           // row-major

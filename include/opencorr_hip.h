@@ -60,7 +60,8 @@ typedef enum oc_hip_kind {
     OC_HIP_ICGN3D1 = 5,
     OC_HIP_NR2D1 = 6,
     OC_HIP_ICLM2D1 = 7,
-    OC_HIP_ICLM2D2 = 8
+    OC_HIP_ICLM2D2 = 8,
+    OC_HIP_STRAIN = 9
 } oc_hip_kind;
 
 #define OC_HIP_POI2D_BYTES 100
@@ -101,6 +102,24 @@ int oc_hip_iclm2d2_create(int radius_x, int radius_y, float conv_criterion, floa
 /* ICLM2D1::setDamping / ICLM2D2::setDamping(float lambda, float alpha, float beta)  src/oc_iclm.cpp:114-119, 466-471;
  * defaults 100, 0.1, 10 (struct DampingParameter, src/oc_iclm.h:33-38).  lambda must be > 0. */
 int oc_hip_set_damping(oc_hip_engine* engine, float lambda, float alpha, float beta);
+/* Strain(float subregion_radius, int neighbor_number_min, int thread_number)  src/oc_strain.cpp:31-46
+ * (first consumer of the device-resident displacement field).  The handle supports set_stream,
+ * synchronize, profile_* and destroy like the other engines; it holds no images. */
+int oc_hip_strain_create(float subregion_radius, int neighbor_number_min, int device, oc_hip_engine** out);
+/* setSubregionRadius / setNeighborMin / setZnccThreshold / setApproximation  src/oc_strain.cpp:72-95
+ * (defaults of the constructor: threshold 0.9, approximation 1 = Cauchy; 2 = Green).  A new radius needs a new
+ * oc_hip_strain_prepare. */
+int oc_hip_strain_set(oc_hip_engine* engine, float subregion_radius, int neighbor_number_min, float zncc_threshold,
+                      int approximation);
+/* Strain::prepare(std::vector<POI2D>&) / (std::vector<POI3D>&)  src/oc_strain.cpp:96-107, 136-147: builds the
+ * neighbour search over the queue's coordinates (the reference: one kd-tree per thread; here a cell-sorted order on
+ * the device).  ndim 2 = POI2D records, 3 = POI3D records; layout and `memory` as for oc_hip_compute. */
+int oc_hip_strain_prepare(oc_hip_engine* engine, const void* pois, size_t count, size_t stride_bytes, int ndim, int memory);
+/* Strain::compute(std::vector<POI2D>&) src/oc_strain.cpp:236-247 / (std::vector<POI3D>&) :476-488.  Writes
+ * strain.exx, eyy, exy (POI2D floats 20..22) or exx, eyy, ezz, exy, eyz, ezx (POI3D floats 22..27) of every POI with
+ * ZNCC >= threshold that finds at least neighbor_number_min accepted neighbours; everything else is left untouched.
+ * The queue must be the one prepare() saw (same length and coordinates). */
+int oc_hip_strain_compute(oc_hip_engine* engine, void* pois, size_t count, size_t stride_bytes, int ndim, int memory);
 /* FFTCC3D(int rx, int ry, int rz, int thread_number)  src/oc_fftcc.cpp:300-313 */
 int oc_hip_fftcc3d_create(int radius_x, int radius_y, int radius_z, int device, oc_hip_engine** out);
 /* ICGN3D1(int rx, int ry, int rz, float conv, float stop, int thread_number)  src/oc_icgn.cpp:1197-1213 */

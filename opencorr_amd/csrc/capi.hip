@@ -131,6 +131,12 @@ struct oc_hip_engine {
     DevBuf poi_stage, off_stage;
     DevBuf cursors;  // small device scratch (batch maxima)
     DevBuf perm, tiles;  // locality schedule of the ICGN2D queue (poi_order.hip)
+    // Strain (src/oc_strain.cpp:31-46: radius, min neighbours; ZNCC threshold 0.9, Cauchy approximation)
+    float st_radius = 0.f, st_zncc = 0.9f;
+    int st_nmin = 0, st_approx = 1, st_ndim = 0;
+    size_t st_count = 0;  // queue length the grid was prepared for (0 = not prepared)
+    ochip::StrainGrid st_grid{};
+    DevBuf st_box, st_counts, st_start, st_cursor, st_slots, st_order, st_recs, st_fallback;
     float lm_lambda = 100.f, lm_alpha = 0.1f, lm_beta = 10.f;  // DampingParameter defaults, src/oc_iclm.h:33-38
     int icgn2d_tile_px = 64;   // 0 = visit the queue in its own order
     // FFTCC working set
@@ -545,6 +551,120 @@ int oc_hip_set_damping(oc_hip_engine* e, float lambda, float alpha, float beta) 
     e->lm_lambda = lambda;
     e->lm_alpha = alpha;
     e->lm_beta = beta;
+    return OC_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Strain
+// ---------------------------------------------------------------------------
+static int strain_check(const oc_hip_engine* e, float radius, int nmin, int approximation) {
+    (void)e;
+    if (!(radius > 0.f)) return fail(OC_HIP_ERR_INVALID, "Strain: subregion radius must be > 0 (got %g)", (double)radius);
+    if (nmin < 1) return fail(OC_HIP_ERR_INVALID, "Strain: neighbor_number_min must be >= 1 (got %d)", nmin);
+    if (nmin > ochip::strain_knn_max())
+        return fail(OC_HIP_ERR_UNSUPPORTED, "Strain: neighbor_number_min %d exceeds the KNN path's limit of %d", nmin,
+                    ochip::strain_knn_max());
+    if (approximation != 1 && approximation != 2)
+        return fail(OC_HIP_ERR_INVALID, "Strain: approximation must be 1 (Cauchy) or 2 (Green), got %d", approximation);
+    return OC_HIP_OK;
+}
+
+int oc_hip_strain_create(float subregion_radius, int neighbor_number_min, int device, oc_hip_engine** out) {
+    if (out) *out = nullptr;
+    OC_TRY(strain_check(nullptr, subregion_radius, neighbor_number_min, 1));
+    OC_TRY(create_engine(OC_HIP_STRAIN, 1, 1, 0, 0.f, 0.f, device, out));
+    (*out)->st_radius = subregion_radius;
+    (*out)->st_nmin = neighbor_number_min;
+    return OC_HIP_OK;
+}
+
+int oc_hip_strain_set(oc_hip_engine* e, float subregion_radius, int neighbor_number_min, float zncc_threshold,
+                      int approximation) {
+    OC_TRY(check_engine(e));
+    if (e->kind != OC_HIP_STRAIN) return fail(OC_HIP_ERR_INVALID, "strain_set: not a Strain engine");
+    OC_TRY(strain_check(e, subregion_radius, neighbor_number_min, approximation));
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (subregion_radius != e->st_radius) e->st_count = 0;  // the grid pitch follows the radius: prepare() again
+    e->st_radius = subregion_radius;
+    e->st_nmin = neighbor_number_min;
+    e->st_zncc = zncc_threshold;
+    e->st_approx = approximation;
+    return OC_HIP_OK;
+}
+
+static int strain_stage(oc_hip_engine* e, const void* pois, size_t count, size_t stride_bytes, int ndim, int memory,
+                        float** d_pois) {
+    if (e->kind != OC_HIP_STRAIN) return fail(OC_HIP_ERR_INVALID, "not a Strain engine");
+    if (ndim != 2 && ndim != 3) return fail(OC_HIP_ERR_INVALID, "Strain: ndim must be 2 (POI2D) or 3 (POI3D), got %d", ndim);
+    if (!pois) return fail(OC_HIP_ERR_INVALID, "null POI buffer");
+    const size_t rec = ndim == 2 ? OC_HIP_POI2D_BYTES : OC_HIP_POI3D_BYTES;
+    if (stride_bytes < rec || (stride_bytes & 3))
+        return fail(OC_HIP_ERR_INVALID, "bad POI stride %zu (record is %zu bytes, stride must be a multiple of 4)", stride_bytes, rec);
+    if (count > 0x7fffffffull) return fail(OC_HIP_ERR_UNSUPPORTED, "Strain: at most 2^31-1 POIs per queue");
+    if (memory == OC_HIP_DEVICE) {
+        *d_pois = static_cast<float*>(const_cast<void*>(pois));
+        return OC_HIP_OK;
+    }
+    OC_TRY(e->poi_stage.reserve(count * stride_bytes));
+    OC_HIP_TRY(hipMemcpyAsync(e->poi_stage.p, pois, count * stride_bytes, hipMemcpyHostToDevice, e->stream));
+    *d_pois = e->poi_stage.as<float>();
+    return OC_HIP_OK;
+}
+
+int oc_hip_strain_prepare(oc_hip_engine* e, const void* pois, size_t count, size_t stride_bytes, int ndim, int memory) {
+    OC_TRY(activate(e));
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->st_count = 0;
+    if (count == 0) return OC_HIP_OK;
+    float* d_pois = nullptr;
+    OC_TRY(strain_stage(e, pois, count, stride_bytes, ndim, memory, &d_pois));
+    const int stride_f = (int)(stride_bytes / 4);
+    // bounding box -> grid (the cell count is needed on the host to size the tables)
+    OC_TRY(e->st_box.reserve(6 * sizeof(unsigned)));
+    OC_HIP_TRY(ochip::launch_strain_bbox(ndim, d_pois, stride_f, count, e->st_box.as<unsigned>(), e->stream));
+    unsigned box[6];
+    OC_HIP_TRY(hipMemcpyAsync(box, e->st_box.p, sizeof(box), hipMemcpyDeviceToHost, e->stream));
+    OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    const ochip::StrainGrid g = ochip::strain_make_grid(ndim, box, e->st_radius);
+    const size_t ncell = ochip::strain_cell_count(g);
+    OC_TRY(e->st_counts.reserve(ncell * sizeof(unsigned)));
+    OC_TRY(e->st_cursor.reserve(ncell * sizeof(unsigned)));
+    OC_TRY(e->st_start.reserve((ncell + 1) * sizeof(unsigned)));
+    OC_TRY(e->st_slots.reserve(count * sizeof(unsigned)));
+    OC_TRY(e->st_order.reserve(count * sizeof(unsigned)));
+    OC_HIP_TRY(ochip::launch_strain_sort(ndim, d_pois, stride_f, count, g, e->st_counts.as<unsigned>(), e->st_start.as<unsigned>(),
+                                         e->st_cursor.as<unsigned>(), e->st_slots.as<unsigned>(), e->st_order.as<unsigned>(),
+                                         e->stream));
+    if (memory == OC_HIP_HOST) OC_HIP_TRY(hipStreamSynchronize(e->stream));  // the staging buffer is reused by compute
+    e->st_grid = g;
+    e->st_ndim = ndim;
+    e->st_count = count;
+    return OC_HIP_OK;
+}
+
+int oc_hip_strain_compute(oc_hip_engine* e, void* pois, size_t count, size_t stride_bytes, int ndim, int memory) {
+    OC_TRY(activate(e));
+    if (count == 0) return OC_HIP_OK;
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (e->kind != OC_HIP_STRAIN) return fail(OC_HIP_ERR_INVALID, "not a Strain engine");
+    if (e->st_count == 0) return fail(OC_HIP_ERR_INVALID, "Strain: prepare(poi_queue) has not been called (or the radius changed since)");
+    if (e->st_count != count || e->st_ndim != ndim)
+        return fail(OC_HIP_ERR_INVALID, "Strain: prepare() saw %zu POI%dD, compute() got %zu POI%dD", e->st_count, e->st_ndim, count, ndim);
+    float* d_pois = nullptr;
+    OC_TRY(strain_stage(e, pois, count, stride_bytes, ndim, memory, &d_pois));
+    const int stride_f = (int)(stride_bytes / 4);
+    OC_TRY(e->st_recs.reserve(count * 32));
+    OC_TRY(e->st_fallback.reserve((count + 1) * sizeof(unsigned)));
+    const ochip::StrainParams P = {e->st_radius * e->st_radius, e->st_zncc, e->st_nmin, e->st_approx};
+    {
+        ProfScope prof(e);
+        OC_HIP_TRY(ochip::launch_strain_compute(ndim, d_pois, stride_f, count, e->st_grid, P, e->st_start.as<unsigned>(),
+                                                e->st_order.as<unsigned>(), e->st_recs.p, e->st_fallback.as<unsigned>(), e->stream));
+    }
+    if (memory == OC_HIP_HOST) {
+        OC_HIP_TRY(hipMemcpyAsync(pois, d_pois, count * stride_bytes, hipMemcpyDeviceToHost, e->stream));
+        OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     return OC_HIP_OK;
 }
 

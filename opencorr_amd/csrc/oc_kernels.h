@@ -53,6 +53,29 @@ size_t poi2d_tile_count(int height, int width, int tile_px);
 hipError_t launch_poi2d_tile_order(const float* pois, int stride_floats, size_t count, int height, int width, int tile_px,
                                    unsigned* tiles, unsigned* perm, hipStream_t stream);
 
+// ---- strain.hip -------------------------------------------------------------
+// Strain::prepare / Strain::compute (src/oc_strain.cpp): uniform grid over the queue's coordinates
+struct StrainGrid {
+    float x0, y0, z0, inv_pitch;
+    int ncx, ncy, ncz;
+};
+struct StrainParams {
+    float radius2;         // subregion_radius * subregion_radius, in float
+    float zncc_threshold;  // Strain::setZnccThreshold, default 0.9
+    int neighbor_min;      // neighbor_number_min
+    int approximation;     // 1 = Cauchy, 2 = Green
+};
+int strain_knn_max();  // largest neighbor_number_min the KNN path holds
+hipError_t launch_strain_bbox(int ndim, const float* pois, int stride_floats, size_t count, unsigned* box6, hipStream_t stream);
+StrainGrid strain_make_grid(int ndim, const unsigned* box6_host, float radius);
+size_t strain_cell_count(const StrainGrid& g);
+hipError_t launch_strain_sort(int ndim, const float* pois, int stride_floats, size_t count, const StrainGrid& g,
+                              unsigned* counts, unsigned* start, unsigned* cursor, unsigned* slots, unsigned* order,
+                              hipStream_t stream);
+hipError_t launch_strain_compute(int ndim, float* pois, int stride_floats, size_t count, const StrainGrid& g,
+                                 const StrainParams& P, const unsigned* start, const unsigned* order, void* recs,
+                                 unsigned* fallback, hipStream_t stream);
+
 // ---- nr2d.hip --------------------------------------------------------------
 struct Nr2dParams {
     const float* ref;     // reference image, row-major

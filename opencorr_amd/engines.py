@@ -253,6 +253,91 @@ class ICLM2D2(_Engine, _IclmMixin):
                                                     device, ctypes.byref(self._h)))
 
 
+class Strain:
+    """Strain(subregion_radius, neighbor_number_min, thread_number) -- src/oc_strain.h:34-73, src/oc_strain.cpp:31-46.
+
+    ``prepare(pois)`` builds the neighbour search over the queue's coordinates, ``compute(pois)`` writes the strain
+    fields of every POI that can be fitted, in place (POI2D: exx, eyy, exy; POI3D: exx, eyy, ezz, exy, eyz, ezx).
+    ``pois`` is a float32 (n, 25) / (n, 31) NumPy array (host path) or CUDA torch tensor (used in place)."""
+
+    def __init__(self, subregion_radius, neighbor_number_min, thread_number=1, device=0):
+        self._h = ctypes.c_void_p()
+        self.thread_number = thread_number
+        self._p = dict(radius=float(subregion_radius), nmin=int(neighbor_number_min), zncc=0.9, approx=1)
+        capi.check(capi.lib().oc_hip_strain_create(self._p["radius"], self._p["nmin"], device, ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            capi.lib().oc_hip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _push(self, **kw):
+        p = dict(self._p, **kw)
+        capi.check(capi.lib().oc_hip_strain_set(self._h, p["radius"], p["nmin"], p["zncc"], p["approx"]))
+        self._p = p
+
+    # src/oc_strain.cpp:72-95
+    def set_subregion_radius(self, subregion_radius):
+        self._push(radius=float(subregion_radius))
+
+    def set_neighbor_min(self, neighbor_number_min):
+        self._push(nmin=int(neighbor_number_min))
+
+    def set_zncc_threshold(self, zncc_threshold):
+        self._push(zncc=float(zncc_threshold))
+
+    def set_approximation(self, approximation):
+        """1 = Cauchy strain, 2 = Green strain."""
+        self._push(approx=int(approximation))
+
+    def set_stream(self, stream_handle):
+        capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(stream_handle or None)))
+
+    def synchronize(self):
+        capi.check(capi.lib().oc_hip_synchronize(self._h))
+
+    @staticmethod
+    def _queue(pois):
+        if _is_torch(pois):
+            p, mem, _ = _buf(pois)
+            n, floats, stride = pois.shape[0], pois.shape[1], pois.stride(0) * 4
+        else:
+            if pois.dtype != np.float32 or not pois.flags.c_contiguous or pois.ndim != 2:
+                raise ValueError("pois must be a C-contiguous float32 array of shape (n, 25) or (n, 31)")
+            p, mem = ctypes.c_void_p(pois.ctypes.data), capi.HOST
+            n, floats, stride = pois.shape[0], pois.shape[1], pois.strides[0]
+        if floats not in (capi.POI2D_FLOATS, capi.POI3D_FLOATS):
+            raise ValueError("POI records have 25 (POI2D) or 31 (POI3D) floats, got %d" % floats)
+        return p, n, stride, (2 if floats == capi.POI2D_FLOATS else 3), mem
+
+    def prepare(self, pois):
+        p, n, stride, ndim, mem = self._queue(pois)
+        capi.check(capi.lib().oc_hip_strain_prepare(self._h, p, n, stride, ndim, mem))
+
+    def compute(self, pois):
+        p, n, stride, ndim, mem = self._queue(pois)
+        capi.check(capi.lib().oc_hip_strain_compute(self._h, p, n, stride, ndim, mem))
+        return pois
+
+    def profile_enable(self, on=True):
+        capi.check(capi.lib().oc_hip_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        capi.check(capi.lib().oc_hip_profile_reset(self._h))
+
+    def profile_read(self):
+        ms = ctypes.c_double()
+        n = ctypes.c_long()
+        capi.check(capi.lib().oc_hip_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+
 class FFTCC3D(_Engine):
     """FFTCC3D(rx, ry, rz, thread_number) -- src/oc_fftcc.h:75-89."""
     _ndim = 3

@@ -129,6 +129,30 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        // Strain over the ICGN result (examples/test_2d_dic_strain.cpp usage): a smooth field gives small, finite strains
+        {
+            std::vector<POI2D> q = poi_queue;
+            Strain strain(20.f, 5, cpu_thread_number);
+            strain.prepare(q);
+            strain.compute(q);
+            int fitted = 0;
+            for (size_t i = 0; i < q.size(); i++) {
+                if (q[i].result.zncc < 0.9f) {
+                    if (q[i].strain.exx != 0.f) { std::cerr << "Strain touched a POI below the ZNCC threshold" << std::endl; return 15; }
+                    continue;
+                }
+                if (!(std::fabs(q[i].strain.exx) < 0.05f) || !(std::fabs(q[i].strain.eyy) < 0.05f)) {
+                    std::cerr << "implausible strain at POI " << i << ": " << q[i].strain.exx << " " << q[i].strain.eyy << std::endl;
+                    return 15;
+                }
+                fitted += q[i].strain.exx != 0.f;
+            }
+            if (fitted * 2 < (int)q.size()) { std::cerr << "Strain fitted only " << fitted << " POIs" << std::endl; return 15; }
+            POI2D probe = q[q.size() / 2];
+            std::vector<POI2D> q2 = poi_queue;
+            strain.compute(&q2[q2.size() / 2], q2);
+            if (q2[q2.size() / 2].strain.exy != probe.strain.exy) { std::cerr << "Strain::compute(POI*, queue) disagrees" << std::endl; return 15; }
+        }
         // the reference's CUDA-module shape (gpu_lib/opencorr_gpu.h:31-101): ICGN2D1GPU fed with row-major Img2D
         {
             Img2D ref2{w, h, ref.data()}, tar2{w, h, tar.data()};

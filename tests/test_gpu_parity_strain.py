@@ -1,0 +1,129 @@
+"""GPU parity of Strain against the oracle and the reference's golden table.
+Bars: bit-exact vs the oracle (same neighbour sets, same row order, same double sums -> same float bits); the OHT
+table within the tolerance of the oracle's own golden test; untouched fields stay untouched."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_strain2d_on_the_reference_table(golden_strain):
+    import opencorr_amd as eng
+    import oracle
+    from test_oracle_strain import strain_golden_check, strain_queue_from_golden
+    g = golden_strain
+    p = strain_queue_from_golden(g)
+    want = p.copy()
+    oracle.strain2d(want, g["radius"], g["neighbors"], g["zncc_threshold"], g["approximation"])
+    st = eng.Strain(g["radius"], g["neighbors"])
+    st.prepare(p)
+    got = st.compute(p.copy())
+    strain_golden_check(got, g)
+    assert np.array_equal(_bits(got), _bits(want))
+
+
+@pytest.mark.parametrize("approximation", [1, 2])
+def test_strain2d_bit_exact_on_scattered_pois(approximation):
+    import opencorr_amd as eng
+    import oracle
+    from test_oracle_strain import affine_queue_2d
+    P = oracle.P2
+    p, _ = affine_queue_2d(n=20000, seed=11, extent=900.0)
+    rng = np.random.default_rng(2)
+    p[:, P["u"]] += rng.normal(0, 0.02, len(p)).astype(np.float32)
+    p[:, P["v"]] += rng.normal(0, 0.02, len(p)).astype(np.float32)
+    bad = rng.random(len(p)) < 0.15
+    p[bad, P["zncc"]] = rng.choice(np.array([-3.0, -4.0, 0.5], dtype=np.float32), bad.sum())
+    p[rng.random(len(p)) < 0.01, P["u"]] = np.nan  # NaN displacement with a good ZNCC poisons its neighbours alike
+    p[:, P["exx"]] = 7.0  # sentinel: untouched fields must survive
+    want = p.copy()
+    oracle.strain2d(want, 17.5, 6, 0.9, approximation)
+    st = eng.Strain(17.5, 6)
+    st.set_approximation(approximation)
+    st.prepare(p)
+    got = st.compute(p.copy())
+    both_nan = np.isnan(got) & np.isnan(want)
+    assert np.array_equal(_bits(got)[~both_nan], _bits(want)[~both_nan])
+    assert (got[bad, P["exx"]] == 7.0).all()
+    assert (got[~bad, P["exx"]] != 7.0).mean() > 0.99
+
+
+def test_strain2d_knn_path_and_device_resident_queue():
+    import torch
+    import opencorr_amd as eng
+    import oracle
+    P = oracle.P2
+    rng = np.random.default_rng(4)
+    # sparse cloud + a dense blob: with radius 6 most sparse POIs see fewer than 5 neighbours -> KNN path
+    xs = np.concatenate([rng.random(3000) * 2000, 500 + rng.random(3000) * 60]).astype(np.float32)
+    ys = np.concatenate([rng.random(3000) * 1500, 400 + rng.random(3000) * 60]).astype(np.float32)
+    p = oracle.make_pois2d(xs, ys)
+    p[:, P["u"]] = (0.002 * xs - 0.001 * ys + rng.normal(0, 0.01, len(xs))).astype(np.float32)
+    p[:, P["v"]] = (0.001 * xs + 0.003 * ys).astype(np.float32)
+    p[:, P["zncc"]] = np.where(rng.random(len(xs)) < 0.1, 0.3, 0.97).astype(np.float32)
+    want = p.copy()
+    oracle.strain2d(want, 6.0, 5)
+    st = eng.Strain(6.0, 5)
+    d = torch.from_numpy(p.copy()).cuda()
+    st.set_stream(torch.cuda.current_stream().cuda_stream)
+    st.prepare(d)
+    st.compute(d)
+    torch.cuda.synchronize()
+    got = d.cpu().numpy()
+    assert np.array_equal(_bits(got), _bits(want))
+    touched = got[:, P["exx"]] != 0
+    assert 0.3 < touched[:3000].mean() < 1.0  # the KNN path fitted some and left others (filtered neighbours) alone
+    # a second compute on new displacements reuses the prepared grid
+    p2 = p.copy()
+    p2[:, P["u"]] *= 2
+    want2 = p2.copy()
+    oracle.strain2d(want2, 6.0, 5)
+    got2 = st.compute(torch.from_numpy(p2).cuda()).cpu().numpy()
+    assert np.array_equal(_bits(got2), _bits(want2))
+
+
+@pytest.mark.parametrize("approximation", [1, 2])
+def test_strain3d_bit_exact(approximation):
+    import opencorr_amd as eng
+    import oracle
+    from test_oracle_strain import affine_queue_3d
+    P = oracle.P3
+    p, _ = affine_queue_3d(n=12000, seed=9, extent=200.0)
+    rng = np.random.default_rng(6)
+    for k in ("u", "v", "w"):
+        p[:, P[k]] += rng.normal(0, 0.02, len(p)).astype(np.float32)
+    bad = rng.random(len(p)) < 0.1
+    p[bad, P["zncc"]] = -4.0
+    want = p.copy()
+    oracle.strain3d(want, 21.0, 10, 0.9, approximation)
+    st = eng.Strain(21.0, 10)
+    st.set_approximation(approximation)
+    st.prepare(p)
+    got = st.compute(p.copy())
+    assert np.array_equal(_bits(got), _bits(want))
+    assert (got[~bad, P["ezz"]] != 0).mean() > 0.9
+
+
+def test_strain_errors_and_lifecycle():
+    import opencorr_amd as eng
+    import oracle
+    p = oracle.make_pois2d(np.arange(50, dtype=np.float32), np.arange(50, dtype=np.float32))
+    st = eng.Strain(10.0, 5)
+    with pytest.raises(eng.capi.OpenCorrHipError):
+        st.compute(p)  # no prepare
+    st.prepare(p)
+    with pytest.raises(eng.capi.OpenCorrHipError):
+        st.compute(p[:40].copy())  # a different queue
+    st.set_subregion_radius(12.0)
+    with pytest.raises(eng.capi.OpenCorrHipError):
+        st.compute(p)  # radius changed: the grid is stale
+    with pytest.raises(eng.capi.OpenCorrHipError):
+        st.set_neighbor_min(1000)
+    with pytest.raises(eng.capi.OpenCorrHipError):
+        eng.Strain(-1.0, 5)
+    st.prepare(p[:0])  # empty queue is a no-op
+    st.compute(p[:0])
