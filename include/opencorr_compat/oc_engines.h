@@ -363,6 +363,50 @@ private:
     }
 };
 
+// RegionFit2D / RegionFit3D(float neighbor_search_radius, int neighbor_number_min, int thread_number)
+// src/oc_region_fit.h:28-80: setNeighbor(reliable) ; prepare() ; compute(poi_queue).  The reference derives them from
+// DIC / DVC without using the images; here they are plain classes.
+template <class Poi, int NDIM>
+class RegionFitShim {
+public:
+    RegionFitShim(float neighbor_search_radius_, int neighbor_number_min_, int thread_number_)
+        : neighbor_search_radius(neighbor_search_radius_), neighbor_number_min(neighbor_number_min_), thread_number(thread_number_) {
+        hipdetail::check(oc_hip_region_fit_create(neighbor_search_radius_, neighbor_number_min_, hipdetail::default_device(), &engine_));
+    }
+    ~RegionFitShim() { if (engine_) oc_hip_destroy(engine_); }
+    RegionFitShim(const RegionFitShim&) = delete;
+    RegionFitShim& operator=(const RegionFitShim&) = delete;
+
+    float getSearchRadius() const { return neighbor_search_radius; }
+    int getNeighborMin() const { return neighbor_number_min; }
+    void setSearchRadius(float v) {
+        hipdetail::check(oc_hip_region_fit_set(engine_, v, neighbor_number_min));
+        neighbor_search_radius = v;
+    }
+    void setNeighborMin(int v) {
+        hipdetail::check(oc_hip_region_fit_set(engine_, neighbor_search_radius, v));
+        neighbor_number_min = v;
+    }
+    void setNeighbor(std::vector<Poi>& reliable_pois) { neighbor_reliable = &reliable_pois; }
+    void prepare() {
+        if (!neighbor_reliable) throw std::string("RegionFit::prepare: setNeighbor has not been called");
+        hipdetail::check(oc_hip_region_fit_prepare(engine_, neighbor_reliable->data(), neighbor_reliable->size(), sizeof(Poi), NDIM, OC_HIP_HOST));
+    }
+    void compute(Poi* poi) { hipdetail::check(oc_hip_region_fit_compute(engine_, poi, 1, sizeof(Poi), NDIM, OC_HIP_HOST)); }
+    void compute(std::vector<Poi>& q) { hipdetail::check(oc_hip_region_fit_compute(engine_, q.data(), q.size(), sizeof(Poi), NDIM, OC_HIP_HOST)); }
+
+protected:
+    std::vector<Poi>* neighbor_reliable = nullptr;
+    float neighbor_search_radius;
+    int neighbor_number_min;
+    int thread_number;
+
+private:
+    oc_hip_engine* engine_ = nullptr;
+};
+using RegionFit2D = RegionFitShim<POI2D, 2>;
+using RegionFit3D = RegionFitShim<POI3D, 3>;
+
 // ---- the reference's CUDA-module shapes (gpu_lib/opencorr_gpu.h:31-101), so that
 // examples/test_2d_dic_gpu_icgn.cpp / test_dvc_gpu_icgn.cpp compile against this header --------------
 struct Img2D { int width, height; float* data; };           // row-major

@@ -61,7 +61,8 @@ typedef enum oc_hip_kind {
     OC_HIP_NR2D1 = 6,
     OC_HIP_ICLM2D1 = 7,
     OC_HIP_ICLM2D2 = 8,
-    OC_HIP_STRAIN = 9
+    OC_HIP_STRAIN = 9,
+    OC_HIP_REGION_FIT = 10
 } oc_hip_kind;
 
 #define OC_HIP_POI2D_BYTES 100
@@ -120,6 +121,22 @@ int oc_hip_strain_prepare(oc_hip_engine* engine, const void* pois, size_t count,
  * ZNCC >= threshold that finds at least neighbor_number_min accepted neighbours; everything else is left untouched.
  * The queue must be the one prepare() saw (same length and coordinates). */
 int oc_hip_strain_compute(oc_hip_engine* engine, void* pois, size_t count, size_t stride_bytes, int ndim, int memory);
+/* RegionFit2D / RegionFit3D(float neighbor_search_radius, int neighbor_number_min, int thread_number)
+ * src/oc_region_fit.cpp:32-46, 189-203: re-initialises POIs from the plane fitted through the
+ * reliable POIs around them, before they are handed to ICGN again. */
+int oc_hip_region_fit_create(float neighbor_search_radius, int neighbor_number_min, int device, oc_hip_engine** out);
+/* setSearchRadius / setNeighborMin  src/oc_region_fit.cpp:65-73, 222-230.  A new radius needs a new prepare. */
+int oc_hip_region_fit_set(oc_hip_engine* engine, float neighbor_search_radius, int neighbor_number_min);
+/* setNeighbor(reliable_pois) + prepare()  src/oc_region_fit.cpp:75-92, 232-249: neighbour search over the reliable
+ * POIs' coordinates.  Their displacements are snapshotted here (the reference keeps a pointer and reads them during
+ * compute; editing the reliable queue between prepare and compute needs a new prepare). */
+int oc_hip_region_fit_prepare(oc_hip_engine* engine, const void* reliable_pois, size_t count, size_t stride_bytes, int ndim,
+                              int memory);
+/* RegionFit2D::compute(std::vector<POI2D>&) src/oc_region_fit.cpp:166-174 (-> :94-164) / RegionFit3D :334-342
+ * (-> :251-332): every POI that finds at least neighbor_number_min reliable POIs (inside the radius, else the K
+ * nearest) gets deformation.{u,ux,uy,v,vx,vy} (POI3D: all twelve) from the fitted plane and result.zncc = 0; other
+ * POIs and all other fields are left untouched. */
+int oc_hip_region_fit_compute(oc_hip_engine* engine, void* pois, size_t count, size_t stride_bytes, int ndim, int memory);
 /* FFTCC3D(int rx, int ry, int rz, int thread_number)  src/oc_fftcc.cpp:300-313 */
 int oc_hip_fftcc3d_create(int radius_x, int radius_y, int radius_z, int device, oc_hip_engine** out);
 /* ICGN3D1(int rx, int ry, int rz, float conv, float stop, int thread_number)  src/oc_icgn.cpp:1197-1213 */

@@ -14,7 +14,7 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_ROCFFT, ERR_NOMEM, ERR_UNSUPPORTED = 1, 2, 3, 4, 5
 HOST, DEVICE = 0, 1
 ROW_MAJOR, COL_MAJOR = 0, 1
-FFTCC2D, ICGN2D1, ICGN2D2, FFTCC3D, ICGN3D1, NR2D1, ICLM2D1, ICLM2D2, STRAIN = 1, 2, 3, 4, 5, 6, 7, 8, 9
+FFTCC2D, ICGN2D1, ICGN2D2, FFTCC3D, ICGN3D1, NR2D1, ICLM2D1, ICLM2D2, STRAIN, REGION_FIT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 POI2D_BYTES, POI3D_BYTES = 100, 124
 POI2D_FLOATS, POI3D_FLOATS = 25, 31
 
@@ -24,6 +24,7 @@ SYMBOLS = [
     "oc_hip_fftcc2d_create", "oc_hip_icgn2d1_create", "oc_hip_icgn2d2_create", "oc_hip_nr2d1_create",
     "oc_hip_iclm2d1_create", "oc_hip_iclm2d2_create", "oc_hip_set_damping",
     "oc_hip_strain_create", "oc_hip_strain_set", "oc_hip_strain_prepare", "oc_hip_strain_compute",
+    "oc_hip_region_fit_create", "oc_hip_region_fit_set", "oc_hip_region_fit_prepare", "oc_hip_region_fit_compute",
     "oc_hip_fftcc3d_create", "oc_hip_icgn3d1_create", "oc_hip_destroy",
     "oc_hip_set_images2d", "oc_hip_set_images3d", "oc_hip_share_images", "oc_hip_set_subset",
     "oc_hip_set_iteration", "oc_hip_set_stream", "oc_hip_reset_stream", "oc_hip_set_tuning",
@@ -71,6 +72,10 @@ def lib():
     L.oc_hip_strain_set.argtypes = [vp, f, i, f, i]
     L.oc_hip_strain_prepare.argtypes = [vp, vp, sz, sz, i, i]
     L.oc_hip_strain_compute.argtypes = [vp, vp, sz, sz, i, i]
+    L.oc_hip_region_fit_create.argtypes = [f, i, i, pp]
+    L.oc_hip_region_fit_set.argtypes = [vp, f, i]
+    L.oc_hip_region_fit_prepare.argtypes = [vp, vp, sz, sz, i, i]
+    L.oc_hip_region_fit_compute.argtypes = [vp, vp, sz, sz, i, i]
     L.oc_hip_fftcc3d_create.argtypes = [i, i, i, i, pp]
     L.oc_hip_icgn3d1_create.argtypes = [i, i, i, f, f, i, pp]
     L.oc_hip_destroy.argtypes = [vp]

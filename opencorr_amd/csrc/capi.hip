@@ -578,6 +578,26 @@ int oc_hip_strain_create(float subregion_radius, int neighbor_number_min, int de
     return OC_HIP_OK;
 }
 
+int oc_hip_region_fit_create(float neighbor_search_radius, int neighbor_number_min, int device, oc_hip_engine** out) {
+    if (out) *out = nullptr;
+    OC_TRY(strain_check(nullptr, neighbor_search_radius, neighbor_number_min, 1));
+    OC_TRY(create_engine(OC_HIP_REGION_FIT, 1, 1, 0, 0.f, 0.f, device, out));
+    (*out)->st_radius = neighbor_search_radius;
+    (*out)->st_nmin = neighbor_number_min;
+    return OC_HIP_OK;
+}
+
+int oc_hip_region_fit_set(oc_hip_engine* e, float neighbor_search_radius, int neighbor_number_min) {
+    OC_TRY(check_engine(e));
+    if (e->kind != OC_HIP_REGION_FIT) return fail(OC_HIP_ERR_INVALID, "region_fit_set: not a RegionFit engine");
+    OC_TRY(strain_check(e, neighbor_search_radius, neighbor_number_min, 1));
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (neighbor_search_radius != e->st_radius) e->st_count = 0;
+    e->st_radius = neighbor_search_radius;
+    e->st_nmin = neighbor_number_min;
+    return OC_HIP_OK;
+}
+
 int oc_hip_strain_set(oc_hip_engine* e, float subregion_radius, int neighbor_number_min, float zncc_threshold,
                       int approximation) {
     OC_TRY(check_engine(e));
@@ -594,8 +614,8 @@ int oc_hip_strain_set(oc_hip_engine* e, float subregion_radius, int neighbor_num
 
 static int strain_stage(oc_hip_engine* e, const void* pois, size_t count, size_t stride_bytes, int ndim, int memory,
                         float** d_pois) {
-    if (e->kind != OC_HIP_STRAIN) return fail(OC_HIP_ERR_INVALID, "not a Strain engine");
-    if (ndim != 2 && ndim != 3) return fail(OC_HIP_ERR_INVALID, "Strain: ndim must be 2 (POI2D) or 3 (POI3D), got %d", ndim);
+    if (e->kind != OC_HIP_STRAIN && e->kind != OC_HIP_REGION_FIT) return fail(OC_HIP_ERR_INVALID, "not a Strain / RegionFit engine");
+    if (ndim != 2 && ndim != 3) return fail(OC_HIP_ERR_INVALID, "ndim must be 2 (POI2D) or 3 (POI3D), got %d", ndim);
     if (!pois) return fail(OC_HIP_ERR_INVALID, "null POI buffer");
     const size_t rec = ndim == 2 ? OC_HIP_POI2D_BYTES : OC_HIP_POI3D_BYTES;
     if (stride_bytes < rec || (stride_bytes & 3))
@@ -611,8 +631,11 @@ static int strain_stage(oc_hip_engine* e, const void* pois, size_t count, size_t
     return OC_HIP_OK;
 }
 
-int oc_hip_strain_prepare(oc_hip_engine* e, const void* pois, size_t count, size_t stride_bytes, int ndim, int memory) {
+// neighbour search over a queue's coordinates; gather_records: also snapshot the fit records (RegionFit's cloud)
+static int plane_prepare(oc_hip_engine* e, int kind, const void* pois, size_t count, size_t stride_bytes, int ndim, int memory,
+                         bool gather_records) {
     OC_TRY(activate(e));
+    if (e->kind != kind) return fail(OC_HIP_ERR_INVALID, "prepare: wrong engine kind for this entry point");
     std::lock_guard<std::mutex> lock(e->mu);
     e->st_count = 0;
     if (count == 0) return OC_HIP_OK;
@@ -635,10 +658,50 @@ int oc_hip_strain_prepare(oc_hip_engine* e, const void* pois, size_t count, size
     OC_HIP_TRY(ochip::launch_strain_sort(ndim, d_pois, stride_f, count, g, e->st_counts.as<unsigned>(), e->st_start.as<unsigned>(),
                                          e->st_cursor.as<unsigned>(), e->st_slots.as<unsigned>(), e->st_order.as<unsigned>(),
                                          e->stream));
+    if (gather_records) {
+        OC_TRY(e->st_recs.reserve(count * 32));
+        OC_HIP_TRY(ochip::launch_strain_gather(ndim, d_pois, stride_f, count, e->st_order.as<unsigned>(), e->st_recs.p, e->stream));
+    }
     if (memory == OC_HIP_HOST) OC_HIP_TRY(hipStreamSynchronize(e->stream));  // the staging buffer is reused by compute
     e->st_grid = g;
     e->st_ndim = ndim;
     e->st_count = count;
+    return OC_HIP_OK;
+}
+
+int oc_hip_strain_prepare(oc_hip_engine* e, const void* pois, size_t count, size_t stride_bytes, int ndim, int memory) {
+    OC_TRY(check_engine(e));
+    return plane_prepare(e, OC_HIP_STRAIN, pois, count, stride_bytes, ndim, memory, false);
+}
+
+int oc_hip_region_fit_prepare(oc_hip_engine* e, const void* reliable_pois, size_t count, size_t stride_bytes, int ndim,
+                              int memory) {
+    OC_TRY(check_engine(e));
+    return plane_prepare(e, OC_HIP_REGION_FIT, reliable_pois, count, stride_bytes, ndim, memory, true);
+}
+
+int oc_hip_region_fit_compute(oc_hip_engine* e, void* pois, size_t count, size_t stride_bytes, int ndim, int memory) {
+    OC_TRY(activate(e));
+    if (count == 0) return OC_HIP_OK;
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (e->kind != OC_HIP_REGION_FIT) return fail(OC_HIP_ERR_INVALID, "not a RegionFit engine");
+    if (e->st_count == 0)
+        return fail(OC_HIP_ERR_INVALID, "RegionFit: setNeighbor + prepare has not been called (or the radius changed since)");
+    if (e->st_ndim != ndim) return fail(OC_HIP_ERR_INVALID, "RegionFit: prepared for POI%dD, compute() got POI%dD", e->st_ndim, ndim);
+    float* d_pois = nullptr;
+    OC_TRY(strain_stage(e, pois, count, stride_bytes, ndim, memory, &d_pois));
+    const int stride_f = (int)(stride_bytes / 4);
+    OC_TRY(e->st_fallback.reserve((count + 1) * sizeof(unsigned)));
+    const ochip::StrainParams P = {e->st_radius * e->st_radius, 0.f, e->st_nmin, 1};
+    {
+        ProfScope prof(e);
+        OC_HIP_TRY(ochip::launch_region_fit_compute(ndim, d_pois, stride_f, count, e->st_grid, P, e->st_start.as<unsigned>(),
+                                                    e->st_recs.p, e->st_fallback.as<unsigned>(), e->stream));
+    }
+    if (memory == OC_HIP_HOST) {
+        OC_HIP_TRY(hipMemcpyAsync(pois, d_pois, count * stride_bytes, hipMemcpyDeviceToHost, e->stream));
+        OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     return OC_HIP_OK;
 }
 

@@ -72,6 +72,12 @@ size_t strain_cell_count(const StrainGrid& g);
 hipError_t launch_strain_sort(int ndim, const float* pois, int stride_floats, size_t count, const StrainGrid& g,
                               unsigned* counts, unsigned* start, unsigned* cursor, unsigned* slots, unsigned* order,
                               hipStream_t stream);
+hipError_t launch_strain_gather(int ndim, const float* pois, int stride_floats, size_t count, const unsigned* order, void* recs,
+                                hipStream_t stream);
+// RegionFit2D/3D::compute (src/oc_region_fit.cpp): plane through the reliable cloud (recs) for every POI of `pois`
+hipError_t launch_region_fit_compute(int ndim, float* pois, int stride_floats, size_t count, const StrainGrid& g,
+                                     const StrainParams& P, const unsigned* start, const void* recs, unsigned* fallback,
+                                     hipStream_t stream);
 hipError_t launch_strain_compute(int ndim, float* pois, int stride_floats, size_t count, const StrainGrid& g,
                                  const StrainParams& P, const unsigned* start, const unsigned* order, void* recs,
                                  unsigned* fallback, hipStream_t stream);

@@ -292,8 +292,14 @@ __device__ __forceinline__ void write_strain(float* __restrict__ poi, Fit<DIM>& 
     }
 }
 
+// the POI a thread fits a plane for: a record of the cloud itself (Strain) or a POI of a second queue (RegionFit)
+struct Query {
+    float x, y, z;
+    float* poi;  // record the result is written to
+};
+
 template <int DIM>
-__device__ __forceinline__ float dist2(const StrainRec& me, float x, float y, float z) {
+__device__ __forceinline__ float dist2(const Query& me, float x, float y, float z) {
     // nanoflann L2_Simple: sum over the dimensions of (query - point)^2, in order
     const float dx = me.x - x, dy = me.y - y;
     float d = dx * dx;
@@ -305,18 +311,60 @@ __device__ __forceinline__ float dist2(const StrainRec& me, float x, float y, fl
     return d;
 }
 
+// MODE 0 (Strain): query k is record k of the cloud, skipped when its ZNCC is below the threshold.
+// MODE 1 (RegionFit): query k is POI k of `pois`.
+template <int DIM, int MODE>
+__device__ __forceinline__ bool load_query(Query& me, unsigned k, float* __restrict__ pois, int stride_f,
+                                           const float4* __restrict__ rv, const StrainParams& P) {
+    if constexpr (MODE == 0) {
+        const float4 m0 = rv[2 * (size_t)k], m1 = rv[2 * (size_t)k + 1];
+        me.x = m0.x;
+        me.y = m0.y;
+        me.z = m0.z;
+        me.poi = pois + (size_t)__float_as_uint(m1.w) * stride_f;
+        return m1.z >= P.zncc_threshold;  // src/oc_strain.cpp:241 / :481
+    } else {
+        me.poi = pois + (size_t)k * stride_f;
+        me.x = me.poi[0];
+        me.y = me.poi[1];
+        me.z = DIM == 3 ? me.poi[2] : 0.f;
+        return true;
+    }
+}
+
+// RegionFit2D/3D::compute: the plane itself becomes the deformation, ZNCC is reset
+// (src/oc_region_fit.cpp:153-162, 314-330)
 template <int DIM>
+__device__ __forceinline__ void write_plane(float* __restrict__ poi, Fit<DIM>& fit) {
+    constexpr int D = DIM + 1;
+    double grad[DIM][D];
+    fit.solve(grad);
+    if constexpr (DIM == 2) {
+        poi[poi2d::U] = (float)grad[0][0];
+        poi[poi2d::UX] = (float)grad[0][1];
+        poi[poi2d::UY] = (float)grad[0][2];
+        poi[poi2d::V] = (float)grad[1][0];
+        poi[poi2d::VX] = (float)grad[1][1];
+        poi[poi2d::VY] = (float)grad[1][2];
+        poi[poi2d::ZNCC] = 0.f;
+    } else {
+#pragma unroll
+        for (int r = 0; r < DIM; r++)
+#pragma unroll
+            for (int k = 0; k < D; k++) poi[poi3d::P + r * D + k] = (float)grad[r][k];  // u ux uy uz v ... wz
+        poi[poi3d::ZNCC] = 0.f;
+    }
+}
+
+template <int DIM, int MODE>
 __global__ __launch_bounds__(256) void strain_fit_kernel(float* __restrict__ pois, int stride_f, unsigned count, StrainGrid g,
                                                          StrainParams P, const unsigned* __restrict__ start,
                                                          const StrainRec* __restrict__ recs, unsigned* __restrict__ fallback) {
     const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count) return;
     const float4* rv = reinterpret_cast<const float4*>(recs);
-    const float4 m0 = rv[2 * (size_t)k], m1 = rv[2 * (size_t)k + 1];
-    StrainRec me;
-    me.x = m0.x; me.y = m0.y; me.z = m0.z; me.u = m0.w;
-    me.v = m1.x; me.w = m1.y; me.zncc = m1.z; me.idx = __float_as_uint(m1.w);
-    if (!(me.zncc >= P.zncc_threshold)) return;  // src/oc_strain.cpp:241 / :481
+    Query me;
+    if (!load_query<DIM, MODE>(me, k, pois, stride_f, rv, P)) return;
     const float pos[3] = {me.x, me.y, me.z};
     int cx, cy, cz;
     cell_of<DIM>(pos, g, cx, cy, cz);
@@ -335,7 +383,7 @@ __global__ __launch_bounds__(256) void strain_fit_kernel(float* __restrict__ poi
                 const float4 a = rv[2 * (size_t)q], b = rv[2 * (size_t)q + 1];
                 if (dist2<DIM>(me, a.x, a.y, a.z) < P.radius2) {
                     inside++;
-                    if (b.z >= P.zncc_threshold) fit.add(a.x - me.x, a.y - me.y, a.z - me.z, a.w, b.x, b.y);
+                    if (MODE == 1 || b.z >= P.zncc_threshold) fit.add(a.x - me.x, a.y - me.y, a.z - me.z, a.w, b.x, b.y);
                 }
             }
         }
@@ -344,14 +392,17 @@ __global__ __launch_bounds__(256) void strain_fit_kernel(float* __restrict__ poi
         return;
     }
     if (fit.n < P.neighbor_min) return;  // src/oc_strain.cpp:190
-    write_strain<DIM>(pois + (size_t)me.idx * stride_f, fit, P.approximation);
+    if constexpr (MODE == 0)
+        write_strain<DIM>(me.poi, fit, P.approximation);
+    else
+        write_plane<DIM>(me.poi, fit);
 }
 
 // KNN path (src/oc_strain.cpp:177-186): the K = neighbor_number_min nearest POIs by ascending (distance^2, queue
 // index), found ring by ring; one thread per POI of the fallback list.
 constexpr int kKnnMax = 64;
 
-template <int DIM>
+template <int DIM, int MODE>
 __global__ __launch_bounds__(64) void strain_knn_kernel(float* __restrict__ pois, int stride_f, StrainGrid g, StrainParams P,
                                                         const unsigned* __restrict__ start, const StrainRec* __restrict__ recs,
                                                         const unsigned* __restrict__ fallback) {
@@ -359,10 +410,8 @@ __global__ __launch_bounds__(64) void strain_knn_kernel(float* __restrict__ pois
     if (t >= fallback[0]) return;
     const unsigned k = fallback[1 + t];
     const float4* rv = reinterpret_cast<const float4*>(recs);
-    const float4 m0 = rv[2 * (size_t)k], m1 = rv[2 * (size_t)k + 1];
-    StrainRec me;
-    me.x = m0.x; me.y = m0.y; me.z = m0.z; me.u = m0.w;
-    me.v = m1.x; me.w = m1.y; me.zncc = m1.z; me.idx = __float_as_uint(m1.w);
+    Query me;
+    load_query<DIM, MODE>(me, k, pois, stride_f, rv, P);
     const float pos[3] = {me.x, me.y, me.z};
     int cx, cy, cz;
     cell_of<DIM>(pos, g, cx, cy, cz);
@@ -412,10 +461,13 @@ __global__ __launch_bounds__(64) void strain_knn_kernel(float* __restrict__ pois
     fit.clear();
     for (int j = 0; j < have; j++) {
         const float4 a = rv[2 * (size_t)bq[j]], b = rv[2 * (size_t)bq[j] + 1];
-        if (b.z >= P.zncc_threshold) fit.add(a.x - me.x, a.y - me.y, a.z - me.z, a.w, b.x, b.y);
+        if (MODE == 1 || b.z >= P.zncc_threshold) fit.add(a.x - me.x, a.y - me.y, a.z - me.z, a.w, b.x, b.y);
     }
     if (fit.n < K) return;
-    write_strain<DIM>(pois + (size_t)me.idx * stride_f, fit, P.approximation);
+    if constexpr (MODE == 0)
+        write_strain<DIM>(me.poi, fit, P.approximation);
+    else
+        write_plane<DIM>(me.poi, fit);
 }
 
 float unord(unsigned u) {
@@ -496,31 +548,55 @@ hipError_t launch_strain_sort(int ndim, const float* pois, int stride_f, size_t 
                      : sort_t<3>(pois, stride_f, count, g, counts, start, cursor, slots, order, stream);
 }
 
-template <int DIM>
-static hipError_t compute_t(float* pois, int stride_f, size_t count, const StrainGrid& g, const StrainParams& P,
-                            const unsigned* start, const unsigned* order, void* recs, unsigned* fallback, hipStream_t stream) {
+template <int DIM, int MODE>
+static hipError_t fit_t(float* pois, int stride_f, size_t count, const StrainGrid& g, const StrainParams& P,
+                        const unsigned* start, const void* recs, unsigned* fallback, hipStream_t stream) {
     hipError_t err = hipMemsetAsync(fallback, 0, sizeof(unsigned), stream);
     if (err != hipSuccess) return err;
     const unsigned blocks = (unsigned)((count + 255) / 256);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(strain_gather_kernel<DIM>, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, order,
-                       static_cast<StrainRec*>(recs));
-    hipLaunchKernelGGL(strain_fit_kernel<DIM>, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, g, P, start,
-                       static_cast<const StrainRec*>(recs), fallback);
+    hipLaunchKernelGGL((strain_fit_kernel<DIM, MODE>), dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, g, P,
+                       start, static_cast<const StrainRec*>(recs), fallback);
     // the KNN list is normally empty; the kernel sizes itself from the device-side counter
     const unsigned kblocks = (unsigned)((count + 63) / 64);
-    hipLaunchKernelGGL(strain_knn_kernel<DIM>, dim3(kblocks), dim3(64), 0, stream, pois, stride_f, g, P, start,
+    hipLaunchKernelGGL((strain_knn_kernel<DIM, MODE>), dim3(kblocks), dim3(64), 0, stream, pois, stride_f, g, P, start,
                        static_cast<const StrainRec*>(recs), fallback);
     return hipGetLastError();
 }
 
-// Strain::compute(poi_queue).  recs: count * 32 bytes; fallback: count + 1 unsigned
+// the cloud's fit records in cell order (Strain: at every compute; RegionFit: once at prepare).  recs: count * 32 bytes
+hipError_t launch_strain_gather(int ndim, const float* pois, int stride_f, size_t count, const unsigned* order, void* recs,
+                                hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    (void)hipGetLastError();
+    if (ndim == 2)
+        hipLaunchKernelGGL(strain_gather_kernel<2>, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, order,
+                           static_cast<StrainRec*>(recs));
+    else
+        hipLaunchKernelGGL(strain_gather_kernel<3>, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, order,
+                           static_cast<StrainRec*>(recs));
+    return hipGetLastError();
+}
+
+// Strain::compute(poi_queue): `pois` is the cloud itself.  fallback: count + 1 unsigned
 hipError_t launch_strain_compute(int ndim, float* pois, int stride_f, size_t count, const StrainGrid& g, const StrainParams& P,
                                  const unsigned* start, const unsigned* order, void* recs, unsigned* fallback,
                                  hipStream_t stream) {
     if (count == 0) return hipSuccess;
-    return ndim == 2 ? compute_t<2>(pois, stride_f, count, g, P, start, order, recs, fallback, stream)
-                     : compute_t<3>(pois, stride_f, count, g, P, start, order, recs, fallback, stream);
+    hipError_t err = launch_strain_gather(ndim, pois, stride_f, count, order, recs, stream);
+    if (err != hipSuccess) return err;
+    return ndim == 2 ? fit_t<2, 0>(pois, stride_f, count, g, P, start, recs, fallback, stream)
+                     : fit_t<3, 0>(pois, stride_f, count, g, P, start, recs, fallback, stream);
+}
+
+// RegionFit2D/3D::compute(poi_queue): `pois` are the POIs to initialise, `recs` the reliable cloud gathered at prepare
+hipError_t launch_region_fit_compute(int ndim, float* pois, int stride_f, size_t count, const StrainGrid& g,
+                                     const StrainParams& P, const unsigned* start, const void* recs, unsigned* fallback,
+                                     hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    return ndim == 2 ? fit_t<2, 1>(pois, stride_f, count, g, P, start, recs, fallback, stream)
+                     : fit_t<3, 1>(pois, stride_f, count, g, P, start, recs, fallback, stream);
 }
 
 }  // namespace ochip

@@ -338,6 +338,52 @@ class Strain:
         return ms.value, n.value
 
 
+class RegionFit:
+    """RegionFit2D / RegionFit3D(neighbor_search_radius, neighbor_number_min, thread_number) -- src/oc_region_fit.h.
+
+    ``set_neighbor(reliable)`` + ``prepare()`` build the neighbour search over the reliable POIs (their displacements
+    are snapshotted at ``prepare``); ``compute(pois)`` gives every POI of a second queue the plane fitted through the
+    reliable POIs around it as its deformation, with ``zncc = 0`` -- ready for another ICGN pass.  2D or 3D by the
+    record size of the queues."""
+
+    def __init__(self, neighbor_search_radius, neighbor_number_min, thread_number=1, device=0):
+        self._h = ctypes.c_void_p()
+        self.thread_number = thread_number
+        self._radius, self._nmin = float(neighbor_search_radius), int(neighbor_number_min)
+        self._reliable = None
+        capi.check(capi.lib().oc_hip_region_fit_create(self._radius, self._nmin, device, ctypes.byref(self._h)))
+
+    close = Strain.close
+    __del__ = Strain.__del__
+    set_stream = Strain.set_stream
+    synchronize = Strain.synchronize
+    profile_enable = Strain.profile_enable
+    profile_reset = Strain.profile_reset
+    profile_read = Strain.profile_read
+
+    def set_search_radius(self, neighbor_search_radius):
+        capi.check(capi.lib().oc_hip_region_fit_set(self._h, float(neighbor_search_radius), self._nmin))
+        self._radius = float(neighbor_search_radius)
+
+    def set_neighbor_min(self, neighbor_number_min):
+        capi.check(capi.lib().oc_hip_region_fit_set(self._h, self._radius, int(neighbor_number_min)))
+        self._nmin = int(neighbor_number_min)
+
+    def set_neighbor(self, reliable_pois):
+        self._reliable = reliable_pois
+
+    def prepare(self):
+        if self._reliable is None:
+            raise ValueError("RegionFit.prepare: call set_neighbor(reliable_pois) first")
+        p, n, stride, ndim, mem = Strain._queue(self._reliable)
+        capi.check(capi.lib().oc_hip_region_fit_prepare(self._h, p, n, stride, ndim, mem))
+
+    def compute(self, pois):
+        p, n, stride, ndim, mem = Strain._queue(pois)
+        capi.check(capi.lib().oc_hip_region_fit_compute(self._h, p, n, stride, ndim, mem))
+        return pois
+
+
 class FFTCC3D(_Engine):
     """FFTCC3D(rx, ry, rz, thread_number) -- src/oc_fftcc.h:75-89."""
     _ndim = 3

@@ -68,6 +68,10 @@ def lib():
         L.oc_oracle_strain2d.restype = None
         L.oc_oracle_strain3d.argtypes = [fp, l, i, f, i, f, i, i]
         L.oc_oracle_strain3d.restype = None
+        L.oc_oracle_region_fit2d.argtypes = [fp, l, i, fp, l, i, f, i, i]
+        L.oc_oracle_region_fit2d.restype = None
+        L.oc_oracle_region_fit3d.argtypes = [fp, l, i, fp, l, i, f, i, i]
+        L.oc_oracle_region_fit3d.restype = None
         L.oc_oracle_pow_lambda.argtypes = [f, f]
         L.oc_oracle_pow_lambda.restype = f
         L.oc_oracle_icgn2d1_ex.restype = None
@@ -227,6 +231,17 @@ def strain3d(pois, subregion_radius, neighbor_number_min, zncc_threshold=0.9, ap
     assert pois.dtype == np.float32 and pois.flags.c_contiguous and pois.shape[1] == POI3D_FLOATS
     lib().oc_oracle_strain3d(_fp(pois), pois.shape[0], POI3D_FLOATS, float(subregion_radius), int(neighbor_number_min),
                              float(zncc_threshold), int(approximation), threads)
+
+
+def region_fit(reliable, pois, neighbor_search_radius, neighbor_number_min, threads=0):
+    """RegionFit2D / RegionFit3D: setNeighbor(reliable); prepare(); compute(pois) (src/oc_region_fit.cpp), in place on
+    ``pois``.  Both arrays are (n, 25) POI2D or (n, 31) POI3D records."""
+    for a in (reliable, pois):
+        assert a.dtype == np.float32 and a.flags.c_contiguous and a.ndim == 2
+    assert reliable.shape[1] == pois.shape[1] and pois.shape[1] in (POI2D_FLOATS, POI3D_FLOATS)
+    fn = lib().oc_oracle_region_fit2d if pois.shape[1] == POI2D_FLOATS else lib().oc_oracle_region_fit3d
+    fn(_fp(reliable), reliable.shape[0], reliable.shape[1], _fp(pois), pois.shape[0], pois.shape[1], float(neighbor_search_radius),
+       int(neighbor_number_min), threads)
 
 
 class PreparedNR2D:

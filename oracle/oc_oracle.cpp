@@ -1135,13 +1135,25 @@ static void strain_solve(const double* S, const double* B, int nrhs, double* gra
         }
 }
 
+// mode 0: Strain -- the queries are the cloud itself (queries == pois, nq == n), POIs below the ZNCC threshold are
+//         neither computed nor used, the strain fields are written.
+// mode 1: RegionFit2D/3D::compute(poi_queue) (src/oc_region_fit.cpp:94-174, 251-342) -- the cloud is the queue of
+//         reliable POIs given to setNeighbor (:75-78), every cloud POI counts (no ZNCC filter), and the fitted plane
+//         itself becomes the query POI's deformation (u, ux, uy(, uz), v, ..., :153-159 / :314-327) with
+//         result.zncc reset to 0 (:162 / :330).  Same neighbour rule, KNN fallback and row order as Strain.
 template <int DIM>
-static void strain_queue(float* pois, long n, int stride, float radius, int nmin, float thr, int approximation, int threads) {
+static void strain_queue(float* pois, long n, int stride, float radius, int nmin, float thr, int approximation, int threads,
+                         int mode = 0, float* queries = nullptr, long nq = 0, int qstride = 0) {
     constexpr int D = DIM + 1;
     constexpr int ZNCC = DIM == 2 ? 16 : 18;
     constexpr int U = DIM == 2 ? 2 : 3, V = DIM == 2 ? 8 : 7, Wf = 11;
     constexpr int E0 = DIM == 2 ? 20 : 22;
-    if (n <= 0) return;
+    if (mode == 0) {
+        queries = pois;
+        nq = n;
+        qstride = stride;
+    }
+    if (n <= 0 || nq <= 0) return;
     // grid
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (long i = 0; i < n; i++)
@@ -1178,13 +1190,13 @@ static void strain_queue(float* pois, long n, int stride, float radius, int nmin
         for (long i = 0; i < n; i++) order[cur[cell[i]]++] = (int)i;  // ascending index inside a cell
     }
     const float r2 = radius * radius;
-    std::vector<float> out((size_t)n * 6, 0.f);
-    std::vector<char> wrote(n, 0);
+    std::vector<float> out((size_t)nq * 12, 0.f);
+    std::vector<char> wrote(nq, 0);
     const int nt = threads <= 0 ? omp_get_max_threads() : threads;
 #pragma omp parallel for num_threads(nt) schedule(dynamic, 64)
-    for (long i = 0; i < n; i++) {
-        const float* pi = pois + i * stride;
-        if (!(pi[ZNCC] >= thr)) continue;  // src/oc_strain.cpp:241 / :481
+    for (long i = 0; i < nq; i++) {
+        const float* pi = queries + i * qstride;
+        if (mode == 0 && !(pi[ZNCC] >= thr)) continue;  // src/oc_strain.cpp:241 / :481
         double S[D * D] = {0.0}, B[3 * D] = {0.0};
         int nfit = 0;
         auto add_row = [&](const float* pj) {
@@ -1208,7 +1220,8 @@ static void strain_queue(float* pois, long n, int stride, float radius, int nmin
         };
         // radius search
         int inside = 0;
-        const int cx = cell[i] % g.ncx, cy = (cell[i] / g.ncx) % g.ncy, cz = cell[i] / (g.ncx * g.ncy);
+        const int cx = strain_cell_axis(pi[0], g.x0, g.inv_pitch, g.ncx), cy = strain_cell_axis(pi[1], g.y0, g.inv_pitch, g.ncy);
+        const int cz = DIM == 3 ? strain_cell_axis(pi[2], g.z0, g.inv_pitch, g.ncz) : 0;
         for (int dz = (DIM == 3 ? -1 : 0); dz <= (DIM == 3 ? 1 : 0); dz++)
             for (int dy = -1; dy <= 1; dy++)
                 for (int dx = -1; dx <= 1; dx++) {
@@ -1219,7 +1232,7 @@ static void strain_queue(float* pois, long n, int stride, float radius, int nmin
                         const float* pj = pois + (long)order[k] * stride;
                         if (dist2(pj) < r2) {
                             inside++;
-                            if (pj[ZNCC] >= thr) add_row(pj);
+                            if (mode == 1 || pj[ZNCC] >= thr) add_row(pj);
                         }
                     }
                 }
@@ -1245,13 +1258,19 @@ static void strain_queue(float* pois, long n, int stride, float radius, int nmin
                 last_d = best_d;
                 last_j = best_j;
                 const float* pj = pois + best_j * stride;
-                if (pj[ZNCC] >= thr) add_row(pj);
+                if (mode == 1 || pj[ZNCC] >= thr) add_row(pj);
             }
         }
         if (nfit < nmin) continue;  // src/oc_strain.cpp:190
         double grad[3 * D];
         strain_solve<DIM>(S, B, DIM, grad);
-        float* e = out.data() + (size_t)i * 6;
+        float* e = out.data() + (size_t)i * 12;
+        if (mode == 1) {
+            for (int r = 0; r < DIM; r++)
+                for (int k = 0; k < D; k++) e[r * D + k] = (float)grad[r * D + k];
+            wrote[i] = 1;
+            continue;
+        }
         if (DIM == 2) {
             const float ux = (float)grad[1], uy = (float)grad[2], vx = (float)grad[D + 1], vy = (float)grad[D + 2];
             if (approximation == 1) {
@@ -1285,9 +1304,21 @@ static void strain_queue(float* pois, long n, int stride, float radius, int nmin
         }
     }
     // the strain fields are the only thing written, and only for POIs that were fitted (everything else untouched)
-    for (long i = 0; i < n; i++)
-        if (wrote[i])
-            for (int k = 0; k < (DIM == 2 ? 3 : 6); k++) pois[i * stride + E0 + k] = out[(size_t)i * 6 + k];
+    for (long i = 0; i < nq; i++) {
+        if (!wrote[i]) continue;
+        float* q = queries + i * qstride;
+        const float* e = out.data() + (size_t)i * 12;
+        if (mode == 0) {
+            for (int k = 0; k < (DIM == 2 ? 3 : 6); k++) q[E0 + k] = e[k];
+        } else if (DIM == 2) {
+            q[2] = e[0]; q[3] = e[1]; q[4] = e[2];  // u ux uy
+            q[8] = e[3]; q[9] = e[4]; q[10] = e[5];  // v vx vy
+            q[ZNCC] = 0.f;
+        } else {
+            for (int k = 0; k < 12; k++) q[3 + k] = e[k];  // u ux uy uz v vx vy vz w wx wy wz
+            q[ZNCC] = 0.f;
+        }
+    }
 }
 
 static int resolve_threads(int threads) {
@@ -1530,6 +1561,18 @@ void oc_oracle_strain2d(float* pois, long n, int stride_floats, float subregion_
 void oc_oracle_strain3d(float* pois, long n, int stride_floats, float subregion_radius, int neighbor_number_min,
                         float zncc_threshold, int approximation, int threads) {
     strain_queue<3>(pois, n, stride_floats, subregion_radius, neighbor_number_min, zncc_threshold, approximation, threads);
+}
+
+void oc_oracle_region_fit2d(const float* reliable, long n_reliable, int reliable_stride, float* pois, long n, int stride_floats,
+                            float neighbor_search_radius, int neighbor_number_min, int threads) {
+    strain_queue<2>(const_cast<float*>(reliable), n_reliable, reliable_stride, neighbor_search_radius, neighbor_number_min, 0.f, 1,
+                    threads, 1, pois, n, stride_floats);
+}
+
+void oc_oracle_region_fit3d(const float* reliable, long n_reliable, int reliable_stride, float* pois, long n, int stride_floats,
+                            float neighbor_search_radius, int neighbor_number_min, int threads) {
+    strain_queue<3>(const_cast<float*>(reliable), n_reliable, reliable_stride, neighbor_search_radius, neighbor_number_min, 0.f, 1,
+                    threads, 1, pois, n, stride_floats);
 }
 
 float oc_oracle_pow_lambda(float lambda, float q) { return pow_lambda(std::log((double)lambda), q); }

@@ -104,6 +104,15 @@ void oc_oracle_strain2d(float* pois, long n, int stride_floats, float subregion_
 void oc_oracle_strain3d(float* pois, long n, int stride_floats, float subregion_radius, int neighbor_number_min,
                         float zncc_threshold, int approximation, int threads);
 
+/* RegionFit2D::compute(poi_queue) (src/oc_region_fit.cpp:94-174) / RegionFit3D::compute (:251-342) after
+ * setNeighbor(reliable) + prepare(): every POI of `pois` gets the plane fitted through the reliable POIs around it as
+ * its deformation (2D: u ux uy v vx vy; 3D: all twelve) and result.zncc = 0; POIs without enough neighbours are left
+ * untouched.  Same neighbour rule, KNN fallback, row order and double-precision solve as oc_oracle_strain*. */
+void oc_oracle_region_fit2d(const float* reliable, long n_reliable, int reliable_stride, float* pois, long n, int stride_floats,
+                            float neighbor_search_radius, int neighbor_number_min, int threads);
+void oc_oracle_region_fit3d(const float* reliable, long n_reliable, int reliable_stride, float* pois, long n, int stride_floats,
+                            float neighbor_search_radius, int neighbor_number_min, int threads);
+
 /* src/oc_gradient.cpp:143-231 */
 void oc_oracle_gradient3d(const float* vol, int dz, int dy, int dx, float* gx, float* gy, float* gz, int threads);
 /* src/oc_cubic_bspline.cpp:214-351 */

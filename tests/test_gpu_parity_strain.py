@@ -127,3 +127,83 @@ def test_strain_errors_and_lifecycle():
         eng.Strain(-1.0, 5)
     st.prepare(p[:0])  # empty queue is a no-op
     st.compute(p[:0])
+
+
+# ---- RegionFit2D / RegionFit3D --------------------------------------------------------------------------------------
+def test_region_fit2d_bit_exact_including_knn_and_outside_queries():
+    import opencorr_amd as eng
+    import oracle
+    from test_oracle_strain import affine_queue_2d
+    P = oracle.P2
+    cloud, _ = affine_queue_2d(n=15000, seed=31, extent=800.0)
+    rng = np.random.default_rng(12)
+    cloud[:, P["u"]] += rng.normal(0, 0.02, len(cloud)).astype(np.float32)
+    # a hole in the cloud (the unreliable region) -> queries there take the KNN path
+    hole = (np.abs(cloud[:, 0] - 400) < 60) & (np.abs(cloud[:, 1] - 300) < 60)
+    cloud = np.ascontiguousarray(cloud[~hole])
+    qx = np.concatenate([rng.random(4000) * 800, 340 + rng.random(500) * 120, [-500.0, 5000.0]]).astype(np.float32)
+    qy = np.concatenate([rng.random(4000) * 560, 240 + rng.random(500) * 120, [100.0, -900.0]]).astype(np.float32)
+    q = oracle.make_pois2d(qx, qy)
+    q[:, P["zncc"]] = -4.0
+    q[:, P["uxx"]] = 5.0
+    want = q.copy()
+    oracle.region_fit(cloud, want, 14.0, 7)
+    rf = eng.RegionFit(14.0, 7)
+    rf.set_neighbor(cloud)
+    rf.prepare()
+    got = rf.compute(q.copy())
+    assert np.array_equal(_bits(got), _bits(want))
+    assert (got[:, P["zncc"]] == 0).all() and (got[:, P["uxx"]] == 5.0).all()
+
+
+def test_region_fit3d_bit_exact_and_device_queues():
+    import torch
+    import opencorr_amd as eng
+    import oracle
+    from test_oracle_strain import affine_queue_3d
+    P = oracle.P3
+    cloud, _ = affine_queue_3d(n=9000, seed=17, extent=150.0)
+    rng = np.random.default_rng(5)
+    xyz = (rng.random((2500, 3)) * 170 - 10).astype(np.float32)  # some outside the cloud's bounding box
+    q = oracle.make_pois3d(xyz[:, 0], xyz[:, 1], xyz[:, 2])
+    want = q.copy()
+    oracle.region_fit(cloud, want, 16.0, 9)
+    rf = eng.RegionFit(16.0, 9)
+    dc, dq = torch.from_numpy(cloud).cuda(), torch.from_numpy(q.copy()).cuda()
+    rf.set_stream(torch.cuda.current_stream().cuda_stream)
+    rf.set_neighbor(dc)
+    rf.prepare()
+    rf.compute(dq)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(dq.cpu().numpy()), _bits(want))
+
+
+def test_region_fit_then_icgn_recovers_bad_initial_guesses(speckle_small):
+    """The loop of examples/test_3d_reconstruction_sift_icgn2_regfit.cpp:225-245: POIs that failed are re-initialised
+    from their reliable neighbours and refined again."""
+    import opencorr_amd as eng
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    P = oracle.P2
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 30, 26, 30)
+    fftcc = eng.FFTCC2D(16, 16)
+    fftcc.set_images(ref, tar)
+    pois = eng.make_pois2d(xs, ys)
+    fftcc.compute(pois)
+    rng = np.random.default_rng(9)
+    spoiled = rng.random(len(pois)) < 0.2
+    pois[spoiled, P["u"]] += 9.0  # a guess far outside the convergence radius
+    icgn = eng.ICGN2D1(16, 16, 0.001, 10)
+    icgn.share_images(fftcc)
+    icgn.prepare()
+    icgn.compute(pois)
+    good = pois[:, P["zncc"]] > 0.9
+    assert (~good).sum() >= 0.5 * spoiled.sum()
+    reliable, unreliable = np.ascontiguousarray(pois[good]), np.ascontiguousarray(pois[~good])
+    rf = eng.RegionFit(40.0, 6)
+    rf.set_neighbor(reliable)
+    rf.prepare()
+    rf.compute(unreliable)
+    icgn.compute(unreliable)
+    assert (unreliable[:, P["zncc"]] > 0.9).mean() > 0.95

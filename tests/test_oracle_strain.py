@@ -134,3 +134,47 @@ def test_strain3d_recovers_an_affine_field(approximation):
     for k, w in want.items():
         assert np.abs(p[ok][fitted, P3[k]] - w).max() <= 3e-6, k
     assert not p[bad][:, P3["exx"]:P3["ezx"] + 1].any()
+
+
+# ---- RegionFit2D / RegionFit3D (src/oc_region_fit.cpp): the same plane fit, evaluated for POIs of a second queue ----
+def test_region_fit2d_transfers_an_affine_field_to_new_pois():
+    cloud, g = affine_queue_2d(n=3000, seed=21)
+    rng = np.random.default_rng(8)
+    qx, qy = (rng.random(500) * 380 + 10).astype(np.float32), (rng.random(500) * 260 + 10).astype(np.float32)
+    q = oracle.make_pois2d(qx, qy)
+    q[:, P2["zncc"]] = -4.0  # the unreliable POIs being re-initialised (examples/test_3d_reconstruction_sift_icgn2_regfit.cpp:233-239)
+    q[:, P2["uxx"]] = 9.0    # not part of the fit: must survive
+    oracle.region_fit(cloud, q, 20.0, 7)
+    x, y = qx.astype(np.float64), qy.astype(np.float64)
+    assert np.abs(q[:, P2["u"]] - (1.5 + g["ux"] * x + g["uy"] * y)).max() <= 2e-5
+    assert np.abs(q[:, P2["v"]] - (-0.5 + g["vx"] * x + g["vy"] * y)).max() <= 2e-5
+    for k in ("ux", "uy", "vx", "vy"):
+        assert np.abs(q[:, P2[k]] - g[k]).max() <= 2e-6
+    assert (q[:, P2["zncc"]] == 0).all() and (q[:, P2["uxx"]] == 9.0).all()
+
+
+def test_region_fit2d_knn_fallback_and_small_clouds():
+    cloud, g = affine_queue_2d(n=40, seed=2, extent=1000.0)  # ~1 POI per 150 px
+    q = oracle.make_pois2d(np.array([100.0, 5000.0], dtype=np.float32), np.array([100.0, 300.0], dtype=np.float32))
+    q[:, P2["zncc"]] = 0.5
+    a = q.copy()
+    oracle.region_fit(cloud, a, 10.0, 6)  # nobody inside 10 px: the 6 nearest are used, also far outside the cloud
+    assert (a[:, P2["zncc"]] == 0).all()
+    assert np.abs(a[:, P2["ux"]] - g["ux"]).max() <= 1e-5 and np.abs(a[:, P2["vy"]] - g["vy"]).max() <= 1e-5
+    b = q.copy()
+    oracle.region_fit(cloud[:4], b, 10.0, 6)  # fewer reliable POIs than required: untouched
+    assert np.array_equal(b, q)
+
+
+def test_region_fit3d_transfers_an_affine_field():
+    cloud, G = affine_queue_3d(n=4000, seed=13)
+    rng = np.random.default_rng(3)
+    xyz = (rng.random((300, 3)) * 100 + 10).astype(np.float32)
+    q = oracle.make_pois3d(xyz[:, 0], xyz[:, 1], xyz[:, 2])
+    oracle.region_fit(cloud, q, 18.0, 10)
+    x = xyz.astype(np.float64)
+    for r, k in enumerate(("u", "v", "w")):
+        assert np.abs(q[:, P3[k]] - (0.3 * (r + 1) + x @ G[r])).max() <= 3e-5
+        for c, ax in enumerate("xyz"):
+            assert np.abs(q[:, P3[k + ax]] - G[r, c]).max() <= 3e-6
+    assert (q[:, P3["zncc"]] == 0).all()
