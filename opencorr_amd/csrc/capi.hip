@@ -130,7 +130,7 @@ struct oc_hip_engine {
     bool ref_ready = false, tar_ready = false;
     DevBuf poi_stage, off_stage;
     DevBuf cursors;  // small device scratch (batch maxima)
-    DevBuf perm, tiles;  // locality schedule of the ICGN2D queue (poi_order.hip)
+    DevBuf perm, tiles, perm_slots;  // locality schedule of the ICGN2D queue (poi_order.hip)
     // Strain (src/oc_strain.cpp:31-46: radius, min neighbours; ZNCC threshold 0.9, Cauchy approximation)
     float st_radius = 0.f, st_zncc = 0.9f;
     int st_nmin = 0, st_approx = 1, st_ndim = 0;
@@ -377,8 +377,9 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
         if (e->icgn2d_tile_px > 0 && n >= 16384) {
             OC_TRY(e->perm.reserve(n * sizeof(unsigned)));
             OC_TRY(e->tiles.reserve(ochip::poi2d_tile_count(im.dy, im.dx, e->icgn2d_tile_px) * sizeof(unsigned)));
+            OC_TRY(e->perm_slots.reserve(n * sizeof(unsigned)));
             OC_HIP_TRY(ochip::launch_poi2d_tile_order(pois, stride_f, n, im.dy, im.dx, e->icgn2d_tile_px, e->tiles.as<unsigned>(),
-                                                      e->perm.as<unsigned>(), e->stream));
+                                                      e->perm_slots.as<unsigned>(), e->perm.as<unsigned>(), e->stream));
             P.perm = e->perm.as<unsigned>();
         }
         ProfScope prof(e);  // the solver kernel alone (what rocprofv3 reports for it)

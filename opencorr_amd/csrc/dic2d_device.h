@@ -125,6 +125,39 @@ struct SampleWalk {
     }
 };
 
+// Two floats that travel through the packed-fp32 pipe (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per issue
+// slot, each rounded on its own, so results are those of the scalar instructions).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) {
+    f2 r = {a, b};
+    return r;
+}
+
+// SampleWalk for the engines whose local coordinates are integers (no centre offset): the lane's sample as the
+// float pair (x_local, y_local) -- small integers, so every step is exact -- plus its byte offset from the subset
+// origin in a row-major float image.  One wrap test serves both.
+struct FloatWalk {
+    f2 xy;
+    unsigned off;
+    f2 step, wstep;
+    unsigned offs, offw;
+    float xmax;
+    __device__ __forceinline__ FloatWalk(int r0, int c0, int rx, int ry, int W, int q64, int r64, unsigned row_bytes)
+        : xy(mk2((float)(c0 - rx), (float)(r0 - ry))),
+          off((unsigned)r0 * row_bytes + ((unsigned)c0 << 2)),
+          step(mk2((float)r64, (float)q64)),
+          wstep(mk2((float)(r64 - W), (float)(q64 + 1))),
+          offs((unsigned)q64 * row_bytes + ((unsigned)r64 << 2)),
+          offw((unsigned)(q64 + 1) * row_bytes + ((unsigned)r64 << 2) - ((unsigned)W << 2)),
+          xmax((float)rx) {}
+    __device__ __forceinline__ void next() {
+        const f2 a = xy + step, b = xy + wstep;
+        const bool wrap = a.x > xmax;  // column index ran past the subset width
+        xy = wrap ? b : a;
+        off += wrap ? offw : offs;
+    }
+};
+
 // One LUT entry in flight: address generation and the four 16-byte loads are issued for a
 // whole group of G samples before any polynomial is evaluated, so each lane keeps G*64 B
 // of gathers outstanding (the interpolation sweep is latency/L1-bandwidth bound).  Only the
@@ -171,28 +204,57 @@ __device__ __forceinline__ void lut_fetch(LutFetch& f, __amdgpu_buffer_rsrc_t lu
     f.c3 = buf_f32x4(lut, e + 48);
 }
 
+// the same with the point as a packed pair (x, y): the fractional offsets come out of one packed subtraction
+__device__ __forceinline__ void lut_fetch(LutFetch& f, __amdgpu_buffer_rsrc_t lut, int height, int width, f2 p) {
+    const f2 fl = mk2(floorf(p.x), floorf(p.y));
+    const int xi = (int)__builtin_amdgcn_fmed3f(fl.x, -2.f, 2.0e9f), yi = (int)__builtin_amdgcn_fmed3f(fl.y, -2.f, 2.0e9f);
+    const bool out = (unsigned)(xi - 1) > (unsigned)(width - 4) || (unsigned)(yi - 1) > (unsigned)(height - 4);
+    const f2 fr = p - fl;
+    f.dx = fr.x;
+    f.dy = out ? -1.f : fr.y;
+    const unsigned e = out ? 0u : (__umul24((unsigned)yi, (unsigned)width) + (unsigned)xi) << 6;
+    f.c0 = buf_f32x4(lut, e);
+    f.c1 = buf_f32x4(lut, e + 16);
+    f.c2 = buf_f32x4(lut, e + 32);
+    f.c3 = buf_f32x4(lut, e + 48);
+}
+
 // explicit 16-term left-to-right polynomial of src/oc_cubic_bspline.cpp:144-177
-__device__ __forceinline__ float lut_eval(const LutFetch& f) {
+// The 28 multiplications are independent and are issued in pairs: a 16-byte load leaves (c_k0, c_k1) and (c_k2, c_k3)
+// in adjacent registers, so row k costs  (c_k0, c_k1) * dy^k,  ((c_k2, c_k3) * dy^k) * (dx^2, dx^3)  and one scalar
+// (c_k1 dy^k) * dx -- every product is the one the reference forms, in its order ((c * dy^k) * dx^l); the 15
+// additions stay a left-to-right chain.
+__device__ __forceinline__ float lut_poly(const LutFetch& f) {
     const float dx = f.dx, dy = f.dy;
-    const float dx2 = dx * dx, dy2 = dy * dy;
-    const float dx3 = dx2 * dx, dy3 = dy2 * dy;
+    const f2 d1 = mk2(dx, dy);
+    const f2 d2 = d1 * d1;  // (dx^2, dy^2)
+    const f2 d3 = d2 * d1;  // (dx^3, dy^3)
+    const f2 xh = mk2(d2.x, d3.x);
+    const f2 r0 = mk2(f.c0.z, f.c0.w) * xh;
     float v = f.c0.x;
     v = v + f.c0.y * dx;
-    v = v + f.c0.z * dx2;
-    v = v + f.c0.w * dx3;
-    v = v + f.c1.x * dy;
-    v = v + f.c1.y * dy * dx;
-    v = v + f.c1.z * dy * dx2;
-    v = v + f.c1.w * dy * dx3;
-    v = v + f.c2.x * dy2;
-    v = v + f.c2.y * dy2 * dx;
-    v = v + f.c2.z * dy2 * dx2;
-    v = v + f.c2.w * dy2 * dx3;
-    v = v + f.c3.x * dy3;
-    v = v + f.c3.y * dy3 * dx;
-    v = v + f.c3.z * dy3 * dx2;
-    v = v + f.c3.w * dy3 * dx3;
-    return dy < 0.f ? -1.f : v;
+    v = v + r0.x;
+    v = v + r0.y;
+    const f2 l1 = mk2(f.c1.x, f.c1.y) * dy, h1 = (mk2(f.c1.z, f.c1.w) * dy) * xh;
+    v = v + l1.x;
+    v = v + l1.y * dx;
+    v = v + h1.x;
+    v = v + h1.y;
+    const f2 l2 = mk2(f.c2.x, f.c2.y) * d2.y, h2 = (mk2(f.c2.z, f.c2.w) * d2.y) * xh;
+    v = v + l2.x;
+    v = v + l2.y * dx;
+    v = v + h2.x;
+    v = v + h2.y;
+    const f2 l3 = mk2(f.c3.x, f.c3.y) * d3.y, h3 = (mk2(f.c3.z, f.c3.w) * d3.y) * xh;
+    v = v + l3.x;
+    v = v + l3.y * dx;
+    v = v + h3.x;
+    v = v + h3.y;
+    return v;
+}
+__device__ __forceinline__ float lut_eval(const LutFetch& f) {
+    const float v = lut_poly(f);
+    return f.dy < 0.f ? -1.f : v;
 }
 
 // Deformation2D2::setWarp, src/oc_deformation.cpp:301-350; q = u ux uy uxx uxy uyy v vx vy vxx vxy vyy
@@ -252,11 +314,6 @@ __device__ __forceinline__ float pow_lambda(double log_lambda, float q) {
     return (float)ldexp(e, (int)kf);
 }
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 mk2(float a, float b) {
-    f2 r = {a, b};
-    return r;
-}
 
 // steepest-descent row of one sample (src/oc_icgn.cpp:191-196; 2D2: 725-745; center-offset
 // overloads :390-398 / :953-972).  The local coordinates arrive as floats: without a centre

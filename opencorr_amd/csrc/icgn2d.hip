@@ -302,9 +302,11 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     const float xl = (float)(w.c - rx) - offx, yl = (float)(w.r - ry) - offy;
                     float wx, wy;
                     if constexpr (DOF == 6) {
-                        // Deformation2D1::warp, src/oc_deformation.cpp:94-105
-                        wx = (Wm[0] * xl + Wm[1] * yl) + Wm[2] * 1.f;
-                        wy = (Wm[3] * xl + Wm[4] * yl) + Wm[5] * 1.f;
+                        // Deformation2D1::warp, src/oc_deformation.cpp:94-105: (W0 x + W1 y) + W2 * 1 for both rows at
+                        // once on the packed pipe (the product with 1.f is exact and dropped)
+                        const f2 wv = (mk2(Wm[0], Wm[3]) * xl + mk2(Wm[1], Wm[4]) * yl) + mk2(Wm[2], Wm[5]);
+                        wx = wv.x;
+                        wy = wv.y;
                     } else {
                         // Deformation2D2::warp, src/oc_deformation.cpp:268-282: rows 3, 4 of W * [x^2 xy y^2 x y 1]
                         const float pv[6] = {xl * xl, xl * yl, yl * yl, xl, yl, 1.f};
@@ -318,7 +320,8 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     }
                     // a lane past the end of the subset fetches a harmless in-range point
                     // tar_subset->center = POI + center_offset, then + warped_coor (src/oc_icgn.cpp:425-426,452)
-                    lut_fetch(f[g], r_lut, height, width, valid[g] ? tcx + wx : 1.f, valid[g] ? tcy + wy : 1.f);
+                    const f2 at = mk2(tcx, tcy) + mk2(wx, wy);
+                    lut_fetch(f[g], r_lut, height, width, valid[g] ? at : mk2(1.f, 1.f));
                 }
             };
             auto consume = [&](const LutFetch(&f)[G], const bool(&valid)[G], int t0) {
@@ -380,6 +383,8 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         float ssd = 0.f;
         {
             SampleWalk w(lane, r0, c0, W, q64, r64);
+            FloatWalk fw(r0, c0, rx, ry, W, q64, r64, w4);  // DOF 6 without centre offsets
+            constexpr bool kFloatWalk = DOF == 6 && !OFFS;
             f2 nA = mk2(0.f, 0.f), nB = nA;  // DOF 6: (num1, num2) and (num4, num5) as packed pairs
             auto sample = [&](int t, bool valid) {
                 float g_x, g_y;
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     g_x = l_gx[t * kWave];
                     g_y = l_gy[t * kWave];
                 } else {
-                    const unsigned off = soff(w);
+                    const unsigned off = kFloatWalk ? fw.off : soff(w);
                     g_x = valid ? buf_f32(r_gx, off, goff) : 0.f;
                     g_y = valid ? buf_f32(r_gy, off, goff) : 0.f;
                 }
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 const float e2 = e * e;
                 ssd = valid ? ssd + e2 : ssd;
                 if constexpr (DOF == 6) {
-                    const f2 xy = mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
+                    const f2 xy = kFloatWalk ? fw.xy : mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
                     const f2 A = g_x * xy, B = g_y * xy;  // (sd1, sd2), (sd4, sd5)
                     const f2 mA = nA + A * e, mB = nB + B * e;
                     const float m0 = num[0] + g_x * e, m3 = num[3] + g_y * e;
@@ -413,9 +418,15 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     }
                 }
             };
+            if constexpr (kFloatWalk) {
 #pragma unroll 3
-            for (int t = 0; t < NF; t++, w.next()) sample(t, true);
-            if (NF < NT) sample(NF, w.s < N);
+                for (int t = 0; t < NF; t++, fw.next()) sample(t, true);
+                if (NF < NT) sample(NF, (NF * kWave + lane) < N);
+            } else {
+#pragma unroll 3
+                for (int t = 0; t < NF; t++, w.next()) sample(t, true);
+                if (NF < NT) sample(NF, w.s < N);
+            }
             if constexpr (DOF == 6) {
                 num[1] = nA.x; num[2] = nA.y; num[4] = nB.x; num[5] = nB.y;
             }

@@ -47,11 +47,11 @@ int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int
 int icgn2d_max_samples(int variant);
 
 // ---- poi_order.hip ---------------------------------------------------------
-// locality schedule: perm[k] = index of the k-th POI to visit (tile by tile); tiles = scratch of
-// poi2d_tile_count(height, width, tile_px) unsigned ints
+// locality schedule: perm[k] = index of the k-th POI to visit (tile by tile, queue order inside a tile); tiles =
+// scratch of poi2d_tile_count(height, width, tile_px) unsigned ints, slots = scratch of `count` unsigned ints
 size_t poi2d_tile_count(int height, int width, int tile_px);
 hipError_t launch_poi2d_tile_order(const float* pois, int stride_floats, size_t count, int height, int width, int tile_px,
-                                   unsigned* tiles, unsigned* perm, hipStream_t stream);
+                                   unsigned* tiles, unsigned* slots, unsigned* perm, hipStream_t stream);
 
 // ---- strain.hip -------------------------------------------------------------
 // Strain::prepare / Strain::compute (src/oc_strain.cpp): uniform grid over the queue's coordinates

@@ -7,7 +7,9 @@
 // row-major order, any order inside a tile) keeps the footprint of the POIs in flight near 2 MB.
 // Every POI is computed exactly as before -- only the order of the independent per-POI solves changes.
 //
-// Counting sort in three small kernels: histogram of tile ids, exclusive scan (one workgroup), scatter.
+// Counting sort in small kernels: histogram of tile ids, exclusive scan (one workgroup), scatter, and a rank pass
+// that orders the POIs of a tile by queue index (so the schedule does not depend on the atomics' timing, and the
+// waves of a workgroup get neighbouring POIs of a row-major queue).
 #include "oc_device.h"
 #include "oc_kernels.h"
 
@@ -64,15 +66,35 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(const float* __restri
     perm[slot] = i;
 }
 
+// counts[] holds the END of every tile after the scatter; order the indices inside each tile ascending
+__global__ __launch_bounds__(256) void tile_rank_kernel(const float* __restrict__ pois, int stride_f, unsigned count,
+                                                        int height, int width, int tile_px, int ntx,
+                                                        const unsigned* __restrict__ ends, const unsigned* __restrict__ slots,
+                                                        unsigned* __restrict__ perm) {
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const unsigned i = slots[k];
+    const unsigned t = tile_of(pois + (size_t)i * stride_f, height, width, tile_px, ntx);
+    const unsigned s = t ? ends[t - 1] : 0u, e = ends[t];
+    if (e - s > 4096u) {  // a pathologically crowded tile: keep the scatter's order (the whole tile takes this branch)
+        perm[k] = i;
+        return;
+    }
+    unsigned r = 0;
+    for (unsigned q = s; q < e; q++) r += slots[q] < i ? 1u : 0u;
+    perm[s + r] = i;
+}
+
 }  // namespace
 
 size_t poi2d_tile_count(int height, int width, int tile_px) {
     return (size_t)((width + tile_px - 1) / tile_px) * (size_t)((height + tile_px - 1) / tile_px);
 }
 
-// perm[k] = index of the k-th POI to visit.  `tiles` is scratch for poi2d_tile_count() unsigned ints.
+// perm[k] = index of the k-th POI to visit.  `tiles` is scratch for poi2d_tile_count() unsigned ints, `slots` for
+// `count` unsigned ints.
 hipError_t launch_poi2d_tile_order(const float* pois, int stride_f, size_t count, int height, int width, int tile_px,
-                                   unsigned* tiles, unsigned* perm, hipStream_t stream) {
+                                   unsigned* tiles, unsigned* slots, unsigned* perm, hipStream_t stream) {
     if (count == 0) return hipSuccess;
     if (count > 0xffffffffull) return hipErrorInvalidValue;
     const int ntx = (width + tile_px - 1) / tile_px;
@@ -85,7 +107,9 @@ hipError_t launch_poi2d_tile_order(const float* pois, int stride_f, size_t count
                        tile_px, ntx, tiles);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, tiles, ntiles);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, height, width,
-                       tile_px, ntx, tiles, perm);
+                       tile_px, ntx, tiles, slots);
+    hipLaunchKernelGGL(tile_rank_kernel, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, height, width, tile_px,
+                       ntx, tiles, slots, perm);
     return hipGetLastError();
 }
 
