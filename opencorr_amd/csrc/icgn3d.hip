@@ -259,6 +259,7 @@ __device__ __forceinline__ void hessian_rows(const Icgn3dParams& P, int tid, int
 #pragma unroll
     for (int i = 0; i < NE; i++) h[i] = 0.f;
     Walk3 w(tid, SX, SY);
+#pragma unroll 4
     for (; w.s < N; w.next()) {
         const int xl = w.k - rx, yl = w.j - ry, zl = w.i - rz;
         const size_t g = ((size_t)(cz + zl) * DY + (cy + yl)) * DX + (cx + xl);
@@ -338,12 +339,14 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
         {
             float acc[1] = {0.f};
             Walk3 w(tid, SX, SY);
+#pragma unroll 8
             for (; w.s < N; w.next())
                 acc[0] += P.ref[((size_t)(int)(szf + w.i) * DY + (int)(syf + w.j)) * DX + (int)(sxf + w.k)];
             block_allreduce<1>(acc, red, wave, lane);
             ref_mean = acc[0] / fN;
             acc[0] = 0.f;
             Walk3 w2(tid, SX, SY);
+#pragma unroll 8
             for (; w2.s < N; w2.next()) {
                 const float d = P.ref[((size_t)(int)(szf + w2.i) * DY + (int)(syf + w2.j)) * DX + (int)(sxf + w2.k)] - ref_mean;
                 acc[0] += d * d;
@@ -456,14 +459,42 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
                             const int rows = n[1] * n[2];
                             int zr = wave / n[1], yr = wave - zr * n[1];
                             const int dzr = kWaves3d / n[1], dyr = kWaves3d - dzr * n[1];
-                            for (int row = wave; row < rows; row += kWaves3d) {
-                                const float* __restrict__ src = P.coef + ((size_t)(o[2] + zr) * DY + (o[1] + yr)) * DX + o[0];
-                                for (int x = lane; x < nx; x += kWave) win[row * nx + x] = src[x];
-                                yr += dyr;
-                                zr += dzr;
-                                if (yr >= n[1]) {
-                                    yr -= n[1];
-                                    zr++;
+                            if (nx <= kWave) {
+                                // a row fits one wave-wide load: fetch kStageRows rows before the first LDS write, so
+                                // that their latencies overlap (one row at a time left the wave waiting ~30 times per
+                                // pass); (zr, yr) are wave-uniform and advance on the scalar unit
+                                constexpr int kStageRows = 8;
+                                for (int row0 = wave; row0 < rows; row0 += kStageRows * kWaves3d) {
+                                    float v[kStageRows];
+#pragma unroll
+                                    for (int u = 0; u < kStageRows; u++) {
+                                        const int row = row0 + u * kWaves3d;
+                                        v[u] = 0.f;
+                                        if (row < rows && lane < nx)
+                                            v[u] = P.coef[((size_t)(o[2] + zr) * DY + (o[1] + yr)) * DX + o[0] + lane];
+                                        yr += dyr;
+                                        zr += dzr;
+                                        if (yr >= n[1]) {
+                                            yr -= n[1];
+                                            zr++;
+                                        }
+                                    }
+#pragma unroll
+                                    for (int u = 0; u < kStageRows; u++) {
+                                        const int row = row0 + u * kWaves3d;
+                                        if (row < rows && lane < nx) win[row * nx + lane] = v[u];
+                                    }
+                                }
+                            } else {
+                                for (int row = wave; row < rows; row += kWaves3d) {
+                                    const float* __restrict__ src = P.coef + ((size_t)(o[2] + zr) * DY + (o[1] + yr)) * DX + o[0];
+                                    for (int x = lane; x < nx; x += kWave) win[row * nx + x] = src[x];
+                                    yr += dyr;
+                                    zr += dzr;
+                                    if (yr >= n[1]) {
+                                        yr -= n[1];
+                                        zr++;
+                                    }
                                 }
                             }
                             __syncthreads();
@@ -490,6 +521,7 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
             block_allreduce<1>(acc, red, wave, lane);
             const float tmean = acc[0] / fN;
             acc[0] = 0.f;
+#pragma unroll 8
             for (int s = tid; s < N; s += kBlock3d) {
                 const float d = ts[s] - tmean;
                 acc[0] += d * d;
@@ -503,6 +535,7 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
             for (int i = 0; i < 13; i++) num[i] = 0.f;
             {
                 Walk3 w(tid, SX, SY);
+#pragma unroll 4
                 for (; w.s < N; w.next()) {
                     const int xl = w.k - rx, yl = w.j - ry, zl = w.i - rz;
                     const float rsv = P.ref[((size_t)(int)(szf + w.i) * DY + (int)(syf + w.j)) * DX + (int)(sxf + w.k)] - ref_mean;
