@@ -147,6 +147,7 @@ struct oc_hip_engine {
     bool self_adaptive = false;  // DIC::setSelfAdaptive
     int icgn2d_xcd = 1;
     int fftcc2d_fused = 1;    // single-kernel FFTCC2D when the window is 32 x 32
+    int fftcc3d_fused = 1;    // single-kernel FFTCC3D when the window is 32 x 32 x 32
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -436,6 +437,18 @@ size_t fftcc3d_chunk_limit() {
 int run_fftcc3d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     if (!e->img || e->img->ndim != 3) return fail(OC_HIP_ERR_INVALID, "FFTCC3D: set_images3d has not been called");
     const ImagePair& im = *e->img;
+    if (e->fftcc3d_fused && ochip::fftcc3d_fused_supported(e->rx, e->ry, e->rz)) {
+        ochip::Fftcc3dParams P = {im.ref_ptr(), im.tar_ptr(), im.dz, im.dy, im.dx, e->rx, e->ry, e->rz};
+        ProfScope prof(e);
+        const size_t kMaxGrid = 1u << 30;
+        for (size_t first = 0; first < count; first += kMaxGrid) {
+            const size_t n = (count - first) < kMaxGrid ? (count - first) : kMaxGrid;
+            hipError_t err = ochip::launch_fftcc3d_fused(P, d_pois + first * (size_t)stride_f, stride_f, n, e->icgn2d_xcd != 0,
+                                                         e->stream);
+            if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "fused FFTCC3D kernel launch failed: %s", hipGetErrorString(err));
+        }
+        return OC_HIP_OK;
+    }
     const size_t chunk = count < fftcc3d_chunk_limit() ? count : fftcc3d_chunk_limit();
     if (chunk == 0) return OC_HIP_OK;
     OC_TRY(ensure_fft(e, chunk));
@@ -886,6 +899,8 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
         e->icgn2d_tile_px = value;
     } else if (k == "fftcc2d_fused") {
         e->fftcc2d_fused = value != 0;
+    } else if (k == "fftcc3d_fused") {
+        e->fftcc3d_fused = value != 0;
     } else {
         return fail(OC_HIP_ERR_INVALID, "unknown tuning key '%s'", key);
     }

@@ -17,59 +17,19 @@
 // FFTW's in the last bits like any other FFT implementation (tested to 1e-5 against the
 // oracle's double-precision DFT).
 #include "dic2d_device.h"
+#include "fft_device.h"
 #include "oc_kernels.h"
 
 namespace ochip {
 
 namespace {
 
+using namespace fftdev;
+
 constexpr int FN = 32;               // window side (2 * radius)
 constexpr int FP = FN + 1;           // LDS row pitch in complex elements
 constexpr int FWAVE_LDS = FN * FP;   // float2 elements per wave
 constexpr int kFusedWaves = 4;       // POIs (waves) per workgroup
-
-__device__ constexpr float kCos16[8] = {1.000000000e+00f, 9.238795325e-01f, 7.071067812e-01f, 3.826834324e-01f, 6.123233996e-17f, -3.826834324e-01f, -7.071067812e-01f, -9.238795325e-01f};
-__device__ constexpr float kSin16[8] = {0.000000000e+00f, 3.826834324e-01f, 7.071067812e-01f, 9.238795325e-01f, 1.000000000e+00f, 9.238795325e-01f, 7.071067812e-01f, 3.826834324e-01f};
-__device__ constexpr float kCos32[16] = {1.000000000e+00f, 9.807852804e-01f, 9.238795325e-01f, 8.314696123e-01f, 7.071067812e-01f, 5.555702330e-01f, 3.826834324e-01f, 1.950903220e-01f, 6.123233996e-17f, -1.950903220e-01f, -3.826834324e-01f, -5.555702330e-01f, -7.071067812e-01f, -8.314696123e-01f, -9.238795325e-01f, -9.807852804e-01f};
-__device__ constexpr float kSin32[16] = {0.000000000e+00f, 1.950903220e-01f, 3.826834324e-01f, 5.555702330e-01f, 7.071067812e-01f, 8.314696123e-01f, 9.238795325e-01f, 9.807852804e-01f, 1.000000000e+00f, 9.807852804e-01f, 9.238795325e-01f, 8.314696123e-01f, 7.071067812e-01f, 5.555702330e-01f, 3.826834324e-01f, 1.950903220e-01f};
-
-// complex numbers as 2-wide vectors (re, im): additions and the twiddle products then run on the packed-fp32
-// pipe (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), one instruction per complex operation
-typedef float c2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ c2 mkc(float re, float im) {
-    c2 r = {re, im};
-    return r;
-}
-
-// d * exp(-/+ i*angle) with (c, s) = (cos, sin) of the angle; INV selects the + sign:
-// forward (d.x c + d.y s, d.y c - d.x s), inverse (d.x c - d.y s, d.y c + d.x s)
-template <bool INV>
-__device__ __forceinline__ c2 cmul_tw(c2 d, float c, float s) {
-#pragma clang fp contract(fast)
-    return d * c + d.yx * (INV ? mkc(-s, s) : mkc(s, -s));
-}
-
-// 16-point FFT in registers: radix-2 decimation in frequency, X[k] ends in v[bitrev4(k)]
-template <bool INV>
-__device__ __forceinline__ void fft16(c2 (&v)[16]) {
-#pragma unroll
-    for (int span = 8; span >= 1; span >>= 1) {
-#pragma unroll
-        for (int i0 = 0; i0 < 16; i0++) {
-            if (i0 & span) continue;
-            const int i1 = i0 + span;
-            const int m = (i0 & (span - 1)) * (8 / span);  // twiddle W16^m
-            const c2 a = v[i0], b = v[i1];
-            v[i0] = a + b;
-            const c2 d = a - b;
-            if (m == 0) v[i1] = d;
-            else if (m == 4) v[i1] = INV ? mkc(-d.y, d.x) : mkc(d.y, -d.x);
-            else v[i1] = cmul_tw<INV>(d, kCos16[m], kSin16[m]);
-        }
-    }
-}
-
-__device__ constexpr int bitrev4(int k) { return ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3); }
 
 // One length-32 transform along a line of the LDS tile.  The lane reads elements n and n+16
 // (n = 0..15) at `line + n*step`, forms its half of the first radix-2 stage (h = 0: sums ->

@@ -154,4 +154,10 @@ hipError_t launch_fftcc3d_gather(const Fftcc3dParams& p, const float* pois, int 
 hipError_t launch_fftcc3d_argmax(const Fftcc3dParams& p, const float* surf, const float* norms, float* pois,
                                  int stride_floats, size_t count, hipStream_t stream);
 
+// ---- fftcc3d_fused.hip -----------------------------------------------------
+// all of FFTCC3D::compute(POI3D*) in one kernel for 32 x 32 x 32 windows (radius 16)
+bool fftcc3d_fused_supported(int rx, int ry, int rz);
+hipError_t launch_fftcc3d_fused(const Fftcc3dParams& p, float* pois, int stride_floats, size_t count, bool xcd,
+                                hipStream_t stream);
+
 }  // namespace ochip

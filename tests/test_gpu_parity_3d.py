@@ -60,6 +60,42 @@ def test_fftcc3d_matches_oracle(volumes, r):
     assert np.array_equal(_bits(got[:, untouched]), _bits(want[:, untouched]))
 
 
+def test_fftcc3d_fused_kernel_matches_oracle_and_rocfft_pipeline(volumes):
+    """r = 16: the single-kernel FFTCC3D (fftcc3d_fused.hip).  Same integer peak as the oracle and as the rocFFT
+    pipeline; ZNCC within 2e-6 of the pipeline and within north_star's 1e-4 of the oracle -- at 32^3 voxels the
+    oracle's (= the reference's, src/oc_fftcc.cpp:340-376) sequential float sums of means and norms carry ~8e-5 of
+    rounding that the GPU's tree sums do not (the rocFFT pipeline differs from the oracle by the same amount).
+    Initial guesses and POIs near the border (clamped windows, like the pipeline's gather) included."""
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = volumes
+    xs, ys, zs = synth.poi_grid_3d(*SHAPE, 5, 4, 3, 20)
+    pois = oracle.make_pois3d(xs, ys, zs)
+    P = oracle.P3
+    rng = np.random.default_rng(2)
+    pois[::3, P["u"]] = rng.integers(-2, 3, len(pois[::3]))  # integer initial guesses displace the target window
+    pois[1::3, P["w"]] = rng.integers(-2, 3, len(pois[1::3]))
+    inner = len(pois)
+    border = oracle.make_pois3d([6.0, 30.0, SHAPE[2] - 5.0], [30.0, 4.0, 30.0], [30.0, 30.0, SHAPE[0] - 7.0])
+    pois = np.concatenate([pois, border]).astype(np.float32)
+    want = pois.copy()
+    oracle.fftcc3d(ref, tar, 16, 16, 16, want)
+    f = opencorr_amd.FFTCC3D(16, 16, 16)
+    f.set_images(ref, tar)
+    fused = f.compute(pois.copy())
+    f.set_tuning("fftcc3d_fused", 0)
+    base = f.compute(pois.copy())
+    for key in ("u", "v", "w", "u0", "v0", "w0"):
+        assert np.array_equal(fused[:inner, P[key]], want[:inner, P[key]]), key
+        assert np.array_equal(fused[:, P[key]], base[:, P[key]]), key  # border POIs: same clamping as the pipeline
+    assert np.abs(fused[:inner, P["zncc"]] - want[:inner, P["zncc"]]).max() <= 1e-4
+    assert np.abs(fused[:, P["zncc"]] - base[:, P["zncc"]]).max() <= 2e-6
+    untouched = [c for c in range(31) if c not in (P["u"], P["v"], P["w"], P["u0"], P["v0"], P["w0"], P["zncc"])]
+    assert np.array_equal(_bits(fused[:, untouched]), _bits(pois[:, untouched]))
+    assert (fused[:inner, P["zncc"]] > 0.5).mean() > 0.9
+
+
 @pytest.mark.parametrize("r", [(8, 8, 8), (5, 7, 6)])
 def test_icgn3d1_bit_exact_vs_oracle(volumes, r):
     import opencorr_amd
