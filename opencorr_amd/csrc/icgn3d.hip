@@ -195,8 +195,12 @@ __device__ __forceinline__ float bspline3d_eval(const float* __restrict__ coef, 
 // The same evaluation with the 64 coefficients taken from the staged box: `win` is the box in
 // LDS, (ox, oy, oz) its origin in the volume, nx / nxy its row and plane pitches.  Same range
 // rule, same weights, same order of operations as bspline3d_eval: identical bits.
-__device__ __forceinline__ float bspline3d_eval_lds(const float* __restrict__ win, int ox, int oy, int oz, int nx, int nxy,
+// PX > 0: the row pitch is the compile-time constant PX (nx == PX), so the 16 taps of a plane are immediate
+// offsets of ONE address instead of 12 more address computations.
+template <int PX>
+__device__ __forceinline__ float bspline3d_eval_lds(const float* __restrict__ win, int ox, int oy, int oz, int nx_rt, int nxy,
                                                     int dz, int dy, int dx, float x, float y, float z) {
+    const int nx = PX ? PX : nx_rt;
     const bool out = (x < 1 || y < 1 || z < 1 || x >= dx - 2 || y >= dy - 2 || z >= dz - 2 || isnan(x) || isnan(y) ||
                       isnan(z));
     const int xi = out ? ox + 1 : (int)floorf(x), yi = out ? oy + 1 : (int)floorf(y), zi = out ? oz + 1 : (int)floorf(z);
@@ -209,9 +213,14 @@ __device__ __forceinline__ float bspline3d_eval_lds(const float* __restrict__ wi
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         float sum_x[4];
+        // LDS byte address of the plane; with a compile-time pitch it is made opaque to the optimiser so that the 16
+        // taps stay "address + constant" and fold into the offset fields of the ds_read instructions
+        typedef const float __attribute__((address_space(3))) * lds_cfp;
+        lds_cfp pl = (lds_cfp)(base + i * nxy);
+        if constexpr (PX != 0) asm volatile("" : "+v"(pl));
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const float* __restrict__ row = base + i * nxy + j * nx;
+            lds_cfp row = pl + j * nx;
             sum_x[j] = ((bx0 * row[0] + bx1 * row[1]) + bx2 * row[2]) + bx3 * row[3];
         }
         sum_y[i] = ((by[0] * sum_x[0] + by[1] * sum_x[1]) + by[2] * sum_x[2]) + by[3] * sum_x[3];
@@ -294,6 +303,8 @@ __device__ __forceinline__ void hessian_rows(const Icgn3dParams& P, int tid, int
         }
 }
 
+// PX: row pitch of the staged coefficient box in LDS (0 = the box's own width, decided per pass)
+template <int PX>
 __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, float* __restrict__ pois, int stride_f,
                                                            unsigned long long count) {
     __shared__ __attribute__((aligned(16))) float lds[kRedChunk * kWaves3d + 12 * kWave + kWinCap + 6 * kBoxSlots];
@@ -436,7 +447,8 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
                         }
                         // n[0] = 0 marks "do not stage": nothing of the pass is in range (every sample evaluates
                         // to -1), or the box does not fit -> global taps
-                        const bool stage = usable && n[0] >= 4 && n[1] >= 4 && n[2] >= 4 && (long long)n[0] * n[1] * n[2] <= kWinCap;
+                        const bool stage = usable && n[0] >= 4 && n[1] >= 4 && n[2] >= 4 && (PX == 0 || n[0] <= PX) &&
+                                           (long long)(PX ? PX : n[0]) * n[1] * n[2] <= kWinCap;
                         int* slot = boxes + (pass - round0) * 6;
                         slot[0] = o[0]; slot[1] = o[1]; slot[2] = o[2];
                         slot[3] = stage ? n[0] : 0; slot[4] = n[1]; slot[5] = n[2];
@@ -452,7 +464,9 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
                             n[a] = __builtin_amdgcn_readfirstlane(slot[3 + a]);
                         }
                         const bool staged = n[0] > 0;
-                        const int nx = n[0], nxy = n[0] * n[1];
+                        const int nx = n[0];                 // floats fetched per row
+                        const int pitch = PX ? PX : n[0];    // floats between rows in LDS
+                        const int nxy = pitch * n[1];
                         if (staged) {
                             __syncthreads();  // the previous pass has finished reading the box
                             // rows of the box, round-robin over the waves; (zr, yr) advance without a division
@@ -482,13 +496,13 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
 #pragma unroll
                                     for (int u = 0; u < kStageRows; u++) {
                                         const int row = row0 + u * kWaves3d;
-                                        if (row < rows && lane < nx) win[row * nx + lane] = v[u];
+                                        if (row < rows && lane < nx) win[row * pitch + lane] = v[u];
                                     }
                                 }
                             } else {
                                 for (int row = wave; row < rows; row += kWaves3d) {
                                     const float* __restrict__ src = P.coef + ((size_t)(o[2] + zr) * DY + (o[1] + yr)) * DX + o[0];
-                                    for (int x = lane; x < nx; x += kWave) win[row * nx + x] = src[x];
+                                    for (int x = lane; x < nx; x += kWave) win[row * pitch + x] = src[x];
                                     yr += dyr;
                                     zr += dzr;
                                     if (yr >= n[1]) {
@@ -503,7 +517,7 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
                             if (w.s < N) {
                                 const float xl = (float)(w.k - rx), yl = (float)(w.j - ry), zl = (float)(w.i - rz);
                                 const float x = warp_x(xl, yl, zl), y = warp_y(xl, yl, zl), z = warp_z(xl, yl, zl);
-                                const float v = staged ? bspline3d_eval_lds(win, o[0], o[1], o[2], nx, nxy, DZ, DY, DX, x, y, z)
+                                const float v = staged ? bspline3d_eval_lds<PX>(win, o[0], o[1], o[2], pitch, nxy, DZ, DY, DX, x, y, z)
                                                        : bspline3d_eval(P.coef, DZ, DY, DX, x, y, z);
                                 out_of_range = out_of_range || (v < 0.f);
                                 ts[w.s] = v;
@@ -636,19 +650,28 @@ hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_f, size
     // gradients) inside the LDS window; passes that still overflow fall back to global taps
     Icgn3dParams q = p;
     q.samples_per_pass = 1;
+    // row pitch of the staged box: the nominal box is (2rx+1) + 5 floats wide; a compile-time pitch makes the tap
+    // offsets immediates
+    const int want = 2 * p.rx + 1 + 5;
+    const int px = want <= 40 ? 40 : want <= 48 ? 48 : want <= 64 ? 64 : 0;
     for (int m = 4; m >= 1; m >>= 1) {
         const long long sx = 2 * p.rx + 1, sy = 2 * p.ry + 1, sz = 2 * p.rz + 1, len = (long long)m * kBlock3d;
         const long long planes = (len + sx * sy - 1) / (sx * sy) + 1;
         const long long nz = (planes < sz ? planes : sz) + 3 + 1;
         const long long rows = planes > 1 ? sy : (len + sx - 1) / sx + 1;
-        const long long ny = (rows < sy ? rows : sy) + 3 + 2, nx = sx + 3 + 2;
+        const long long ny = (rows < sy ? rows : sy) + 3 + 2, nx = px ? px : sx + 3 + 2;
         if (nx * ny * nz <= kWinCap) {
             q.samples_per_pass = m;
             break;
         }
     }
     (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
-    hipLaunchKernelGGL(icgn3d1_kernel, dim3(grid), dim3(kBlock3d), 0, stream, q, pois, stride_f, (unsigned long long)count);
+    switch (px) {
+        case 40: hipLaunchKernelGGL(icgn3d1_kernel<40>, dim3(grid), dim3(kBlock3d), 0, stream, q, pois, stride_f, (unsigned long long)count); break;
+        case 48: hipLaunchKernelGGL(icgn3d1_kernel<48>, dim3(grid), dim3(kBlock3d), 0, stream, q, pois, stride_f, (unsigned long long)count); break;
+        case 64: hipLaunchKernelGGL(icgn3d1_kernel<64>, dim3(grid), dim3(kBlock3d), 0, stream, q, pois, stride_f, (unsigned long long)count); break;
+        default: hipLaunchKernelGGL(icgn3d1_kernel<0>, dim3(grid), dim3(kBlock3d), 0, stream, q, pois, stride_f, (unsigned long long)count); break;
+    }
     return hipGetLastError();
 }
 
