@@ -158,6 +158,12 @@ __device__ __forceinline__ void set_warp_3d1(float (&w)[16], const float (&q)[12
     w[12] = 0.f; w[13] = 0.f; w[14] = 0.f; w[15] = 1.f;
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) {
+    f2 r = {a, b};
+    return r;
+}
+
 // cubic B-spline basis functions, src/oc_cubic_bspline.cpp:35-53
 __device__ __forceinline__ float basis0(float t) { return (1.f / 6.f) * (t * (t * (-t + 3.f) - 3.f) + 1.f); }
 __device__ __forceinline__ float basis1(float t) { return (1.f / 6.f) * (t * t * (3.f * t - 6.f) + 4.f); }
@@ -230,10 +236,14 @@ __device__ __forceinline__ float bspline3d_eval_lds(const float* __restrict__ wi
 }
 
 // walks the samples owned by one thread: s = tid, tid+1024, ... as (i = z, j = y, k = x) indices
+// `off` = (i*DY + j)*DX + k, the sample's offset (in voxels) from the subvolume's first voxel inside a DZ x DY x DX
+// volume, advanced incrementally (DX = DY = 0: not needed).
 struct Walk3 {
     int i, j, k, s;
     int SX, SY, di, dj, dk;
-    __device__ __forceinline__ Walk3(int tid, int SX_, int SY_, int first_pass = 0)
+    unsigned off;
+    int doff, coff_k, coff_j;
+    __device__ __forceinline__ Walk3(int tid, int SX_, int SY_, int first_pass = 0, int DX = 0, int DY = 0)
         : s(tid + first_pass * kBlock3d), SX(SX_), SY(SY_) {
         const int plane = SX_ * SY_;
         i = s / plane;
@@ -244,15 +254,22 @@ struct Walk3 {
         rem = kBlock3d - di * plane;
         dj = rem / SX_;
         dk = rem - dj * SX_;
+        off = (unsigned)((i * DY + j) * DX + k);
+        doff = (di * DY + dj) * DX + dk;
+        coff_k = DX - SX_;          // k wrapped: one row further, SX columns back
+        coff_j = (DY - SY_) * DX;   // j wrapped: one plane further, SY rows back
     }
     __device__ __forceinline__ void next() {
         s += kBlock3d;
         k += dk;
+        off += doff;
         const bool ck = k >= SX;
         k = ck ? k - SX : k;
+        off += ck ? coff_k : 0;
         j += dj + (ck ? 1 : 0);
         const bool cj = j >= SY;
         j = cj ? j - SY : j;
+        off += cj ? coff_j : 0;
         i += di + (cj ? 1 : 0);
     }
 };
@@ -264,23 +281,47 @@ __device__ __forceinline__ void hessian_rows(const Icgn3dParams& P, int tid, int
                                              int rx, int ry, int rz, int cx, int cy, int cz, int DX, int DY, float* red,
                                              float (&col)[12]) {
     constexpr int NE = (R1 * (R1 + 1) - R0 * (R0 + 1)) / 2;
-    float h[NE];
+    // The running sums H(r,c) += sd[r]*sd[c] as packed-fp32 pairs over adjacent columns (v_pk_mul_f32 /
+    // v_pk_add_f32: two IEEE operations per issue slot, each rounded on its own -- every H(r,c) receives the same
+    // products in the same order).  sd = g_a * (1, x | y, z) for a = x, y, z: six pairs; row r takes the column
+    // pairs (0,1), (2,3), ... below the diagonal and, when r is even, the single diagonal term.
+    f2 hp[12][6];
+    float hd[12];
 #pragma unroll
-    for (int i = 0; i < NE; i++) h[i] = 0.f;
-    Walk3 w(tid, SX, SY);
-#pragma unroll 4
+    for (int r = 0; r < 12; r++) {
+        hd[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; q++) hp[r][q] = mk2(0.f, 0.f);
+    }
+    Walk3 w(tid, SX, SY, 0, DX, DY);
+    // gradient voxel of sample (i, j, k): (cz - rz + i, cy - ry + j, cx - rx + k) -- integer arithmetic, so the
+    // subvolume is one box and the walk's offset addresses it
+    const size_t gbase = ((size_t)(cz - rz) * DY + (cy - ry)) * DX + (cx - rx);
+    const float* __restrict__ pgx = P.gx + gbase;
+    const float* __restrict__ pgy = P.gy + gbase;
+    const float* __restrict__ pgz = P.gz + gbase;
+#pragma unroll 1
     for (; w.s < N; w.next()) {
         const int xl = w.k - rx, yl = w.j - ry, zl = w.i - rz;
-        const size_t g = ((size_t)(cz + zl) * DY + (cy + yl)) * DX + (cx + xl);
-        const float g_x = P.gx[g], g_y = P.gy[g], g_z = P.gz[g];
-        const float fx = (float)xl, fy = (float)yl, fz = (float)zl;
-        const float sd[12] = {g_x, g_x * fx, g_x * fy, g_x * fz, g_y, g_y * fx,
-                              g_y * fy, g_y * fz, g_z, g_z * fx, g_z * fy, g_z * fz};
+        const float g_x = pgx[w.off], g_y = pgy[w.off], g_z = pgz[w.off];
+        const f2 m01 = mk2(1.f, (float)xl), m23 = mk2((float)yl, (float)zl);  // g * 1.f is exact
+        const f2 sdp[6] = {g_x * m01, g_x * m23, g_y * m01, g_y * m23, g_z * m01, g_z * m23};
+#pragma unroll
+        for (int r = R0; r < R1; r++) {
+            const float sr = (r & 1) ? sdp[r / 2].y : sdp[r / 2].x;
+#pragma unroll
+            for (int q = 0; q < (r + 1) / 2; q++) hp[r][q] = hp[r][q] + sr * sdp[q];
+            if ((r & 1) == 0) hd[r] = hd[r] + sr * sr;
+        }
+    }
+    float h[NE];
+    {
         int t = 0;
 #pragma unroll
         for (int r = R0; r < R1; r++)
 #pragma unroll
-            for (int c = 0; c <= r; c++, t++) h[t] += sd[r] * sd[c];
+            for (int c = 0; c <= r; c++, t++)
+                h[t] = (c == r && (r & 1) == 0) ? hd[r] : ((c & 1) ? hp[r][c / 2].y : hp[r][c / 2].x);
     }
     constexpr int NCH = (NE + kRedChunk - 1) / kRedChunk;
 #pragma unroll
@@ -346,20 +387,35 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
 
         // ---- reference subvolume mean + norm (src/oc_subset.cpp:89-135)
         const float sxf = px - rx, syf = py - ry, szf = pz - rz;
+        // Subset3D::fill reads voxel (int(start.z + i), int(start.y + j), int(start.x + k)) (src/oc_subset.cpp:89-103):
+        // float additions, truncated per element.  Unless an addition rounds across an integer (non-integer POI
+        // coordinates next to a power of two), that is the box starting at (int)start -- checked per POI, and then the
+        // walk's incremental offset replaces three conversions and a 64-bit address per sample.
+        bool ref_box = true;
+        for (int q = tid; q < SX + SY + SZ; q += kBlock3d) {
+            const int ax = q < SX ? 0 : (q < SX + SY ? 1 : 2);
+            const int e = ax == 0 ? q : (ax == 1 ? q - SX : q - SX - SY);
+            const float st = ax == 0 ? sxf : (ax == 1 ? syf : szf);
+            ref_box = ref_box && ((int)(st + e) == (int)st + e);
+        }
+        ref_box = __syncthreads_and(ref_box ? 1 : 0) != 0;
+        const float* __restrict__ pref = P.ref + (((size_t)(int)szf * DY + (int)syf) * DX + (int)sxf);
+        auto ref_at = [&](const Walk3& w) {
+            return ref_box ? pref[w.off] : P.ref[((size_t)(int)(szf + w.i) * DY + (int)(syf + w.j)) * DX + (int)(sxf + w.k)];
+        };
         float ref_mean, ref_norm;
         {
             float acc[1] = {0.f};
-            Walk3 w(tid, SX, SY);
+            Walk3 w(tid, SX, SY, 0, DX, DY);
 #pragma unroll 8
-            for (; w.s < N; w.next())
-                acc[0] += P.ref[((size_t)(int)(szf + w.i) * DY + (int)(syf + w.j)) * DX + (int)(sxf + w.k)];
+            for (; w.s < N; w.next()) acc[0] += ref_at(w);
             block_allreduce<1>(acc, red, wave, lane);
             ref_mean = acc[0] / fN;
             acc[0] = 0.f;
-            Walk3 w2(tid, SX, SY);
+            Walk3 w2(tid, SX, SY, 0, DX, DY);
 #pragma unroll 8
             for (; w2.s < N; w2.next()) {
-                const float d = P.ref[((size_t)(int)(szf + w2.i) * DY + (int)(syf + w2.j)) * DX + (int)(sxf + w2.k)] - ref_mean;
+                const float d = ref_at(w2) - ref_mean;
                 acc[0] += d * d;
             }
             block_allreduce<1>(acc, red, wave, lane);
@@ -376,9 +432,7 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
             float col[12];
 #pragma unroll
             for (int i = 0; i < 12; i++) col[i] = 0.f;
-            hessian_rows<0, 6>(P, tid, wave, lane, SX, SY, N, rx, ry, rz, cx, cy, cz, DX, DY, red, col);
-            hessian_rows<6, 9>(P, tid, wave, lane, SX, SY, N, rx, ry, rz, cx, cy, cz, DX, DY, red, col);
-            hessian_rows<9, 12>(P, tid, wave, lane, SX, SY, N, rx, ry, rz, cx, cy, cz, DX, DY, red, col);
+            hessian_rows<0, 12>(P, tid, wave, lane, SX, SY, N, rx, ry, rz, cx, cy, cz, DX, DY, red, col);
             lu_inverse_lanes3<12>(col, hinv_col, lane);  // every wave redundantly, identical results
             if (wave == 0) {
 #pragma unroll
@@ -548,15 +602,18 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
 #pragma unroll
             for (int i = 0; i < 13; i++) num[i] = 0.f;
             {
-                Walk3 w(tid, SX, SY);
+                Walk3 w(tid, SX, SY, 0, DX, DY);
+                const size_t gbase = ((size_t)(cz - rz) * DY + (cy - ry)) * DX + (cx - rx);
+                const float* __restrict__ pgx = P.gx + gbase;
+                const float* __restrict__ pgy = P.gy + gbase;
+                const float* __restrict__ pgz = P.gz + gbase;
 #pragma unroll 4
                 for (; w.s < N; w.next()) {
                     const int xl = w.k - rx, yl = w.j - ry, zl = w.i - rz;
-                    const float rsv = P.ref[((size_t)(int)(szf + w.i) * DY + (int)(syf + w.j)) * DX + (int)(sxf + w.k)] - ref_mean;
+                    const float rsv = ref_at(w) - ref_mean;
                     const float tz = ts[w.s] - tmean;
                     const float e = factor * tz - rsv;
-                    const size_t g = ((size_t)(cz + zl) * DY + (cy + yl)) * DX + (cx + xl);
-                    const float g_x = P.gx[g], g_y = P.gy[g], g_z = P.gz[g];
+                    const float g_x = pgx[w.off], g_y = pgy[w.off], g_z = pgz[w.off];
                     const float fx = (float)xl, fy = (float)yl, fz = (float)zl;
                     num[12] += e * e;
                     num[0] += g_x * e; num[1] += (g_x * fx) * e; num[2] += (g_x * fy) * e; num[3] += (g_x * fz) * e;
