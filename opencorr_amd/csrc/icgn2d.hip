@@ -203,6 +203,17 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             h[10] = hxB.x; h[11] = hAB.x; h[12] = hAs.y; h[13] = hyB.x; h[14] = hBB.x;                // (4,0..4)
             h[15] = hxB.y; h[16] = hAs.x; h[17] = hAB.y; h[18] = hyB.y; h[19] = h54; h[20] = hBB.y;   // (5,0..5)
         } else {
+            // 12 DoF: the 78 running sums as packed pairs over adjacent columns.  sd = g * (1, x | y, xx | xy, yy)
+            // for g = g_x, g_y (sd_row<12>): six pairs; row r takes the column pairs below the diagonal and, when r
+            // is even, the single diagonal term.  Same products, same order per sum.
+            f2 hp[12][6];
+            float hd[12];
+#pragma unroll
+            for (int r = 0; r < 12; r++) {
+                hd[r] = 0.f;
+#pragma unroll
+                for (int q = 0; q < 6; q++) hp[r][q] = mk2(0.f, 0.f);
+            }
             auto sample = [&](int t, bool valid) {
                 const unsigned off = soff(w);
                 const float g_x = valid ? buf_f32(r_gx, off, goff) : 0.f;
@@ -211,17 +222,30 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     l_gx[t * kWave] = g_x;
                     l_gy[t * kWave] = g_y;
                 }
-                float sd[DOF];
-                sd_row<DOF>(g_x, g_y, (float)(w.c - rx) - offx, (float)(w.r - ry) - offy, sd);
-                int k = 0;
+                const float fxl = (float)(w.c - rx) - offx, fyl = (float)(w.r - ry) - offy;
+                const float xx = (fxl * fxl) * 0.5f, xy = fxl * fyl, yy = (fyl * fyl) * 0.5f;
+                const f2 m01 = mk2(1.f, fxl), m23 = mk2(fyl, xx), m45 = mk2(xy, yy);  // g * 1.f is exact
+                const f2 sdp[6] = {g_x * m01, g_x * m23, g_x * m45, g_y * m01, g_y * m23, g_y * m45};
 #pragma unroll
-                for (int i = 0; i < DOF; i++)
+                for (int r = 0; r < 12; r++) {
+                    const float sr = (r & 1) ? sdp[r / 2].y : sdp[r / 2].x;
 #pragma unroll
-                    for (int j = 0; j <= i; j++, k++) h[k] = valid ? h[k] + sd[i] * sd[j] : h[k];
+                    for (int q = 0; q < (r + 1) / 2; q++) {
+                        const f2 nv = hp[r][q] + sr * sdp[q];
+                        hp[r][q] = valid ? nv : hp[r][q];
+                    }
+                    if ((r & 1) == 0) hd[r] = valid ? hd[r] + sr * sr : hd[r];
+                }
             };
 #pragma unroll 1
             for (int t = 0; t < NF; t++, w.next()) sample(t, true);
             if (NF < NT) sample(NF, w.s < N);
+            int k = 0;
+#pragma unroll
+            for (int r = 0; r < 12; r++)
+#pragma unroll
+                for (int c = 0; c <= r; c++, k++)
+                    h[k % NH] = (c == r && (r & 1) == 0) ? hd[r] : ((c & 1) ? hp[r][c / 2].y : hp[r][c / 2].x);
         }
         // lane j < DOF assembles column j of the symmetric Hessian
         float col[DOF];
@@ -386,6 +410,9 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             FloatWalk fw(r0, c0, rx, ry, W, q64, r64, w4);  // DOF 6 without centre offsets
             constexpr bool kFloatWalk = DOF == 6 && !OFFS;
             f2 nA = mk2(0.f, 0.f), nB = nA;  // DOF 6: (num1, num2) and (num4, num5) as packed pairs
+            f2 np12[6];                       // DOF 12: (num0, num1) .. (num10, num11)
+#pragma unroll
+            for (int q = 0; q < 6; q++) np12[q] = mk2(0.f, 0.f);
             auto sample = [&](int t, bool valid) {
                 float g_x, g_y;
                 if constexpr (MODE == 0) {
@@ -409,12 +436,14 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                         nA = mA; nB = mB; num[0] = m0; num[3] = m3;
                     }
                 } else {
-                    float sd[DOF];
-                    sd_row<DOF>(g_x, g_y, (float)(w.c - rx) - offx, (float)(w.r - ry) - offy, sd);
+                    const float fxl = (float)(w.c - rx) - offx, fyl = (float)(w.r - ry) - offy;
+                    const float xx = (fxl * fxl) * 0.5f, xy = fxl * fyl, yy = (fyl * fyl) * 0.5f;
+                    const f2 m01 = mk2(1.f, fxl), m23 = mk2(fyl, xx), m45 = mk2(xy, yy);
+                    const f2 sdp[6] = {g_x * m01, g_x * m23, g_x * m45, g_y * m01, g_y * m23, g_y * m45};
 #pragma unroll
-                    for (int i = 0; i < DOF; i++) {
-                        const float n = sd[i] * e;
-                        num[i] = valid ? num[i] + n : num[i];
+                    for (int q = 0; q < 6; q++) {
+                        const f2 nv = np12[q] + sdp[q] * e;
+                        np12[q] = valid ? nv : np12[q];
                     }
                 }
             };
@@ -429,6 +458,12 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             }
             if constexpr (DOF == 6) {
                 num[1] = nA.x; num[2] = nA.y; num[4] = nB.x; num[5] = nB.y;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    num[(2 * q) % DOF] = np12[q].x;
+                    num[(2 * q + 1) % DOF] = np12[q].y;
+                }
             }
         }
         znssd = uni(wave_allreduce_sum(ssd)) / (ref_norm * ref_norm);

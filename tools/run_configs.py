@@ -93,7 +93,7 @@ def run_2d(name, side, r, nside, engine, oracle_sample, so=None):
     bit_exact = bool(np.array_equal(sample.view(np.uint32), after[::step_s].view(np.uint32)))
     return dict(config=name, engine="FFTCC2D+" + {1: "ICGN2D1", 2: "ICGN2D2", 3: "NR2D1"}[engine], image="%dx%d" % (side, side), radius=r, pois=n,
                 seconds=secs, pois_per_s=float(conv.sum() / secs), converged=int(conv.sum()),
-                mean_iterations=float(after[conv, 17].mean()), prepare_s=prepare_s,
+                mean_iterations=float(after[conv, 17].astype(np.float64).mean()), prepare_s=prepare_s,
                 median_abs_err_u=float(np.median(du)), max_abs_err_u=float(du.max()), max_abs_err_v=float(dv.max()),
                 oracle_sample=len(sample), oracle_bit_exact=bit_exact, split_queue_same_bits=same_split)
 
@@ -144,7 +144,7 @@ def run_3d(name, dim, r, nside, oracle_sample):
     bit_exact = bool(np.array_equal(sample.view(np.uint32), after[::step_s].view(np.uint32)))
     return dict(config=name, engine="FFTCC3D+ICGN3D1", volume="%d^3" % dim, radius=r, pois=n, fftcc_seconds=t_f,
                 icgn_seconds=t_g, pois_per_s=float(conv.sum() / (t_f + t_g)), converged=int(conv.sum()),
-                mean_iterations=float(after[conv, P["iteration"]].mean()), prepare_s=prepare_s, generate_s=gen_s,
+                mean_iterations=float(after[conv, P["iteration"]].astype(np.float64).mean()), prepare_s=prepare_s, generate_s=gen_s,
                 median_abs_err=float(np.median(err)), max_abs_err=float(err.max()), oracle_sample=len(sample),
                 oracle_seconds=oracle_s, oracle_pois_per_s=len(sample) / oracle_s, oracle_cores=oracle.max_threads(),
                 oracle_bit_exact=bit_exact)
