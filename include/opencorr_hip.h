@@ -21,7 +21,10 @@
  *     larger struct (must be a multiple of 4).
  *   - `memory` says where a buffer lives: OC_HIP_HOST buffers are copied by the
  *     engine (pageable or pinned), OC_HIP_DEVICE buffers are used in place on the
- *     engine's device and stream (no copy, no synchronisation).
+ *     engine's device and stream (no copy).  On a stream the caller chose with
+ *     oc_hip_set_stream such a call is asynchronous and stream-ordered (chain the
+ *     engines of a pipeline on one stream); on the engine's own private stream it
+ *     completes before it returns.
  *   - Images are snapshotted at set_images time (like the CUDA module of the
  *     reference, examples/test_2d_dic_gpu_icgn.cpp:99-136): later edits of the
  *     host image need another set_images + prepare.

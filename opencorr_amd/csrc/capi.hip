@@ -331,6 +331,21 @@ int run_fftcc2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     return OC_HIP_OK;
 }
 
+// Locality schedule of a 2D queue (poi_order.hip): worth four tiny kernels once the queue is much larger than what
+// is in flight.  *perm = nullptr when the queue is short or the schedule is switched off.
+int tile_order(oc_hip_engine* e, const float* pois, int stride_f, size_t n, const unsigned** perm) {
+    *perm = nullptr;
+    if (e->icgn2d_tile_px <= 0 || n < 16384) return OC_HIP_OK;
+    const ImagePair& im = *e->img;
+    OC_TRY(e->perm.reserve(n * sizeof(unsigned)));
+    OC_TRY(e->tiles.reserve(ochip::poi2d_tile_count(im.dy, im.dx, e->icgn2d_tile_px) * sizeof(unsigned)));
+    OC_TRY(e->perm_slots.reserve(n * sizeof(unsigned)));
+    OC_HIP_TRY(ochip::launch_poi2d_tile_order(pois, stride_f, n, im.dy, im.dx, e->icgn2d_tile_px, e->tiles.as<unsigned>(),
+                                              e->perm_slots.as<unsigned>(), e->perm.as<unsigned>(), e->stream));
+    *perm = e->perm.as<unsigned>();
+    return OC_HIP_OK;
+}
+
 // ---------------------------------------------------------------------------
 // ICGN2D
 // ---------------------------------------------------------------------------
@@ -373,16 +388,7 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
         const size_t n = (count - first) < kMaxGrid ? (count - first) : kMaxGrid;
         float* pois = d_pois + first * (size_t)stride_f;
         if (d_offsets) P.offsets = d_offsets + 2 * first;
-        // locality schedule: worth three tiny kernels once the queue is much larger than what is in flight
-        P.perm = nullptr;
-        if (e->icgn2d_tile_px > 0 && n >= 16384) {
-            OC_TRY(e->perm.reserve(n * sizeof(unsigned)));
-            OC_TRY(e->tiles.reserve(ochip::poi2d_tile_count(im.dy, im.dx, e->icgn2d_tile_px) * sizeof(unsigned)));
-            OC_TRY(e->perm_slots.reserve(n * sizeof(unsigned)));
-            OC_HIP_TRY(ochip::launch_poi2d_tile_order(pois, stride_f, n, im.dy, im.dx, e->icgn2d_tile_px, e->tiles.as<unsigned>(),
-                                                      e->perm_slots.as<unsigned>(), e->perm.as<unsigned>(), e->stream));
-            P.perm = e->perm.as<unsigned>();
-        }
+        OC_TRY(tile_order(e, pois, stride_f, n, &P.perm));
         ProfScope prof(e);  // the solver kernel alone (what rocprofv3 reports for it)
         hipError_t err;
         if (lm)
@@ -411,11 +417,12 @@ int run_nr2d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
                     2 * e->rx + 1, 2 * e->ry + 1, N, ochip::nr2d1_max_samples());
     ochip::Nr2dParams P = {im.ref_ptr(), e->coef.as<float>(), e->coef_gx.as<float>(), e->coef_gy.as<float>(),
                            im.dy,        im.dx,               e->rx,                  e->ry,
-                           e->conv,      e->stop};
-    ProfScope prof(e);
+                           e->conv,      e->stop,             nullptr};
     const size_t kMaxGrid = 1u << 30;
     for (size_t first = 0; first < count; first += kMaxGrid) {
         const size_t n = (count - first) < kMaxGrid ? (count - first) : kMaxGrid;
+        OC_TRY(tile_order(e, d_pois + first * (size_t)stride_f, stride_f, n, &P.perm));
+        ProfScope prof(e);
         hipError_t err = ochip::launch_nr2d1(P, d_pois + first * (size_t)stride_f, stride_f, n, e->stream);
         if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "NR2D1 kernel launch failed: %s", hipGetErrorString(err));
     }
@@ -568,6 +575,14 @@ int oc_hip_set_damping(oc_hip_engine* e, float lambda, float alpha, float beta) 
     return OC_HIP_OK;
 }
 
+// A call on a device-resident queue is asynchronous on a stream the CALLER chose (oc_hip_set_stream: stream-ordered
+// with the caller's other work, e.g. the next engine on the same stream).  On the engine's own private stream nobody
+// else could order against it, so the call completes before it returns.
+static int finish_device_call(oc_hip_engine* e) {
+    if (e->stream == e->own_stream) OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    return OC_HIP_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Strain
 // ---------------------------------------------------------------------------
@@ -677,6 +692,7 @@ static int plane_prepare(oc_hip_engine* e, int kind, const void* pois, size_t co
         OC_HIP_TRY(ochip::launch_strain_gather(ndim, d_pois, stride_f, count, e->st_order.as<unsigned>(), e->st_recs.p, e->stream));
     }
     if (memory == OC_HIP_HOST) OC_HIP_TRY(hipStreamSynchronize(e->stream));  // the staging buffer is reused by compute
+    else OC_TRY(finish_device_call(e));
     e->st_grid = g;
     e->st_ndim = ndim;
     e->st_count = count;
@@ -715,6 +731,8 @@ int oc_hip_region_fit_compute(oc_hip_engine* e, void* pois, size_t count, size_t
     if (memory == OC_HIP_HOST) {
         OC_HIP_TRY(hipMemcpyAsync(pois, d_pois, count * stride_bytes, hipMemcpyDeviceToHost, e->stream));
         OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    } else {
+        OC_TRY(finish_device_call(e));
     }
     return OC_HIP_OK;
 }
@@ -741,6 +759,8 @@ int oc_hip_strain_compute(oc_hip_engine* e, void* pois, size_t count, size_t str
     if (memory == OC_HIP_HOST) {
         OC_HIP_TRY(hipMemcpyAsync(pois, d_pois, count * stride_bytes, hipMemcpyDeviceToHost, e->stream));
         OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    } else {
+        OC_TRY(finish_device_call(e));
     }
     return OC_HIP_OK;
 }
@@ -979,7 +999,10 @@ static int compute_impl(oc_hip_engine* e, void* pois, const float* offsets, size
                     stride_bytes, e->poi_bytes());
     std::lock_guard<std::mutex> lock(e->mu);
     const int stride_f = (int)(stride_bytes / 4);
-    if (memory == OC_HIP_DEVICE) return run_compute_device(e, static_cast<float*>(pois), stride_f, count, offsets);
+    if (memory == OC_HIP_DEVICE) {
+        OC_TRY(run_compute_device(e, static_cast<float*>(pois), stride_f, count, offsets));
+        return finish_device_call(e);
+    }
     // host queue: H2D of the AoS, kernels, D2H (the reference's CUDA module does the same,
     // examples/test_2d_dic_gpu_icgn.cpp:136-149)
     const size_t bytes = count * stride_bytes;

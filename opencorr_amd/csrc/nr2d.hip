@@ -38,8 +38,10 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned long long grp = blockIdx.x;
     if (L.xcd_chunk > 0) grp = (unsigned long long)(blockIdx.x & 7u) * L.xcd_chunk + (blockIdx.x >> 3);
-    const unsigned long long idx = grp * kNrWaves + wave;
-    if (idx >= L.count) return;
+    const unsigned long long slot = grp * kNrWaves + wave;
+    if (slot >= L.count) return;
+    // the k-th wave of the launch solves POI perm[k] (the locality schedule of icgn2d.hip) or simply POI k
+    const unsigned long long idx = P.perm ? (unsigned long long)__builtin_amdgcn_readfirstlane((int)P.perm[slot]) : slot;
     float* __restrict__ l_rs = lds + (size_t)wave * 4 * NT * kWave + lane;
     float* __restrict__ l_ts = l_rs + NT * kWave;
     float* __restrict__ l_gx = l_ts + NT * kWave;

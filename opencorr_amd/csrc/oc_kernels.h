@@ -91,6 +91,7 @@ struct Nr2dParams {
     int height, width;
     int rx, ry;
     float conv, stop;
+    const unsigned* perm;  // visiting order of the queue (poi_order.hip), or nullptr: queue order
 };
 hipError_t launch_nr2d1(const Nr2dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);
 int nr2d1_max_samples();

@@ -109,3 +109,24 @@ def test_nr2d1_throughput_config_b_shape():
     assert conv.mean() > 0.999
     eu, ev = synth.expected_deformation_2d(xs, ys, 4096, 4096)
     assert np.abs(p[conv, 2] - eu[conv]).max() < 0.03 and np.abs(p[conv, 8] - ev[conv]).max() < 0.03
+
+
+def test_nr2d1_tile_schedule_changes_no_bits(speckle_small):
+    """Queues of >= 16 384 POIs are visited tile by tile (poi_order.hip), like ICGN2D: same bits as queue order."""
+    import opencorr_amd as eng
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 150, 120, 24)
+    fftcc = eng.FFTCC2D(16, 16)
+    fftcc.set_images(ref, tar)
+    start = eng.make_pois2d(xs, ys)
+    fftcc.compute(start)
+    nr = eng.NR2D1(16, 16, 0.001, 10)
+    nr.set_images(ref, tar)
+    nr.prepare()
+    outs = []
+    for px in (0, 64):
+        nr.set_tuning("icgn2d_tile_px", px)
+        outs.append(nr.compute(start.copy()))
+    both_nan = np.isnan(outs[0]) & np.isnan(outs[1])
+    assert np.array_equal(_bits(outs[0])[~both_nan], _bits(outs[1])[~both_nan])

@@ -98,6 +98,45 @@ def run_2d(name, side, r, nside, engine, oracle_sample, so=None):
                 oracle_sample=len(sample), oracle_bit_exact=bit_exact, split_queue_same_bits=same_split)
 
 
+def run_strain(name, side, r, nside, radius, nmin):
+    """FFTCC2D -> ICGN2D1 -> Strain on the device-resident queue."""
+    import torch
+    import opencorr_amd as oc
+    import oracle
+    from opencorr_amd import synth
+    dev = torch.device("cuda", 0)
+    ref, tar = synth.speckle_pair_2d(side, side, seed=20260925, device=dev)
+    xs, ys = synth.poi_grid_2d(side, side, nside, nside, r + 8)
+    stream = torch.cuda.current_stream().cuda_stream
+    f = oc.FFTCC2D(r, r)
+    f.set_stream(stream)
+    f.set_images(ref, tar)
+    g = oc.ICGN2D1(r, r, 0.001, 10.0)
+    g.set_stream(stream)
+    g.share_images(f)
+    g.prepare()
+    pois = torch.from_numpy(oc.make_pois2d(xs, ys)).to(dev)
+    f.compute(pois)
+    g.compute(pois)
+    st = oc.Strain(radius, nmin)
+    st.set_stream(stream)
+    t_prep = timed(lambda: st.prepare(pois), torch.cuda.synchronize)
+    t_comp = timed(lambda: st.compute(pois), torch.cuda.synchronize)
+    got = pois.cpu().numpy()
+    want = got.copy()
+    want[:, 20:23] = 0
+    t0 = time.perf_counter()
+    oracle.strain2d(want, radius, nmin)
+    oracle_s = time.perf_counter() - t0
+    fitted = got[:, 16] >= 0.9
+    exx = got[fitted, 20]
+    return dict(config=name, engine="FFTCC2D+ICGN2D1 -> Strain", pois=len(xs), subregion_radius=radius, neighbor_min=nmin,
+                neighbours_per_poi=float(np.pi * radius * radius / ((side - 2 * (r + 8)) / nside) ** 2),
+                prepare_seconds=t_prep, compute_seconds=t_comp, pois_per_s=float(fitted.sum() / t_comp),
+                exx_median=float(np.median(exx)), exx_expected=1e-3, oracle_seconds=oracle_s, oracle_cores=oracle.max_threads(),
+                oracle_bit_exact=bool(np.array_equal(got.view(np.uint32), want.view(np.uint32))))
+
+
 def run_3d(name, dim, r, nside, oracle_sample):
     import torch
     import opencorr_amd as oc
@@ -165,6 +204,8 @@ def main():
             rec = run_2d("D on ONE GPU (8192^2, r=16, 1414x1414 POIs)", 8192, 16, 1414, 1, 4000)
         elif c == "BNR":
             rec = run_2d("B with NR2D1 (4096^2, r=16, 500x500 POIs)", 4096, 16, 500, 3, 4000)
+        elif c == "BST":
+            rec = run_strain("B + Strain (4096^2, 500x500 POIs, subregion radius 40 px, >= 5 neighbours)", 4096, 16, 500, 40.0, 5)
         elif c == "E":
             rec = run_3d("E on ONE GPU (512^3, r=16, 37^3 POIs)", 512, 16, 37, 96)
         elif c == "Es":
