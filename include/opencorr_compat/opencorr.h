@@ -2,4 +2,5 @@
 // (the reference's umbrella is src/opencorr.h:20-42; only the hot-path classes exist here).
 #pragma once
 #include "oc_engines.h"
+#include "oc_io.h"
 #include "oc_types.h"

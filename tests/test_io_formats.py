@@ -57,3 +57,37 @@ def test_bin_volume_round_trip(tmp_path):
     raw = np.fromfile(tmp_path / "v.bin", dtype=np.int32, count=3)
     assert raw.tolist() == [4, 3, 2]           # dim_x, dim_y, dim_z (src/oc_image.cpp:96-101)
     assert np.array_equal(io.load_bin_volume(tmp_path / "v.bin"), vol)
+
+
+def test_cpp_io_header_exchanges_files_with_the_python_twin(tmp_path):
+    """include/opencorr_compat/oc_io.h (IO2D / IO3D with the reference's names) reads what io.py writes and writes
+    what io.py reads: same columns, same 8-decimal fixed notation."""
+    import subprocess
+    rng = np.random.default_rng(4)
+    p2 = np.zeros((6, 25), np.float32)
+    p2[:, :2] = [[1, 2], [3, 4], [5, 6], [7, 1], [9, 8], [11, 3]]
+    p2[:, 2:] = rng.uniform(-3, 3, (6, 23)).astype(np.float32)
+    p3 = rng.uniform(-3, 3, (5, 31)).astype(np.float32)
+    io.save_table2d(tmp_path / "in2.csv", p2)
+    io.save_table3d(tmp_path / "in3.csv", p3)
+    exe = str(tmp_path / "io_driver")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "io_driver.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "opencorr_amd", "lib"), "-lopencorr_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "opencorr_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"])
+    out = [str(tmp_path / n) for n in ("out2.csv", "outd.csv", "in3.csv", "out3.csv", "map.csv")]
+    subprocess.check_call([exe, str(tmp_path / "in2.csv"), out[0], out[1], out[2], out[3], out[4]])
+    # the C++ writer reproduces the Python writer's file byte for byte (both print what was read back from 8 decimals)
+    io.save_table2d(tmp_path / "ref2.csv", io.load_table2d(tmp_path / "in2.csv"))
+    assert open(out[0]).read() == open(tmp_path / "ref2.csv").read()
+    io.save_table3d(tmp_path / "ref3.csv", io.load_table3d(tmp_path / "in3.csv"))
+    assert open(out[3]).read() == open(tmp_path / "ref3.csv").read()
+    io.save_deformation_table2d(tmp_path / "refd.csv", io.load_table2d(tmp_path / "in2.csv"))
+    # the deformation table carries fields the result table does not (ux, uy, ...): they were zero after the load
+    assert open(out[1]).read() == open(tmp_path / "refd.csv").read()
+    m = np.loadtxt(out[4], delimiter=",", usecols=range(12))
+    assert m.shape == (9, 12)
+    back = io.load_table2d(tmp_path / "in2.csv")
+    for row in back:
+        assert abs(m[int(row[1]), int(row[0])] - row[21]) < 1e-6
+    assert np.count_nonzero(m) == 6
