@@ -140,6 +140,16 @@ int oc_hip_region_fit_prepare(oc_hip_engine* engine, const void* reliable_pois, 
  * nearest) gets deformation.{u,ux,uy,v,vx,vy} (POI3D: all twelve) from the fitted plane and result.zncc = 0; other
  * POIs and all other fields are left untouched. */
 int oc_hip_region_fit_compute(oc_hip_engine* engine, void* pois, size_t count, size_t stride_bytes, int ndim, int memory);
+/* Candidate batching for callers like EpipolarSearch::compute(POI2D*) (src/oc_epipolar_search.cpp:133-195): the
+ * reference refines a few trial positions per POI with icgn1->compute(&candidate) one at a time and keeps the one
+ * with the highest ZNCC (:181-190).  Here the trials of all POIs are ONE queue for oc_hip_compute, and this call
+ * does the selection: candidates segment_starts[s] .. segment_starts[s+1]-1 belong to POI s (n_segments + 1 offsets,
+ * uint32, same memory space as the queues); the winner's deformation and result vectors are copied into POI s
+ * (poi->deformation = best.deformation; poi->result = best.result), nothing else is touched; highest ZNCC wins, the
+ * earliest candidate among equals, NaN never; an empty segment leaves its POI as it was.  POI2D records; any 2D
+ * engine handle supplies the device and stream. */
+int oc_hip_select_best(oc_hip_engine* engine, const void* candidates, size_t n_candidates, size_t candidate_stride_bytes,
+                       const unsigned* segment_starts, size_t n_segments, void* pois, size_t stride_bytes, int memory);
 /* FFTCC3D(int rx, int ry, int rz, int thread_number)  src/oc_fftcc.cpp:300-313 */
 int oc_hip_fftcc3d_create(int radius_x, int radius_y, int radius_z, int device, oc_hip_engine** out);
 /* ICGN3D1(int rx, int ry, int rz, float conv, float stop, int thread_number)  src/oc_icgn.cpp:1197-1213 */

@@ -30,7 +30,7 @@ SYMBOLS = [
     "oc_hip_set_iteration", "oc_hip_set_stream", "oc_hip_reset_stream", "oc_hip_set_tuning",
     "oc_hip_prepare", "oc_hip_prepare_ref", "oc_hip_prepare_tar",
     "oc_hip_compute", "oc_hip_compute_one", "oc_hip_compute_with_offsets", "oc_hip_compute_one_with_offset",
-    "oc_hip_set_self_adaptive", "oc_hip_synchronize",
+    "oc_hip_set_self_adaptive", "oc_hip_synchronize", "oc_hip_select_best",
     "oc_hip_get_kind", "oc_hip_get_field", "oc_hip_read_field",
     "oc_hip_profile_enable", "oc_hip_profile_read", "oc_hip_profile_reset",
 ]
@@ -68,6 +68,7 @@ def lib():
     L.oc_hip_iclm2d1_create.argtypes = [i, i, f, f, i, pp]
     L.oc_hip_iclm2d2_create.argtypes = [i, i, f, f, i, pp]
     L.oc_hip_set_damping.argtypes = [vp, f, f, f]
+    L.oc_hip_select_best.argtypes = [vp, vp, sz, sz, vp, sz, vp, sz, i]
     L.oc_hip_strain_create.argtypes = [f, i, i, pp]
     L.oc_hip_strain_set.argtypes = [vp, f, i, f, i]
     L.oc_hip_strain_prepare.argtypes = [vp, vp, sz, sz, i, i]

@@ -1043,6 +1043,43 @@ int oc_hip_compute_one_with_offset(oc_hip_engine* e, void* poi, const float* cen
     return compute_impl(e, poi, center_offset, 1, e->poi_bytes(), OC_HIP_HOST);
 }
 
+int oc_hip_select_best(oc_hip_engine* e, const void* candidates, size_t n_candidates, size_t candidate_stride_bytes,
+                       const unsigned* segment_starts, size_t n_segments, void* pois, size_t stride_bytes, int memory) {
+    OC_TRY(activate(e));
+    if (n_segments == 0) return OC_HIP_OK;
+    if (!candidates || !segment_starts || !pois) return fail(OC_HIP_ERR_INVALID, "select_best: null argument");
+    if (candidate_stride_bytes < OC_HIP_POI2D_BYTES || (candidate_stride_bytes & 3) || stride_bytes < OC_HIP_POI2D_BYTES ||
+        (stride_bytes & 3))
+        return fail(OC_HIP_ERR_INVALID, "select_best: POI2D records need a stride >= %d bytes, multiple of 4", OC_HIP_POI2D_BYTES);
+    std::lock_guard<std::mutex> lock(e->mu);
+    const float* d_cand = static_cast<const float*>(candidates);
+    const unsigned* d_seg = segment_starts;
+    float* d_pois = static_cast<float*>(pois);
+    if (memory == OC_HIP_HOST) {
+        if (segment_starts[n_segments] > n_candidates)
+            return fail(OC_HIP_ERR_INVALID, "select_best: the last segment ends at %u, the queue has %zu candidates",
+                        segment_starts[n_segments], n_candidates);
+        const size_t cb = n_candidates * candidate_stride_bytes, sb = (n_segments + 1) * sizeof(unsigned), pb = n_segments * stride_bytes;
+        const size_t off_s = (cb + 255) & ~(size_t)255, off_p = (off_s + sb + 255) & ~(size_t)255;
+        OC_TRY(e->poi_stage.reserve(off_p + pb));
+        char* base = e->poi_stage.as<char>();
+        OC_HIP_TRY(hipMemcpyAsync(base, candidates, cb, hipMemcpyHostToDevice, e->stream));
+        OC_HIP_TRY(hipMemcpyAsync(base + off_s, segment_starts, sb, hipMemcpyHostToDevice, e->stream));
+        OC_HIP_TRY(hipMemcpyAsync(base + off_p, pois, pb, hipMemcpyHostToDevice, e->stream));
+        d_cand = reinterpret_cast<const float*>(base);
+        d_seg = reinterpret_cast<const unsigned*>(base + off_s);
+        d_pois = reinterpret_cast<float*>(base + off_p);
+    }
+    OC_HIP_TRY(ochip::launch_poi2d_best_of_segments(d_cand, (int)(candidate_stride_bytes / 4), d_seg, n_segments, d_pois,
+                                                    (int)(stride_bytes / 4), e->stream));
+    if (memory == OC_HIP_HOST) {
+        OC_HIP_TRY(hipMemcpyAsync(pois, d_pois, n_segments * stride_bytes, hipMemcpyDeviceToHost, e->stream));
+        OC_HIP_TRY(hipStreamSynchronize(e->stream));
+        return OC_HIP_OK;
+    }
+    return finish_device_call(e);
+}
+
 int oc_hip_set_self_adaptive(oc_hip_engine* e, int enable) {
     OC_TRY(check_engine(e));
     if (!e->is_icgn2d())

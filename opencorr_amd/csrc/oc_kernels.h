@@ -82,6 +82,10 @@ hipError_t launch_strain_compute(int ndim, float* pois, int stride_floats, size_
                                  const StrainParams& P, const unsigned* start, const unsigned* order, void* recs,
                                  unsigned* fallback, hipStream_t stream);
 
+// best candidate (highest ZNCC) of every segment of a candidate queue -> deformation + result of the segment's POI
+hipError_t launch_poi2d_best_of_segments(const float* cand, int cand_stride_floats, const unsigned* seg_start, size_t nseg,
+                                         float* pois, int stride_floats, hipStream_t stream);
+
 // ---- nr2d.hip --------------------------------------------------------------
 struct Nr2dParams {
     const float* ref;     // reference image, row-major

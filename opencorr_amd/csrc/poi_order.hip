@@ -114,3 +114,55 @@ hipError_t launch_poi2d_tile_order(const float* pois, int stride_f, size_t count
 }
 
 }  // namespace ochip
+
+// ---------------------------------------------------------------------------------------------------------------
+// Candidate batching for callers like EpipolarSearch::compute(POI2D*) (src/oc_epipolar_search.cpp:133-195): the
+// reference refines a handful of trial positions per POI one compute(POI2D*) at a time and keeps the one with the
+// highest ZNCC (std::sort by ZNCC, :186-190).  With the engine, the trials of ALL POIs form one queue (one ICGN launch)
+// and this kernel does the "keep the best" step: segment s of the candidate queue belongs to POI s.
+// One wave per segment; the winner's deformation and result vectors are copied into the POI (`poi->deformation =
+// best.deformation; poi->result = best.result`), nothing else is touched.  Highest ZNCC wins, the earliest candidate
+// among equals, NaN never; an empty segment leaves its POI untouched.
+// ---------------------------------------------------------------------------------------------------------------
+namespace ochip {
+
+__global__ __launch_bounds__(256) void poi2d_best_of_segments_kernel(const float* __restrict__ cand, int cand_stride_f,
+                                                                      const unsigned* __restrict__ seg_start, unsigned nseg,
+                                                                      float* __restrict__ pois, int stride_f) {
+    const unsigned seg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (seg >= nseg) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned lo = seg_start[seg], hi = seg_start[seg + 1];
+    float best = -INFINITY;
+    unsigned bidx = 0xffffffffu;
+    for (unsigned c = lo + lane; c < hi; c += 64) {
+        const float z = cand[(size_t)c * cand_stride_f + poi2d::ZNCC];
+        if (z > best || (z == best && c < bidx) || (bidx == 0xffffffffu && z == z)) {
+            best = z;
+            bidx = c;
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const unsigned oi = (unsigned)__shfl_xor((int)bidx, off, 64);
+        const bool take = oi != 0xffffffffu && (bidx == 0xffffffffu || ov > best || (ov == best && oi < bidx));
+        best = take ? ov : best;
+        bidx = take ? oi : bidx;
+    }
+    if (bidx == 0xffffffffu) return;  // no candidate (or only NaNs)
+    // deformation.p[12] = floats 2..13, result.r[6] = floats 14..19 (src/oc_poi.h:102-136)
+    if (lane < 18) pois[(size_t)seg * stride_f + 2 + lane] = cand[(size_t)bidx * cand_stride_f + 2 + lane];
+}
+
+hipError_t launch_poi2d_best_of_segments(const float* cand, int cand_stride_f, const unsigned* seg_start, size_t nseg, float* pois,
+                                         int stride_f, hipStream_t stream) {
+    if (nseg == 0) return hipSuccess;
+    if (nseg > 0x7fffffffull) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(poi2d_best_of_segments_kernel, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, stream, cand, cand_stride_f,
+                       seg_start, (unsigned)nseg, pois, stride_f);
+    return hipGetLastError();
+}
+
+}  // namespace ochip

@@ -147,6 +147,30 @@ class _Engine:
         capi.check(capi.lib().oc_hip_compute_with_offsets(self._h, p, o, n, stride, mem))
         return pois
 
+    def select_best(self, candidates, segment_starts, pois):
+        """Keeps, for POI s, the candidate with the highest ZNCC among candidates[segment_starts[s]:segment_starts[s+1]]
+        (deformation and result vectors are copied into pois[s]) -- the selection step of
+        EpipolarSearch::compute (src/oc_epipolar_search.cpp:181-190) for a batched candidate queue."""
+        if _is_torch(pois):
+            import torch
+            cp, mem, _ = _buf(candidates)
+            pp_, pmem, _ = _buf(pois)
+            if segment_starts.dtype != torch.int32 or not segment_starts.is_cuda or mem != pmem:
+                raise ValueError("device queues need an int32 CUDA tensor of segment starts")
+            sp = ctypes.c_void_p(segment_starts.data_ptr())
+            nc, cs, ns, ps = candidates.shape[0], candidates.stride(0) * 4, pois.shape[0], pois.stride(0) * 4
+        else:
+            seg = np.ascontiguousarray(segment_starts, dtype=np.uint32)
+            self._keep_seg = seg
+            cp, mem = ctypes.c_void_p(candidates.ctypes.data), capi.HOST
+            pp_ = ctypes.c_void_p(pois.ctypes.data)
+            sp = ctypes.c_void_p(seg.ctypes.data)
+            nc, cs, ns, ps = candidates.shape[0], candidates.strides[0], pois.shape[0], pois.strides[0]
+        if len(segment_starts) != ns + 1:
+            raise ValueError("segment_starts needs len(pois) + 1 entries")
+        capi.check(capi.lib().oc_hip_select_best(self._h, cp, nc, cs, sp, ns, pp_, ps, mem))
+        return pois
+
     def compute_one(self, poi):
         assert poi.dtype == np.float32 and poi.flags.c_contiguous
         capi.check(capi.lib().oc_hip_compute_one(self._h, ctypes.c_void_p(poi.ctypes.data)))

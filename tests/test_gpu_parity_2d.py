@@ -459,3 +459,47 @@ def test_large_subsets_and_the_on_chip_limit(eng):
     with pytest.raises(eng.capi.OpenCorrHipError) as err:
         big.compute(pois.copy())
     assert err.value.status == eng.capi.ERR_UNSUPPORTED
+
+
+def test_candidate_batching_and_select_best(eng, speckle_small):
+    """The EpipolarSearch pattern (src/oc_epipolar_search.cpp:150-190) as one batch: several trial guesses per POI are
+    refined in ONE ICGN2D1 launch, then oc_hip_select_best keeps the highest ZNCC per POI -- identical to doing it
+    candidate by candidate and sorting on the host."""
+    import torch
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    P = {"u": 2, "v": 8, "zncc": 16}
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 14, 12, 30)
+    n = len(xs)
+    rng = np.random.default_rng(6)
+    counts = rng.integers(0, 6, n)          # 0..5 trials per POI, some POIs get none
+    counts[:3] = [5, 1, 0]
+    starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+    cx = np.repeat(xs, counts).astype(np.float32)
+    cy = np.repeat(ys, counts).astype(np.float32)
+    cand = eng.make_pois2d(cx, cy)
+    trial = np.concatenate([np.arange(c) for c in counts]).astype(np.float32) if counts.sum() else np.zeros(0, np.float32)
+    cand[:, P["u"]] = 2.0 + 3.0 * (trial - 2)     # trials along a line, like the epipolar search; trial 2 is close
+    cand[:, P["v"]] = -2.0
+    icgn = eng.ICGN2D1(16, 16, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    icgn.compute(cand)                            # one launch for all trials of all POIs
+    pois = eng.make_pois2d(xs, ys)
+    pois[:, 20:23] = 4.5                          # strain fields: not touched by the selection
+    want = pois.copy()
+    for s in range(n):
+        seg = cand[starts[s]:starts[s + 1]]
+        z = seg[:, P["zncc"]]
+        if len(seg) == 0 or np.all(np.isnan(z)):
+            continue
+        k = int(np.nanargmax(z))                  # first maximum
+        want[s, 2:20] = seg[k, 2:20]
+    got = icgn.select_best(cand, starts, pois.copy())
+    assert np.array_equal(_bits(got), _bits(want))
+    have = counts >= 3
+    assert (got[have, P["zncc"]] > 0.9).mean() > 0.95 and np.abs(got[have, P["u"]] - 2.3).max() < 0.5
+    # device-resident queues
+    d = icgn.select_best(torch.from_numpy(cand).cuda(), torch.from_numpy(starts.astype(np.int32)).cuda(),
+                         torch.from_numpy(pois.copy()).cuda())
+    assert np.array_equal(_bits(d.cpu().numpy()), _bits(want))
