@@ -186,7 +186,8 @@ int oc_hip_reset_stream(oc_hip_engine* engine);
  *                     software pipelining, waves per workgroup)
  *   "icgn2d_xcd"      1: workgroups of one XCD serve a contiguous range of the POI queue
  *   "icgn2d_tile_px"  side of the square image tiles the ICGN2D queue is visited by (L2 locality; 0 = queue order)
- *   "fftcc2d_fused"   1: single-kernel FFTCC2D (LDS FFT) for 32 x 32 windows; 0: rocFFT pipeline
+ *   "fftcc2d_fused"   1: single-kernel FFTCC2D (LDS / register FFT) for square windows of side 20, 24, 30, 32,
+ *                     36, 40, 48 (radius 10, 12, 15, 16, 18, 20, 24); 0: rocFFT pipeline
  *   "fftcc3d_fused"   1: single-kernel FFTCC3D (register/LDS FFT) for 32 x 32 x 32 windows; 0: rocFFT pipeline */
 int oc_hip_set_tuning(oc_hip_engine* engine, const char* key, int value);
 

@@ -279,14 +279,16 @@ int ensure_fft(oc_hip_engine* e, size_t chunk) {
 int run_fftcc2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     if (!e->img || e->img->ndim != 2) return fail(OC_HIP_ERR_INVALID, "FFTCC2D: set_images2d has not been called");
     const ImagePair& im = *e->img;
-    if (e->fftcc2d_fused && ochip::fftcc2d_fused_supported(e->rx, e->ry)) {
+    const bool fused32 = ochip::fftcc2d_fused_supported(e->rx, e->ry);
+    if (e->fftcc2d_fused && (fused32 || ochip::fftcc2d_fusedn_supported(e->rx, e->ry))) {
         ochip::Fftcc2dParams P = {im.ref_ptr(), im.tar_ptr(), im.dy, im.dx, e->rx, e->ry};
         ProfScope prof(e);
         const size_t kMaxBatch = 1u << 30;
         for (size_t first = 0; first < count; first += kMaxBatch) {
             const size_t n = (count - first) < kMaxBatch ? (count - first) : kMaxBatch;
-            hipError_t err = ochip::launch_fftcc2d_fused(P, d_pois + first * (size_t)stride_f, stride_f, n,
-                                                         e->icgn2d_xcd != 0, e->stream);
+            float* q = d_pois + first * (size_t)stride_f;
+            hipError_t err = fused32 ? ochip::launch_fftcc2d_fused(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream)
+                                     : ochip::launch_fftcc2d_fusedn(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream);
             if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "fused FFTCC2D launch failed: %s", hipGetErrorString(err));
         }
         return OC_HIP_OK;

@@ -8,6 +8,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace ochip {
 namespace fftdev {
 
@@ -76,6 +78,166 @@ __device__ __forceinline__ void fft32(c2 (&v)[32]) {
     }
     fft16_at<INV, 0, 32>(v);
     fft16_at<INV, 16, 32>(v);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Mixed-radix transforms for window sides other than 32 (fftcc2d_fusedn.hip): N = product of 2, 3, 4, 5.
+// One decimation-in-frequency step per factor R (N = R * M): the R elements n2 + M*j are transformed, twiddled by
+// W_N^(n2*s) and left in place; the R blocks of M elements are then transformed recursively.  Everything is unrolled
+// at compile time on register arrays; X[k] ends in v[fft_pos(N, k)].
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int fft_radix(int n) { return n % 4 == 0 ? 4 : n % 2 == 0 ? 2 : n % 3 == 0 ? 3 : n % 5 == 0 ? 5 : n; }
+constexpr int fft_pos(int n, int idx) {
+    int pos = 0;
+    while (n > 1) {
+        const int r = fft_radix(n), m = n / r;
+        pos += (idx % r) * m;
+        idx /= r;
+        n = m;
+    }
+    return pos;
+}
+
+// compile-time loop: f(std::integral_constant<int, B>{}), ..., f(std::integral_constant<int, E-1>{}).  Unlike
+// `#pragma unroll`, the loop index is a constant EXPRESSION inside the body, so fft_pos() and the twiddle indices are
+// evaluated by the front end (a run-time fft_pos() would turn the register arrays into scratch memory).
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// cos / sin of 2*pi*k / N for the supported top-level sizes (generated: tools/gen_twiddles.py)
+template <int N>
+struct Twiddle;
+
+template <>
+struct Twiddle<20> {
+    static constexpr float c[20] = {1.0000000000e+00f, 9.5105651630e-01f, 8.0901699437e-01f, 5.8778525229e-01f, 3.0901699437e-01f, 6.1232339957e-17f, -3.0901699437e-01f, -5.8778525229e-01f, -8.0901699437e-01f, -9.5105651630e-01f, -1.0000000000e+00f, -9.5105651630e-01f, -8.0901699437e-01f, -5.8778525229e-01f, -3.0901699437e-01f, -1.8369701987e-16f, 3.0901699437e-01f, 5.8778525229e-01f, 8.0901699437e-01f, 9.5105651630e-01f};
+    static constexpr float s[20] = {0.0000000000e+00f, 3.0901699437e-01f, 5.8778525229e-01f, 8.0901699437e-01f, 9.5105651630e-01f, 1.0000000000e+00f, 9.5105651630e-01f, 8.0901699437e-01f, 5.8778525229e-01f, 3.0901699437e-01f, 1.2246467991e-16f, -3.0901699437e-01f, -5.8778525229e-01f, -8.0901699437e-01f, -9.5105651630e-01f, -1.0000000000e+00f, -9.5105651630e-01f, -8.0901699437e-01f, -5.8778525229e-01f, -3.0901699437e-01f};
+};
+
+template <>
+struct Twiddle<36> {
+    static constexpr float c[36] = {1.0000000000e+00f, 9.8480775301e-01f, 9.3969262079e-01f, 8.6602540378e-01f, 7.6604444312e-01f, 6.4278760969e-01f, 5.0000000000e-01f, 3.4202014333e-01f, 1.7364817767e-01f, 6.1232339957e-17f, -1.7364817767e-01f, -3.4202014333e-01f, -5.0000000000e-01f, -6.4278760969e-01f, -7.6604444312e-01f, -8.6602540378e-01f, -9.3969262079e-01f, -9.8480775301e-01f, -1.0000000000e+00f, -9.8480775301e-01f, -9.3969262079e-01f, -8.6602540378e-01f, -7.6604444312e-01f, -6.4278760969e-01f, -5.0000000000e-01f, -3.4202014333e-01f, -1.7364817767e-01f, -1.8369701987e-16f, 1.7364817767e-01f, 3.4202014333e-01f, 5.0000000000e-01f, 6.4278760969e-01f, 7.6604444312e-01f, 8.6602540378e-01f, 9.3969262079e-01f, 9.8480775301e-01f};
+    static constexpr float s[36] = {0.0000000000e+00f, 1.7364817767e-01f, 3.4202014333e-01f, 5.0000000000e-01f, 6.4278760969e-01f, 7.6604444312e-01f, 8.6602540378e-01f, 9.3969262079e-01f, 9.8480775301e-01f, 1.0000000000e+00f, 9.8480775301e-01f, 9.3969262079e-01f, 8.6602540378e-01f, 7.6604444312e-01f, 6.4278760969e-01f, 5.0000000000e-01f, 3.4202014333e-01f, 1.7364817767e-01f, 1.2246467991e-16f, -1.7364817767e-01f, -3.4202014333e-01f, -5.0000000000e-01f, -6.4278760969e-01f, -7.6604444312e-01f, -8.6602540378e-01f, -9.3969262079e-01f, -9.8480775301e-01f, -1.0000000000e+00f, -9.8480775301e-01f, -9.3969262079e-01f, -8.6602540378e-01f, -7.6604444312e-01f, -6.4278760969e-01f, -5.0000000000e-01f, -3.4202014333e-01f, -1.7364817767e-01f};
+};
+
+template <>
+struct Twiddle<24> {
+    static constexpr float c[24] = {1.0000000000e+00f, 9.6592582629e-01f, 8.6602540378e-01f, 7.0710678119e-01f, 5.0000000000e-01f, 2.5881904510e-01f, 6.1232339957e-17f, -2.5881904510e-01f, -5.0000000000e-01f, -7.0710678119e-01f, -8.6602540378e-01f, -9.6592582629e-01f, -1.0000000000e+00f, -9.6592582629e-01f, -8.6602540378e-01f, -7.0710678119e-01f, -5.0000000000e-01f, -2.5881904510e-01f, -1.8369701987e-16f, 2.5881904510e-01f, 5.0000000000e-01f, 7.0710678119e-01f, 8.6602540378e-01f, 9.6592582629e-01f};
+    static constexpr float s[24] = {0.0000000000e+00f, 2.5881904510e-01f, 5.0000000000e-01f, 7.0710678119e-01f, 8.6602540378e-01f, 9.6592582629e-01f, 1.0000000000e+00f, 9.6592582629e-01f, 8.6602540378e-01f, 7.0710678119e-01f, 5.0000000000e-01f, 2.5881904510e-01f, 1.2246467991e-16f, -2.5881904510e-01f, -5.0000000000e-01f, -7.0710678119e-01f, -8.6602540378e-01f, -9.6592582629e-01f, -1.0000000000e+00f, -9.6592582629e-01f, -8.6602540378e-01f, -7.0710678119e-01f, -5.0000000000e-01f, -2.5881904510e-01f};
+};
+
+template <>
+struct Twiddle<30> {
+    static constexpr float c[30] = {1.0000000000e+00f, 9.7814760073e-01f, 9.1354545764e-01f, 8.0901699437e-01f, 6.6913060636e-01f, 5.0000000000e-01f, 3.0901699437e-01f, 1.0452846327e-01f, -1.0452846327e-01f, -3.0901699437e-01f, -5.0000000000e-01f, -6.6913060636e-01f, -8.0901699437e-01f, -9.1354545764e-01f, -9.7814760073e-01f, -1.0000000000e+00f, -9.7814760073e-01f, -9.1354545764e-01f, -8.0901699437e-01f, -6.6913060636e-01f, -5.0000000000e-01f, -3.0901699437e-01f, -1.0452846327e-01f, 1.0452846327e-01f, 3.0901699437e-01f, 5.0000000000e-01f, 6.6913060636e-01f, 8.0901699437e-01f, 9.1354545764e-01f, 9.7814760073e-01f};
+    static constexpr float s[30] = {0.0000000000e+00f, 2.0791169082e-01f, 4.0673664308e-01f, 5.8778525229e-01f, 7.4314482548e-01f, 8.6602540378e-01f, 9.5105651630e-01f, 9.9452189537e-01f, 9.9452189537e-01f, 9.5105651630e-01f, 8.6602540378e-01f, 7.4314482548e-01f, 5.8778525229e-01f, 4.0673664308e-01f, 2.0791169082e-01f, 5.6655388976e-16f, -2.0791169082e-01f, -4.0673664308e-01f, -5.8778525229e-01f, -7.4314482548e-01f, -8.6602540378e-01f, -9.5105651630e-01f, -9.9452189537e-01f, -9.9452189537e-01f, -9.5105651630e-01f, -8.6602540378e-01f, -7.4314482548e-01f, -5.8778525229e-01f, -4.0673664308e-01f, -2.0791169082e-01f};
+};
+
+template <>
+struct Twiddle<40> {
+    static constexpr float c[40] = {1.0000000000e+00f, 9.8768834060e-01f, 9.5105651630e-01f, 8.9100652419e-01f, 8.0901699437e-01f, 7.0710678119e-01f, 5.8778525229e-01f, 4.5399049974e-01f, 3.0901699437e-01f, 1.5643446504e-01f, 6.1232339957e-17f, -1.5643446504e-01f, -3.0901699437e-01f, -4.5399049974e-01f, -5.8778525229e-01f, -7.0710678119e-01f, -8.0901699437e-01f, -8.9100652419e-01f, -9.5105651630e-01f, -9.8768834060e-01f, -1.0000000000e+00f, -9.8768834060e-01f, -9.5105651630e-01f, -8.9100652419e-01f, -8.0901699437e-01f, -7.0710678119e-01f, -5.8778525229e-01f, -4.5399049974e-01f, -3.0901699437e-01f, -1.5643446504e-01f, -1.8369701987e-16f, 1.5643446504e-01f, 3.0901699437e-01f, 4.5399049974e-01f, 5.8778525229e-01f, 7.0710678119e-01f, 8.0901699437e-01f, 8.9100652419e-01f, 9.5105651630e-01f, 9.8768834060e-01f};
+    static constexpr float s[40] = {0.0000000000e+00f, 1.5643446504e-01f, 3.0901699437e-01f, 4.5399049974e-01f, 5.8778525229e-01f, 7.0710678119e-01f, 8.0901699437e-01f, 8.9100652419e-01f, 9.5105651630e-01f, 9.8768834060e-01f, 1.0000000000e+00f, 9.8768834060e-01f, 9.5105651630e-01f, 8.9100652419e-01f, 8.0901699437e-01f, 7.0710678119e-01f, 5.8778525229e-01f, 4.5399049974e-01f, 3.0901699437e-01f, 1.5643446504e-01f, 1.2246467991e-16f, -1.5643446504e-01f, -3.0901699437e-01f, -4.5399049974e-01f, -5.8778525229e-01f, -7.0710678119e-01f, -8.0901699437e-01f, -8.9100652419e-01f, -9.5105651630e-01f, -9.8768834060e-01f, -1.0000000000e+00f, -9.8768834060e-01f, -9.5105651630e-01f, -8.9100652419e-01f, -8.0901699437e-01f, -7.0710678119e-01f, -5.8778525229e-01f, -4.5399049974e-01f, -3.0901699437e-01f, -1.5643446504e-01f};
+};
+
+template <>
+struct Twiddle<48> {
+    static constexpr float c[48] = {1.0000000000e+00f, 9.9144486137e-01f, 9.6592582629e-01f, 9.2387953251e-01f, 8.6602540378e-01f, 7.9335334029e-01f, 7.0710678119e-01f, 6.0876142901e-01f, 5.0000000000e-01f, 3.8268343237e-01f, 2.5881904510e-01f, 1.3052619222e-01f, 6.1232339957e-17f, -1.3052619222e-01f, -2.5881904510e-01f, -3.8268343237e-01f, -5.0000000000e-01f, -6.0876142901e-01f, -7.0710678119e-01f, -7.9335334029e-01f, -8.6602540378e-01f, -9.2387953251e-01f, -9.6592582629e-01f, -9.9144486137e-01f, -1.0000000000e+00f, -9.9144486137e-01f, -9.6592582629e-01f, -9.2387953251e-01f, -8.6602540378e-01f, -7.9335334029e-01f, -7.0710678119e-01f, -6.0876142901e-01f, -5.0000000000e-01f, -3.8268343237e-01f, -2.5881904510e-01f, -1.3052619222e-01f, -1.8369701987e-16f, 1.3052619222e-01f, 2.5881904510e-01f, 3.8268343237e-01f, 5.0000000000e-01f, 6.0876142901e-01f, 7.0710678119e-01f, 7.9335334029e-01f, 8.6602540378e-01f, 9.2387953251e-01f, 9.6592582629e-01f, 9.9144486137e-01f};
+    static constexpr float s[48] = {0.0000000000e+00f, 1.3052619222e-01f, 2.5881904510e-01f, 3.8268343237e-01f, 5.0000000000e-01f, 6.0876142901e-01f, 7.0710678119e-01f, 7.9335334029e-01f, 8.6602540378e-01f, 9.2387953251e-01f, 9.6592582629e-01f, 9.9144486137e-01f, 1.0000000000e+00f, 9.9144486137e-01f, 9.6592582629e-01f, 9.2387953251e-01f, 8.6602540378e-01f, 7.9335334029e-01f, 7.0710678119e-01f, 6.0876142901e-01f, 5.0000000000e-01f, 3.8268343237e-01f, 2.5881904510e-01f, 1.3052619222e-01f, 1.2246467991e-16f, -1.3052619222e-01f, -2.5881904510e-01f, -3.8268343237e-01f, -5.0000000000e-01f, -6.0876142901e-01f, -7.0710678119e-01f, -7.9335334029e-01f, -8.6602540378e-01f, -9.2387953251e-01f, -9.6592582629e-01f, -9.9144486137e-01f, -1.0000000000e+00f, -9.9144486137e-01f, -9.6592582629e-01f, -9.2387953251e-01f, -8.6602540378e-01f, -7.9335334029e-01f, -7.0710678119e-01f, -6.0876142901e-01f, -5.0000000000e-01f, -3.8268343237e-01f, -2.5881904510e-01f, -1.3052619222e-01f};
+};
+
+
+// multiplication by -i (forward) / +i (inverse)
+template <bool INV>
+__device__ __forceinline__ c2 rot90(c2 d) {
+    return INV ? mkc(-d.y, d.x) : mkc(d.y, -d.x);
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft2(c2& a, c2& b) {
+    const c2 t = a + b;
+    b = a - b;
+    a = t;
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft3(c2& a0, c2& a1, c2& a2) {
+#pragma clang fp contract(fast)
+    const c2 t = a1 + a2, d = rot90<INV>((a1 - a2) * 8.6602540378e-01f);  // sin(2 pi / 3), times -/+ i
+    const c2 m = a0 - t * 0.5f;
+    a0 = a0 + t;
+    a1 = m + d;
+    a2 = m - d;
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft4(c2& a0, c2& a1, c2& a2, c2& a3) {
+    const c2 s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = rot90<INV>(a1 - a3);
+    a0 = s02 + s13;
+    a1 = d02 + d13;
+    a2 = s02 - s13;
+    a3 = d02 - d13;
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft5(c2& a0, c2& a1, c2& a2, c2& a3, c2& a4) {
+#pragma clang fp contract(fast)
+    constexpr float c1 = 3.0901699437e-01f, c2_ = -8.0901699437e-01f, s1 = 9.5105651630e-01f, s2 = 5.8778525229e-01f;
+    const c2 p14 = a1 + a4, m14 = a1 - a4, p23 = a2 + a3, m23 = a2 - a3;
+    const c2 r1 = a0 + p14 * c1 + p23 * c2_, r2 = a0 + p14 * c2_ + p23 * c1;
+    const c2 i1 = rot90<INV>(m14 * s1 + m23 * s2), i2 = rot90<INV>(m14 * s2 - m23 * s1);
+    a0 = a0 + p14 + p23;
+    a1 = r1 + i1;
+    a4 = r1 - i1;
+    a2 = r2 + i2;
+    a3 = r2 - i2;
+}
+
+template <bool INV, int TOP, int M, int OFF, int LEN, int S, int R>
+__device__ __forceinline__ void fft_mixed_blocks(c2 (&v)[LEN]);
+
+// N-point transform on v[OFF .. OFF+N); TOP is the size whose twiddle table is used (TOP % N == 0)
+template <bool INV, int TOP, int N, int OFF, int LEN>
+__device__ __forceinline__ void fft_mixed_at(c2 (&v)[LEN]) {
+    if constexpr (N > 1) {
+        constexpr int R = fft_radix(N), M = N / R;
+        static_assert(R <= 5, "window side must factor into 2, 3, 4, 5");
+        static_for<0, M>([&](auto n2c) {
+            constexpr int n2 = decltype(n2c)::value;
+            if constexpr (R == 2) dft2<INV>(v[OFF + n2], v[OFF + n2 + M]);
+            if constexpr (R == 3) dft3<INV>(v[OFF + n2], v[OFF + n2 + M], v[OFF + n2 + 2 * M]);
+            if constexpr (R == 4) dft4<INV>(v[OFF + n2], v[OFF + n2 + M], v[OFF + n2 + 2 * M], v[OFF + n2 + 3 * M]);
+            if constexpr (R == 5)
+                dft5<INV>(v[OFF + n2], v[OFF + n2 + M], v[OFF + n2 + 2 * M], v[OFF + n2 + 3 * M], v[OFF + n2 + 4 * M]);
+            if constexpr (n2 != 0) {
+                static_for<1, R>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    constexpr int m = (n2 * s) % N * (TOP / N);  // W_N^(n2 s) = W_TOP^m
+                    constexpr float tc = Twiddle<TOP>::c[m], ts = Twiddle<TOP>::s[m];
+                    v[OFF + n2 + s * M] = cmul_tw<INV>(v[OFF + n2 + s * M], tc, ts);
+                });
+            }
+        });
+        fft_mixed_blocks<INV, TOP, M, OFF, LEN, 0, R>(v);
+    }
+}
+
+// the R sub-transforms of M elements each (compile-time recursion: the block offset is a template argument)
+template <bool INV, int TOP, int M, int OFF, int LEN, int S, int R>
+__device__ __forceinline__ void fft_mixed_blocks(c2 (&v)[LEN]) {
+    if constexpr (S < R) {
+        fft_mixed_at<INV, TOP, M, OFF + S * M, LEN>(v);
+        fft_mixed_blocks<INV, TOP, M, OFF, LEN, S + 1, R>(v);
+    }
+}
+
+template <bool INV, int N>
+__device__ __forceinline__ void fft_mixed(c2 (&v)[N]) {
+    fft_mixed_at<INV, N, N, 0, N>(v);
 }
 
 }  // namespace fftdev

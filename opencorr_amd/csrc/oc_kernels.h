@@ -141,6 +141,13 @@ hipError_t launch_fftcc_conjmul(const float2* rf, const float2* tf, float2* zf, 
 hipError_t launch_fftcc2d_argmax(const Fftcc2dParams& p, const float* surf, const float* norms, const int* flags,
                                  float* pois, int stride_floats, size_t count, hipStream_t stream);
 
+// ---- fftcc2d_fusedn.hip ----------------------------------------------------
+// the same for square windows of side 20, 24, 30, 36, 40, 48 (radii 10, 12, 15, 18, 20, 24): mixed-radix FFT, one line
+// per lane
+bool fftcc2d_fusedn_supported(int rx, int ry);
+hipError_t launch_fftcc2d_fusedn(const Fftcc2dParams& p, float* pois, int stride_floats, size_t count, bool xcd,
+                                 hipStream_t stream);
+
 // ---- fftcc2d_fused.hip -----------------------------------------------------
 // whole FFTCC2D::compute for 32 x 32 windows (rx == ry == 16) in one kernel, no rocFFT, no scratch
 bool fftcc2d_fused_supported(int rx, int ry);
