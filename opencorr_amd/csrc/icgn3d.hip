@@ -164,11 +164,16 @@ __device__ __forceinline__ f2 mk2(float a, float b) {
     return r;
 }
 
-// cubic B-spline basis functions, src/oc_cubic_bspline.cpp:35-53
-__device__ __forceinline__ float basis0(float t) { return (1.f / 6.f) * (t * (t * (-t + 3.f) - 3.f) + 1.f); }
-__device__ __forceinline__ float basis1(float t) { return (1.f / 6.f) * (t * t * (3.f * t - 6.f) + 4.f); }
-__device__ __forceinline__ float basis2(float t) { return (1.f / 6.f) * (t * (t * (-3.f * t + 3.f) + 3.f) + 1.f); }
-__device__ __forceinline__ float basis3(float t) { return (1.f / 6.f) * (t * t * t); }
+// cubic B-spline basis functions, src/oc_cubic_bspline.cpp:35-53; T = float, or a packed pair of arguments (the same
+// IEEE operations, two per issue slot)
+template <class T>
+__device__ __forceinline__ T basis0(T t) { return (1.f / 6.f) * (t * (t * (-t + 3.f) - 3.f) + 1.f); }
+template <class T>
+__device__ __forceinline__ T basis1(T t) { return (1.f / 6.f) * (t * t * (3.f * t - 6.f) + 4.f); }
+template <class T>
+__device__ __forceinline__ T basis2(T t) { return (1.f / 6.f) * (t * (t * (-3.f * t + 3.f) + 3.f) + 1.f); }
+template <class T>
+__device__ __forceinline__ T basis3(T t) { return (1.f / 6.f) * (t * t * t); }
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned 16-byte load
 
@@ -210,9 +215,12 @@ __device__ __forceinline__ float bspline3d_eval_lds(const float* __restrict__ wi
     const bool out = (x < 1 || y < 1 || z < 1 || x >= dx - 2 || y >= dy - 2 || z >= dz - 2 || isnan(x) || isnan(y) ||
                       isnan(z));
     const int xi = out ? ox + 1 : (int)floorf(x), yi = out ? oy + 1 : (int)floorf(y), zi = out ? oz + 1 : (int)floorf(z);
-    const float fx = x - (float)xi, fy = y - (float)yi, fz = z - (float)zi;
-    const float bx0 = basis0(fx), bx1 = basis1(fx), bx2 = basis2(fx), bx3 = basis3(fx);
-    const float by[4] = {basis0(fy), basis1(fy), basis2(fy), basis3(fy)};
+    // the x and y weights are evaluated as packed pairs (same operations per component), z scalar
+    const f2 fxy = mk2(x, y) - mk2((float)xi, (float)yi);
+    const float fz = z - (float)zi;
+    const f2 b0 = basis0(fxy), b1 = basis1(fxy), b2 = basis2(fxy), b3 = basis3(fxy);
+    const float bx0 = b0.x, bx1 = b1.x, bx2 = b2.x, bx3 = b3.x;
+    const float by[4] = {b0.y, b1.y, b2.y, b3.y};
     const float bz[4] = {basis0(fz), basis1(fz), basis2(fz), basis3(fz)};
     const float* __restrict__ base = win + ((zi - 1 - oz) * nxy + (yi - 1 - oy) * nx + (xi - 1 - ox));
     float sum_y[4];

@@ -208,6 +208,9 @@ def main():
             rec = run_strain("B + Strain (4096^2, 500x500 POIs, subregion radius 40 px, >= 5 neighbours)", 4096, 16, 500, 40.0, 5)
         elif c == "E":
             rec = run_3d("E on ONE GPU (512^3, r=16, 37^3 POIs)", 512, 16, 37, 96)
+        elif c == "E30":
+            # the radius of the reference's own DVC example (examples/test_dvc_fftcc_icgn1.cpp:45-47)
+            rec = run_3d("DVC example shape (256^3, r=30, 8^3 POIs)", 256, 30, 8, 16)
         elif c == "Es":
             rec = run_3d("E-small (256^3, r=16, 12^3 POIs)", 256, 16, 12, 48)
         else:
