@@ -32,8 +32,8 @@ namespace ochip {
 
 constexpr int kBlock3d = 512;
 constexpr int kWaves3d = kBlock3d / kWave;  // 8
-constexpr int kWinCap = 14080;              // floats of LDS for the staged coefficient box (55 KB)
-constexpr int kBoxSlots = 512;              // passes whose boxes are precomputed together
+constexpr int kWinCap = 16768;              // floats of LDS for the staged coefficient box (65.5 KB)
+constexpr int kBoxSlots = 64;               // passes whose boxes are precomputed together
 constexpr int kRedChunk = 13;               // values reduced per LDS round trip
 
 __device__ __forceinline__ float uni3(float v) {
@@ -719,7 +719,8 @@ hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_f, size
     // offsets immediates
     const int want = 2 * p.rx + 1 + 5;
     const int px = want <= 40 ? 40 : want <= 48 ? 48 : want <= 64 ? 64 : 0;
-    for (int m = 4; m >= 1; m >>= 1) {
+    const int tries[] = {16, 12, 10, 8, 6, 4, 3, 2, 1};
+    for (int m : tries) {
         const long long sx = 2 * p.rx + 1, sy = 2 * p.ry + 1, sz = 2 * p.rz + 1, len = (long long)m * kBlock3d;
         const long long planes = (len + sx * sy - 1) / (sx * sy) + 1;
         const long long nz = (planes < sz ? planes : sz) + 3 + 1;
