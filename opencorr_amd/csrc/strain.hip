@@ -487,7 +487,8 @@ static hipError_t bbox_t(const float* pois, int stride_f, size_t count, unsigned
     const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     hipError_t err = hipMemcpyAsync(box, init, sizeof(init), hipMemcpyHostToDevice, stream);
     if (err != hipSuccess) return err;
-    const unsigned blocks = (unsigned)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
+    // few workgroups: every wave ends in atomics on the same six words
+    const unsigned blocks = (unsigned)((count + 255) / 256 < 128 ? (count + 255) / 256 : 128);
     (void)hipGetLastError();
     hipLaunchKernelGGL(strain_bbox_kernel<DIM>, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, box);
     return hipGetLastError();
