@@ -11,9 +11,14 @@
  * Parity status of the oracle itself:
  *   - FFTCC2D + ICGN2D1: pinned against the reference's own golden vectors
  *     (examples/2d_dic/oht_cfrp_4_fftcc_icgn1_r16*.csv) in tests/test_oracle_golden.py.
- *   - ICGN2D2, FFTCC3D, ICGN3D1: "parity unpinned" -- the reference ships no
- *     usable fixture for them in this mount; they are checked
- *     against analytic warps only.
+ *   - NR2D1: pinned against examples/2d_dic/oht_cfrp_4_fftcc_nr1_r16.csv (same test file).
+ *   - Strain (2D): pinned against the exx, eyy, exy columns of the same golden table
+ *     (tests/test_oracle_strain.py), at the rounding of the reference's float QR (~2e-7).
+ *   - ICGN2D2: soft anchor only (the reference's CUDA results from unrecorded initial guesses).
+ *   - FFTCC3D, ICGN3D1, the centre-offset / self-adaptive overloads, ICLM2D1/2D2, 3D strain,
+ *     RegionFit2D/3D: "parity unpinned" -- the reference ships no usable fixture for them in
+ *     this mount; they are checked against analytic fields and against the
+ *     pinned code they share.
  *
  * All images are row-major float32 (x fastest): img[y*width + x]; volumes are
  * vol[(z*dim_y + y)*dim_x + x] (same as Image3D::vol_mat, src/oc_array.h:57-74).
