@@ -3,10 +3,10 @@
 all of them produce the same bits (against variant 0 on the GPU, and against the CPU oracle
 on a strided sample of the queue).
 
-    python tools/icgn_sweep.py [--size 4096 --pois 500 --radius 16 --engine 1 --launches 3]
+    python tests/fullsize/icgn_sweep.py [--size 4096 --pois 500 --radius 16 --engine 1 --launches 3]
                                [--variants 0,3,4] [--out gpurun_out/sweep.json]
 
-Test/bench infrastructure only: the oracle import is the checker.
+Test infrastructure (lives under tests/ because the oracle import is its checker).
 """
 import argparse
 import json
@@ -15,7 +15,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

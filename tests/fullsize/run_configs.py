@@ -1,9 +1,11 @@
 #!/usr/bin/env python
-"""Runs the BASELINE.json configurations that are not the bench line (A, C, D on one GPU, E) at
+"""Full-size checks (part of the test infrastructure: lives under tests/ because it uses the oracle as its checker).
+
+Runs the BASELINE.json configurations that are not the bench line (A, C, D on one GPU, E) at
 their full sizes on one MI355X and checks them through size-independent properties plus a strided
 oracle sample.  One JSON line per configuration.
 
-    python tools/run_configs.py [--configs A,C,D1,E] [--out gpurun_out/configs.json]
+    python tests/fullsize/run_configs.py [--configs A,C,D1,E] [--out gpurun_out/configs.json]
 
 Checks per configuration
   * converged fraction and recovery of the analytic displacement field the synthetic pair was
@@ -21,7 +23,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

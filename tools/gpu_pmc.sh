@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over tools/icgn_sweep.py for the given variants: bash tools/gpu_pmc.sh <tag> <variants> [extra sweep args]
+# PMC passes over tests/fullsize/icgn_sweep.py for the given variants: bash tools/gpu_pmc.sh <tag> <variants> [extra sweep args]
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-pmc}
 VARS=${2:-0}
@@ -11,7 +11,7 @@ cd /tmp
 pmc() {
   name=$1; shift
   timeout 300 rocprofv3 --pmc "$@" --kernel-include-regex "icgn2d_kernel" --output-format csv -d $OUT/pmc_$name -o $name -- \
-      python $ROOT/tools/icgn_sweep.py --launches 1 --oracle-sample 200 --variants $VARS --xcd 1 $EXTRA > $OUT/pmc_$name.log 2>&1
+      python $ROOT/tests/fullsize/icgn_sweep.py --launches 1 --oracle-sample 200 --variants $VARS --xcd 1 $EXTRA > $OUT/pmc_$name.log 2>&1
   echo "pmc $name rc=$?"
 }
 EXTRA="$@"

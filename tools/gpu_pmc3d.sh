@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over the ICGN3D1 kernel (tools/run_configs.py --configs Es): bash tools/gpu_pmc3d.sh <tag>
+# PMC passes over the ICGN3D1 kernel (tests/fullsize/run_configs.py --configs Es): bash tools/gpu_pmc3d.sh <tag>
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-pmc3d}
 CFG=${2:-Es}
@@ -10,7 +10,7 @@ cd /tmp
 pmc() {
   name=$1; shift
   timeout 300 rocprofv3 --pmc "$@" --kernel-include-regex "icgn3d1_kernel" --output-format csv -d $OUT/pmc_$name -o $name -- \
-      python $ROOT/tools/run_configs.py --configs $CFG > $OUT/pmc_$name.log 2>&1
+      python $ROOT/tests/fullsize/run_configs.py --configs $CFG > $OUT/pmc_$name.log 2>&1
   echo "pmc $name rc=$?"
 }
 pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU

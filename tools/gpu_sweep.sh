@@ -9,14 +9,14 @@ export TMPDIR=/tmp
 echo "== pytest -m gpu"; 
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/pytest.log
 echo "== sweep ICGN2D1 config B"
-timeout 600 python tools/icgn_sweep.py --out $OUT/sweep_2d1.json 2>&1 | tail -40 | tee $OUT/sweep_2d1.log
+timeout 600 python tests/fullsize/icgn_sweep.py --out $OUT/sweep_2d1.json 2>&1 | tail -40 | tee $OUT/sweep_2d1.log
 echo "== sweep ICGN2D2 config C"
-timeout 600 python tools/icgn_sweep.py --engine 2 --radius 20 --pois 316 --variants 0,1,4,6,7,10,11 --out $OUT/sweep_2d2.json 2>&1 | tail -30 | tee $OUT/sweep_2d2.log
+timeout 600 python tests/fullsize/icgn_sweep.py --engine 2 --radius 20 --pois 316 --variants 0,1,4,6,7,10,11 --out $OUT/sweep_2d2.json 2>&1 | tail -30 | tee $OUT/sweep_2d2.log
 cd /tmp
 pmc() {  # name, counters...
   name=$1; shift
   timeout 600 rocprofv3 --pmc "$@" --kernel-include-regex "icgn2d_kernel" --output-format csv -d $OUT/pmc_$name -o $name -- \
-      python $ROOT/tools/icgn_sweep.py --launches 1 --oracle-sample 200 > $OUT/pmc_$name.log 2>&1
+      python $ROOT/tests/fullsize/icgn_sweep.py --launches 1 --oracle-sample 200 > $OUT/pmc_$name.log 2>&1
   echo "pmc $name rc=$?"
 }
 pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU

@@ -33,7 +33,7 @@ def main(root, out=None):
     counters = sorted({c for k in per for o in per[k] for c in per[k][o]})
     rows = []
     for key in sorted(per):
-        # every (variant, mapping) is dispatched twice by tools/icgn_sweep.py --launches 1: warm-up, then the timed one
+        # every (variant, mapping) is dispatched twice by tests/fullsize/icgn_sweep.py --launches 1: warm-up, then the timed one
         for n, ordinal in enumerate(sorted(per[key])[1::2]):
             c = per[key][ordinal]
             ms = [v for (t, o), v in dur[key].items() if o == ordinal]
