@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box session: parity tests, bench line, rocprofv3 kernel-trace summary of the bench.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r01c}
+TAG=${1:-round}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT

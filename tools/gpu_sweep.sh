@@ -11,7 +11,7 @@ timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/pytes
 echo "== sweep ICGN2D1 config B"
 timeout 600 python tests/fullsize/icgn_sweep.py --out $OUT/sweep_2d1.json 2>&1 | tail -40 | tee $OUT/sweep_2d1.log
 echo "== sweep ICGN2D2 config C"
-timeout 600 python tests/fullsize/icgn_sweep.py --engine 2 --radius 20 --pois 316 --variants 0,1,4,6,7,10,11 --out $OUT/sweep_2d2.json 2>&1 | tail -30 | tee $OUT/sweep_2d2.log
+timeout 600 python tests/fullsize/icgn_sweep.py --engine 2 --radius 20 --pois 316 --out $OUT/sweep_2d2.json 2>&1 | tail -30 | tee $OUT/sweep_2d2.log
 cd /tmp
 pmc() {  # name, counters...
   name=$1; shift
