@@ -251,12 +251,13 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         float col[DOF];
 #pragma unroll
         for (int i = 0; i < DOF; i++) col[i] = 0.f;
+        wave_allreduce_sum_multi<NH>(h, lane);  // all NH sums in one transposing butterfly (oc_device.h)
         int k = 0;
 #pragma unroll
         for (int i = 0; i < DOF; i++)
 #pragma unroll
             for (int j = 0; j <= i; j++) {
-                const float v = wave_allreduce_sum(h[k++]);
+                const float v = h[k++];
                 if (lane == j) col[i] = v;  // H(i,j)
                 if (lane == i) col[j] = v;  // H(j,i)
             }
@@ -466,7 +467,13 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 }
             }
         }
-        znssd = uni(wave_allreduce_sum(ssd)) / (ref_norm * ref_norm);
+        // the DOF numerator sums and the sum of squared errors in one transposing butterfly
+        float red[DOF + 1];
+#pragma unroll
+        for (int j = 0; j < DOF; j++) red[j] = num[j];
+        red[DOF] = ssd;
+        wave_allreduce_sum_multi<DOF + 1>(red, lane);
+        znssd = uni(red[DOF]) / (ref_norm * ref_norm);
         if constexpr (LM) {
             // src/oc_iclm.cpp:250-257: lambda from the first ZNSSD; (H + lambda * I)^-1 every iteration
             if (iter == 1) lambda = uni(pow_lambda(P.lm_log_lambda, znssd / znssd0) - 1.f);
@@ -479,10 +486,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         // products of row i are then added in ascending j exactly like the reference loop
         float numj = 0.f;
 #pragma unroll
-        for (int j = 0; j < DOF; j++) {
-            const float v = wave_allreduce_sum(num[j]);
-            numj = lane == j ? v : numj;
-        }
+        for (int j = 0; j < DOF; j++) numj = lane == j ? red[j] : numj;
         float dp[DOF];
 #pragma unroll
         for (int i = 0; i < DOF; i++) {

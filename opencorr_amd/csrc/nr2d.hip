@@ -191,8 +191,9 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
         // (3) Hessian: lane j < 6 assembles column j; inverse (:241)
         float hinv_col[6];
         {
-            const float h[21] = {h00,   hxA.x, hAA.x, hxA.y, h21,   hAA.y, h30,   hyA.x, hyA.y, h33,  hxB.x,
-                                 hAB.x, hAs.y, hyB.x, hBB.x, hxB.y, hAs.x, hAB.y, hyB.y, h54,   hBB.y};
+            float h[21] = {h00,   hxA.x, hAA.x, hxA.y, h21,   hAA.y, h30,   hyA.x, hyA.y, h33,  hxB.x,
+                           hAB.x, hAs.y, hyB.x, hBB.x, hxB.y, hAs.x, hAB.y, hyB.y, h54,   hBB.y};
+            wave_allreduce_sum_multi<21>(h, lane);  // one transposing butterfly for the 21 sums (oc_device.h)
             float col[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) col[i] = 0.f;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
             for (int i = 0; i < 6; i++)
 #pragma unroll
                 for (int j = 0; j <= i; j++) {
-                    const float v = wave_allreduce_sum(h[k++]);
+                    const float v = h[k++];
                     if (lane == j) col[i] = v;  // H(i,j)
                     if (lane == i) col[j] = v;  // H(j,i)
                 }
@@ -229,14 +230,12 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
             for (int t = 0; t < NF; t++, w.next()) sample(t, true);
             if (NF < NT) sample(NF, w.s < N);
         }
-        znssd = uni(wave_allreduce_sum(ssd)) / (tar_norm * tar_norm);
-        const float num[6] = {n0, nA.x, nA.y, n3, nB.x, nB.y};
+        float num[7] = {n0, nA.x, nA.y, n3, nB.x, nB.y, ssd};
+        wave_allreduce_sum_multi<7>(num, lane);
+        znssd = uni(num[6]) / (tar_norm * tar_norm);
         float numj = 0.f;
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const float v = wave_allreduce_sum(num[j]);
-            numj = lane == j ? v : numj;
-        }
+        for (int j = 0; j < 6; j++) numj = lane == j ? num[j] : numj;
         // (5) dp = H^-1 * numerator (:265-272), p += dp (:277-279), convergence norm (:285-293)
         float dp[6];
 #pragma unroll

@@ -56,6 +56,49 @@ __device__ __forceinline__ float wave_allreduce_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// K sums at once.  On return every v[k] is the wave-wide sum of the lanes' v[k], wave-uniform, with exactly the
+// association of wave_allreduce_sum (xor butterfly, offsets 1, 2, 4, 8, 16, 32: every level adds the same two partial
+// sums, and a + b is commutative).  What changes is where the work is done: after the quad levels the values are
+// dealt out -- level 4 keeps the first half of the list in the even quads and the second half in the odd quads
+// (each lane adds its partner's copy of the half it keeps), level 8 splits again between the low and the high eight
+// lanes of a row -- so the row levels (LDS-crossbar permutes) run on a quarter of the registers, and one v_readlane
+// per value fetches the total from the lane class that holds it.  ~6 K instead of 11 K instructions.
+template <int K>
+__device__ __forceinline__ void wave_allreduce_sum_multi(float (&v)[K], int lane) {
+    constexpr int H = (K + 1) / 2, H2 = (H + 1) / 2;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        v[k] = v[k] + dpp_perm<0xB1>(v[k]);  // xor 1
+        v[k] = v[k] + dpp_perm<0x4E>(v[k]);  // xor 2
+    }
+    const bool odd_quad = (lane & 4) != 0, high8 = (lane & 8) != 0;
+    float d[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+        const float a = v[i], b = (i + H < K) ? v[(i + H) % K] : 0.f;
+        const float keep = odd_quad ? b : a, give = odd_quad ? a : b;
+        d[i] = keep + dpp_perm<0x141>(give);  // row_half_mirror: the neighbouring quad (xor 4 on quad-uniform values)
+    }
+    float e[H2];
+#pragma unroll
+    for (int j = 0; j < H2; j++) {
+        const float a = d[j], b = (j + H2 < H) ? d[(j + H2) % H] : 0.f;
+        const float keep = high8 ? b : a, give = high8 ? a : b;
+        e[j] = keep + dpp_perm<0x128>(give);  // row_ror:8 == xor 8: same quad parity, i.e. the same half of the list
+    }
+#pragma unroll
+    for (int j = 0; j < H2; j++) {
+        e[j] = e[j] + __shfl_xor(e[j], 16, kWave);
+        e[j] = e[j] + __shfl_xor(e[j], 32, kWave);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int i = k % H, j = i % H2;                            // register that ends up holding value k
+        const int holder = (k >= H ? 4 : 0) + (i >= H2 ? 8 : 0);    // odd quad / high eight of row 0
+        v[k] = wave_bcast(e[j], holder);
+    }
+}
+
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
 }  // namespace ochip
