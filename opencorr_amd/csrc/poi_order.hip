@@ -1,10 +1,12 @@
-// poi_order.hip -- locality schedule for a POI queue: a permutation that visits the queue tile by tile.
+// poi_order.hip -- queue-level helpers around the per-POI solvers: (1) the locality schedule of a POI queue (a
+// permutation that visits the queue tile by tile), (2) at the end of the file, the best-candidate selection over a
+// segmented candidate queue (oc_hip_select_best).
 //
 // The ICGN2D kernels are served by per-XCD L2 caches (4 MB each); POIs that are neighbours in the image
 // share most of their coefficient-table lines.  A caller's queue is usually row-major over the whole
 // image, so a workgroup batch covers one long thin strip whose table footprint (33 rows x image width
 // x 64 B) overflows the L2.  Visiting the POIs tile by tile (square tiles of `tile_px` pixels, tiles in
-// row-major order, any order inside a tile) keeps the footprint of the POIs in flight near 2 MB.
+// row-major order, queue order inside a tile) keeps the footprint of the POIs in flight near 2 MB.
 // Every POI is computed exactly as before -- only the order of the independent per-POI solves changes.
 //
 // Counting sort in small kernels: histogram of tile ids, exclusive scan (one workgroup), scatter, and a rank pass
