@@ -539,7 +539,7 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
                                 // a row fits one wave-wide load: fetch kStageRows rows before the first LDS write, so
                                 // that their latencies overlap (one row at a time left the wave waiting ~30 times per
                                 // pass); (zr, yr) are wave-uniform and advance on the scalar unit
-                                constexpr int kStageRows = 8;
+                                constexpr int kStageRows = 16;
                                 for (int row0 = wave; row0 < rows; row0 += kStageRows * kWaves3d) {
                                     float v[kStageRows];
 #pragma unroll
