@@ -1,0 +1,32 @@
+"""Host-side checks of bench.py that need no GPU: the algorithmic-bytes formula of SURVEY 8(d) and the keys of the
+JSON line the driver parses."""
+import ast
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_algorithmic_bytes_formula():
+    import bench
+    pois = np.zeros((5, 25), np.float32)
+    pois[:, 17] = [3, 4, 0, 10, 2]  # iterations; a POI that never iterated (guard) only moves its record
+    n2 = 33 * 33
+    total, mean_iter = bench.algorithmic_bytes_icgn2d1(pois, 16, 16)
+    want = 4 * (3 * n2 * 4 + 200) + (3 + 4 + 10 + 2) * n2 * 64 + 200   # B1 = 3*N2*4 + k*N2*64 + 200 per POI
+    assert total == want and abs(mean_iter - 19 / 4) < 1e-12
+    # SURVEY's worked number: k = 4.5 at r = 16 -> 326.9 KB per POI
+    assert abs((3 * n2 * 4 + 200 + 4.5 * n2 * 64) - 326_900) < 100
+
+
+def test_bench_prints_the_contract_keys():
+    """The one JSON line carries every key of the driver's contract plus roofline and cpu_baseline."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    keys = {c.value for n in ast.walk(tree) if isinstance(n, ast.Dict) for c in n.keys if isinstance(c, ast.Constant)}
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "workload", "roofline", "bound", "achieved", "peak", "frac",
+              "traffic", "cores", "kind", "sample"):
+        assert k in keys or ('"%s"' % k) in src, k
+    assert 'out["cpu_baseline"]' in src and "--no-cpu-baseline" in src
