@@ -217,6 +217,15 @@ public:
         const float off[2] = {center_offset.x, center_offset.y};
         hipdetail::check(oc_hip_compute_one_with_offset(engine_, poi, off));
     }
+    // Batched form of "refine several trial guesses per POI, keep the one with the highest ZNCC"
+    // (EpipolarSearch::compute, src/oc_epipolar_search.cpp:150-190): `candidates` holds the trials of all POIs,
+    // those of poi_queue[s] at [segment_starts[s], segment_starts[s+1]).  One ICGN launch, one selection kernel.
+    void computeBestOf(std::vector<POI2D>& candidates, const std::vector<unsigned>& segment_starts, std::vector<POI2D>& poi_queue) {
+        if (segment_starts.size() != poi_queue.size() + 1) throw std::string("computeBestOf: need one segment start per POI plus the end");
+        compute(candidates);
+        hipdetail::check(oc_hip_select_best(engine_, candidates.data(), candidates.size(), sizeof(POI2D), segment_starts.data(),
+                                            poi_queue.size(), poi_queue.data(), sizeof(POI2D), OC_HIP_HOST));
+    }
     void compute(std::vector<POI2D>& poi_queue, std::vector<Point2D>& center_offset_queue) {
         if (center_offset_queue.size() < poi_queue.size()) throw std::string("center_offset_queue is shorter than poi_queue");
         uploadIfNeeded();

@@ -153,6 +153,28 @@ int main(int argc, char** argv) {
             strain.compute(&q2[q2.size() / 2], q2);
             if (q2[q2.size() / 2].strain.exy != probe.strain.exy) { std::cerr << "Strain::compute(POI*, queue) disagrees" << std::endl; return 15; }
         }
+        // candidate batching (the EpipolarSearch pattern): three trial guesses per POI, the middle one is FFTCC's
+        {
+            std::vector<POI2D> cand;
+            std::vector<unsigned> starts;
+            const size_t m = after_fftcc.size() < 40 ? after_fftcc.size() : 40;
+            for (size_t i = 0; i < m; i++) {
+                starts.push_back((unsigned)cand.size());
+                for (int t = -1; t <= 1; t++) {
+                    POI2D c = after_fftcc[i];
+                    c.deformation.u += 4.f * t;
+                    cand.push_back(c);
+                }
+            }
+            starts.push_back((unsigned)cand.size());
+            std::vector<POI2D> best(after_fftcc.begin(), after_fftcc.begin() + m);
+            icgn1->computeBestOf(cand, starts, best);
+            for (size_t i = 0; i < m; i++) {
+                float top = cand[3 * i].result.zncc;
+                for (int t = 1; t < 3; t++) top = cand[3 * i + t].result.zncc > top ? cand[3 * i + t].result.zncc : top;
+                if (best[i].result.zncc != top) { std::cerr << "computeBestOf did not keep the highest ZNCC at POI " << i << std::endl; return 16; }
+            }
+        }
         // the reference's CUDA-module shape (gpu_lib/opencorr_gpu.h:31-101): ICGN2D1GPU fed with row-major Img2D
         {
             Img2D ref2{w, h, ref.data()}, tar2{w, h, tar.data()};
