@@ -24,7 +24,12 @@
  *     engine's device and stream (no copy).  On a stream the caller chose with
  *     oc_hip_set_stream such a call is asynchronous and stream-ordered (chain the
  *     engines of a pipeline on one stream); on the engine's own private stream it
- *     completes before it returns.
+ *     completes before it returns.  Producer ordering of OC_HIP_DEVICE inputs (queues,
+ *     offsets, images used in place): on a caller-chosen stream they are read in that
+ *     stream's order; on the private stream the engine first waits for everything the
+ *     caller has enqueued on HIP's legacy default stream at the time of the call.  Data
+ *     still being written on any OTHER stream must be complete (or that stream be named
+ *     with oc_hip_set_stream) before the call.
  *   - Images are snapshotted at set_images time (like the CUDA module of the
  *     reference, examples/test_2d_dic_gpu_icgn.cpp:99-136): later edits of the
  *     host image need another set_images + prepare.
@@ -176,7 +181,8 @@ int oc_hip_set_iteration(oc_hip_engine* engine, float conv_criterion, float stop
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of
  * the engine's own stream.  The handle is used as given: NULL is HIP's default
  * (null) stream, which is what torch.cuda.current_stream().cuda_stream returns
- * for torch's default stream. */
+ * for torch's default stream.  The stream in use so far is drained first, so work
+ * already enqueued (prepare()'s kernels) cannot race with calls on the new stream. */
 int oc_hip_set_stream(oc_hip_engine* engine, void* hip_stream);
 /* Go back to the engine's own (non-blocking) stream. */
 int oc_hip_reset_stream(oc_hip_engine* engine);
@@ -230,8 +236,10 @@ int oc_hip_get_kind(const oc_hip_engine* engine, int* kind);
 /* Device pointers of the precomputed fields (row-major float32):
  *   "ref","tar"           height*width            (3D: dz*dy*dx)
  *   "gx","gy"[,"gz"]      same shape              ICGN engines after prepare_ref
- *   "lut"                 height*width*16         ICGN2D* / NR2D1 after prepare_tar  (3D: "coef", dz*dy*dx)
- *   "lut_gx","lut_gy"     height*width*16         NR2D1 after prepare: tables of the target gradients
+ *   "lut"                 4*height*width*4        ICGN2D* / NR2D1 after prepare_tar: the bicubic coefficient table of
+ *                                                 src/oc_cubic_bspline.cpp:123-129, stored planar as [k][y][x][l]
+ *                                                 (plane k = coef[k][0..3] of every pixel)  (3D: "coef", dz*dy*dx)
+ *   "lut_gx","lut_gy"     4*height*width*4        NR2D1 after prepare: tables of the target gradients, same layout
  * Returns OC_HIP_ERR_INVALID for an unknown name or a field not built yet. */
 int oc_hip_get_field(const oc_hip_engine* engine, const char* name, const float** device_ptr, size_t* count);
 /* Copy a field to host memory (test helper). */

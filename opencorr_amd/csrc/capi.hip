@@ -123,6 +123,7 @@ struct oc_hip_engine {
     float conv = 0.001f, stop = 10.f;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t order_ev = nullptr;  // orders the private stream behind the caller's default-stream work
     std::shared_ptr<ImagePair> img;
     DevBuf gx, gy, gz, coef;  // coef: 2D LUT (16 floats / px) or 3D coefficient volume
     DevBuf coef_gx, coef_gy;  // NR2D1: LUTs of the target gradients
@@ -198,6 +199,19 @@ int create_engine(int kind, int rx, int ry, int rz, float conv, float stop, int 
     OC_HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     *out = e.release();
+    return OC_HIP_OK;
+}
+
+// The engine's private stream is non-blocking: nothing the caller enqueued is ordered against it.  Inputs that
+// live on the device (OC_HIP_DEVICE queues, offsets, images used in place) are usually produced on the legacy
+// default stream -- hipMemcpy, plain launches, torch unless told otherwise -- so every entry point that enqueues work
+// on the private stream first makes it wait for what the default stream holds at that moment.  Producers on OTHER
+// streams must be complete, or be named with oc_hip_set_stream (documented in opencorr_hip.h).
+int order_after_default_stream(oc_hip_engine* e) {
+    if (e->stream != e->own_stream) return OC_HIP_OK;  // caller-chosen stream: stream order is the caller's
+    if (!e->order_ev) OC_HIP_TRY(hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming));
+    OC_HIP_TRY(hipEventRecord(e->order_ev, nullptr));
+    OC_HIP_TRY(hipStreamWaitEvent(e->own_stream, e->order_ev, 0));
     return OC_HIP_OK;
 }
 
@@ -348,6 +362,17 @@ int tile_order(oc_hip_engine* e, const float* pois, int stride_f, size_t n, cons
     return OC_HIP_OK;
 }
 
+// The 2D solvers address image-sized arrays with 32-bit byte offsets (buffer resources, dic2d_device.h): a plane of
+// the coefficient table is 16 B per pixel and must stay below 4 GiB (ICGN2D / ICLM: one descriptor per plane ->
+// 2^28 pixels; NR2D1: one descriptor per table -> 2^26 pixels), and the row index times the width goes through a
+// 24-bit multiply (width * 4 < 2^24).  Larger images are refused instead of wrapping silently.
+int check_image2d_limits(const char* who, const ImagePair& im, unsigned long long max_pixels) {
+    if ((unsigned long long)im.dy * (unsigned long long)im.dx > max_pixels || im.dx >= (1 << 22) || im.dy >= (1 << 22))
+        return fail(OC_HIP_ERR_UNSUPPORTED, "%s: image %d x %d exceeds the engine's limit of %llu pixels (width, height < 2^22)", who,
+                    im.dx, im.dy, max_pixels);
+    return OC_HIP_OK;
+}
+
 // ---------------------------------------------------------------------------
 // ICGN2D
 // ---------------------------------------------------------------------------
@@ -356,6 +381,7 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
     if (!e->ref_ready || !e->tar_ready)
         return fail(OC_HIP_ERR_INVALID, "ICGN2D: prepare() has not been called since the last set_images");
     const ImagePair& im = *e->img;
+    OC_TRY(check_image2d_limits("ICGN2D", im, 1ull << 28));
     const int dof = (e->kind == OC_HIP_ICGN2D1 || e->kind == OC_HIP_ICLM2D1) ? 6 : 12;
     const bool lm = e->is_iclm();
     int rx = e->rx, ry = e->ry;
@@ -411,8 +437,7 @@ int run_nr2d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     if (!e->img || e->img->ndim != 2) return fail(OC_HIP_ERR_INVALID, "NR2D1: set_images2d has not been called");
     if (!e->tar_ready) return fail(OC_HIP_ERR_INVALID, "NR2D1: prepare() has not been called since the last set_images");
     const ImagePair& im = *e->img;
-    if ((unsigned long long)im.dy * im.dx * 64ull > (1ull << 32))
-        return fail(OC_HIP_ERR_UNSUPPORTED, "NR2D1: image %d x %d exceeds the 4 GiB coefficient-table limit (max 8192 x 8192)", im.dx, im.dy);
+    OC_TRY(check_image2d_limits("NR2D1", im, 1ull << 26));
     const long long N = (2LL * e->rx + 1) * (2LL * e->ry + 1);
     if (N > ochip::nr2d1_max_samples())
         return fail(OC_HIP_ERR_UNSUPPORTED, "NR2D1: subset %dx%d (%lld samples) exceeds the on-chip limit of %d samples",
@@ -670,6 +695,7 @@ static int plane_prepare(oc_hip_engine* e, int kind, const void* pois, size_t co
     std::lock_guard<std::mutex> lock(e->mu);
     e->st_count = 0;
     if (count == 0) return OC_HIP_OK;
+    OC_TRY(order_after_default_stream(e));
     float* d_pois = nullptr;
     OC_TRY(strain_stage(e, pois, count, stride_bytes, ndim, memory, &d_pois));
     const int stride_f = (int)(stride_bytes / 4);
@@ -720,6 +746,7 @@ int oc_hip_region_fit_compute(oc_hip_engine* e, void* pois, size_t count, size_t
     if (e->st_count == 0)
         return fail(OC_HIP_ERR_INVALID, "RegionFit: setNeighbor + prepare has not been called (or the radius changed since)");
     if (e->st_ndim != ndim) return fail(OC_HIP_ERR_INVALID, "RegionFit: prepared for POI%dD, compute() got POI%dD", e->st_ndim, ndim);
+    OC_TRY(order_after_default_stream(e));
     float* d_pois = nullptr;
     OC_TRY(strain_stage(e, pois, count, stride_bytes, ndim, memory, &d_pois));
     const int stride_f = (int)(stride_bytes / 4);
@@ -747,6 +774,7 @@ int oc_hip_strain_compute(oc_hip_engine* e, void* pois, size_t count, size_t str
     if (e->st_count == 0) return fail(OC_HIP_ERR_INVALID, "Strain: prepare(poi_queue) has not been called (or the radius changed since)");
     if (e->st_count != count || e->st_ndim != ndim)
         return fail(OC_HIP_ERR_INVALID, "Strain: prepare() saw %zu POI%dD, compute() got %zu POI%dD", e->st_count, e->st_ndim, count, ndim);
+    OC_TRY(order_after_default_stream(e));
     float* d_pois = nullptr;
     OC_TRY(strain_stage(e, pois, count, stride_bytes, ndim, memory, &d_pois));
     const int stride_f = (int)(stride_bytes / 4);
@@ -786,6 +814,7 @@ int oc_hip_destroy(oc_hip_engine* e) {
     }
     clear_events(e);
     e->fft.destroy();
+    if (e->order_ev) (void)hipEventDestroy(e->order_ev);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
     return OC_HIP_OK;
@@ -806,6 +835,7 @@ int oc_hip_set_images2d(oc_hip_engine* e, const float* ref, const float* tar, in
     if (height < 5 || width < 5) return fail(OC_HIP_ERR_INVALID, "image too small: %d x %d", width, height);
     if (layout != OC_HIP_ROW_MAJOR && layout != OC_HIP_COL_MAJOR) return fail(OC_HIP_ERR_INVALID, "bad layout %d", layout);
     std::lock_guard<std::mutex> lock(e->mu);
+    OC_TRY(order_after_default_stream(e));
     auto img = std::make_shared<ImagePair>();
     img->ndim = 2;
     img->dx = width;
@@ -841,6 +871,7 @@ int oc_hip_set_images3d(oc_hip_engine* e, const float* ref, const float* tar, in
     if (dim_x < 15 || dim_y < 15 || dim_z < 15)
         return fail(OC_HIP_ERR_INVALID, "volume too small: %d x %d x %d", dim_x, dim_y, dim_z);
     std::lock_guard<std::mutex> lock(e->mu);
+    OC_TRY(order_after_default_stream(e));
     auto img = std::make_shared<ImagePair>();
     img->ndim = 3;
     img->dx = dim_x;
@@ -891,16 +922,21 @@ int oc_hip_set_iteration(oc_hip_engine* e, float conv, float stop) {
     return OC_HIP_OK;
 }
 
+// Switching streams: work already enqueued on the old stream (prepare()'s gradient and table kernels, a layout
+// conversion) must not race with computes on the new one, so the old stream is drained first.
 int oc_hip_set_stream(oc_hip_engine* e, void* hip_stream) {
-    OC_TRY(check_engine(e));
+    OC_TRY(activate(e));
     std::lock_guard<std::mutex> lock(e->mu);
-    e->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    const hipStream_t next = reinterpret_cast<hipStream_t>(hip_stream);
+    if (next != e->stream) OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stream = next;
     return OC_HIP_OK;
 }
 
 int oc_hip_reset_stream(oc_hip_engine* e) {
-    OC_TRY(check_engine(e));
+    OC_TRY(activate(e));
     std::lock_guard<std::mutex> lock(e->mu);
+    if (e->stream != e->own_stream) OC_HIP_TRY(hipStreamSynchronize(e->stream));
     e->stream = e->own_stream;
     return OC_HIP_OK;
 }
@@ -934,6 +970,7 @@ int oc_hip_prepare_ref(oc_hip_engine* e) {
     if (!e->is_icgn()) return OC_HIP_OK;  // FFTCC::prepare() is empty in the reference
     if (!e->img) return fail(OC_HIP_ERR_INVALID, "prepare: set_images has not been called");
     std::lock_guard<std::mutex> lock(e->mu);
+    OC_TRY(order_after_default_stream(e));  // images used in place may have been written on the default stream
     const ImagePair& im = *e->img;
     const size_t bytes = im.count() * sizeof(float);
     if (e->kind == OC_HIP_NR2D1) {
@@ -960,8 +997,10 @@ int oc_hip_prepare_tar(oc_hip_engine* e) {
     if (!e->is_icgn()) return OC_HIP_OK;
     if (!e->img) return fail(OC_HIP_ERR_INVALID, "prepare: set_images has not been called");
     std::lock_guard<std::mutex> lock(e->mu);
+    OC_TRY(order_after_default_stream(e));
     const ImagePair& im = *e->img;
     if (im.ndim == 2) {
+        OC_TRY(check_image2d_limits(e->kind == OC_HIP_NR2D1 ? "NR2D1" : "ICGN2D", im, e->kind == OC_HIP_NR2D1 ? 1ull << 26 : 1ull << 28));
         OC_TRY(e->coef.reserve(im.count() * 16 * sizeof(float)));
         OC_HIP_TRY(ochip::launch_bspline2d_lut(im.tar_ptr(), im.dy, im.dx, e->coef.as<float>(), e->stream));
         if (e->kind == OC_HIP_NR2D1) {
@@ -1002,6 +1041,7 @@ static int compute_impl(oc_hip_engine* e, void* pois, const float* offsets, size
     std::lock_guard<std::mutex> lock(e->mu);
     const int stride_f = (int)(stride_bytes / 4);
     if (memory == OC_HIP_DEVICE) {
+        OC_TRY(order_after_default_stream(e));
         OC_TRY(run_compute_device(e, static_cast<float*>(pois), stride_f, count, offsets));
         return finish_device_call(e);
     }
@@ -1054,6 +1094,7 @@ int oc_hip_select_best(oc_hip_engine* e, const void* candidates, size_t n_candid
         (stride_bytes & 3))
         return fail(OC_HIP_ERR_INVALID, "select_best: POI2D records need a stride >= %d bytes, multiple of 4", OC_HIP_POI2D_BYTES);
     std::lock_guard<std::mutex> lock(e->mu);
+    OC_TRY(order_after_default_stream(e));
     const float* d_cand = static_cast<const float*>(candidates);
     const unsigned* d_seg = segment_starts;
     float* d_pois = static_cast<float*>(pois);

@@ -171,7 +171,7 @@ struct LutFetch {
 // All image-sized arrays are read through buffer resources (V#): a 32-bit per-lane byte offset plus a
 // wave-uniform SGPR offset replace the 64-bit per-lane address arithmetic of flat loads -- in these loops
 // the address math used to cost as many VALU slots as the arithmetic it fed.  Raw buffer, stride 0,
-// num_records = 2^32 - 1 bytes: the images (<= 268 MB) and the LUT (<= 4 GiB) both fit.
+// num_records = 2^32 - 1 bytes: an image (<= 2^28 pixels = 1 GiB) and one plane of the LUT (<= 4 GiB) both fit.
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
@@ -183,40 +183,68 @@ __device__ __forceinline__ float4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned v
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
 }
 
+// The bicubic coefficient table is stored PLANAR: plane k (the power of dy, k = 0..3) holds for every pixel the
+// float4 (coef[k][0], coef[k][1], coef[k][2], coef[k][3]) of src/oc_cubic_bspline.cpp:123-129, pixels in row-major
+// order; plane stride = height * width * 16 bytes.  Lanes that own row-consecutive samples of a subset then read 16
+// CONSECUTIVE bytes each: one buffer_load_b128 of a wave touches ~10 128-byte lines (two subset rows of ~530 B)
+// instead of the ~34 lines it touched -- four times over, once per k -- when an entry was 64 contiguous bytes
+// ([y][x][k][l], round 1: TA_TA_BUSY 82 %, 29 tag lookups per load instruction).
+//
+// LutPlanes4: one descriptor per plane -- a plane may be 4 GiB, i.e. images up to 2^28 pixels.
+struct LutPlanes4 {
+    __amdgpu_buffer_rsrc_t p0, p1, p2, p3;
+    __device__ __forceinline__ LutPlanes4(const float* lut, int height, int width) {
+        const size_t plane = (size_t)height * (size_t)width * 4;  // floats
+        p0 = make_rsrc(lut);
+        p1 = make_rsrc(lut + plane);
+        p2 = make_rsrc(lut + 2 * plane);
+        p3 = make_rsrc(lut + 3 * plane);
+    }
+    __device__ __forceinline__ void load(LutFetch& f, unsigned e) const {
+        f.c0 = buf_f32x4(p0, e);
+        f.c1 = buf_f32x4(p1, e);
+        f.c2 = buf_f32x4(p2, e);
+        f.c3 = buf_f32x4(p3, e);
+    }
+};
+// LutPlanesS: one descriptor per table, the plane selected by the scalar offset (three SGPRs shared by all tables
+// of the same image size): the whole table must stay below 4 GiB, i.e. 2^26 pixels.  NR2D1 reads three tables.
+__device__ __forceinline__ float4 buf_f32x4s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+struct LutPlanesS {
+    __amdgpu_buffer_rsrc_t r;
+    unsigned plane;  // bytes
+    __device__ __forceinline__ LutPlanesS(const float* lut, int height, int width)
+        : r(make_rsrc(lut)), plane((unsigned)height * (unsigned)width * 16u) {}
+    __device__ __forceinline__ void load(LutFetch& f, unsigned e) const {
+        f.c0 = buf_f32x4(r, e);
+        f.c1 = buf_f32x4s(r, e, plane);
+        f.c2 = buf_f32x4s(r, e, 2u * plane);
+        f.c3 = buf_f32x4s(r, e, 3u * plane);
+    }
+};
+
 // range rule of BicubicBspline::compute (src/oc_cubic_bspline.cpp:137-142): x < 1 || y < 1 ||
 // x >= width-2 || y >= height-2 || NaN -> -1.  With xi = (int)floor(x) that is
 // (unsigned)(xi - 1) > width - 4; the median clamp keeps the float -> int conversion defined for wild
 // values and sends NaN to -2 (v_med3_f32 returns the minimum of the other two for a NaN input), i.e.
 // outside.  floor(x) is exactly (float)xi for in-range x, so dx = x - floor(x) has the reference's bits.
-// Out-of-range samples fetch entry (0,0), which is always mapped, and are replaced by -1.f afterwards.
-__device__ __forceinline__ void lut_fetch(LutFetch& f, __amdgpu_buffer_rsrc_t lut, int height, int width, float x,
-                                          float y) {
-    const float fx = floorf(x), fy = floorf(y);
-    const int xi = (int)__builtin_amdgcn_fmed3f(fx, -2.f, 2.0e9f), yi = (int)__builtin_amdgcn_fmed3f(fy, -2.f, 2.0e9f);
-    const bool out = (unsigned)(xi - 1) > (unsigned)(width - 4) || (unsigned)(yi - 1) > (unsigned)(height - 4);
-    f.dx = x - fx;
-    f.dy = out ? -1.f : y - fy;
-    // 24-bit multiply: full rate, and exact because in-range yi and the width are below 2^24
-    const unsigned e = out ? 0u : (__umul24((unsigned)yi, (unsigned)width) + (unsigned)xi) << 6;
-    f.c0 = buf_f32x4(lut, e);
-    f.c1 = buf_f32x4(lut, e + 16);
-    f.c2 = buf_f32x4(lut, e + 32);
-    f.c3 = buf_f32x4(lut, e + 48);
-}
-
-// the same with the point as a packed pair (x, y): the fractional offsets come out of one packed subtraction
-__device__ __forceinline__ void lut_fetch(LutFetch& f, __amdgpu_buffer_rsrc_t lut, int height, int width, f2 p) {
+// Out-of-range samples fetch pixel (0,0), which is always mapped, and are replaced by -1.f afterwards.
+// Returns the byte offset of the sample's pixel inside a plane (16 B per pixel; 0 when out of range).
+__device__ __forceinline__ unsigned lut_locate(LutFetch& f, int height, int width, f2 p) {
     const f2 fl = mk2(floorf(p.x), floorf(p.y));
     const int xi = (int)__builtin_amdgcn_fmed3f(fl.x, -2.f, 2.0e9f), yi = (int)__builtin_amdgcn_fmed3f(fl.y, -2.f, 2.0e9f);
     const bool out = (unsigned)(xi - 1) > (unsigned)(width - 4) || (unsigned)(yi - 1) > (unsigned)(height - 4);
-    const f2 fr = p - fl;
+    const f2 fr = p - fl;  // the fractional offsets out of one packed subtraction
     f.dx = fr.x;
     f.dy = out ? -1.f : fr.y;
-    const unsigned e = out ? 0u : (__umul24((unsigned)yi, (unsigned)width) + (unsigned)xi) << 6;
-    f.c0 = buf_f32x4(lut, e);
-    f.c1 = buf_f32x4(lut, e + 16);
-    f.c2 = buf_f32x4(lut, e + 32);
-    f.c3 = buf_f32x4(lut, e + 48);
+    // 24-bit multiply: full rate, and exact because in-range yi and the width are below 2^24
+    return out ? 0u : (__umul24((unsigned)yi, (unsigned)width) + (unsigned)xi) << 4;
+}
+template <class Planes>
+__device__ __forceinline__ void lut_fetch(LutFetch& f, const Planes& lut, int height, int width, f2 p) {
+    lut.load(f, lut_locate(f, height, width, p));
 }
 
 // explicit 16-term left-to-right polynomial of src/oc_cubic_bspline.cpp:144-177

@@ -118,8 +118,8 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     const int c0 = lane - r0 * W;
     // subset origin as a wave-uniform byte offset (images are <= 2^28 bytes)
     const unsigned goff = (unsigned)__builtin_amdgcn_readfirstlane((((int)py - ry) * width + ((int)px - rx)) * 4);
-    const __amdgpu_buffer_rsrc_t r_gx = make_rsrc(P.gx), r_gy = make_rsrc(P.gy), r_ref = make_rsrc(P.ref),
-                                 r_lut = make_rsrc(P.lut);
+    const __amdgpu_buffer_rsrc_t r_gx = make_rsrc(P.gx), r_gy = make_rsrc(P.gy), r_ref = make_rsrc(P.ref);
+    const LutPlanesS r_lut(P.lut, height, width);
     const unsigned w4 = (unsigned)width * 4u;
     // byte offset of sample (r, c) from the subset origin
     auto soff = [&](const SampleWalk& w) { return __umul24((unsigned)w.r, w4) + ((unsigned)w.c << 2); };

@@ -79,8 +79,8 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
     const int q64 = kWave / W, r64 = kWave - q64 * W;
     const int r0 = lane / W;
     const int c0 = lane - r0 * W;
-    const __amdgpu_buffer_rsrc_t r_ref = make_rsrc(P.ref), r_lut = make_rsrc(P.lut), r_lgx = make_rsrc(P.lut_gx),
-                                 r_lgy = make_rsrc(P.lut_gy);
+    const __amdgpu_buffer_rsrc_t r_ref = make_rsrc(P.ref);
+    const LutPlanesS r_lut(P.lut, height, width), r_lgx(P.lut_gx, height, width), r_lgy(P.lut_gy, height, width);
     const unsigned w4 = (unsigned)width * 4u;
     auto soff = [&](const SampleWalk& w) { return __umul24((unsigned)w.r, w4) + ((unsigned)w.c << 2); };
 
@@ -144,16 +144,13 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
                 const float x = valid ? px + wx : 1.f, y = valid ? py + wy : 1.f;
                 // one range test and one entry offset serve the three tables
                 // (BicubicBspline::compute, src/oc_cubic_bspline.cpp:134-181; rule explained at lut_fetch)
-                const float fx = floorf(x), fy = floorf(y);
-                const int xi = (int)__builtin_amdgcn_fmed3f(fx, -2.f, 2.0e9f), yi = (int)__builtin_amdgcn_fmed3f(fy, -2.f, 2.0e9f);
-                const bool out = (unsigned)(xi - 1) > (unsigned)(width - 4) || (unsigned)(yi - 1) > (unsigned)(height - 4);
-                const unsigned e = out ? 0u : (__umul24((unsigned)yi, (unsigned)width) + (unsigned)xi) << 6;
                 LutFetch ft, fgx, fgy;
-                ft.dx = fgx.dx = fgy.dx = x - fx;
-                ft.dy = fgx.dy = fgy.dy = out ? -1.f : y - fy;
-                ft.c0 = buf_f32x4(r_lut, e); ft.c1 = buf_f32x4(r_lut, e + 16); ft.c2 = buf_f32x4(r_lut, e + 32); ft.c3 = buf_f32x4(r_lut, e + 48);
-                fgx.c0 = buf_f32x4(r_lgx, e); fgx.c1 = buf_f32x4(r_lgx, e + 16); fgx.c2 = buf_f32x4(r_lgx, e + 32); fgx.c3 = buf_f32x4(r_lgx, e + 48);
-                fgy.c0 = buf_f32x4(r_lgy, e); fgy.c1 = buf_f32x4(r_lgy, e + 16); fgy.c2 = buf_f32x4(r_lgy, e + 32); fgy.c3 = buf_f32x4(r_lgy, e + 48);
+                const unsigned e = lut_locate(ft, height, width, mk2(x, y));
+                fgx.dx = fgy.dx = ft.dx;
+                fgx.dy = fgy.dy = ft.dy;
+                r_lut.load(ft, e);
+                r_lgx.load(fgx, e);
+                r_lgy.load(fgy, e);
                 const float tv = lut_eval(ft), g_x = lut_eval(fgx), g_y = lut_eval(fgy);
                 l_ts[t * kWave] = tv;
                 l_gx[t * kWave] = g_x;

@@ -5,7 +5,7 @@
 //   colmajor_to_rowmajor Eigen::MatrixXf (column-major, src/oc_image.h:37) -> x-fastest
 //
 // All three are HBM streaming kernels: one thread per pixel, 4 B read (neighbours
-// come from L1/L2), 8 B (gradients) or 64 B (LUT) written per pixel.
+// come from L1/L2), 8 B (gradients) or 64 B (LUT: 4 planes x 16 B) written per pixel.
 #include "oc_device.h"
 #include "oc_kernels.h"
 
@@ -54,16 +54,19 @@ __device__ constexpr float kBC[4][4] = {
 // neighbourhood accumulated in the reference's k,l,m,n loop order
 // (acc += BC[l][m] * BC[k][n] * q[n][m], src/oc_cubic_bspline.cpp:108-120), stored
 // flipped coef[k][l] = P[3-k][3-l] (:123-129).  Border entries are zero (calloc in
-// the reference, src/oc_array.h:92).  LUT entry = 16 floats = 64 B, [k][l] at 4k+l.
+// the reference, src/oc_array.h:92).  The table is stored PLANAR (dic2d_device.h): plane k holds the float4
+// coef[k][0..3] of every pixel, row-major -- a wave's store is 1 KiB of consecutive bytes per plane, and the
+// solvers' gathers touch a quarter of the cache lines an interleaved 64-byte entry cost them.
 __global__ __launch_bounds__(256) void bspline2d_lut_kernel(const float* __restrict__ img, int height, int width,
                                                             float* __restrict__ lut) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     if (c >= width) return;
-    float4* out = reinterpret_cast<float4*>(lut + ((size_t)r * width + c) * 16);
+    const size_t plane = (size_t)height * width;  // float4 elements per plane
+    float4* out = reinterpret_cast<float4*>(lut) + ((size_t)r * width + c);
     if (r < 1 || r >= height - 2 || c < 1 || c >= width - 2) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        out[0] = z; out[1] = z; out[2] = z; out[3] = z;
+        out[0] = z; out[plane] = z; out[2 * plane] = z; out[3 * plane] = z;
         return;
     }
     float q[4][4];
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void bspline2d_lut_kernel(const float* __restr
             pm[k][l] = acc;
         }
 #pragma unroll
-    for (int k = 0; k < 4; k++) out[k] = make_float4(pm[3 - k][3], pm[3 - k][2], pm[3 - k][1], pm[3 - k][0]);
+    for (int k = 0; k < 4; k++) out[k * plane] = make_float4(pm[3 - k][3], pm[3 - k][2], pm[3 - k][1], pm[3 - k][0]);
 }
 
 // dst[r*width + c] = src[c*height + r]; LDS-tiled so both sides stay coalesced.

@@ -41,6 +41,8 @@ class _Engine:
     def __init__(self):
         self._h = ctypes.c_void_p()
         self._keep = []
+        self._stream_pinned = False  # set_stream() was called by the user
+        self._auto_stream = None     # torch stream adopted for CUDA-tensor arguments
 
     # -- lifecycle ---------------------------------------------------------
     def close(self):
@@ -64,6 +66,7 @@ class _Engine:
             rp, rmem, rkeep = ctypes.c_void_p(ref.ctypes.data), capi.HOST, ref
             tp, tmem, tkeep = ctypes.c_void_p(tar.ctypes.data), capi.HOST, tar
         else:
+            self._adopt_stream_of(ref)
             rp, rmem, rkeep = _buf(ref)
             tp, tmem, tkeep = _buf(tar)
         if rmem != tmem:
@@ -92,6 +95,19 @@ class _Engine:
     def set_stream(self, stream_handle):
         """Run on a caller-owned hipStream_t (0 / None = HIP's default stream, as torch reports it)."""
         capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(stream_handle or None)))
+        self._stream_pinned = True
+
+    def _adopt_stream_of(self, x):
+        """CUDA torch tensors are produced on torch's current stream: unless the user pinned a stream, the engine
+        runs on that stream too, so the tensor is read after whatever wrote it and torch ops that follow see the
+        results (stream order instead of timing)."""
+        if self._stream_pinned or not _is_torch(x) or not x.is_cuda:
+            return
+        import torch
+        s = torch.cuda.current_stream(x.device).cuda_stream
+        if s != self._auto_stream:
+            capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(s or None)))
+            self._auto_stream = s
 
     def set_tuning(self, key, value):
         """Performance knob of the C-ABI (``oc_hip_set_tuning``); results never change."""
@@ -99,6 +115,8 @@ class _Engine:
 
     def reset_stream(self):
         capi.check(capi.lib().oc_hip_reset_stream(self._h))
+        self._stream_pinned = False
+        self._auto_stream = None
 
     def prepare(self):
         capi.check(capi.lib().oc_hip_prepare(self._h))
@@ -112,6 +130,7 @@ class _Engine:
     # -- compute(std::vector<POI>&) -------------------------------------------
     def compute(self, pois):
         floats = capi.POI2D_FLOATS if self._ndim == 2 else capi.POI3D_FLOATS
+        self._adopt_stream_of(pois)
         if _is_torch(pois):
             p, mem, _ = _buf(pois)
             n, stride = pois.shape[0], pois.stride(0) * 4
@@ -129,6 +148,7 @@ class _Engine:
         """compute(poi_queue, center_offset_queue) of ICGN2D1/2D2 (src/oc_icgn.h:76,131);
         ``center_offsets`` is (n, 2) float32 (Point2D x, y) in the same memory space as ``pois``."""
         floats = capi.POI2D_FLOATS
+        self._adopt_stream_of(pois)
         if _is_torch(pois):
             p, mem, _ = _buf(pois)
             o, omem, _ = _buf(center_offsets)
@@ -151,6 +171,7 @@ class _Engine:
         """Keeps, for POI s, the candidate with the highest ZNCC among candidates[segment_starts[s]:segment_starts[s+1]]
         (deformation and result vectors are copied into pois[s]) -- the selection step of
         EpipolarSearch::compute (src/oc_epipolar_search.cpp:181-190) for a batched candidate queue."""
+        self._adopt_stream_of(pois)
         if _is_torch(pois):
             import torch
             cp, mem, _ = _buf(candidates)
@@ -187,7 +208,9 @@ class _Engine:
         out = np.empty(count.value, dtype=np.float32)
         capi.check(capi.lib().oc_hip_read_field(self._h, name.encode(), ctypes.c_void_p(out.ctypes.data), count.value))
         if name in ("lut", "lut_gx", "lut_gy"):
-            return out.reshape(self.shape + (16,))
+            # stored planar [k][y][x][l]; returned in the reference's order coef[y][x][k][l] (src/oc_cubic_bspline.cpp:123-129)
+            h, w = self.shape
+            return np.ascontiguousarray(out.reshape(4, h, w, 4).transpose(1, 2, 0, 3)).reshape(h, w, 16)
         return out.reshape(self.shape)
 
     def profile_enable(self, on=True):
@@ -322,6 +345,11 @@ class Strain:
 
     def set_stream(self, stream_handle):
         capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(stream_handle or None)))
+        self._stream_pinned = True
+
+    _adopt_stream_of = _Engine._adopt_stream_of
+    _stream_pinned = False
+    _auto_stream = None
 
     def synchronize(self):
         capi.check(capi.lib().oc_hip_synchronize(self._h))
@@ -341,10 +369,12 @@ class Strain:
         return p, n, stride, (2 if floats == capi.POI2D_FLOATS else 3), mem
 
     def prepare(self, pois):
+        self._adopt_stream_of(pois)
         p, n, stride, ndim, mem = self._queue(pois)
         capi.check(capi.lib().oc_hip_strain_prepare(self._h, p, n, stride, ndim, mem))
 
     def compute(self, pois):
+        self._adopt_stream_of(pois)
         p, n, stride, ndim, mem = self._queue(pois)
         capi.check(capi.lib().oc_hip_strain_compute(self._h, p, n, stride, ndim, mem))
         return pois
@@ -380,6 +410,9 @@ class RegionFit:
     close = Strain.close
     __del__ = Strain.__del__
     set_stream = Strain.set_stream
+    _adopt_stream_of = _Engine._adopt_stream_of
+    _stream_pinned = False
+    _auto_stream = None
     synchronize = Strain.synchronize
     profile_enable = Strain.profile_enable
     profile_reset = Strain.profile_reset
@@ -399,10 +432,12 @@ class RegionFit:
     def prepare(self):
         if self._reliable is None:
             raise ValueError("RegionFit.prepare: call set_neighbor(reliable_pois) first")
+        self._adopt_stream_of(self._reliable)
         p, n, stride, ndim, mem = Strain._queue(self._reliable)
         capi.check(capi.lib().oc_hip_region_fit_prepare(self._h, p, n, stride, ndim, mem))
 
     def compute(self, pois):
+        self._adopt_stream_of(pois)
         p, n, stride, ndim, mem = Strain._queue(pois)
         capi.check(capi.lib().oc_hip_region_fit_compute(self._h, p, n, stride, ndim, mem))
         return pois

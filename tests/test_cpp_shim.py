@@ -15,10 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "opencorr_amd", "lib")
 
 
-def _build_driver(tmp_path):
-    exe = str(tmp_path / "shim_driver")
+def _build_driver(tmp_path, name="shim_driver"):
+    exe = str(tmp_path / name)
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "cpp", "shim_driver.cpp"), "-o", exe, "-L" + LIBDIR, "-lopencorr_hip",
+           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe, "-L" + LIBDIR, "-lopencorr_hip",
            "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return exe
@@ -29,6 +29,8 @@ def test_shim_compiles_and_links(tmp_path):
     assert os.path.exists(exe)
     # wrong usage exits with its own code before touching the GPU
     assert subprocess.call([exe]) == 2
+    exe3 = _build_driver(tmp_path, "shim_driver3d")
+    assert subprocess.call([exe3]) == 2
 
 
 @pytest.mark.gpu
@@ -60,3 +62,36 @@ def test_shim_matches_python_mirror(tmp_path, speckle_small):
     icgn.compute(want)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert (got[:, 16] > 0.9).all()
+
+
+@pytest.mark.gpu
+def test_shim3d_matches_python_mirror(tmp_path):
+    """FFTCC3D / ICGN3D1 / ICGN3D1GPU / Strain / RegionFit3D of the C++ shim (the call order of the reference's
+    examples/test_dvc_fftcc_icgn1.cpp:87-106) against the Python mirror, bit for bit."""
+    import opencorr_amd
+    from opencorr_amd import synth
+    dz, dy, dx = 64, 68, 72
+    ref, tar = synth.speckle_pair_3d(dz, dy, dx, seed=33)
+    xs, ys, zs = synth.poi_grid_3d(dz, dy, dx, 3, 3, 3, 22)
+    rx = ry = rz = 8
+    conv, stop = 0.001, 20.0
+    inp, outp = tmp_path / "in3.bin", tmp_path / "out3.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<7i2f", dx, dy, dz, rx, ry, rz, len(xs), conv, stop))
+        f.write(np.ascontiguousarray(ref, np.float32).tobytes())
+        f.write(np.ascontiguousarray(tar, np.float32).tobytes())
+        for a in (xs, ys, zs):
+            f.write(a.astype(np.float32).tobytes())
+    exe = _build_driver(tmp_path, "shim_driver3d")
+    subprocess.check_call([exe, str(inp), str(outp)])
+    got = np.fromfile(outp, dtype=np.float32).reshape(-1, 31)
+    want = opencorr_amd.make_pois3d(xs, ys, zs)
+    f3 = opencorr_amd.FFTCC3D(rx, ry, rz)
+    f3.set_images(ref, tar)
+    f3.compute(want)
+    icgn = opencorr_amd.ICGN3D1(rx, ry, rz, conv, stop)
+    icgn.share_images(f3)
+    icgn.prepare()
+    icgn.compute(want)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert (got[:, 18] > 0.9).mean() > 0.8

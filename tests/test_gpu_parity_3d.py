@@ -126,3 +126,105 @@ def test_icgn3d1_bit_exact_vs_oracle(volumes, r):
     assert want[-1, P["zncc"]] == -3.0
     if min(r) >= 8:
         assert (want[:-4, P["zncc"]] > 0.97).all()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The shapes the path is benchmarked on (BASELINE config E: 33^3 subvolumes; the reference's own DVC example:
+# r = 30, examples/test_dvc_fftcc_icgn1.cpp:45-47), on a volume small enough for the oracle to answer in seconds.
+# Every launch shape of launch_icgn3d1 (icgn3d.hip) is reached:
+#   r = 16 -> icgn3d1_kernel<40>, 6 staging passes of 12 x 512 samples per sweep
+#   r = 21 -> icgn3d1_kernel<48>;  r = 25 -> icgn3d1_kernel<64>;  r = 30 -> icgn3d1_kernel<0> (run-time row pitch)
+#   a 30 degree rotation as initial guess -> the coefficient box of a pass is wider than the compile-time pitch
+#   and the pass falls back to global taps
+# ---------------------------------------------------------------------------------------------------------
+BIG = (96, 100, 104)  # dz, dy, dx
+
+
+@pytest.fixture(scope="module")
+def big_volumes():
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = synth.speckle_pair_3d(*BIG, seed=23)
+    return ref, tar, oracle.Prepared3D(ref, tar)
+
+
+def _icgn3d_case(big_volumes, r, pois, stop=20.0):
+    import opencorr_amd
+    import oracle
+    ref, tar, prep = big_volumes
+    want = pois.copy()
+    oracle.icgn3d1(prep, r, r, r, 0.001, stop, want, order=oracle.ORDER_LANES, lanes=512)
+    icgn = opencorr_amd.ICGN3D1(r, r, r, 0.001, stop)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    got = icgn.compute(pois.copy())
+    P = oracle.P3
+    assert np.array_equal(got[:, P["iteration"]], want[:, P["iteration"]])
+    mism = np.argwhere(_bits(got) != _bits(want))
+    assert mism.size == 0, "first mismatches (poi, field): %s" % mism[:10].tolist()
+    return want
+
+
+def test_icgn3d1_config_e_shape_multi_pass_staging(big_volumes):
+    """r = 16 (config E's 33^3 subvolume): FFTCC3D fused kernel for the guess, then ICGN3D1 with six staging passes
+    per sweep; POIs next to the volume border, rejected and NaN POIs included."""
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    ref, tar, _ = big_volumes
+    xs, ys, zs = synth.poi_grid_3d(*BIG, 3, 3, 3, 24)
+    pois = oracle.make_pois3d(xs, ys, zs)
+    f = opencorr_amd.FFTCC3D(16, 16, 16)
+    f.set_images(ref, tar)
+    f.compute(pois)
+    P = oracle.P3
+    extra = oracle.make_pois3d([16, 60, 60, 60, BIG[2] - 17.0], [50, 50, 50, 50, 50], [48, 48, 48, 48, 48])
+    extra[1, P["u"]] = 80.0      # warped subvolume leaves the volume -> -3 inside the loop
+    extra[2, P["zncc"]] = -2.0   # rejected on entry, flag preserved
+    extra[3, P["v"]] = np.nan
+    pois = np.concatenate([pois, extra]).astype(np.float32)
+    want = _icgn3d_case(big_volumes, 16, pois)
+    assert (want[:27, P["zncc"]] > 0.97).all()
+    assert (want[:27, P["iteration"]] < 20).all()
+    assert want[-4, P["zncc"]] == -3.0 and want[-3, P["zncc"]] == -2.0 and want[-2, P["zncc"]] == -3.0
+
+
+@pytest.mark.parametrize("r,kernel", [(21, "<48>"), (25, "<64>"), (30, "<0>")])
+def test_icgn3d1_large_radii_kernels(big_volumes, r, kernel):
+    """The other row-pitch instantiations; r = 30 is the radius of the reference's DVC example."""
+    import oracle
+    c = [BIG[2] // 2, BIG[1] // 2, BIG[0] // 2]
+    span = [BIG[2] - 2 * (r + 4), BIG[1] - 2 * (r + 4), BIG[0] - 2 * (r + 4)]
+    rng = np.random.default_rng(r)
+    n = 6 if r < 30 else 4
+    xs = [c[0] + int(rng.integers(-span[0] // 2, span[0] // 2 + 1)) for _ in range(n)]
+    ys = [c[1] + int(rng.integers(-span[1] // 2, span[1] // 2 + 1)) for _ in range(n)]
+    zs = [c[2] + int(rng.integers(-span[2] // 2, span[2] // 2 + 1)) for _ in range(n)]
+    pois = oracle.make_pois3d(xs, ys, zs)
+    P = oracle.P3
+    from opencorr_amd import synth
+    w = synth.DEFAULT_WARP_3D
+    pois[:, P["u"]], pois[:, P["v"]], pois[:, P["w"]] = round(w["u"]), round(w["v"]), round(w["w"])  # integer guess, as FFTCC gives
+    want = _icgn3d_case(big_volumes, r, pois)
+    assert (want[:, P["zncc"]] > 0.9).all(), kernel
+
+
+def test_icgn3d1_global_tap_fallback(big_volumes):
+    """A 30 degree rotation about z as the initial guess: the image of a pass's index box is ~45 voxels wide, wider
+    than the 40-float row pitch of icgn3d1_kernel<40>, so those passes evaluate their taps from global memory.  Bits
+    must not depend on which path a pass took (the oracle knows only one)."""
+    import oracle
+    P = oracle.P3
+    cx, cy, cz = BIG[2] // 2, BIG[1] // 2, BIG[0] // 2
+    pois = oracle.make_pois3d([cx, cx + 3, cx - 2, cx], [cy, cy - 2, cy + 1, cy], [cz, cz + 1, cz - 1, cz])
+    ang = np.deg2rad(30.0)
+    for i, a in enumerate([ang, -ang, 0.6 * ang]):
+        pois[i, P["ux"]] = np.cos(a) - 1.0
+        pois[i, P["uy"]] = -np.sin(a)
+        pois[i, P["vx"]] = np.sin(a)
+        pois[i, P["vy"]] = np.cos(a) - 1.0
+    pois[3, P["ux"]] = 0.35   # 35 % stretch along x: box 33 * 1.35 + 5 > 40 as well
+    pois[3, P["wz"]] = 0.2
+    pois = pois.astype(np.float32)
+    want = _icgn3d_case(big_volumes, 16, pois, stop=6.0)
+    assert np.isfinite(want[:, P["u"]]).all()

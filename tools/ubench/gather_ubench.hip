@@ -6,6 +6,8 @@
 //   1 coop      : 4 lanes share an entry; instruction q covers entries 16q..16q+15 contiguously
 //   2 coop+lds  : as 1, then ds_write_b128 x4 / ds_read_b128 x4 so lane s ends with entry s
 //   3 coop+dma  : as 1 with global_load_lds_dwordx4 into LDS, then ds_read_b128 x4
+//   4 planar    : the table as four planes [k][H][W] of float4; lane s loads 16 B from each plane (lane stride
+//                 16 B: a wave's load covers two subset rows of ~530 contiguous bytes)          [round-2 kernel]
 // Build: hipcc --offload-arch=gfx950 -O3 gather_ubench.hip -o gather_ubench
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -40,6 +42,13 @@ __global__ __launch_bounds__(64 * WPB) void k(const char* __restrict__ lut, floa
             if (VARIANT == 0) {
                 const float4* p = reinterpret_cast<const float4*>(lut + e);
                 c0 = p[0]; c1 = p[1]; c2 = p[2]; c3 = p[3];
+            } else if (VARIANT == 4) {
+                constexpr size_t plane = (size_t)W * H * 16;
+                const char* p = lut + (e >> 2);
+                c0 = *reinterpret_cast<const float4*>(p);
+                c1 = *reinterpret_cast<const float4*>(p + plane);
+                c2 = *reinterpret_cast<const float4*>(p + 2 * plane);
+                c3 = *reinterpret_cast<const float4*>(p + 3 * plane);
             } else {
                 unsigned eq[4];
 #pragma unroll
@@ -129,5 +138,7 @@ int main() {
     bad = 0;
     for (size_t i = 0; i < h.size(); i++) bad += h[i] != h0[i];
     printf("variant 3 coop+dma : %.3f ms  %.2f TB/s  mismatches %zu\n", ms, bytes / ms / 1e9, bad);
+    ms = run<4>(lut, out, npoi, side, h);
+    printf("variant 4 planar   : %.3f ms  %.2f TB/s (sums differ by design: other bytes)\n", ms, bytes / ms / 1e9);
     return 0;
 }
