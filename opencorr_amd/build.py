@@ -18,7 +18,11 @@ LIB = os.path.join(LIBDIR, "libopencorr_hip.so")
 SOURCES = ["capi.hip", "prepare2d.hip", "icgn2d.hip", "nr2d.hip", "poi_order.hip", "strain.hip", "fftcc2d.hip", "fftcc2d_fused.hip", "fftcc2d_fusedn.hip", "prepare3d.hip", "icgn3d.hip", "fftcc3d.hip", "fftcc3d_fused.hip"]
 HEADERS = ["oc_device.h", "oc_kernels.h", "dic2d_device.h", "fft_device.h", os.path.join("..", "..", "include", "opencorr_hip.h")]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: the SLP vectoriser pairs independent scalar fp32 operations into v_pk_mul_f32 / v_pk_add_f32.  On gfx950 a
+# packed op occupies a SIMD for 4.3 cycles against 2.4 for the plain one (profiles/r02b_valu_ubench.json) -- a 10 % gain that the
+# v_mov_b32 forming the register pairs turn into a loss (ICGN2D sweep: 48 moves per 3 samples, 17 % more issue cycles).
+# Code that wants packed arithmetic says so with float2 vector types.
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc():

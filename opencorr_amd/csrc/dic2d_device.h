@@ -226,58 +226,61 @@ struct LutPlanesS {
 };
 
 // range rule of BicubicBspline::compute (src/oc_cubic_bspline.cpp:137-142): x < 1 || y < 1 ||
-// x >= width-2 || y >= height-2 || NaN -> -1.  With xi = (int)floor(x) that is
-// (unsigned)(xi - 1) > width - 4; the median clamp keeps the float -> int conversion defined for wild
-// values and sends NaN to -2 (v_med3_f32 returns the minimum of the other two for a NaN input), i.e.
-// outside.  floor(x) is exactly (float)xi for in-range x, so dx = x - floor(x) has the reference's bits.
-// Out-of-range samples fetch pixel (0,0), which is always mapped, and are replaced by -1.f afterwards.
-// Returns the byte offset of the sample's pixel inside a plane (16 B per pixel; 0 when out of range).
-__device__ __forceinline__ unsigned lut_locate(LutFetch& f, int height, int width, f2 p) {
-    const f2 fl = mk2(floorf(p.x), floorf(p.y));
-    const int xi = (int)__builtin_amdgcn_fmed3f(fl.x, -2.f, 2.0e9f), yi = (int)__builtin_amdgcn_fmed3f(fl.y, -2.f, 2.0e9f);
-    const bool out = (unsigned)(xi - 1) > (unsigned)(width - 4) || (unsigned)(yi - 1) > (unsigned)(height - 4);
-    const f2 fr = p - fl;  // the fractional offsets out of one packed subtraction
-    f.dx = fr.x;
-    f.dy = out ? -1.f : fr.y;
+// x >= width-2 || y >= height-2 || NaN -> -1.  With xi = (int)floor(x) that is (unsigned)(xi - 1) > width - 4.
+// v_cvt_flr_i32_f32 converts with floor in one instruction, saturates +-huge values to INT_MAX / INT_MIN and sends NaN
+// to 0 -- all of them "outside" under the unsigned test.  v_fract_f32 returns x - floor(x), which is exact in float,
+// i.e. the reference's x - (float)x_integral bit for bit for every in-range x.
+__device__ __forceinline__ int floor_to_int(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+// Fills the fractional offsets and returns the byte offset of the sample's pixel inside a plane (16 B per pixel).
+// `out` = the sample is outside the interpolatable range; it fetches pixel (0,0), which is always mapped, and the
+// caller discards the value.
+// MARK: also record "outside" in f.dy (-1; a valid dy lies in [0, 1)) for callers that keep the reference's -1.f
+// sentinel as a sample value (lut_eval) instead of abandoning the POI.
+template <bool MARK>
+__device__ __forceinline__ unsigned lut_locate(LutFetch& f, int height, int width, float x, float y, bool& out) {
+    const int xi = floor_to_int(x), yi = floor_to_int(y);
+    out = (unsigned)(xi - 1) > (unsigned)(width - 4) || (unsigned)(yi - 1) > (unsigned)(height - 4);
+    f.dx = __builtin_amdgcn_fractf(x);
+    const float fy = __builtin_amdgcn_fractf(y);
+    f.dy = (MARK && out) ? -1.f : fy;
     // 24-bit multiply: full rate, and exact because in-range yi and the width are below 2^24
     return out ? 0u : (__umul24((unsigned)yi, (unsigned)width) + (unsigned)xi) << 4;
 }
-template <class Planes>
-__device__ __forceinline__ void lut_fetch(LutFetch& f, const Planes& lut, int height, int width, f2 p) {
-    lut.load(f, lut_locate(f, height, width, p));
+template <bool MARK, class Planes>
+__device__ __forceinline__ void lut_fetch(LutFetch& f, const Planes& lut, int height, int width, float x, float y, bool& out) {
+    lut.load(f, lut_locate<MARK>(f, height, width, x, y, out));
 }
 
-// explicit 16-term left-to-right polynomial of src/oc_cubic_bspline.cpp:144-177
-// The 28 multiplications are independent and are issued in pairs: a 16-byte load leaves (c_k0, c_k1) and (c_k2, c_k3)
-// in adjacent registers, so row k costs  (c_k0, c_k1) * dy^k,  ((c_k2, c_k3) * dy^k) * (dx^2, dx^3)  and one scalar
-// (c_k1 dy^k) * dx -- every product is the one the reference forms, in its order ((c * dy^k) * dx^l); the 15
-// additions stay a left-to-right chain.
+// explicit 16-term left-to-right polynomial of src/oc_cubic_bspline.cpp:144-177: every product is the one the
+// reference forms, in its order ((c * dy^k) * dx^l); the 15 additions are a left-to-right chain.  Plain (unpacked)
+// fp32 instructions on purpose: on gfx950 a v_pk_mul_f32 / v_pk_add_f32 occupies a SIMD for 4.3 cycles against 2.4 for
+// v_mul_f32 / v_add_f32 (tools/ubench/valu_ubench.hip, profiles/r02b_valu_ubench.json), so a packed pair saves ~10 %
+// at best and loses it again to the v_mov_b32 that form the register pairs (the 16-byte loads leave the coefficients
+// in the wrong pairing for half of the products).
 __device__ __forceinline__ float lut_poly(const LutFetch& f) {
     const float dx = f.dx, dy = f.dy;
-    const f2 d1 = mk2(dx, dy);
-    const f2 d2 = d1 * d1;  // (dx^2, dy^2)
-    const f2 d3 = d2 * d1;  // (dx^3, dy^3)
-    const f2 xh = mk2(d2.x, d3.x);
-    const f2 r0 = mk2(f.c0.z, f.c0.w) * xh;
+    const float dx2 = dx * dx, dy2 = dy * dy;
+    const float dx3 = dx2 * dx, dy3 = dy2 * dy;
     float v = f.c0.x;
     v = v + f.c0.y * dx;
-    v = v + r0.x;
-    v = v + r0.y;
-    const f2 l1 = mk2(f.c1.x, f.c1.y) * dy, h1 = (mk2(f.c1.z, f.c1.w) * dy) * xh;
-    v = v + l1.x;
-    v = v + l1.y * dx;
-    v = v + h1.x;
-    v = v + h1.y;
-    const f2 l2 = mk2(f.c2.x, f.c2.y) * d2.y, h2 = (mk2(f.c2.z, f.c2.w) * d2.y) * xh;
-    v = v + l2.x;
-    v = v + l2.y * dx;
-    v = v + h2.x;
-    v = v + h2.y;
-    const f2 l3 = mk2(f.c3.x, f.c3.y) * d3.y, h3 = (mk2(f.c3.z, f.c3.w) * d3.y) * xh;
-    v = v + l3.x;
-    v = v + l3.y * dx;
-    v = v + h3.x;
-    v = v + h3.y;
+    v = v + f.c0.z * dx2;
+    v = v + f.c0.w * dx3;
+    v = v + f.c1.x * dy;
+    v = v + (f.c1.y * dy) * dx;
+    v = v + (f.c1.z * dy) * dx2;
+    v = v + (f.c1.w * dy) * dx3;
+    v = v + f.c2.x * dy2;
+    v = v + (f.c2.y * dy2) * dx;
+    v = v + (f.c2.z * dy2) * dx2;
+    v = v + (f.c2.w * dy2) * dx3;
+    v = v + f.c3.x * dy3;
+    v = v + (f.c3.y * dy3) * dx;
+    v = v + (f.c3.z * dy3) * dx2;
+    v = v + (f.c3.w * dy3) * dx3;
     return v;
 }
 __device__ __forceinline__ float lut_eval(const LutFetch& f) {

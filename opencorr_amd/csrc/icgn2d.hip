@@ -17,6 +17,7 @@
 // Wave-uniform state (warp matrix, inverse Hessian, norms) is held in SGPRs.
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "dic2d_device.h"
 #include "oc_kernels.h"
@@ -318,20 +319,24 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         float acc = 0.f;
         {
             SampleWalk w(lane, r0, c0, W, q64, r64);
-            // warp the next G samples of this lane and issue their LUT gathers
-            auto issue = [&](LutFetch(&f)[G], bool(&valid)[G]) {
+            // warp the next G samples of this lane and issue their LUT gathers.  CHECKED = std::false_type: every
+            // lane owns a sample in all G passes (the common case: no validity selects at all).
+            // !LM: a sample outside the interpolatable range makes the reference abandon the POI (:251-255: -1.f is
+            // the only way out of range shows, and any negative value aborts), so "outside" is folded into `negative`
+            // right here and the sample's value is never looked at; LM keeps the -1.f sentinel as a value (MARK).
+            auto issue = [&](LutFetch(&f)[G], bool(&valid)[G], auto checked) {
+                constexpr bool CHECKED = decltype(checked)::value;
 #pragma unroll
                 for (int g = 0; g < G; g++, w.next()) {
-                    valid[g] = w.s < N;
+                    valid[g] = CHECKED ? w.s < N : true;
                     // local_coor = (c - rx) - center_offset (src/oc_icgn.cpp:447-450); "- 0.f" is exact
                     const float xl = (float)(w.c - rx) - offx, yl = (float)(w.r - ry) - offy;
                     float wx, wy;
                     if constexpr (DOF == 6) {
-                        // Deformation2D1::warp, src/oc_deformation.cpp:94-105: (W0 x + W1 y) + W2 * 1 for both rows at
-                        // once on the packed pipe (the product with 1.f is exact and dropped)
-                        const f2 wv = (mk2(Wm[0], Wm[3]) * xl + mk2(Wm[1], Wm[4]) * yl) + mk2(Wm[2], Wm[5]);
-                        wx = wv.x;
-                        wy = wv.y;
+                        // Deformation2D1::warp, src/oc_deformation.cpp:94-105: (W0 x + W1 y) + W2 * 1 (the product
+                        // with 1.f is exact and dropped)
+                        wx = (Wm[0] * xl + Wm[1] * yl) + Wm[2];
+                        wy = (Wm[3] * xl + Wm[4] * yl) + Wm[5];
                     } else {
                         // Deformation2D2::warp, src/oc_deformation.cpp:268-282: rows 3, 4 of W * [x^2 xy y^2 x y 1]
                         const float pv[6] = {xl * xl, xl * yl, yl * yl, xl, yl, 1.f};
@@ -343,40 +348,63 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                             wy = wy + row4[k] * pv[k];
                         }
                     }
+                    // tar_subset->center = POI + center_offset, then + warped_coor (src/oc_icgn.cpp:425-426,452);
                     // a lane past the end of the subset fetches a harmless in-range point
-                    // tar_subset->center = POI + center_offset, then + warped_coor (src/oc_icgn.cpp:425-426,452)
-                    const f2 at = mk2(tcx, tcy) + mk2(wx, wy);
-                    lut_fetch(f[g], r_lut, height, width, valid[g] ? at : mk2(1.f, 1.f));
+                    float ax = tcx + wx, ay = tcy + wy;
+                    if constexpr (CHECKED) {
+                        ax = valid[g] ? ax : 1.f;
+                        ay = valid[g] ? ay : 1.f;
+                    }
+                    bool out;
+                    lut_fetch<LM != 0>(f[g], r_lut, height, width, ax, ay, out);
+                    if constexpr (!LM) negative = negative || out;
                 }
             };
-            auto consume = [&](const LutFetch(&f)[G], const bool(&valid)[G], int t0) {
+            auto consume = [&](const LutFetch(&f)[G], const bool(&valid)[G], int t0, auto checked) {
+                constexpr bool CHECKED = decltype(checked)::value;
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    const float v = lut_eval(f[g]);
-                    negative = negative || (valid[g] && v < 0.f);
-                    acc = valid[g] ? acc + v : acc;
-                    if (t0 + g < NT) l_ts[(t0 + g) * kWave] = v;
+                    const float v = LM ? lut_eval(f[g]) : lut_poly(f[g]);
+                    if constexpr (CHECKED) {
+                        negative = negative || (valid[g] && v < 0.f);
+                        acc = valid[g] ? acc + v : acc;
+                        if (t0 + g < NT) l_ts[(t0 + g) * kWave] = v;
+                    } else {
+                        negative = negative || v < 0.f;
+                        acc = acc + v;
+                        l_ts[(t0 + g) * kWave] = v;
+                    }
                 }
             };
+            // groups of G passes in which every lane owns a sample need no validity logic
+            const int full_groups = NF / G;
             if constexpr (PIPE == 0) {
+                int t0 = 0;
 #pragma nounroll
-                for (int t0 = 0; t0 < NT; t0 += G) {
+                for (int q = 0; q < full_groups; q++, t0 += G) {
                     LutFetch f[G];
                     bool valid[G];
-                    issue(f, valid);
-                    consume(f, valid, t0);
+                    issue(f, valid, std::false_type{});
+                    consume(f, valid, t0, std::false_type{});
+                }
+#pragma nounroll
+                for (; t0 < NT; t0 += G) {
+                    LutFetch f[G];
+                    bool valid[G];
+                    issue(f, valid, std::true_type{});
+                    consume(f, valid, t0, std::true_type{});
                 }
             } else {
                 LutFetch fa[G], fb[G];
                 bool va[G], vb[G];
-                issue(fa, va);
+                issue(fa, va, std::true_type{});
 #pragma nounroll
                 for (int t0 = 0; t0 < NT; t0 += 2 * G) {
                     const bool more_b = t0 + G < NT, more_a = t0 + 2 * G < NT;
-                    if (more_b) issue(fb, vb);
-                    consume(fa, va, t0);
-                    if (more_a) issue(fa, va);
-                    if (more_b) consume(fb, vb, t0 + G);
+                    if (more_b) issue(fb, vb, std::true_type{});
+                    consume(fa, va, t0, std::true_type{});
+                    if (more_a) issue(fa, va, std::true_type{});
+                    if (more_b) consume(fb, vb, t0 + G, std::true_type{});
                 }
             }
         }

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
                 // one range test and one entry offset serve the three tables
                 // (BicubicBspline::compute, src/oc_cubic_bspline.cpp:134-181; rule explained at lut_fetch)
                 LutFetch ft, fgx, fgy;
-                const unsigned e = lut_locate(ft, height, width, mk2(x, y));
+                bool out;
+                const unsigned e = lut_locate<true>(ft, height, width, x, y, out);
                 fgx.dx = fgy.dx = ft.dx;
                 fgx.dy = fgy.dy = ft.dy;
                 r_lut.load(ft, e);

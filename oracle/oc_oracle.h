@@ -9,16 +9,19 @@
  * cpu_baseline leg load it.
  *
  * Parity status of the oracle itself:
- *   - FFTCC2D + ICGN2D1: pinned against the reference's own golden vectors
- *     (examples/2d_dic/oht_cfrp_4_fftcc_icgn1_r16*.csv) in tests/test_oracle_golden.py.
- *   - NR2D1: pinned against examples/2d_dic/oht_cfrp_4_fftcc_nr1_r16.csv (same test file).
- *   - Strain (2D): pinned against the exx, eyy, exy columns of the same golden table
- *     (tests/test_oracle_strain.py), at the rounding of the reference's float QR (~2e-7).
- *   - ICGN2D2: soft anchor only (the reference's CUDA results from unrecorded initial guesses).
- *   - FFTCC3D, ICGN3D1, the centre-offset / self-adaptive overloads, ICLM2D1/2D2, 3D strain,
- *     RegionFit2D/3D: "parity unpinned" -- the reference ships no usable fixture for them in
- *     this mount; they are checked against analytic fields and against the
- *     pinned code they share.
+ *   - Pinned on the reference ITSELF: oracle/_ref/liboc_ref.so is /root/reference/src/oc_{fftcc,icgn,iclm,nr,
+ *     cubic_bspline,gradient,subset,deformation,dic,image}.cpp compiled UNMODIFIED (oracle/Makefile `ref`) against
+ *     stand-in Eigen / FFTW / OpenCV headers (oracle/ref_stubs).  tests/test_oracle_vs_ref.py: in OC_ORDER_SEQ this
+ *     oracle equals the reference bit for bit -- every float of every POI -- for ICGN2D1, ICGN2D2, both centre-offset
+ *     overloads, self-adaptive subsets, ICLM2D1 / ICLM2D2, NR2D1, ICGN3D1, Gradient2D4 / 3D4, BicubicBspline and
+ *     TricubicBspline; FFTCC2D / FFTCC3D give identical integer displacements and ZNCC within 1e-5 / 1e-4.
+ *   - Pinned on the reference's golden vectors (its authors' own runs, real Eigen + FFTW): FFTCC2D + ICGN2D1
+ *     (examples/2d_dic/oht_cfrp_4_fftcc_icgn1_r16*.csv), NR2D1 (oht_cfrp_4_fftcc_nr1_r16.csv) and Strain (2D) in
+ *     tests/test_oracle_golden.py, tests/test_oracle_strain.py; ICGN2D2 soft-anchored on the authors' CUDA results.
+ *   - Still "parity unpinned": only what lives INSIDE the third-party libraries -- Eigen's association of mean() /
+ *     squaredNorm() and of its LU / cofactor inverses, FFTW's butterflies (the stand-ins restate them the same way
+ *     this file does), glibc vs MSVC powf in IC-LM's first damping value -- plus 3D strain and RegionFit2D/3D, whose
+ *     reference code needs nanoflann and is not part of oracle/_ref.
  *
  * All images are row-major float32 (x fastest): img[y*width + x]; volumes are
  * vol[(z*dim_y + y)*dim_x + x] (same as Image3D::vol_mat, src/oc_array.h:57-74).

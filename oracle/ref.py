@@ -1,0 +1,130 @@
+"""ctypes binding of ``oracle/_ref/liboc_ref.so``: the REFERENCE's own hot-path sources, compiled unmodified.
+
+TEST INFRASTRUCTURE ONLY (same rule as ``oracle/__init__.py``).  The library is built by ``make -C oracle ref`` from
+``/root/reference/src/*.cpp`` against the stand-in Eigen / FFTW / OpenCV headers of ``oracle/ref_stubs`` and exists
+only where the reference tree is mounted (this container; the GPU box receives the prebuilt file with the snapshot
+but no test there depends on it).  ``available()`` says whether it can be used; tests skip otherwise.
+
+What it pins: the oracle's reading of the reference's LOOPS -- guards, window fills, summation order of the hand
+written reductions, the steepest-descent / Hessian / numerator loops, warp composition, output and error-code logic --
+bit for bit (``tests/test_oracle_vs_ref.py``).  What it cannot pin: the arithmetic INSIDE Eigen and FFTW (inverse(),
+products, mean(), squaredNorm(), the FFT butterflies), which the stand-ins restate like the oracle does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_ref", "liboc_ref.so")
+REFERENCE_ROOT = os.environ.get("OC_REFERENCE_ROOT", "/root/reference")
+
+ICGN2D1, ICGN2D2, ICLM2D1, ICLM2D2, NR2D1 = 0, 1, 2, 3, 4
+
+_lib = None
+
+
+def build(force=False):
+    """``make -C oracle ref`` when the reference tree is present; returns the library path or None."""
+    if not os.path.isdir(os.path.join(REFERENCE_ROOT, "src")):
+        return _LIB_PATH if os.path.exists(_LIB_PATH) else None
+    cmd = ["make", "-C", _HERE, "ref", "REF=" + REFERENCE_ROOT] + (["-B"] if force else ["-s"])
+    subprocess.check_call(cmd)
+    return _LIB_PATH
+
+
+def available():
+    try:
+        return lib() is not None
+    except Exception:
+        return False
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH) and build() is None:
+            return None
+        L = ctypes.CDLL(_LIB_PATH)
+        fp = ctypes.POINTER(ctypes.c_float)
+        i, f, l = ctypes.c_int, ctypes.c_float, ctypes.c_long
+        L.oc_ref_fftcc2d.argtypes = [fp, fp, i, i, i, i, fp, l, i]
+        L.oc_ref_solve2d.argtypes = [i, fp, fp, i, i, i, i, f, f, fp, l, fp, i, fp, i]
+        L.oc_ref_prepare2d.argtypes = [fp, fp, i, i, fp, fp, fp]
+        L.oc_ref_bspline2d_eval.argtypes = [fp, i, i, fp, l, fp]
+        L.oc_ref_fftcc3d.argtypes = [fp, fp, i, i, i, i, i, i, fp, l, i]
+        L.oc_ref_icgn3d1.argtypes = [fp, fp, i, i, i, i, i, i, f, f, fp, l, i]
+        L.oc_ref_prepare3d.argtypes = [fp, fp, i, i, i, fp, fp, fp, fp, l, fp]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if a is not None else None
+
+
+def _img(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("reference %s failed (rc %d: the reference threw std::string)" % (what, rc))
+
+
+def fftcc2d(ref, tar, rx, ry, pois, threads=0):
+    ref, tar = _img(ref), _img(tar)
+    h, w = ref.shape
+    _check(lib().oc_ref_fftcc2d(_fp(ref), _fp(tar), h, w, rx, ry, _fp(pois), pois.shape[0], threads), "FFTCC2D")
+
+
+def solve2d(engine, ref, tar, rx, ry, conv, stop, pois, center_offsets=None, self_adaptive=False, damping=None, threads=0):
+    """prepare() + compute(poi_queue[, center_offset_queue]) of ICGN2D1 / ICGN2D2 / ICLM2D1 / ICLM2D2 / NR2D1, in place."""
+    ref, tar = _img(ref), _img(tar)
+    h, w = ref.shape
+    off = None if center_offsets is None else np.ascontiguousarray(center_offsets, dtype=np.float32)
+    dmp = None if damping is None else np.asarray(damping, dtype=np.float32)
+    _check(lib().oc_ref_solve2d(engine, _fp(ref), _fp(tar), h, w, rx, ry, float(conv), float(stop), _fp(pois), pois.shape[0],
+                                _fp(off), 1 if self_adaptive else 0, _fp(dmp), threads), "2D solver %d" % engine)
+
+
+def gradient2d(img):
+    img = _img(img)
+    h, w = img.shape
+    gx, gy = np.empty_like(img), np.empty_like(img)
+    _check(lib().oc_ref_prepare2d(_fp(img), _fp(img), h, w, _fp(gx), _fp(gy), None), "Gradient2D4")
+    return gx, gy
+
+
+def bspline2d_eval(img, xy):
+    img = _img(img)
+    xy = np.ascontiguousarray(xy, dtype=np.float32)
+    out = np.empty(len(xy), dtype=np.float32)
+    _check(lib().oc_ref_bspline2d_eval(_fp(img), img.shape[0], img.shape[1], _fp(xy), len(xy), _fp(out)), "BicubicBspline")
+    return out
+
+
+def fftcc3d(ref, tar, rx, ry, rz, pois, threads=0):
+    ref, tar = _img(ref), _img(tar)
+    dz, dy, dx = ref.shape
+    _check(lib().oc_ref_fftcc3d(_fp(ref), _fp(tar), dz, dy, dx, rx, ry, rz, _fp(pois), pois.shape[0], threads), "FFTCC3D")
+
+
+def icgn3d1(ref, tar, rx, ry, rz, conv, stop, pois, threads=0):
+    ref, tar = _img(ref), _img(tar)
+    dz, dy, dx = ref.shape
+    _check(lib().oc_ref_icgn3d1(_fp(ref), _fp(tar), dz, dy, dx, rx, ry, rz, float(conv), float(stop), _fp(pois), pois.shape[0],
+                                threads), "ICGN3D1")
+
+
+def prepare3d(ref, tar, xyz):
+    """Gradient3D4 of ``ref`` and TricubicBspline(tar).compute at the points ``xyz`` (n x 3)."""
+    ref, tar = _img(ref), _img(tar)
+    dz, dy, dx = ref.shape
+    gx, gy, gz = np.empty_like(ref), np.empty_like(ref), np.empty_like(ref)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    out = np.empty(len(xyz), dtype=np.float32)
+    _check(lib().oc_ref_prepare3d(_fp(ref), _fp(tar), dz, dy, dx, _fp(gx), _fp(gy), _fp(gz), _fp(xyz), len(xyz), _fp(out)),
+           "Gradient3D4 / TricubicBspline")
+    return gx, gy, gz, out

@@ -1,0 +1,231 @@
+// ref_driver.cpp -- C entry points around the REFERENCE's own classes (oracle/_ref/liboc_ref.so).
+//
+// TEST INFRASTRUCTURE ONLY.  oracle/Makefile (target `ref`) compiles the reference's sources UNMODIFIED, where they lie
+// under /root/reference/src -- oc_fftcc.cpp, oc_icgn.cpp, oc_iclm.cpp, oc_nr.cpp, oc_cubic_bspline.cpp,
+// oc_gradient.cpp, oc_subset.cpp, oc_deformation.cpp, oc_dic.cpp, oc_image.cpp -- against the stand-in headers of
+// oracle/ref_stubs (mini Eigen, FFTW and OpenCV), plus this file.  Nothing of the reference is copied into the
+// repository; the library exists only where /root/reference does (this container) and is what pins the oracle's
+// reading of the reference's loops: tests/test_oracle_vs_ref.py asserts oracle(OC_ORDER_SEQ) == liboc_ref.
+//
+// Data conventions are the oracle's (oc_oracle.h): row-major float images, POI2D / POI3D AoS records.
+#include <omp.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "oc_fftcc.h"
+#include "oc_icgn.h"
+#include "oc_iclm.h"
+#include "oc_nr.h"
+
+using namespace opencorr;
+
+static_assert(sizeof(POI2D) == 100, "POI2D is 25 packed floats");
+static_assert(sizeof(POI3D) == 124, "POI3D is 31 packed floats");
+
+namespace {
+
+void fill2d(Image2D& img, const float* src) {
+    for (int r = 0; r < img.height; r++)
+        for (int c = 0; c < img.width; c++) img.eg_mat(r, c) = src[(size_t)r * img.width + c];
+}
+
+void fill3d(Image3D& img, const float* src) { std::memcpy(&img.vol_mat[0][0][0], src, sizeof(float) * (size_t)img.dim_x * img.dim_y * img.dim_z); }
+
+std::vector<POI2D> load2d(const float* pois, long n) {
+    std::vector<POI2D> q((size_t)n, POI2D(0.f, 0.f));
+    if (n) std::memcpy(static_cast<void*>(q.data()), pois, sizeof(POI2D) * (size_t)n);
+    return q;
+}
+std::vector<POI3D> load3d(const float* pois, long n) {
+    std::vector<POI3D> q((size_t)n, POI3D(0.f, 0.f, 0.f));
+    if (n) std::memcpy(static_cast<void*>(q.data()), pois, sizeof(POI3D) * (size_t)n);
+    return q;
+}
+
+int threads_or_all(int threads) { return threads > 0 ? threads : omp_get_max_threads(); }
+
+// engine: 0 = ICGN2D1, 1 = ICGN2D2, 2 = ICLM2D1, 3 = ICLM2D2, 4 = NR2D1
+template <class Engine>
+void run2d(Engine& e, Image2D& ref, Image2D& tar, std::vector<POI2D>& q, const float* offsets, int self_adaptive) {
+    e.setImages(ref, tar);
+    e.prepare();
+    e.setSelfAdaptive(self_adaptive != 0);
+    if (offsets) {
+        std::vector<Point2D> off(q.size());
+        for (size_t i = 0; i < q.size(); i++) off[i] = Point2D(offsets[2 * i], offsets[2 * i + 1]);
+        if constexpr (std::is_same<Engine, ICGN2D1>::value || std::is_same<Engine, ICGN2D2>::value) e.compute(q, off);
+    } else {
+        e.compute(q);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int oc_ref_available(void) { return 1; }
+
+// FFTCC2D::compute(std::vector<POI2D>&), src/oc_fftcc.cpp:277-285
+int oc_ref_fftcc2d(const float* ref, const float* tar, int height, int width, int rx, int ry, float* pois, long n, int threads) {
+    try {
+        Image2D ref_img(width, height), tar_img(width, height);
+        fill2d(ref_img, ref);
+        fill2d(tar_img, tar);
+        std::vector<POI2D> q = load2d(pois, n);
+        FFTCC2D fftcc(rx, ry, threads_or_all(threads));
+        fftcc.setImages(ref_img, tar_img);
+        fftcc.compute(q);
+        if (n) std::memcpy(pois, static_cast<void*>(q.data()), sizeof(POI2D) * (size_t)n);
+    } catch (const std::string&) {
+        return 1;
+    }
+    return 0;
+}
+
+// ICGN2D1 / ICGN2D2 (src/oc_icgn.cpp), ICLM2D1 / ICLM2D2 (src/oc_iclm.cpp), NR2D1 (src/oc_nr.cpp): prepare() + compute(queue)
+// offsets (n x 2, or null): compute(poi_queue, center_offset_queue); self_adaptive: DIC::setSelfAdaptive
+// damping (3 floats or null): ICLM*::setDamping(lambda, alpha, beta)
+int oc_ref_solve2d(int engine, const float* ref, const float* tar, int height, int width, int rx, int ry, float conv, float stop,
+                   float* pois, long n, const float* offsets, int self_adaptive, const float* damping, int threads) {
+    try {
+        Image2D ref_img(width, height), tar_img(width, height);
+        fill2d(ref_img, ref);
+        fill2d(tar_img, tar);
+        std::vector<POI2D> q = load2d(pois, n);
+        const int t = threads_or_all(threads);
+        switch (engine) {
+            case 0: { ICGN2D1 e(rx, ry, conv, stop, t); run2d(e, ref_img, tar_img, q, offsets, self_adaptive); break; }
+            case 1: { ICGN2D2 e(rx, ry, conv, stop, t); run2d(e, ref_img, tar_img, q, offsets, self_adaptive); break; }
+            case 2: { ICLM2D1 e(rx, ry, conv, stop, t); if (damping) e.setDamping(damping[0], damping[1], damping[2]); run2d(e, ref_img, tar_img, q, nullptr, self_adaptive); break; }
+            case 3: { ICLM2D2 e(rx, ry, conv, stop, t); if (damping) e.setDamping(damping[0], damping[1], damping[2]); run2d(e, ref_img, tar_img, q, nullptr, self_adaptive); break; }
+            case 4: { NR2D1 e(rx, ry, conv, stop, t); run2d(e, ref_img, tar_img, q, nullptr, 0); break; }
+            default: return 2;
+        }
+        if (n) std::memcpy(pois, static_cast<void*>(q.data()), sizeof(POI2D) * (size_t)n);
+    } catch (const std::string&) {
+        return 1;
+    }
+    return 0;
+}
+
+// what ICGN2D1::prepare() builds, for field-level comparison: Gradient2D4 (src/oc_gradient.cpp:37-79) of `ref` and the
+// BicubicBspline table (src/oc_cubic_bspline.cpp:84-132) of `tar`; lut is [y][x][k][l]
+int oc_ref_prepare2d(const float* ref, const float* tar, int height, int width, float* gx, float* gy, float* lut) {
+    try {
+        Image2D ref_img(width, height), tar_img(width, height);
+        fill2d(ref_img, ref);
+        fill2d(tar_img, tar);
+        Gradient2D4 grad(ref_img);
+        grad.getGradientX();
+        grad.getGradientY();
+        BicubicBspline interp(tar_img);
+        interp.prepare();
+        for (int r = 0; r < height; r++)
+            for (int c = 0; c < width; c++) {
+                gx[(size_t)r * width + c] = grad.gradient_x(r, c);
+                gy[(size_t)r * width + c] = grad.gradient_y(r, c);
+            }
+        // the table is a private member; its values are observable through compute() only, so the comparison of the
+        // table itself is done through interpolated values (oc_ref_bspline2d_eval below) -- lut may be null
+        (void)lut;
+    } catch (const std::string&) {
+        return 1;
+    }
+    return 0;
+}
+
+// BicubicBspline::compute at n points (src/oc_cubic_bspline.cpp:134-181)
+int oc_ref_bspline2d_eval(const float* img, int height, int width, const float* xy, long n, float* out) {
+    try {
+        Image2D im(width, height);
+        fill2d(im, img);
+        BicubicBspline interp(im);
+        interp.prepare();
+        for (long i = 0; i < n; i++) {
+            Point2D p(xy[2 * i], xy[2 * i + 1]);
+            out[i] = interp.compute(p);
+        }
+    } catch (const std::string&) {
+        return 1;
+    }
+    return 0;
+}
+
+// FFTCC3D::compute(std::vector<POI3D>&), src/oc_fftcc.cpp:429-436
+int oc_ref_fftcc3d(const float* ref, const float* tar, int dz, int dy, int dx, int rx, int ry, int rz, float* pois, long n, int threads) {
+    try {
+        Image3D ref_img(dx, dy, dz), tar_img(dx, dy, dz);
+        fill3d(ref_img, ref);
+        fill3d(tar_img, tar);
+        std::vector<POI3D> q = load3d(pois, n);
+        {
+            FFTCC3D fftcc(rx, ry, rz, threads_or_all(threads));
+            fftcc.setImages(ref_img, tar_img);
+            fftcc.compute(q);
+        }
+        ref_img.release();
+        tar_img.release();
+        if (n) std::memcpy(pois, static_cast<void*>(q.data()), sizeof(POI3D) * (size_t)n);
+    } catch (const std::string&) {
+        return 1;
+    }
+    return 0;
+}
+
+// ICGN3D1::prepare() + compute(std::vector<POI3D>&), src/oc_icgn.cpp:1240-1500
+int oc_ref_icgn3d1(const float* ref, const float* tar, int dz, int dy, int dx, int rx, int ry, int rz, float conv, float stop,
+                   float* pois, long n, int threads) {
+    try {
+        Image3D ref_img(dx, dy, dz), tar_img(dx, dy, dz);
+        fill3d(ref_img, ref);
+        fill3d(tar_img, tar);
+        std::vector<POI3D> q = load3d(pois, n);
+        {
+            ICGN3D1 e(rx, ry, rz, conv, stop, threads_or_all(threads));
+            e.setImages(ref_img, tar_img);
+            e.prepare();
+            e.compute(q);
+        }
+        ref_img.release();
+        tar_img.release();
+        if (n) std::memcpy(pois, static_cast<void*>(q.data()), sizeof(POI3D) * (size_t)n);
+    } catch (const std::string&) {
+        return 1;
+    }
+    return 0;
+}
+
+// Gradient3D4 (src/oc_gradient.cpp:143-231) and TricubicBspline::prepare + compute (src/oc_cubic_bspline.cpp:214-405)
+int oc_ref_prepare3d(const float* ref, const float* tar, int dz, int dy, int dx, float* gx, float* gy, float* gz, const float* xyz,
+                     long n, float* interp_out) {
+    try {
+        Image3D ref_img(dx, dy, dz), tar_img(dx, dy, dz);
+        fill3d(ref_img, ref);
+        fill3d(tar_img, tar);
+        {
+            Gradient3D4 grad(ref_img);
+            grad.getGradientX();
+            grad.getGradientY();
+            grad.getGradientZ();
+            const size_t vox = (size_t)dx * dy * dz;
+            std::memcpy(gx, &grad.gradient_x[0][0][0], sizeof(float) * vox);
+            std::memcpy(gy, &grad.gradient_y[0][0][0], sizeof(float) * vox);
+            std::memcpy(gz, &grad.gradient_z[0][0][0], sizeof(float) * vox);
+            TricubicBspline interp(tar_img);
+            interp.prepare();
+            for (long i = 0; i < n; i++) {
+                Point3D p(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+                interp_out[i] = interp.compute(p);
+            }
+        }
+        ref_img.release();
+        tar_img.release();
+    } catch (const std::string&) {
+        return 1;
+    }
+    return 0;
+}
+
+}  // extern "C"

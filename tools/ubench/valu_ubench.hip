@@ -4,8 +4,10 @@
 // every wave runs REPS x 32 instructions of one kind on 32 independent registers (no dependency closer than 32
 // instructions), with W waves resident per SIMD; the figure of merit is
 //     cycles per instruction per SIMD = kernel cycles x SIMDs / wave-instructions issued,
-// cycles from s_memtime deltas inside the waves (shader clock) and, as a cross-check, from the hipEvent time at the
-// clock the first measures.  Instruction kinds: plain fp32 (v_mul_f32, v_add_f32, v_fma_f32), packed fp32
+// cycles from s_memtime stamps inside the waves (shader clock).  Every wave also records WHERE it ran (HW_REG_HW_ID:
+// SE / SH / CU / SIMD, and the XCC id), so the host groups the waves by SIMD and divides that SIMD's busy span
+// (last end - first start) by the instructions its waves issued -- no assumption about how the dispatcher spreads the
+// workgroups.  The hipEvent time is reported beside it (launch overhead included).  Instruction kinds: plain fp32 (v_mul_f32, v_add_f32, v_fma_f32), packed fp32
 // (v_pk_mul_f32, v_pk_add_f32, v_pk_fma_f32: two IEEE results per lane), the movers the compiler inserts to form
 // register pairs (v_mov_b32), integer address arithmetic (v_mul_u32_u24, v_add_u32), v_cndmask_b32, DPP adds and
 // v_readlane_b32 (the reductions), v_floor_f32 / v_cvt_i32_f32 (the range rule).
@@ -13,12 +15,14 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-constexpr int REPS = 2048;
+constexpr int REPS = 16384;
 
 // 32 instructions, destination/source register i of a 32-register file (packed kinds use 16 register pairs, twice)
 #define R4(M, a) M(a) M(a + 1) M(a + 2) M(a + 3)
@@ -30,8 +34,13 @@ static const char* kNames[NKIND] = {"v_mul_f32", "v_add_f32", "v_fma_f32", "v_pk
                                     "v_mul_u32_u24", "v_add_u32", "v_cndmask_b32", "v_add_f32_dpp", "v_readlane_b32", "v_floor_f32",
                                     "v_cvt_i32_f32"};
 
+struct WaveRec {
+    unsigned long long t0, t1;
+    unsigned hw_id, xcc_id;
+};
+
 template <int KIND>
-__global__ __launch_bounds__(256) void k(float* __restrict__ out, unsigned long long* __restrict__ cycles, float seed) {
+__global__ __launch_bounds__(256) void k(float* __restrict__ out, WaveRec* __restrict__ cycles, float seed) {
     float r[32];
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p[16];
@@ -110,15 +119,22 @@ __global__ __launch_bounds__(256) void k(float* __restrict__ out, unsigned long 
 #pragma unroll
     for (int i = 0; i < 16; i++) acc += p[i].x + p[i].y;
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
-    if ((threadIdx.x & 63) == 0) cycles[(size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) {
+        WaveRec r;
+        r.t0 = t0;
+        r.t1 = t1;
+        r.hw_id = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4);    // HW_REG_HW_ID
+        r.xcc_id = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20);  // HW_REG_XCC_ID
+        cycles[(size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = r;
+    }
 }
 
 struct Result {
-    double ms, wave_cycles_mean;
+    double ms, wave_cycles_mean, cyc_per_inst_simd, waves_per_simd_seen;
 };
 
 template <int KIND>
-Result run(int blocks, float* out, unsigned long long* cyc) {
+Result run(int blocks, float* out, WaveRec* cyc) {
     hipEvent_t a, b;
     CHECK(hipEventCreate(&a));
     CHECK(hipEventCreate(&b));
@@ -130,23 +146,40 @@ Result run(int blocks, float* out, unsigned long long* cyc) {
     CHECK(hipDeviceSynchronize());
     float ms = 0;
     CHECK(hipEventElapsedTime(&ms, a, b));
-    std::vector<unsigned long long> h((size_t)blocks * 4);
-    CHECK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<WaveRec> h((size_t)blocks * 4);
+    CHECK(hipMemcpy(h.data(), cyc, h.size() * sizeof(WaveRec), hipMemcpyDeviceToHost));
     double sum = 0;
-    for (auto v : h) sum += (double)v;
-    return {ms, sum / h.size()};
+    // group by SIMD: key = (xcc, se, sh, cu, simd) out of HW_ID[15:4] (simd 5:4, cu 11:8, sh 12, se 15:13) and XCC_ID[3:0]
+    std::map<unsigned, std::pair<std::pair<unsigned long long, unsigned long long>, int>> simd;
+    for (const WaveRec& r : h) {
+        sum += (double)(r.t1 - r.t0);
+        const unsigned key = ((r.xcc_id & 0xf) << 16) | (r.hw_id & 0xff30);
+        auto it = simd.find(key);
+        if (it == simd.end()) simd[key] = {{r.t0, r.t1}, 1};
+        else {
+            it->second.first.first = std::min(it->second.first.first, r.t0);
+            it->second.first.second = std::max(it->second.first.second, r.t1);
+            it->second.second++;
+        }
+    }
+    double cpi = 0, waves = 0;
+    for (auto& kv : simd) {
+        cpi += (double)(kv.second.first.second - kv.second.first.first) / ((double)kv.second.second * REPS * 32);
+        waves += kv.second.second;
+    }
+    return {ms, sum / h.size(), cpi / simd.size(), waves / simd.size()};
 }
 
-typedef Result (*RunFn)(int, float*, unsigned long long*);
+typedef Result (*RunFn)(int, float*, WaveRec*);
 
 int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     float* out;
-    unsigned long long* cyc;
+    WaveRec* cyc;
     CHECK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4));
-    CHECK(hipMalloc(&cyc, (size_t)cus * 8 * 4 * 8));
+    CHECK(hipMalloc(&cyc, (size_t)cus * 8 * 4 * sizeof(WaveRec)));
     RunFn fns[NKIND] = {run<MUL>, run<ADD>, run<FMA>, run<PK_MUL>, run<PK_ADD>, run<PK_FMA>, run<MOV>, run<MUL_U24>, run<ADD_U32>,
                         run<CNDMASK>, run<DPP_ADD>, run<READLANE>, run<FLOOR>, run<CVT_I32>};
     printf("{\"device\": \"%s\", \"cus\": %d, \"reps\": %d, \"instructions_per_wave\": %d, \"results\": [\n", prop.gcnArchName, cus, REPS, REPS * 32);
@@ -156,11 +189,10 @@ int main() {
         for (int kind = 0; kind < NKIND; kind++) {
             const Result r = fns[kind](cus * wps, out, cyc);
             const double inst = (double)REPS * 32;  // per wave
-            // every SIMD issued wps * inst wave-instructions during ~wave_cycles_mean shader cycles
-            const double cyc_per_inst = r.wave_cycles_mean / (inst * wps);
-            printf("%s  {\"inst\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.4f, \"wave_cycles\": %.0f, \"cycles_per_inst_per_simd\": %.3f, "
-                   "\"mhz_implied\": %.0f}",
-                   first ? "" : ",\n", kNames[kind], wps, r.ms, r.wave_cycles_mean, cyc_per_inst, r.wave_cycles_mean / (r.ms * 1e3));
+            printf("%s  {\"inst\": \"%s\", \"blocks_per_cu\": %d, \"waves_per_simd_seen\": %.2f, \"ms\": %.4f, \"wave_cycles_per_inst\": %.3f, "
+                   "\"cycles_per_inst_per_simd\": %.3f, \"ginst_per_s_chip\": %.1f}",
+                   first ? "" : ",\n", kNames[kind], wps, r.waves_per_simd_seen, r.ms, r.wave_cycles_mean / inst, r.cyc_per_inst_simd,
+                   inst * cus * wps * 4 / (r.ms * 1e6));
             first = false;
         }
     }
