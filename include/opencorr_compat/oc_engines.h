@@ -7,8 +7,8 @@
 // plus prepare(), prepareRef(), prepareTar(), compute(POI*), compute(std::vector<POI>&),
 // setIteration(float,float), setIteration(POI*), setImages, setSubset.
 // `thread_number` is kept for signature compatibility (the GPU parallelises internally);
-// the device is chosen with the extra setter setDevice() or the OC_HIP_DEVICE environment variable
-// BEFORE the first call that needs the GPU.  Failures of the engine (no GPU, bad call order, ...)
+// the device is chosen with the extra setters setDevice() / setDevices() or the OC_HIP_DEVICE / OC_HIP_DEVICES
+// environment variables (OC_HIP_DEVICES=all: every engine spreads its queues over all GPUs of the node).  Failures of the engine (no GPU, bad call order, ...)
 // are thrown as std::string like the reference does (src/oc_fftcc.cpp:145, src/oc_icgn.cpp:65).
 //
 // Differences a caller can observe (documented):
@@ -35,6 +35,32 @@ inline void check(int status) {
 inline int default_device() {
     const char* e = std::getenv("OC_HIP_DEVICE");
     return e ? std::atoi(e) : 0;
+}
+// OC_HIP_DEVICES = "0,1,2,3" or "all": every engine created through these classes becomes a device group over the
+// listed GPUs (oc_hip_set_devices) -- an unmodified OpenCorr main then uses the whole node.
+inline std::vector<int> default_devices() {
+    std::vector<int> ids;
+    const char* e = std::getenv("OC_HIP_DEVICES");
+    if (!e || !*e) return ids;
+    if (std::string(e) == "all") {
+        int n = 0;
+        check(oc_hip_device_count(&n));
+        for (int i = 0; i < n; i++) ids.push_back(i);
+        return ids;
+    }
+    for (const char* p = e; *p;) {
+        char* end = nullptr;
+        const long v = std::strtol(p, &end, 10);
+        if (end == p) break;
+        ids.push_back((int)v);
+        p = *end == ',' ? end + 1 : end;
+    }
+    return ids;
+}
+// applied by every shim constructor right after the engine exists
+inline void apply_default_devices(oc_hip_engine* e) {
+    const std::vector<int> ids = default_devices();
+    if (ids.size() > 1) check(oc_hip_set_devices(e, ids.data(), (int)ids.size()));
 }
 }  // namespace hipdetail
 
@@ -64,7 +90,15 @@ public:
     // DIC::setSelfAdaptive (src/oc_dic.cpp:34-37).  Honoured by ICGN2D1/ICGN2D2 (per-POI radius from
     // poi->subset_radius); FFTCC2D ignores it, as in the reference (src/oc_fftcc.cpp:177-275 never reads it).
     virtual void setSelfAdaptive(bool is_self_adaptive) { self_adaptive = is_self_adaptive; }
-    void setDevice(int device) { device_ = device; }
+    // Moves the engine to another GPU / spreads it over several GPUs of the node (contiguous blocks of every queue,
+    // src/oc_icgn.cpp:343-351 is the loop being shared out).  Images are uploaded again on the next use.
+    void setDevice(int device) { setDevices(std::vector<int>(1, device)); }
+    void setDevices(const std::vector<int>& devices) {
+        if (devices.empty()) throw std::string("setDevices: empty device list");
+        hipdetail::check(oc_hip_set_devices(engine_, devices.data(), (int)devices.size()));
+        device_ = devices[0];
+        images_dirty_ = ref_img != nullptr;
+    }
 
     virtual void prepare() = 0;
     virtual void compute(POI2D* poi) = 0;
@@ -116,7 +150,13 @@ public:
         subset_radius_z = radius_z;
         if (engine_) hipdetail::check(oc_hip_set_subset(engine_, radius_x, radius_y, radius_z));
     }
-    void setDevice(int device) { device_ = device; }
+    void setDevice(int device) { setDevices(std::vector<int>(1, device)); }
+    void setDevices(const std::vector<int>& devices) {
+        if (devices.empty()) throw std::string("setDevices: empty device list");
+        hipdetail::check(oc_hip_set_devices(engine_, devices.data(), (int)devices.size()));
+        device_ = devices[0];
+        images_dirty_ = ref_img != nullptr;
+    }
 
     virtual void prepare() = 0;
     virtual void compute(POI3D* poi) = 0;
@@ -151,6 +191,7 @@ public:
         subset_radius_y = subset_radius_y_;
         thread_number = thread_number_;
         hipdetail::check(oc_hip_fftcc2d_create(subset_radius_x_, subset_radius_y_, device_, &engine_));
+        hipdetail::apply_default_devices(engine_);
     }
     void prepare() override {}  // empty in the reference too (src/oc_fftcc.cpp:175)
     void compute(POI2D* poi) override { computeBatch(poi, 1); }
@@ -165,6 +206,7 @@ public:
         subset_radius_z = rz;
         thread_number = thread_number_;
         hipdetail::check(oc_hip_fftcc3d_create(rx, ry, rz, device_, &engine_));
+        hipdetail::apply_default_devices(engine_);
     }
     void prepare() override {}
     void compute(POI3D* poi) override { computeBatch(poi, 1); }
@@ -245,6 +287,7 @@ public:
         stop_condition = stop_condition_;
         thread_number = thread_number_;
         hipdetail::check(oc_hip_icgn2d1_create(rx, ry, conv_criterion_, stop_condition_, device_, &engine_));
+        hipdetail::apply_default_devices(engine_);
     }
 };
 
@@ -257,6 +300,7 @@ public:
         stop_condition = stop_condition_;
         thread_number = thread_number_;
         hipdetail::check(oc_hip_icgn2d2_create(rx, ry, conv_criterion_, stop_condition_, device_, &engine_));
+        hipdetail::apply_default_devices(engine_);
     }
 };
 
@@ -271,6 +315,7 @@ public:
         stop_condition = stop_condition_;
         thread_number = thread_number_;
         hipdetail::check(oc_hip_nr2d1_create(rx, ry, conv_criterion_, stop_condition_, device_, &engine_));
+        hipdetail::apply_default_devices(engine_);
     }
     void prepare() override {
         uploadIfNeeded();
@@ -291,6 +336,7 @@ public:
         thread_number = thread_number_;
         hipdetail::check(KIND == OC_HIP_ICLM2D1 ? oc_hip_iclm2d1_create(rx, ry, conv_criterion_, stop_condition_, device_, &engine_)
                                                 : oc_hip_iclm2d2_create(rx, ry, conv_criterion_, stop_condition_, device_, &engine_));
+        hipdetail::apply_default_devices(engine_);
     }
     void setDamping(float lambda, float alpha, float beta) { hipdetail::check(oc_hip_set_damping(engine_, lambda, alpha, beta)); }
     void setSelfAdaptive(bool is_self_adaptive) override {
@@ -311,6 +357,7 @@ public:
         stop_condition = stop_condition_;
         thread_number = thread_number_;
         hipdetail::check(oc_hip_icgn3d1_create(rx, ry, rz, conv_criterion_, stop_condition_, device_, &engine_));
+        hipdetail::apply_default_devices(engine_);
     }
 };
 
@@ -429,6 +476,7 @@ public:
     IcgnGpu2D(int rx, int ry, float conv, int stop) {
         hipdetail::check(KIND == OC_HIP_ICGN2D1 ? oc_hip_icgn2d1_create(rx, ry, conv, (float)stop, hipdetail::default_device(), &e_)
                                                 : oc_hip_icgn2d2_create(rx, ry, conv, (float)stop, hipdetail::default_device(), &e_));
+        hipdetail::apply_default_devices(e_);
     }
     ~IcgnGpu2D() { if (e_) oc_hip_destroy(e_); }
     IcgnGpu2D(const IcgnGpu2D&) = delete;
@@ -450,6 +498,7 @@ class ICGN3D1GPU {
 public:
     ICGN3D1GPU(int rx, int ry, int rz, float conv, int stop) {
         hipdetail::check(oc_hip_icgn3d1_create(rx, ry, rz, conv, (float)stop, hipdetail::default_device(), &e_));
+        hipdetail::apply_default_devices(e_);
     }
     ~ICGN3D1GPU() { if (e_) oc_hip_destroy(e_); }
     ICGN3D1GPU(const ICGN3D1GPU&) = delete;

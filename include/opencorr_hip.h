@@ -187,6 +187,32 @@ int oc_hip_set_stream(oc_hip_engine* engine, void* hip_stream);
 /* Go back to the engine's own (non-blocking) stream. */
 int oc_hip_reset_stream(oc_hip_engine* engine);
 
+/* ---- device groups: one engine, several GPUs of the node -------------------------------
+ * The loop being replaced is the reference's per-POI loop, src/oc_icgn.cpp:343-351 (`#pragma omp parallel for` over
+ * poi_queue): every POI is independent, so member g of the group takes the contiguous block
+ * [g * ceil(n / G), (g + 1) * ceil(n / G)) of the queue.  device_ids[0] is where the engine itself lives (it moves
+ * there if necessary: images must then be set again); for each further id a full engine of the same kind and
+ * settings is created on that device.  From then on every call on the handle fans out: setters, set_images (host
+ * images are uploaded by every member, device images are copied peer to peer), prepare (every member builds its own
+ * gradients / tables: cheaper than moving 64 B per pixel over xGMI) and compute:
+ *   - OC_HIP_HOST queues: every member moves and solves its own block from its own host thread; results land in the
+ *     caller's vector, no exchange is needed.
+ *   - OC_HIP_DEVICE queues (resident on device_ids[0]): members pull their block over xGMI (hipMemcpyPeerAsync),
+ *     solve it and push the records back; stream-ordered like a single-device call.  With the tuning key
+ *     "group_allgather" = 1 every member additionally ends up with the COMPLETE result queue in its own mirror
+ *     (oc_hip_group_queue) -- one ncclAllGather (RCCL) of equal, padded blocks when the members sit on distinct
+ *     devices -- for consumers that run on every GPU (Strain / RegionFit per device).
+ * Results are bit-identical for every group size (a POI's arithmetic does not depend on the block it travels in).
+ * A device may be named more than once (two members on one GPU): only useful to exercise the sharding on a one-GPU
+ * machine.  n_devices = 1 dissolves a group.  Strain / RegionFit engines stay on one device. */
+int oc_hip_set_devices(oc_hip_engine* engine, const int* device_ids, int n_devices);
+/* members of the group (1 for a plain engine); device_ids may be NULL */
+int oc_hip_get_devices(const oc_hip_engine* engine, int* device_ids, int capacity, int* n_devices);
+/* after a DEVICE-queue compute with "group_allgather" = 1: member `member`'s copy of the whole queue on ITS device --
+ * G blocks of block_bytes (ceil(n / G) records; the last block padded), valid once the engine's stream has been
+ * synchronised */
+int oc_hip_group_queue(const oc_hip_engine* engine, int member, const void** device_ptr, size_t* block_bytes);
+
 /* Performance knobs; every setting computes bit-identical results.
  *   "icgn2d_variant"  index into the ICGN2D kernel-variant table (gather depth, LDS footprint,
  *                     software pipelining, waves per workgroup)
@@ -194,7 +220,10 @@ int oc_hip_reset_stream(oc_hip_engine* engine);
  *   "icgn2d_tile_px"  side of the square image tiles the ICGN2D queue is visited by (L2 locality; 0 = queue order)
  *   "fftcc2d_fused"   1: single-kernel FFTCC2D (LDS / register FFT) for square windows of side 20, 24, 30, 32,
  *                     36, 40, 48 (radius 10, 12, 15, 16, 18, 20, 24); 0: rocFFT pipeline
- *   "fftcc3d_fused"   1: single-kernel FFTCC3D (register/LDS FFT) for 32 x 32 x 32 windows; 0: rocFFT pipeline */
+ *   "fftcc3d_fused"   1: single-kernel FFTCC3D (register/LDS FFT) for 32 x 32 x 32 windows; 0: rocFFT pipeline
+ *   "host_chunk"      POIs per chunk of the host-queue pipeline (copies of one chunk overlap the kernels of its
+ *                     neighbours); 0 = whole queue at once; default 65536
+ *   "group_allgather" 1: device groups leave the complete result queue on every member (see oc_hip_set_devices) */
 int oc_hip_set_tuning(oc_hip_engine* engine, const char* key, int value);
 
 /* ---- precompute ----------------------------------------------------------- */
@@ -210,8 +239,8 @@ int oc_hip_prepare_tar(oc_hip_engine* engine);
 /* FFTCC2D::compute(std::vector<POI2D>&)  src/oc_fftcc.cpp:277-285
  * ICGN2D1::compute(std::vector<POI2D>&)  src/oc_icgn.cpp:343-351   (2D2 :900-908, 3D1 :1492-1500,
  * FFTCC3D :429-436).  `pois` = poi_queue.data(), `count` = poi_queue.size().
- * With OC_HIP_HOST the call returns after the results are back in `pois`; with
- * OC_HIP_DEVICE it only enqueues work on the engine's stream. */
+ * With OC_HIP_HOST the call returns after the results are back in `pois` (the queue travels in chunks: H2D, kernels
+ * and D2H of neighbouring chunks overlap); with OC_HIP_DEVICE it only enqueues work on the engine's stream. */
 int oc_hip_compute(oc_hip_engine* engine, void* pois, size_t count, size_t stride_bytes, int memory);
 /* FFTCC2D::compute(POI2D*) / ICGN2D1::compute(POI2D*)  src/oc_fftcc.cpp:177, src/oc_icgn.cpp:144:
  * a mutex-guarded batch of one, safe to call from the caller's own OpenMP region

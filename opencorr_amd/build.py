@@ -58,7 +58,7 @@ def build(force=False, verbose=True):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
     if force or procs or _stale(LIB, objs):
-        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrocfft"]
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrocfft", "-ldl", "-lpthread"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

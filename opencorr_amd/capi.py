@@ -33,6 +33,7 @@ SYMBOLS = [
     "oc_hip_set_self_adaptive", "oc_hip_synchronize", "oc_hip_select_best",
     "oc_hip_get_kind", "oc_hip_get_field", "oc_hip_read_field",
     "oc_hip_profile_enable", "oc_hip_profile_read", "oc_hip_profile_reset",
+    "oc_hip_set_devices", "oc_hip_get_devices", "oc_hip_group_queue",
 ]
 
 
@@ -103,6 +104,9 @@ def lib():
     L.oc_hip_profile_enable.argtypes = [vp, i]
     L.oc_hip_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
     L.oc_hip_profile_reset.argtypes = [vp]
+    L.oc_hip_set_devices.argtypes = [vp, ctypes.POINTER(i), i]
+    L.oc_hip_get_devices.argtypes = [vp, ctypes.POINTER(i), i, ctypes.POINTER(i)]
+    L.oc_hip_group_queue.argtypes = [vp, i, pp, ctypes.POINTER(sz)]
     for name in SYMBOLS:
         if name != "oc_hip_last_error":
             getattr(L, name).restype = i

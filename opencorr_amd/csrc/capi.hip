@@ -8,6 +8,9 @@
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
 
+#include <dlfcn.h>
+
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -16,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "oc_kernels.h"
@@ -149,6 +153,22 @@ struct oc_hip_engine {
     int icgn2d_xcd = 1;
     int fftcc2d_fused = 1;    // single-kernel FFTCC2D when the window is 32 x 32
     int fftcc3d_fused = 1;    // single-kernel FFTCC3D when the window is 32 x 32 x 32
+    // host-queue pipeline (compute_host): the queue travels in chunks, copies of one chunk overlap the kernels of
+    // its neighbours; one event per chunk orders the copy-out stream behind the kernels
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> chunk_done;
+    int host_chunk = 65536;  // POIs per chunk ("host_chunk" tuning key; 0 = the whole queue at once)
+    // device group (oc_hip_set_devices): this engine leads, replicas[i] is a full engine of the same kind on
+    // group_devices[i + 1]; every setter, set_images, prepare and compute fans out
+    std::vector<oc_hip_engine*> replicas;
+    std::vector<int> group_devices;
+    bool is_replica = false;
+    int group_allgather = 0;     // DEVICE queues: leave the complete result queue in every member's mirror
+    DevBuf group_mirror;         // full-size copy of a DEVICE queue (members other than the leader work in theirs)
+    DevBuf group_off_mirror;
+    size_t group_mirror_block = 0;  // bytes per member block of the last all-gathered queue
+    hipEvent_t group_ev = nullptr;
+    void* rccl_comm = nullptr;   // ncclComm_t of this member (group_allgather with distinct devices)
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -162,6 +182,8 @@ struct oc_hip_engine {
 };
 
 namespace {
+
+void group_drop_comms(oc_hip_engine* e);  // RCCL communicators of a device group (defined with the group code)
 
 int check_engine(const oc_hip_engine* e) {
     if (!e) return fail(OC_HIP_ERR_INVALID, "null engine handle");
@@ -561,7 +583,7 @@ extern "C" {
 
 const char* oc_hip_last_error(void) { return g_last_error.c_str(); }
 
-int oc_hip_abi_version(void) { return 2; }
+int oc_hip_abi_version(void) { return 3; }
 
 int oc_hip_device_count(int* count) {
     if (!count) return fail(OC_HIP_ERR_INVALID, "null count");
@@ -599,6 +621,7 @@ int oc_hip_set_damping(oc_hip_engine* e, float lambda, float alpha, float beta) 
     e->lm_lambda = lambda;
     e->lm_alpha = alpha;
     e->lm_beta = beta;
+    for (oc_hip_engine* r : e->replicas) OC_TRY(oc_hip_set_damping(r, lambda, alpha, beta));
     return OC_HIP_OK;
 }
 
@@ -807,6 +830,12 @@ int oc_hip_icgn3d1_create(int rx, int ry, int rz, float conv, float stop, int de
 
 int oc_hip_destroy(oc_hip_engine* e) {
     if (!e) return OC_HIP_OK;
+    group_drop_comms(e);
+    for (oc_hip_engine* r : e->replicas) {
+        r->is_replica = false;
+        (void)oc_hip_destroy(r);
+    }
+    e->replicas.clear();
     (void)hipSetDevice(e->device);
     if (e->own_stream) {
         (void)hipStreamSynchronize(e->stream);
@@ -815,8 +844,40 @@ int oc_hip_destroy(oc_hip_engine* e) {
     clear_events(e);
     e->fft.destroy();
     if (e->order_ev) (void)hipEventDestroy(e->order_ev);
+    if (e->group_ev) (void)hipEventDestroy(e->group_ev);
+    for (hipEvent_t ev : e->chunk_done) (void)hipEventDestroy(ev);
+    if (e->copy_stream) {
+        (void)hipStreamSynchronize(e->copy_stream);
+        (void)hipStreamDestroy(e->copy_stream);
+    }
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
+    return OC_HIP_OK;
+}
+
+// A group member on another device receives its own copy of the leader's image pair (peer copy over xGMI; a member on
+// the leader's device simply shares the pair).
+static int replicate_images(oc_hip_engine* leader, oc_hip_engine* r) {
+    std::lock_guard<std::mutex> lock(r->mu);
+    if (r->device == leader->device) {
+        r->img = leader->img;
+    } else {
+        const ImagePair& src = *leader->img;
+        auto img = std::make_shared<ImagePair>();
+        img->ndim = src.ndim;
+        img->dx = src.dx;
+        img->dy = src.dy;
+        img->dz = src.dz;
+        const size_t bytes = src.count() * sizeof(float);
+        OC_HIP_TRY(hipSetDevice(r->device));
+        OC_TRY(img->ref.reserve(bytes));
+        OC_TRY(img->tar.reserve(bytes));
+        OC_HIP_TRY(hipMemcpyPeer(img->ref.p, r->device, src.ref_ptr(), leader->device, bytes));
+        OC_HIP_TRY(hipMemcpyPeer(img->tar.p, r->device, src.tar_ptr(), leader->device, bytes));
+        OC_HIP_TRY(hipSetDevice(leader->device));
+        r->img = img;
+    }
+    r->ref_ready = r->tar_ready = false;
     return OC_HIP_OK;
 }
 
@@ -860,6 +921,7 @@ int oc_hip_set_images2d(oc_hip_engine* e, const float* ref, const float* tar, in
     OC_HIP_TRY(hipStreamSynchronize(e->stream));  // host buffers may be released by the caller
     e->img = img;
     e->ref_ready = e->tar_ready = false;
+    for (oc_hip_engine* r : e->replicas) OC_TRY(replicate_images(e, r));
     return OC_HIP_OK;
 }
 
@@ -888,6 +950,7 @@ int oc_hip_set_images3d(oc_hip_engine* e, const float* ref, const float* tar, in
     OC_HIP_TRY(hipStreamSynchronize(e->stream));
     e->img = img;
     e->ref_ready = e->tar_ready = false;
+    for (oc_hip_engine* r : e->replicas) OC_TRY(replicate_images(e, r));
     return OC_HIP_OK;
 }
 
@@ -900,6 +963,144 @@ int oc_hip_share_images(oc_hip_engine* e, oc_hip_engine* donor) {
     std::lock_guard<std::mutex> lock(e->mu);
     e->img = donor->img;
     e->ref_ready = e->tar_ready = false;
+    // members of a group: share with the donor's member on the same device when there is one, copy otherwise
+    for (oc_hip_engine* r : e->replicas) {
+        oc_hip_engine* twin = nullptr;
+        for (oc_hip_engine* d : donor->replicas)
+            if (d->device == r->device && d->img && d->img->ndim == donor->img->ndim && d->img->dx == donor->img->dx &&
+                d->img->dy == donor->img->dy && d->img->dz == donor->img->dz)
+                twin = d;
+        if (twin && r->device != e->device) {
+            std::lock_guard<std::mutex> rlock(r->mu);
+            r->img = twin->img;
+            r->ref_ready = r->tar_ready = false;
+        } else {
+            OC_TRY(replicate_images(e, r));
+        }
+    }
+    return OC_HIP_OK;
+}
+
+// Clone of an engine's configuration on another device (a group member)
+static int clone_engine(const oc_hip_engine* e, int device, oc_hip_engine** out) {
+    OC_TRY(create_engine(e->kind, e->rx, e->ry, e->rz, e->conv, e->stop, device, out));
+    oc_hip_engine* r = *out;
+    r->is_replica = true;
+    r->lm_lambda = e->lm_lambda;
+    r->lm_alpha = e->lm_alpha;
+    r->lm_beta = e->lm_beta;
+    r->icgn2d_tile_px = e->icgn2d_tile_px;
+    r->icgn2d_variant = e->icgn2d_variant;
+    r->self_adaptive = e->self_adaptive;
+    r->icgn2d_xcd = e->icgn2d_xcd;
+    r->fftcc2d_fused = e->fftcc2d_fused;
+    r->fftcc3d_fused = e->fftcc3d_fused;
+    r->host_chunk = e->host_chunk;
+    return OC_HIP_OK;
+}
+
+// Moves an engine to another device: everything it holds on the old one is released (images included: the caller
+// sets them again, like after construction).
+static int rehome(oc_hip_engine* e, int device) {
+    int ndev = 0;
+    OC_HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(OC_HIP_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    OC_HIP_TRY(hipSetDevice(e->device));
+    OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->stream != e->own_stream) OC_HIP_TRY(hipStreamSynchronize(e->own_stream));
+    clear_events(e);
+    e->fft.destroy();
+    e->fft.work_fwd.release();
+    e->fft.work_inv.release();
+    for (DevBuf* b : {&e->gx, &e->gy, &e->gz, &e->coef, &e->coef_gx, &e->coef_gy, &e->tmp, &e->poi_stage, &e->off_stage, &e->cursors,
+                      &e->perm, &e->tiles, &e->perm_slots, &e->st_box, &e->st_counts, &e->st_start, &e->st_cursor, &e->st_slots,
+                      &e->st_order, &e->st_recs, &e->st_fallback, &e->win, &e->freq, &e->norms, &e->flags, &e->group_mirror,
+                      &e->group_off_mirror})
+        b->release();
+    e->img.reset();
+    e->ref_ready = e->tar_ready = false;
+    e->st_count = 0;
+    if (e->order_ev) { (void)hipEventDestroy(e->order_ev); e->order_ev = nullptr; }
+    if (e->group_ev) { (void)hipEventDestroy(e->group_ev); e->group_ev = nullptr; }
+    for (hipEvent_t ev : e->chunk_done) (void)hipEventDestroy(ev);
+    e->chunk_done.clear();
+    if (e->copy_stream) { (void)hipStreamDestroy(e->copy_stream); e->copy_stream = nullptr; }
+    (void)hipStreamDestroy(e->own_stream);
+    e->own_stream = nullptr;
+    OC_HIP_TRY(hipSetDevice(device));
+    e->device = device;
+    OC_HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    e->stream = e->own_stream;
+    return OC_HIP_OK;
+}
+
+int oc_hip_set_devices(oc_hip_engine* e, const int* device_ids, int n_devices) {
+    OC_TRY(check_engine(e));
+    if (e->is_replica) return fail(OC_HIP_ERR_INVALID, "set_devices: this handle is a group member");
+    if (!device_ids || n_devices < 1) return fail(OC_HIP_ERR_INVALID, "set_devices: need at least one device id");
+    if (n_devices > 1 && (e->kind == OC_HIP_STRAIN || e->kind == OC_HIP_REGION_FIT))
+        return fail(OC_HIP_ERR_UNSUPPORTED, "set_devices: Strain / RegionFit need every neighbour of a POI and stay on one device");
+    int ndev = 0;
+    OC_HIP_TRY(hipGetDeviceCount(&ndev));
+    for (int i = 0; i < n_devices; i++)
+        if (device_ids[i] < 0 || device_ids[i] >= ndev) return fail(OC_HIP_ERR_INVALID, "set_devices: device %d out of range [0,%d)", device_ids[i], ndev);
+    std::lock_guard<std::mutex> lock(e->mu);
+    // dissolve the current group
+    group_drop_comms(e);
+    for (oc_hip_engine* r : e->replicas) {
+        r->is_replica = false;
+        (void)oc_hip_destroy(r);
+    }
+    e->replicas.clear();
+    e->group_devices.clear();
+    if (device_ids[0] != e->device) OC_TRY(rehome(e, device_ids[0]));
+    OC_HIP_TRY(hipSetDevice(e->device));
+    for (int i = 1; i < n_devices; i++) {
+        oc_hip_engine* r = nullptr;
+        OC_TRY(clone_engine(e, device_ids[i], &r));
+        e->replicas.push_back(r);
+        if (device_ids[i] != e->device) {
+            // direct xGMI copies between the members (ignored when the platform has no peer path: copies are then staged)
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, e->device, device_ids[i]) == hipSuccess && can) {
+                (void)hipSetDevice(e->device);
+                (void)hipDeviceEnablePeerAccess(device_ids[i], 0);
+                (void)hipSetDevice(device_ids[i]);
+                (void)hipDeviceEnablePeerAccess(e->device, 0);
+            }
+            (void)hipGetLastError();  // "already enabled" is fine
+        }
+        if (e->img) OC_TRY(replicate_images(e, r));
+    }
+    OC_HIP_TRY(hipSetDevice(e->device));
+    e->group_devices.assign(device_ids, device_ids + n_devices);
+    // precomputed fields exist on the leader only: prepare() again
+    if (n_devices > 1) e->ref_ready = e->tar_ready = false;
+    return OC_HIP_OK;
+}
+
+int oc_hip_get_devices(const oc_hip_engine* e, int* device_ids, int capacity, int* n_devices) {
+    OC_TRY(check_engine(e));
+    if (!n_devices) return fail(OC_HIP_ERR_INVALID, "null argument");
+    *n_devices = (int)e->replicas.size() + 1;
+    if (device_ids) {
+        if (capacity > 0) device_ids[0] = e->device;
+        for (int i = 1; i < *n_devices && i < capacity; i++) device_ids[i] = e->replicas[i - 1]->device;
+    }
+    return OC_HIP_OK;
+}
+
+int oc_hip_group_queue(const oc_hip_engine* e, int member, const void** device_ptr, size_t* block_bytes) {
+    OC_TRY(check_engine(e));
+    if (!device_ptr || !block_bytes) return fail(OC_HIP_ERR_INVALID, "null argument");
+    *device_ptr = nullptr;
+    *block_bytes = 0;
+    if (member < 0 || member > (int)e->replicas.size()) return fail(OC_HIP_ERR_INVALID, "group_queue: member %d out of range", member);
+    const oc_hip_engine* m = member == 0 ? e : e->replicas[member - 1];
+    if (!m->group_mirror.p || m->group_mirror_block == 0)
+        return fail(OC_HIP_ERR_INVALID, "group_queue: no all-gathered queue yet (set_tuning(\"group_allgather\", 1), then compute a DEVICE queue)");
+    *device_ptr = m->group_mirror.p;
+    *block_bytes = m->group_mirror_block;
     return OC_HIP_OK;
 }
 
@@ -910,6 +1111,7 @@ int oc_hip_set_subset(oc_hip_engine* e, int rx, int ry, int rz) {
     e->rx = rx;
     e->ry = ry;
     if (e->is3d()) e->rz = rz;
+    for (oc_hip_engine* r : e->replicas) OC_TRY(oc_hip_set_subset(r, rx, ry, rz));
     return OC_HIP_OK;
 }
 
@@ -919,6 +1121,7 @@ int oc_hip_set_iteration(oc_hip_engine* e, float conv, float stop) {
     std::lock_guard<std::mutex> lock(e->mu);
     e->conv = conv;
     e->stop = stop;
+    for (oc_hip_engine* r : e->replicas) OC_TRY(oc_hip_set_iteration(r, conv, stop));
     return OC_HIP_OK;
 }
 
@@ -959,9 +1162,15 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
         e->fftcc2d_fused = value != 0;
     } else if (k == "fftcc3d_fused") {
         e->fftcc3d_fused = value != 0;
+    } else if (k == "host_chunk") {
+        if (value < 0 || (value > 0 && value < 16384)) return fail(OC_HIP_ERR_INVALID, "host_chunk must be 0 (off) or >= 16384 POIs");
+        e->host_chunk = value;
+    } else if (k == "group_allgather") {
+        e->group_allgather = value != 0;
     } else {
         return fail(OC_HIP_ERR_INVALID, "unknown tuning key '%s'", key);
     }
+    for (oc_hip_engine* r : e->replicas) OC_TRY(oc_hip_set_tuning(r, key, value));
     return OC_HIP_OK;
 }
 
@@ -975,6 +1184,7 @@ int oc_hip_prepare_ref(oc_hip_engine* e) {
     const size_t bytes = im.count() * sizeof(float);
     if (e->kind == OC_HIP_NR2D1) {
         e->ref_ready = true;  // NR2D1::prepare builds target-side tables only (src/oc_nr.cpp:119-158)
+        for (oc_hip_engine* r : e->replicas) OC_TRY(oc_hip_prepare_ref(r));
         return OC_HIP_OK;
     }
     if (im.ndim == 2) {
@@ -989,6 +1199,8 @@ int oc_hip_prepare_ref(oc_hip_engine* e) {
                                         e->gz.as<float>(), e->stream));
     }
     e->ref_ready = true;
+    for (oc_hip_engine* r : e->replicas) OC_TRY(oc_hip_prepare_ref(r));
+    OC_HIP_TRY(hipSetDevice(e->device));
     return OC_HIP_OK;
 }
 
@@ -1023,6 +1235,8 @@ int oc_hip_prepare_tar(oc_hip_engine* e) {
         OC_HIP_TRY(hipStreamSynchronize(e->stream));  // before `pass` is freed
     }
     e->tar_ready = true;
+    for (oc_hip_engine* r : e->replicas) OC_TRY(oc_hip_prepare_tar(r));
+    OC_HIP_TRY(hipSetDevice(e->device));
     return OC_HIP_OK;
 }
 
@@ -1031,6 +1245,273 @@ int oc_hip_prepare(oc_hip_engine* e) {
     return oc_hip_prepare_tar(e);
 }
 
+}  // extern "C"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// host queues: H2D of the AoS, kernels, D2H (the reference's CUDA module does the same,
+// examples/test_2d_dic_gpu_icgn.cpp:136-149) -- but chunk by chunk, so that the copies of one chunk overlap the
+// kernels of its neighbours:   H2D(0) K(0) | H2D(1) K(1) D2H(0) | H2D(2) K(2) D2H(1) | ... | D2H(last)
+// Kernels run on the engine's stream, copies out on a second stream behind a per-chunk event; copies in are issued
+// on the engine's stream ahead of their kernels (a pageable hipMemcpyAsync returns once the data is staged, by which
+// time the previous chunk's kernels are already queued).  A POI's result does not depend on the chunk it travels in
+// (tests: split queue == whole queue), chunks are large enough for the ICGN2D tile schedule.
+// ---------------------------------------------------------------------------
+int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t count, size_t stride_bytes) {
+    const int stride_f = (int)(stride_bytes / 4);
+    const size_t bytes = count * stride_bytes;
+    OC_TRY(e->poi_stage.reserve(bytes));
+    if (offsets) OC_TRY(e->off_stage.reserve(count * 2 * sizeof(float)));
+    size_t chunk = e->host_chunk > 0 ? (size_t)e->host_chunk : count;
+    if (count < 2 * chunk) chunk = count;  // not worth a pipeline
+    const size_t nchunk = (count + chunk - 1) / chunk;
+    if (nchunk > 1) {
+        if (!e->copy_stream) OC_HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        while (e->chunk_done.size() < nchunk) {
+            hipEvent_t ev = nullptr;
+            OC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e->chunk_done.push_back(ev);
+        }
+    }
+    char* stage = e->poi_stage.as<char>();
+    auto copy_out = [&](size_t c) -> int {
+        const size_t first = c * chunk, n = std::min(chunk, count - first);
+        if (nchunk == 1) {
+            OC_HIP_TRY(hipMemcpyAsync(pois + first * stride_bytes, stage + first * stride_bytes, n * stride_bytes, hipMemcpyDeviceToHost, e->stream));
+        } else {
+            OC_HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->chunk_done[c], 0));
+            OC_HIP_TRY(hipMemcpyAsync(pois + first * stride_bytes, stage + first * stride_bytes, n * stride_bytes, hipMemcpyDeviceToHost, e->copy_stream));
+        }
+        return OC_HIP_OK;
+    };
+    for (size_t c = 0; c < nchunk; c++) {
+        const size_t first = c * chunk, n = std::min(chunk, count - first);
+        OC_HIP_TRY(hipMemcpyAsync(stage + first * stride_bytes, pois + first * stride_bytes, n * stride_bytes, hipMemcpyHostToDevice, e->stream));
+        const float* d_off = nullptr;
+        if (offsets) {
+            float* o = e->off_stage.as<float>() + 2 * first;
+            OC_HIP_TRY(hipMemcpyAsync(o, offsets + 2 * first, n * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+            d_off = o;
+        }
+        OC_TRY(run_compute_device(e, reinterpret_cast<float*>(stage + first * stride_bytes), stride_f, n, d_off));
+        if (nchunk > 1) OC_HIP_TRY(hipEventRecord(e->chunk_done[c], e->stream));
+        if (c > 0) OC_TRY(copy_out(c - 1));
+    }
+    OC_TRY(copy_out(nchunk - 1));
+    if (nchunk > 1) OC_HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    return OC_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device groups (oc_hip_set_devices): contiguous blocks of the queue, one per member (the loop that is
+// being replaced is src/oc_icgn.cpp:343-351).  Member g takes POIs [g * ceil(n / G), (g + 1) * ceil(n / G)).
+// ---------------------------------------------------------------------------
+struct GroupBlock {
+    oc_hip_engine* e;
+    size_t first, n;
+};
+
+std::vector<GroupBlock> group_blocks(oc_hip_engine* e, size_t count) {
+    const size_t G = e->replicas.size() + 1, per = (count + G - 1) / G;
+    std::vector<GroupBlock> b;
+    for (size_t g = 0; g < G; g++) {
+        const size_t first = std::min(g * per, count), n = std::min(per, count - first);
+        b.push_back({g == 0 ? e : e->replicas[g - 1], first, n});
+    }
+    return b;
+}
+
+// RCCL, loaded on first use: the single-GPU path never needs it and should not pay for loading it
+struct Rccl {
+    typedef int (*CommInitAll)(void**, int, const int*);
+    typedef int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t);
+    typedef int (*Group)();
+    typedef int (*CommDestroy)(void*);
+    typedef const char* (*ErrStr)(int);
+    CommInitAll comm_init_all = nullptr;
+    AllGather all_gather = nullptr;
+    Group group_start = nullptr, group_end = nullptr;
+    CommDestroy comm_destroy = nullptr;
+    ErrStr err = nullptr;
+    bool ok = false;
+    static Rccl& get() {
+        static Rccl r;
+        static std::once_flag once;
+        std::call_once(once, [] {
+            void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) return;
+            r.comm_init_all = (CommInitAll)dlsym(h, "ncclCommInitAll");
+            r.all_gather = (AllGather)dlsym(h, "ncclAllGather");
+            r.group_start = (Group)dlsym(h, "ncclGroupStart");
+            r.group_end = (Group)dlsym(h, "ncclGroupEnd");
+            r.comm_destroy = (CommDestroy)dlsym(h, "ncclCommDestroy");
+            r.err = (ErrStr)dlsym(h, "ncclGetErrorString");
+            r.ok = r.comm_init_all && r.all_gather && r.group_start && r.group_end && r.comm_destroy;
+        });
+        return r;
+    }
+};
+constexpr int kNcclUint8 = 1;  // ncclUint8 / ncclChar family: ncclInt8 = 0, ncclUint8 = 1 (rccl.h)
+
+void group_drop_comms(oc_hip_engine* e) {
+    bool any = e->rccl_comm != nullptr;
+    for (oc_hip_engine* r : e->replicas) any = any || r->rccl_comm != nullptr;
+    if (!any) return;  // never load RCCL just to find out there is nothing to drop
+    Rccl& R = Rccl::get();
+    auto drop = [&](oc_hip_engine* m) {
+        if (m->rccl_comm && R.ok) {
+            (void)hipSetDevice(m->device);
+            (void)R.comm_destroy(m->rccl_comm);
+        }
+        m->rccl_comm = nullptr;
+    };
+    drop(e);
+    for (oc_hip_engine* r : e->replicas) drop(r);
+}
+
+// Every member's mirror ends up holding the whole queue (blocks of `block` bytes, the last one padded): ONE
+// ncclAllGather over xGMI when the members sit on distinct devices, peer copies otherwise (a group may name a device
+// twice -- that is how the sharding logic is exercised on a one-GPU box).
+int group_allgather(oc_hip_engine* e, const std::vector<GroupBlock>& blocks, size_t block) {
+    const int G = (int)blocks.size();
+    bool distinct = true;
+    for (int a = 0; a < G; a++)
+        for (int b = a + 1; b < G; b++) distinct = distinct && blocks[a].e->device != blocks[b].e->device;
+    Rccl& R = Rccl::get();
+    if (distinct && R.ok && G > 1) {
+        if (!e->rccl_comm) {
+            std::vector<void*> comms(G, nullptr);
+            std::vector<int> devs;
+            for (const GroupBlock& b : blocks) devs.push_back(b.e->device);
+            const int rc = R.comm_init_all(comms.data(), G, devs.data());
+            if (rc != 0) return fail(OC_HIP_ERR_HIP, "ncclCommInitAll over %d devices failed: %s", G, R.err ? R.err(rc) : "?");
+            for (int g = 0; g < G; g++) blocks[g].e->rccl_comm = comms[g];
+        }
+        int rc = R.group_start();
+        for (int g = 0; g < G && rc == 0; g++) {
+            oc_hip_engine* m = blocks[g].e;
+            OC_HIP_TRY(hipSetDevice(m->device));
+            char* mirror = m->group_mirror.as<char>();
+            rc = R.all_gather(mirror + (size_t)g * block, mirror, block, kNcclUint8, m->rccl_comm, m->stream);
+        }
+        const int rc2 = R.group_end();
+        OC_HIP_TRY(hipSetDevice(e->device));
+        if (rc != 0 || rc2 != 0) return fail(OC_HIP_ERR_HIP, "ncclAllGather failed: %s", R.err ? R.err(rc ? rc : rc2) : "?");
+        return OC_HIP_OK;
+    }
+    // peer copies: member g fetches every other member's block once that member is done (its event)
+    for (int g = 0; g < G; g++) {
+        oc_hip_engine* m = blocks[g].e;
+        OC_HIP_TRY(hipSetDevice(m->device));
+        for (int h = 0; h < G; h++) {
+            if (h == g) continue;
+            oc_hip_engine* src = blocks[h].e;
+            OC_HIP_TRY(hipStreamWaitEvent(m->stream, src->group_ev, 0));
+            OC_HIP_TRY(hipMemcpyPeerAsync(m->group_mirror.as<char>() + (size_t)h * block, m->device,
+                                          src->group_mirror.as<char>() + (size_t)h * block, src->device, block, m->stream));
+        }
+    }
+    OC_HIP_TRY(hipSetDevice(e->device));
+    return OC_HIP_OK;
+}
+
+// DEVICE queue of a group: the queue lives on the leader's device.  Every other member pulls its block into its own
+// mirror (peer copy over xGMI), solves it there on its own stream and pushes the records back; the leader solves
+// block 0 in place.  All of it is stream-ordered: members wait for the leader's stream to reach this call, the
+// leader's stream waits for the members' completion events.
+int compute_group_device(oc_hip_engine* e, char* pois, const float* offsets, size_t count, size_t stride_bytes) {
+    const std::vector<GroupBlock> blocks = group_blocks(e, count);
+    const int stride_f = (int)(stride_bytes / 4);
+    const size_t per = blocks[0].n, block = per * stride_bytes;  // blocks[0] is the largest
+    auto event_of = [](oc_hip_engine* m) -> int {
+        if (!m->group_ev) OC_HIP_TRY(hipEventCreateWithFlags(&m->group_ev, hipEventDisableTiming));
+        return OC_HIP_OK;
+    };
+    OC_TRY(event_of(e));
+    OC_HIP_TRY(hipEventRecord(e->group_ev, e->stream));  // the queue is ready when the leader's stream gets here
+    hipEvent_t ready = e->group_ev;
+    for (size_t g = 1; g < blocks.size(); g++) {
+        oc_hip_engine* m = blocks[g].e;
+        const size_t first = blocks[g].first, n = blocks[g].n;
+        std::lock_guard<std::mutex> lock(m->mu);
+        OC_HIP_TRY(hipSetDevice(m->device));
+        OC_TRY(event_of(m));
+        OC_TRY(m->group_mirror.reserve(blocks.size() * block));
+        OC_HIP_TRY(hipStreamWaitEvent(m->stream, ready, 0));
+        if (n) {
+            char* mine = m->group_mirror.as<char>() + g * block;
+            OC_HIP_TRY(hipMemcpyPeerAsync(mine, m->device, pois + first * stride_bytes, e->device, n * stride_bytes, m->stream));
+            const float* d_off = nullptr;
+            if (offsets) {
+                OC_TRY(m->group_off_mirror.reserve(per * 2 * sizeof(float)));
+                OC_HIP_TRY(hipMemcpyPeerAsync(m->group_off_mirror.p, m->device, offsets + 2 * first, e->device, n * 2 * sizeof(float), m->stream));
+                d_off = m->group_off_mirror.as<float>();
+            }
+            OC_TRY(run_compute_device(m, reinterpret_cast<float*>(mine), stride_f, n, d_off));
+            OC_HIP_TRY(hipMemcpyPeerAsync(pois + first * stride_bytes, e->device, mine, m->device, n * stride_bytes, m->stream));
+        }
+        OC_HIP_TRY(hipEventRecord(m->group_ev, m->stream));
+    }
+    OC_HIP_TRY(hipSetDevice(e->device));
+    // the members are busy; now the leader's own block, in place
+    if (blocks[0].n) OC_TRY(run_compute_device(e, reinterpret_cast<float*>(pois), stride_f, blocks[0].n, offsets));
+    if (e->group_allgather) {
+        // the leader's block joins the mirrors, then one all-gather
+        OC_TRY(e->group_mirror.reserve(blocks.size() * block));
+        OC_HIP_TRY(hipMemcpyAsync(e->group_mirror.p, pois, blocks[0].n * stride_bytes, hipMemcpyDeviceToDevice, e->stream));
+        OC_HIP_TRY(hipEventRecord(e->group_ev, e->stream));
+        OC_TRY(group_allgather(e, blocks, block));
+        for (const GroupBlock& b : blocks) {
+            b.e->group_mirror_block = block;
+            if (b.e != e) {
+                OC_HIP_TRY(hipSetDevice(b.e->device));
+                OC_HIP_TRY(hipEventRecord(b.e->group_ev, b.e->stream));
+            }
+        }
+        OC_HIP_TRY(hipSetDevice(e->device));
+    }
+    for (size_t g = 1; g < blocks.size(); g++) OC_HIP_TRY(hipStreamWaitEvent(e->stream, blocks[g].e->group_ev, 0));
+    return OC_HIP_OK;
+}
+
+// HOST queue of a group: every member moves and solves its own block (its own host thread, its own PCIe link), the
+// results land directly in the caller's vector -- no exchange step is needed for a host-resident queue.
+int compute_group_host(oc_hip_engine* e, char* pois, const float* offsets, size_t count, size_t stride_bytes) {
+    const std::vector<GroupBlock> blocks = group_blocks(e, count);
+    std::vector<int> rc(blocks.size(), OC_HIP_OK);
+    std::vector<std::string> msg(blocks.size());
+    auto work = [&](size_t g) {
+        oc_hip_engine* m = blocks[g].e;
+        if (blocks[g].n == 0) return;
+        if (hipSetDevice(m->device) != hipSuccess) {
+            rc[g] = OC_HIP_ERR_HIP;
+            msg[g] = "hipSetDevice failed";
+            return;
+        }
+        rc[g] = compute_host(m, pois + blocks[g].first * stride_bytes, offsets ? offsets + 2 * blocks[g].first : nullptr, blocks[g].n,
+                             stride_bytes);
+        if (rc[g] != OC_HIP_OK) msg[g] = g_last_error;  // thread-local in the worker
+    };
+    std::vector<std::thread> threads;
+    for (size_t g = 1; g < blocks.size(); g++) threads.emplace_back([&, g] {
+        std::lock_guard<std::mutex> lock(blocks[g].e->mu);
+        work(g);
+    });
+    work(0);
+    for (std::thread& t : threads) t.join();
+    OC_HIP_TRY(hipSetDevice(e->device));
+    for (size_t g = 0; g < blocks.size(); g++)
+        if (rc[g] != OC_HIP_OK) return fail(rc[g], "group member %zu (device %d): %s", g, blocks[g].e->device, msg[g].c_str());
+    return OC_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 static int compute_impl(oc_hip_engine* e, void* pois, const float* offsets, size_t count, size_t stride_bytes, int memory) {
     OC_TRY(activate(e));
     if (count == 0) return OC_HIP_OK;
@@ -1038,28 +1519,19 @@ static int compute_impl(oc_hip_engine* e, void* pois, const float* offsets, size
     if (stride_bytes < e->poi_bytes() || (stride_bytes & 3))
         return fail(OC_HIP_ERR_INVALID, "bad POI stride %zu (record is %zu bytes, stride must be a multiple of 4)",
                     stride_bytes, e->poi_bytes());
+    if (offsets && e->kind != OC_HIP_ICGN2D1 && e->kind != OC_HIP_ICGN2D2)
+        return fail(OC_HIP_ERR_INVALID, "center offsets are an ICGN2D1/ICGN2D2 feature (src/oc_icgn.h:75-76,130-131)");
     std::lock_guard<std::mutex> lock(e->mu);
-    const int stride_f = (int)(stride_bytes / 4);
+    // a queue of a few POIs is not worth waking the other devices for
+    const bool grouped = !e->replicas.empty() && count >= 64 * (e->replicas.size() + 1);
     if (memory == OC_HIP_DEVICE) {
         OC_TRY(order_after_default_stream(e));
-        OC_TRY(run_compute_device(e, static_cast<float*>(pois), stride_f, count, offsets));
+        if (grouped) OC_TRY(compute_group_device(e, static_cast<char*>(pois), offsets, count, stride_bytes));
+        else OC_TRY(run_compute_device(e, static_cast<float*>(pois), (int)(stride_bytes / 4), count, offsets));
         return finish_device_call(e);
     }
-    // host queue: H2D of the AoS, kernels, D2H (the reference's CUDA module does the same,
-    // examples/test_2d_dic_gpu_icgn.cpp:136-149)
-    const size_t bytes = count * stride_bytes;
-    OC_TRY(e->poi_stage.reserve(bytes));
-    OC_HIP_TRY(hipMemcpyAsync(e->poi_stage.p, pois, bytes, hipMemcpyHostToDevice, e->stream));
-    const float* d_off = nullptr;
-    if (offsets) {
-        OC_TRY(e->off_stage.reserve(count * 2 * sizeof(float)));
-        OC_HIP_TRY(hipMemcpyAsync(e->off_stage.p, offsets, count * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
-        d_off = e->off_stage.as<float>();
-    }
-    OC_TRY(run_compute_device(e, e->poi_stage.as<float>(), stride_f, count, d_off));
-    OC_HIP_TRY(hipMemcpyAsync(pois, e->poi_stage.p, bytes, hipMemcpyDeviceToHost, e->stream));
-    OC_HIP_TRY(hipStreamSynchronize(e->stream));
-    return OC_HIP_OK;
+    if (grouped) return compute_group_host(e, static_cast<char*>(pois), offsets, count, stride_bytes);
+    return compute_host(e, static_cast<char*>(pois), offsets, count, stride_bytes);
 }
 
 int oc_hip_compute(oc_hip_engine* e, void* pois, size_t count, size_t stride_bytes, int memory) {
@@ -1129,6 +1601,7 @@ int oc_hip_set_self_adaptive(oc_hip_engine* e, int enable) {
         return fail(OC_HIP_ERR_UNSUPPORTED, "self-adaptive subsets are implemented for ICGN2D1/2D2 and ICLM2D1/2D2 (NR2D1 has none in the reference)");
     std::lock_guard<std::mutex> lock(e->mu);
     e->self_adaptive = enable != 0;
+    for (oc_hip_engine* r : e->replicas) OC_TRY(oc_hip_set_self_adaptive(r, enable));
     return OC_HIP_OK;
 }
 

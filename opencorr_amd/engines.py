@@ -109,6 +109,27 @@ class _Engine:
             capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(s or None)))
             self._auto_stream = s
 
+    def set_devices(self, device_ids):
+        """Spread this engine over several GPUs of the node (``oc_hip_set_devices``): contiguous blocks of every
+        queue, one per device; setters, images, prepare() and compute() fan out.  ``device_ids[0]`` is the engine's
+        own device (it moves there if needed -- set the images again).  Results do not depend on the group size."""
+        ids = (ctypes.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        capi.check(capi.lib().oc_hip_set_devices(self._h, ids, len(device_ids)))
+
+    def devices(self):
+        n = ctypes.c_int()
+        capi.check(capi.lib().oc_hip_get_devices(self._h, None, 0, ctypes.byref(n)))
+        ids = (ctypes.c_int * n.value)()
+        capi.check(capi.lib().oc_hip_get_devices(self._h, ids, n.value, ctypes.byref(n)))
+        return list(ids)
+
+    def group_queue(self, member):
+        """(device pointer, bytes per block) of a member's all-gathered copy of the last DEVICE queue."""
+        ptr = ctypes.c_void_p()
+        blk = ctypes.c_size_t()
+        capi.check(capi.lib().oc_hip_group_queue(self._h, int(member), ctypes.byref(ptr), ctypes.byref(blk)))
+        return ptr.value, blk.value
+
     def set_tuning(self, key, value):
         """Performance knob of the C-ABI (``oc_hip_set_tuning``); results never change."""
         capi.check(capi.lib().oc_hip_set_tuning(self._h, key.encode(), int(value)))

@@ -41,14 +41,30 @@ def build(force=False):
 
 
 _lib = None
+_lib_path = _LIB_PATH
+
+
+def use_timing_build():
+    """bench.py's cpu_baseline only: switch this process to ``liboc_oracle_fast.so`` (the same source compiled
+    ``-O3 -march=native`` ON THIS HOST) -- never used for parity.  Returns the build description; falls
+    back to the parity build (``-O2 -march=x86-64-v2``) when the compiler is not available."""
+    global _lib, _lib_path
+    fast = os.path.join(_HERE, "liboc_oracle_fast.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboc_oracle_fast.so"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL, timeout=180)
+    except Exception:
+        return "g++ -O2 -march=x86-64-v2 -fopenmp -ffp-contract=off (parity build: the native build failed)"
+    _lib, _lib_path = None, fast
+    return "g++ -O3 -march=native -fopenmp -ffp-contract=off, built on this host"
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        if _lib_path == _LIB_PATH and not os.path.exists(_LIB_PATH):
             build()
-        L = ctypes.CDLL(_LIB_PATH)
+        L = ctypes.CDLL(_lib_path)
         fp = ctypes.POINTER(ctypes.c_float)
         i, f, l = ctypes.c_int, ctypes.c_float, ctypes.c_long
         L.oc_oracle_gradient2d.argtypes = [fp, i, i, fp, fp, i]

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_string():
     L = capi.lib()
-    assert L.oc_hip_abi_version() == 2
+    assert L.oc_hip_abi_version() == 3
     # a null handle is rejected with a readable message (no GPU needed for this path)
     assert L.oc_hip_prepare(None) == capi.ERR_INVALID
     assert b"null engine" in L.oc_hip_last_error()
