@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libopencorr_hip.so")
+# OPENCORR_HIP_LIB: developer override (tools/ablate_icgn3d.sh loads instrumented builds of the same library)
+LIB_PATH = os.environ.get("OPENCORR_HIP_LIB") or os.path.join(_HERE, "lib", "libopencorr_hip.so")
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_ROCFFT, ERR_NOMEM, ERR_UNSUPPORTED = 1, 2, 3, 4, 5

@@ -28,6 +28,17 @@
 #include "oc_device.h"
 #include "oc_kernels.h"
 
+// Phase ablation for tools/ablate_icgn3d.sh (cdna_hip_programming.md: "ablate, then match"): a build with
+// -DOC_ABLATE=<mask> leaves a phase out and runs a fixed number of iterations, so that timing differences price the
+// phases.  Results of such a build are garbage; the product is always built with the mask at 0.
+//   1 = no coefficient staging (global -> LDS)   2 = no tap evaluation   4 = no Hessian sweep   8 = no numerator sweep
+//   16 = timeline: results stay valid, and the six strain floats of every POI record receive the shader-clock
+//        kilocycles its workgroup spent in  reference stats | Hessian sweep + reduction | LU inverse | warped-subvolume
+//        sweeps (boxes, staging, taps) | mean / norm / numerator sweeps + reductions | solve + warp update
+#ifndef OC_ABLATE
+#define OC_ABLATE 0
+#endif
+
 namespace ochip {
 
 constexpr int kBlock3d = 512;
@@ -41,9 +52,13 @@ __device__ __forceinline__ float uni3(float v) {
 }
 
 // K simultaneous block-wide sums; on return every thread holds the same K results.
-// red: LDS scratch of K * 16 floats.  Two barriers per call.
+// red: LDS scratch of K * 8 floats.  Two barriers per call.  Association: xor butterfly inside each wave, then a balanced
+// tree over the 8 wave sums in wave order.  Lane k (< K) of every wave combines the eight wave sums of value k and the
+// K totals are handed round with v_readlane: 8 LDS reads + 7 adds + K broadcasts per thread instead of 8 K reads and
+// 7 K adds (which the scheduler hoisted into ~100 live registers and spilled).
 template <int K>
 __device__ __forceinline__ void block_allreduce(float (&v)[K], float* red, int wave, int lane) {
+    static_assert(K <= kWave, "one lane per value");
 #pragma unroll
     for (int k = 0; k < K; k++) v[k] = wave_allreduce_sum(v[k]);
     if (lane == 0) {
@@ -51,71 +66,104 @@ __device__ __forceinline__ void block_allreduce(float (&v)[K], float* red, int w
         for (int k = 0; k < K; k++) red[k * kWaves3d + wave] = v[k];
     }
     __syncthreads();
+    float w[kWaves3d];
+    const int mine = lane < K ? lane : 0;
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        float w[kWaves3d];
+    for (int i = 0; i < kWaves3d; i++) w[i] = red[mine * kWaves3d + i];
+    // xor butterfly over the wave index, ascending offsets == balanced tree in wave order
 #pragma unroll
-        for (int i = 0; i < kWaves3d; i++) w[i] = red[k * kWaves3d + i];
-        // xor butterfly over the wave index, ascending offsets == balanced tree in wave order
+    for (int off = 1; off < kWaves3d; off <<= 1)
 #pragma unroll
-        for (int off = 1; off < kWaves3d; off <<= 1)
+        for (int i = 0; i < kWaves3d; i += 2 * off) w[i] = w[i] + w[i + off];
 #pragma unroll
-            for (int i = 0; i < kWaves3d; i += 2 * off) w[i] = w[i] + w[i + off];
-        v[k] = w[0];
-    }
+    for (int k = 0; k < K; k++) v[k] = wave_bcast(w[0], k);
     __syncthreads();
 }
 
-// lane-distributed LU inverse, identical to the one in icgn2d.hip (see there for the contract)
-template <int n>
-__device__ __forceinline__ void lu_inverse_lanes3(float (&col)[n], float (&inv)[n], int lane) {
-    int perm[n];
-#pragma unroll
-    for (int i = 0; i < n; i++) perm[i] = i;
-#pragma unroll
+// Inverse of the 12 x 12 Hessian by LU with partial (row) pivoting + solve against the identity -- every scalar
+// operation (pivot choice with strict >, multipliers f = a_rk / a_kk, eliminations a_rc - f * a_kc, the two triangular
+// solves with ascending inner index) is the one oracle lu_inverse() performs (Eigen PartialPivLU, src/oc_icgn.cpp:1339),
+// so the result is bit-identical.  ONE wave runs it, the matrix lives in LDS (A: 12 x 12 row-major, perm: 12 ints):
+// lane c < 12 owns column c during the elimination and solves for column c of the inverse; everything the lanes share
+// (pivot column, multipliers, the triangular factors) is read from LDS with wave-uniform addresses (broadcast reads).
+// The register-resident, v_readlane-broadcast form this replaces compiled to 4.9 k instructions with 544 scratch
+// accesses inside this kernel and cost 262 k cycles per POI (13 % of the kernel); this one is a few hundred
+// instructions in real loops.  LDS operations of one wave execute in order, so no barrier is needed between them.
+// out[i * kWave + lane] = H^-1(i, lane) for lane < 12 (0 for the other lanes).
+__device__ __forceinline__ void lu_inverse12_lds(float* __restrict__ A, int* __restrict__ perm, float* __restrict__ out, int lane) {
+    constexpr int n = 12;
+    if (lane < n) perm[lane] = lane;
+#pragma unroll 1
     for (int k = 0; k < n; k++) {
+        float colk[n];  // column k, the same in every lane
+#pragma unroll
+        for (int r = 0; r < n; r++) colk[r] = A[r * n + k];
         int piv = k;
-        float best = fabsf(wave_bcast(col[k], k));
+        float best = 0.f;
 #pragma unroll
-        for (int r = k + 1; r < n; r++) {
-            const float v = fabsf(wave_bcast(col[r], k));
-            if (v > best) { best = v; piv = r; }
+        for (int r = 0; r < n; r++) {
+            const float v = fabsf(colk[r]);
+            const bool take = r == k || (r > k && v > best);
+            best = take ? v : best;
+            piv = take ? r : piv;
         }
+        piv = __builtin_amdgcn_readfirstlane(piv);
+        if (piv != k) {  // wave-uniform
+            if (lane < n) {
+                const float a = A[k * n + lane], b = A[piv * n + lane];
+                A[k * n + lane] = b;
+                A[piv * n + lane] = a;
+            }
+            if (lane == 0) {
+                const int t = perm[k];
+                perm[k] = perm[piv];
+                perm[piv] = t;
+            }
+            // column k after the swap
+            float ck = 0.f, cp = 0.f;
 #pragma unroll
-        for (int r = k + 1; r < n; r++) {
-            const bool sw = (piv == r);
-            const float a = col[k], b = col[r];
-            col[k] = sw ? b : a;
-            col[r] = sw ? a : b;
-            const int pa = perm[k], pb = perm[r];
-            perm[k] = sw ? pb : pa;
-            perm[r] = sw ? pa : pb;
+            for (int r = 0; r < n; r++) {
+                ck = r == k ? colk[r] : ck;
+                cp = r == piv ? colk[r] : cp;
+            }
+#pragma unroll
+            for (int r = 0; r < n; r++) colk[r] = r == k ? cp : (r == piv ? ck : colk[r]);
         }
-        const float d = wave_bcast(col[k], k);
+        float d = 0.f;
 #pragma unroll
-        for (int r = k + 1; r < n; r++) {
-            const float f = wave_bcast(col[r], k) / d;
-            const float upd = col[r] - f * col[k];
-            col[r] = lane == k ? f : (lane > k ? upd : col[r]);
+        for (int r = 0; r < n; r++) d = r == k ? colk[r] : d;
+        const float mine = lane < n ? A[k * n + lane] : 0.f;  // row k, this lane's column
+#pragma unroll
+        for (int r = 0; r < n; r++) {
+            if (r > k) {  // wave-uniform
+                const float f = colk[r] / d;
+                if (lane == k) A[r * n + k] = f;
+                else if (lane > k && lane < n) A[r * n + lane] = A[r * n + lane] - f * mine;
+            }
         }
     }
+    // lane c solves L U x = P e_c.  The rows are fenced against the instruction scheduler: unfenced it hoists all 144
+    // broadcast reads of the two unrolled solves to the top and spills ~250 registers to scratch around them (measured:
+    // 244 k cycles per POI for this function, almost all of it scratch traffic).
     float y[n];
 #pragma unroll
     for (int i = 0; i < n; i++) {
         float v = (perm[i] == lane) ? 1.f : 0.f;
 #pragma unroll
-        for (int j = 0; j < i; j++) v = v - wave_bcast(col[i], j) * y[j];
+        for (int j = 0; j < i; j++) v = v - A[i * n + j] * y[j];
         y[i] = v;
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = n - 1; i >= 0; i--) {
         float v = y[i];
 #pragma unroll
-        for (int j = i + 1; j < n; j++) v = v - wave_bcast(col[i], j) * y[j];
-        y[i] = v / wave_bcast(col[i], i);
+        for (int j = i + 1; j < n; j++) v = v - A[i * n + j] * y[j];
+        y[i] = v / A[i * n + i];
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int i = 0; i < n; i++) inv[i] = y[i];
+    for (int i = 0; i < n; i++) out[i * kWave + lane] = lane < n ? y[i] : 0.f;
 }
 
 // 4x4 inverse by cofactor expansion -- same operation order as oracle inverse4()
@@ -282,12 +330,54 @@ struct Walk3 {
     }
 };
 
+// One sample of a thread's walk, recorded so that a batch of samples can be loaded before any of them is used:
+// its offset inside the subvolume's box of the volume and its local coordinates (small integers, exact as floats).
+struct WalkPoint {
+    unsigned off;
+    float x, y, z;
+};
+// The streaming sweeps of the kernel (reference statistics, Hessian, target norm, numerator) read every sample once
+// from the volumes and do little arithmetic on it: they are LATENCY bound -- with one load in flight per wave the
+// whole chip keeps ~1 MB in flight, i.e. ~1 TB/s at the ~1 us a volume read takes under load (round-2 timeline,
+// tools/ablate_icgn3d.sh: 58 % of the kernel's time went here, ~1.7 k cycles per sample and thread).  sweep_batched
+// therefore records B walk states first, issues the B samples' loads as independent instructions, and only then
+// consumes them -- in sample order, so every per-thread sum keeps its increasing-s association (bit-identical).
+// `cnt` = number of samples the thread owns (no per-sample bounds test inside a batch); load(point, s) and
+// use(point, loaded, s) receive the sample index s = tid + 512 * m.
+template <int B, class Load, class Use>
+__device__ __forceinline__ void sweep_batched(Walk3& w, int rx, int ry, int rz, int cnt, Load&& load, Use&& use) {
+    int done = 0;
+    auto point = [&]() {
+        const WalkPoint q = {w.off, (float)(w.k - rx), (float)(w.j - ry), (float)(w.i - rz)};
+        w.next();
+        return q;
+    };
+#pragma unroll 1
+    for (; done + B <= cnt; done += B) {
+        const int s0 = w.s;
+        WalkPoint p[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) p[u] = point();
+        decltype(load(p[0], 0)) v[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) v[u] = load(p[u], s0 + u * kBlock3d);
+#pragma unroll
+        for (int u = 0; u < B; u++) use(p[u], v[u], s0 + u * kBlock3d);
+    }
+#pragma unroll 1
+    for (; done < cnt; done++) {
+        const int s0 = w.s;
+        const WalkPoint q = point();
+        use(q, load(q, s0), s0);
+    }
+}
+
 // Hessian rows [R0, R1): sums of sd[r]*sd[c], c <= r, over all samples (src/oc_icgn.cpp:1299-1337),
-// block-reduced and scattered into the per-lane columns of the symmetric matrix.
+// block-reduced and filed into the symmetric matrix A (LDS).
 template <int R0, int R1>
 __device__ __forceinline__ void hessian_rows(const Icgn3dParams& P, int tid, int wave, int lane, int SX, int SY, int N,
                                              int rx, int ry, int rz, int cx, int cy, int cz, int DX, int DY, float* red,
-                                             float (&col)[12]) {
+                                             float* __restrict__ A) {
     constexpr int NE = (R1 * (R1 + 1) - R0 * (R0 + 1)) / 2;
     // The running sums H(r,c) += sd[r]*sd[c] as packed-fp32 pairs over adjacent columns (v_pk_mul_f32 /
     // v_pk_add_f32: two IEEE operations per issue slot, each rounded on its own -- every H(r,c) receives the same
@@ -308,20 +398,24 @@ __device__ __forceinline__ void hessian_rows(const Icgn3dParams& P, int tid, int
     const float* __restrict__ pgx = P.gx + gbase;
     const float* __restrict__ pgy = P.gy + gbase;
     const float* __restrict__ pgz = P.gz + gbase;
-#pragma unroll 1
-    for (; w.s < N; w.next()) {
-        const int xl = w.k - rx, yl = w.j - ry, zl = w.i - rz;
-        const float g_x = pgx[w.off], g_y = pgy[w.off], g_z = pgz[w.off];
-        const f2 m01 = mk2(1.f, (float)xl), m23 = mk2((float)yl, (float)zl);  // g * 1.f is exact
-        const f2 sdp[6] = {g_x * m01, g_x * m23, g_y * m01, g_y * m23, g_z * m01, g_z * m23};
+    struct G3 {
+        float x, y, z;
+    };
+    const int cnt = N > tid ? (N - tid + kBlock3d - 1) / kBlock3d : 0;
+    sweep_batched<4>(
+        w, rx, ry, rz, cnt, [&](const WalkPoint& q, int) { return G3{pgx[q.off], pgy[q.off], pgz[q.off]}; },
+        [&](const WalkPoint& q, const G3& g, int) {
+            const float g_x = g.x, g_y = g.y, g_z = g.z;
+            const f2 m01 = mk2(1.f, q.x), m23 = mk2(q.y, q.z);  // g * 1.f is exact
+            const f2 sdp[6] = {g_x * m01, g_x * m23, g_y * m01, g_y * m23, g_z * m01, g_z * m23};
 #pragma unroll
-        for (int r = R0; r < R1; r++) {
-            const float sr = (r & 1) ? sdp[r / 2].y : sdp[r / 2].x;
+            for (int r = R0; r < R1; r++) {
+                const float sr = (r & 1) ? sdp[r / 2].y : sdp[r / 2].x;
 #pragma unroll
-            for (int q = 0; q < (r + 1) / 2; q++) hp[r][q] = hp[r][q] + sr * sdp[q];
-            if ((r & 1) == 0) hd[r] = hd[r] + sr * sr;
-        }
-    }
+                for (int q2 = 0; q2 < (r + 1) / 2; q2++) hp[r][q2] = hp[r][q2] + sr * sdp[q2];
+                if ((r & 1) == 0) hd[r] = hd[r] + sr * sr;
+            }
+        });
     float h[NE];
     {
         int t = 0;
@@ -342,14 +436,18 @@ __device__ __forceinline__ void hessian_rows(const Icgn3dParams& P, int tid, int
         for (int q = 0; q < kRedChunk; q++)
             if (ch * kRedChunk + q < NE) h[(ch * kRedChunk + q) % NE] = part[q];
     }
-    int t = 0;
+    // every thread holds the totals: one lane files them into the symmetric matrix in LDS (row-major 12 x 12), where the
+    // LU of wave 0 picks them up (same wave: LDS operations of a wave execute in order)
+    if (tid == 0) {
+        int t = 0;
 #pragma unroll
-    for (int r = R0; r < R1; r++)
+        for (int r = R0; r < R1; r++)
 #pragma unroll
-        for (int c = 0; c <= r; c++, t++) {
-            if (lane == c) col[r] = h[t];
-            if (lane == r) col[c] = h[t];
-        }
+            for (int c = 0; c <= r; c++, t++) {
+                A[r * 12 + c] = h[t];
+                A[c * 12 + r] = h[t];
+            }
+    }
 }
 
 // PX: row pitch of the staged coefficient box in LDS (0 = the box's own width, decided per pass)
@@ -393,6 +491,16 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
             continue;
         }
 
+        [[maybe_unused]] unsigned long long tl_mark = __builtin_readcyclecounter();
+        [[maybe_unused]] unsigned long long tl[6] = {0, 0, 0, 0, 0, 0};
+        auto lap = [&](int slot) {
+            if constexpr (OC_ABLATE & 16) {
+                __builtin_amdgcn_sched_barrier(0);  // keep the surrounding arithmetic on its side of the stamp
+                const unsigned long long now = __builtin_readcyclecounter();
+                tl[slot] += now - tl_mark;
+                tl_mark = now;
+            }
+        };
         // ---- reference subvolume mean + norm (src/oc_subset.cpp:89-135)
         const float sxf = px - rx, syf = py - ry, szf = pz - rz;
         // Subset3D::fill reads voxel (int(start.z + i), int(start.y + j), int(start.x + k)) (src/oc_subset.cpp:89-103):
@@ -408,44 +516,53 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
         }
         ref_box = __syncthreads_and(ref_box ? 1 : 0) != 0;
         const float* __restrict__ pref = P.ref + (((size_t)(int)szf * DY + (int)syf) * DX + (int)sxf);
-        auto ref_at = [&](const Walk3& w) {
-            return ref_box ? pref[w.off] : P.ref[((size_t)(int)(szf + w.i) * DY + (int)(syf + w.j)) * DX + (int)(sxf + w.k)];
-        };
         float ref_mean, ref_norm;
-        {
+        const int cnt = N > tid ? (N - tid + kBlock3d - 1) / kBlock3d : 0;  // samples this thread owns
+        // reference voxel of a sample: the fast path (the subvolume is one box) is a separate instantiation so that a
+        // batch's loads are straight-line code
+        auto ref_fast = [&](const WalkPoint& q, int) { return pref[q.off]; };
+        auto ref_slow = [&](const WalkPoint& q, int) {
+            return P.ref[((size_t)(int)(szf + ((int)q.z + rz)) * DY + (int)(syf + ((int)q.y + ry))) * DX + (int)(sxf + ((int)q.x + rx))];
+        };
+        auto ref_stats = [&](auto&& ref_of) {
             float acc[1] = {0.f};
             Walk3 w(tid, SX, SY, 0, DX, DY);
-#pragma unroll 8
-            for (; w.s < N; w.next()) acc[0] += ref_at(w);
+            sweep_batched<8>(w, rx, ry, rz, cnt, ref_of, [&](const WalkPoint&, float v, int) { acc[0] += v; });
             block_allreduce<1>(acc, red, wave, lane);
             ref_mean = acc[0] / fN;
             acc[0] = 0.f;
             Walk3 w2(tid, SX, SY, 0, DX, DY);
-#pragma unroll 8
-            for (; w2.s < N; w2.next()) {
-                const float d = ref_at(w2) - ref_mean;
+            sweep_batched<8>(w2, rx, ry, rz, cnt, ref_of, [&](const WalkPoint&, float v, int) {
+                const float d = v - ref_mean;
                 acc[0] += d * d;
-            }
+            });
             block_allreduce<1>(acc, red, wave, lane);
             ref_norm = sqrtf(acc[0]);
-        }
+        };
+        if (ref_box) ref_stats(ref_fast);
+        else ref_stats(ref_slow);
 
+        lap(0);
         // ---- SD image + Hessian (src/oc_icgn.cpp:1299-1337) and its inverse (:1339)
         const int cx = (int)px, cy = (int)py, cz = (int)pz;
         {
-            float hinv_col[12];
-            // lane j < 12 assembles column j of the symmetric Hessian.  The 78 unique sums are
-            // accumulated in three sweeps over the samples (rows 0-5, 6-8, 9-11: 21 + 24 + 33
-            // running sums) to stay inside the 128-VGPR budget of a 1024-thread workgroup.
-            float col[12];
-#pragma unroll
-            for (int i = 0; i < 12; i++) col[i] = 0.f;
-            hessian_rows<0, 12>(P, tid, wave, lane, SX, SY, N, rx, ry, rz, cx, cy, cz, DX, DY, red, col);
-            lu_inverse_lanes3<12>(col, hinv_col, lane);  // every wave redundantly, identical results
-            if (wave == 0) {
-#pragma unroll
-                for (int i = 0; i < 12; i++) lds_hinv[i * kWave + lane] = hinv_col[i];
+            // The 78 unique sums are accumulated in two sweeps over the samples (rows 0-7: 36 running sums, rows 8-11: 42)
+            // so that a batch of four samples' gradients fits the 128-VGPR budget beside the accumulators -- one sweep
+            // over all 78 sums spilled 24 registers per sample.  The coefficient window is idle before the first sweep of
+            // the Gauss-Newton loop: it hosts the matrix.
+            float* A = win;
+            if constexpr (OC_ABLATE & 4) {
+                if (tid < 144) A[tid] = (tid / 12 == tid % 12) ? 1.0e12f : 0.f;
+                __syncthreads();
+            } else {
+                hessian_rows<0, 8>(P, tid, wave, lane, SX, SY, N, rx, ry, rz, cx, cy, cz, DX, DY, red, A);
+                hessian_rows<8, 12>(P, tid, wave, lane, SX, SY, N, rx, ry, rz, cx, cy, cz, DX, DY, red, A);
             }
+            lap(1);
+            // one wave inverts; the other seven leave their issue slots to the second workgroup of the CU and pick H^-1
+            // up from LDS after the next barrier
+            if (wave == 0) lu_inverse12_lds(A, reinterpret_cast<int*>(win + 144), lds_hinv, lane);
+            lap(2);
             // visible to every wave after the barriers of the first block_allreduce below
         }
 
@@ -529,7 +646,7 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
                         const int nx = n[0];                 // floats fetched per row
                         const int pitch = PX ? PX : n[0];    // floats between rows in LDS
                         const int nxy = pitch * n[1];
-                        if (staged) {
+                        if (staged && !(OC_ABLATE & 1)) {
                             __syncthreads();  // the previous pass has finished reading the box
                             // rows of the box, round-robin over the waves; (zr, yr) advance without a division
                             const int rows = n[1] * n[2];
@@ -579,8 +696,11 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
                             if (w.s < N) {
                                 const float xl = (float)(w.k - rx), yl = (float)(w.j - ry), zl = (float)(w.i - rz);
                                 const float x = warp_x(xl, yl, zl), y = warp_y(xl, yl, zl), z = warp_z(xl, yl, zl);
-                                const float v = staged ? bspline3d_eval_lds<PX>(win, o[0], o[1], o[2], pitch, nxy, DZ, DY, DX, x, y, z)
-                                                       : bspline3d_eval(P.coef, DZ, DY, DX, x, y, z);
+                                float v;
+                                if constexpr (OC_ABLATE & 2) v = x + y + z;
+                                else
+                                    v = staged ? bspline3d_eval_lds<PX>(win, o[0], o[1], o[2], pitch, nxy, DZ, DY, DX, x, y, z)
+                                               : bspline3d_eval(P.coef, DZ, DY, DX, x, y, z);
                                 out_of_range = out_of_range || (v < 0.f);
                                 ts[w.s] = v;
                                 acc[0] += v;
@@ -589,18 +709,22 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
                     }
                 }
             }
+            lap(3);
             // src/oc_icgn.cpp:1396-1400
-            if (__syncthreads_or(out_of_range ? 1 : 0)) {
+            if (__syncthreads_or(out_of_range && !(OC_ABLATE & 15) ? 1 : 0)) {
                 failed = true;
                 break;
             }
             block_allreduce<1>(acc, red, wave, lane);
             const float tmean = acc[0] / fN;
             acc[0] = 0.f;
-#pragma unroll 8
-            for (int s = tid; s < N; s += kBlock3d) {
-                const float d = ts[s] - tmean;
-                acc[0] += d * d;
+            {
+                Walk3 w(tid, SX, SY, 0, DX, DY);
+                sweep_batched<8>(w, rx, ry, rz, cnt, [&](const WalkPoint&, int sidx) { return ts[sidx]; },
+                                 [&](const WalkPoint&, float v, int) {
+                                     const float d = v - tmean;
+                                     acc[0] += d * d;
+                                 });
             }
             block_allreduce<1>(acc, red, wave, lane);
             const float tar_norm = sqrtf(acc[0]);
@@ -615,21 +739,30 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
                 const float* __restrict__ pgx = P.gx + gbase;
                 const float* __restrict__ pgy = P.gy + gbase;
                 const float* __restrict__ pgz = P.gz + gbase;
-#pragma unroll 4
-                for (; w.s < N; w.next()) {
-                    const int xl = w.k - rx, yl = w.j - ry, zl = w.i - rz;
-                    const float rsv = ref_at(w) - ref_mean;
-                    const float tz = ts[w.s] - tmean;
-                    const float e = factor * tz - rsv;
-                    const float g_x = pgx[w.off], g_y = pgy[w.off], g_z = pgz[w.off];
-                    const float fx = (float)xl, fy = (float)yl, fz = (float)zl;
-                    num[12] += e * e;
-                    num[0] += g_x * e; num[1] += (g_x * fx) * e; num[2] += (g_x * fy) * e; num[3] += (g_x * fz) * e;
-                    num[4] += g_y * e; num[5] += (g_y * fx) * e; num[6] += (g_y * fy) * e; num[7] += (g_y * fz) * e;
-                    num[8] += g_z * e; num[9] += (g_z * fx) * e; num[10] += (g_z * fy) * e; num[11] += (g_z * fz) * e;
-                }
+                struct S5 {
+                    float r, t, x, y, z;
+                };
+                auto numerator = [&](auto&& ref_of) {
+                    sweep_batched<4>(
+                        w, rx, ry, rz, (OC_ABLATE & 8) ? 0 : cnt,
+                        [&](const WalkPoint& q, int sidx) { return S5{ref_of(q, sidx), ts[sidx], pgx[q.off], pgy[q.off], pgz[q.off]}; },
+                        [&](const WalkPoint& q, const S5& v, int) {
+                            const float rsv = v.r - ref_mean;
+                            const float tz = v.t - tmean;
+                            const float e = factor * tz - rsv;
+                            const float g_x = v.x, g_y = v.y, g_z = v.z;
+                            const float fx = q.x, fy = q.y, fz = q.z;
+                            num[12] += e * e;
+                            num[0] += g_x * e; num[1] += (g_x * fx) * e; num[2] += (g_x * fy) * e; num[3] += (g_x * fz) * e;
+                            num[4] += g_y * e; num[5] += (g_y * fx) * e; num[6] += (g_y * fy) * e; num[7] += (g_y * fz) * e;
+                            num[8] += g_z * e; num[9] += (g_z * fx) * e; num[10] += (g_z * fy) * e; num[11] += (g_z * fz) * e;
+                        });
+                };
+                if (ref_box) numerator(ref_fast);
+                else numerator(ref_slow);
             }
             block_allreduce<13>(num, red, wave, lane);
+            lap(4);
             znssd = num[12] / (ref_norm * ref_norm);
             // dp = H^-1 * numerator (src/oc_icgn.cpp:1435-1443)
             float numj = 0.f;
@@ -660,7 +793,8 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
             for (int i = 0; i < 16; i++) Wm[i] = uni3(Wn[i]);
             // src/oc_icgn.cpp:1445
             dp_norm = uni3(sqrtf(dp[0] * dp[0] + dp[4] * dp[4] + dp[8] * dp[8]));
-        } while (iter < P.stop && dp_norm >= P.conv);
+            lap(5);
+        } while (iter < P.stop && ((OC_ABLATE & 15) ? iter < 3 : dp_norm >= P.conv));
 
         if (failed) {
             if (tid == 0) poi[poi3d::ZNCC] = -3.f;
@@ -693,6 +827,10 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
             poi[poi3d::SRX] = (float)rx;
             poi[poi3d::SRY] = (float)ry;
             poi[poi3d::SRZ] = (float)rz;
+            if constexpr (OC_ABLATE & 16) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) poi[22 + i] = (float)tl[i] * 1.0e-3f;
+            }
         }
     }
 }
