@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -155,8 +156,9 @@ struct oc_hip_engine {
     int fftcc3d_fused = 1;    // single-kernel FFTCC3D when the window is 32 x 32 x 32
     // host-queue pipeline (compute_host): the queue travels in chunks, copies of one chunk overlap the kernels of
     // its neighbours; one event per chunk orders the copy-out stream behind the kernels
-    hipStream_t copy_stream = nullptr;
-    std::vector<hipEvent_t> chunk_done;
+    hipStream_t copy_stream = nullptr, copy_in_stream = nullptr;
+    std::vector<hipEvent_t> chunk_done, chunk_in;
+    std::atomic<size_t> chunks_fed{0};  // chunks whose kernels (and event) are enqueued, for the copy-out thread
     int host_chunk = 65536;  // POIs per chunk ("host_chunk" tuning key; 0 = the whole queue at once)
     // device group (oc_hip_set_devices): this engine leads, replicas[i] is a full engine of the same kind on
     // group_devices[i + 1]; every setter, set_images, prepare and compute fans out
@@ -846,10 +848,12 @@ int oc_hip_destroy(oc_hip_engine* e) {
     if (e->order_ev) (void)hipEventDestroy(e->order_ev);
     if (e->group_ev) (void)hipEventDestroy(e->group_ev);
     for (hipEvent_t ev : e->chunk_done) (void)hipEventDestroy(ev);
-    if (e->copy_stream) {
-        (void)hipStreamSynchronize(e->copy_stream);
-        (void)hipStreamDestroy(e->copy_stream);
-    }
+    for (hipEvent_t ev : e->chunk_in) (void)hipEventDestroy(ev);
+    for (hipStream_t* st : {&e->copy_stream, &e->copy_in_stream})
+        if (*st) {
+            (void)hipStreamSynchronize(*st);
+            (void)hipStreamDestroy(*st);
+        }
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
     return OC_HIP_OK;
@@ -1023,8 +1027,11 @@ static int rehome(oc_hip_engine* e, int device) {
     if (e->order_ev) { (void)hipEventDestroy(e->order_ev); e->order_ev = nullptr; }
     if (e->group_ev) { (void)hipEventDestroy(e->group_ev); e->group_ev = nullptr; }
     for (hipEvent_t ev : e->chunk_done) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->chunk_in) (void)hipEventDestroy(ev);
     e->chunk_done.clear();
+    e->chunk_in.clear();
     if (e->copy_stream) { (void)hipStreamDestroy(e->copy_stream); e->copy_stream = nullptr; }
+    if (e->copy_in_stream) { (void)hipStreamDestroy(e->copy_in_stream); e->copy_in_stream = nullptr; }
     (void)hipStreamDestroy(e->own_stream);
     e->own_stream = nullptr;
     OC_HIP_TRY(hipSetDevice(device));
@@ -1253,10 +1260,10 @@ namespace {
 // host queues: H2D of the AoS, kernels, D2H (the reference's CUDA module does the same,
 // examples/test_2d_dic_gpu_icgn.cpp:136-149) -- but chunk by chunk, so that the copies of one chunk overlap the
 // kernels of its neighbours:   H2D(0) K(0) | H2D(1) K(1) D2H(0) | H2D(2) K(2) D2H(1) | ... | D2H(last)
-// Kernels run on the engine's stream, copies out on a second stream behind a per-chunk event; copies in are issued
-// on the engine's stream ahead of their kernels (a pageable hipMemcpyAsync returns once the data is staged, by which
-// time the previous chunk's kernels are already queued).  A POI's result does not depend on the chunk it travels in
-// (tests: split queue == whole queue), chunks are large enough for the ICGN2D tile schedule.
+// Kernels run on the engine's stream, copies out on a second stream behind a per-chunk event and from a second host
+// thread (copies to / from pageable memory block their thread; PCIe is full duplex); copies in are issued on the
+// engine's stream ahead of their kernels.  A POI's result does not depend on the chunk it travels in (tests: split
+// queue == whole queue), chunks are large enough for the ICGN2D tile schedule.
 // ---------------------------------------------------------------------------
 int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t count, size_t stride_bytes) {
     const int stride_f = (int)(stride_bytes / 4);
@@ -1268,39 +1275,84 @@ int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t coun
     const size_t nchunk = (count + chunk - 1) / chunk;
     if (nchunk > 1) {
         if (!e->copy_stream) OC_HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        if (!e->copy_in_stream) OC_HIP_TRY(hipStreamCreateWithFlags(&e->copy_in_stream, hipStreamNonBlocking));
         while (e->chunk_done.size() < nchunk) {
-            hipEvent_t ev = nullptr;
+            hipEvent_t ev = nullptr, ev2 = nullptr;
             OC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             e->chunk_done.push_back(ev);
+            OC_HIP_TRY(hipEventCreateWithFlags(&ev2, hipEventDisableTiming));
+            e->chunk_in.push_back(ev2);
         }
     }
     char* stage = e->poi_stage.as<char>();
-    auto copy_out = [&](size_t c) -> int {
-        const size_t first = c * chunk, n = std::min(chunk, count - first);
-        if (nchunk == 1) {
-            OC_HIP_TRY(hipMemcpyAsync(pois + first * stride_bytes, stage + first * stride_bytes, n * stride_bytes, hipMemcpyDeviceToHost, e->stream));
-        } else {
-            OC_HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->chunk_done[c], 0));
-            OC_HIP_TRY(hipMemcpyAsync(pois + first * stride_bytes, stage + first * stride_bytes, n * stride_bytes, hipMemcpyDeviceToHost, e->copy_stream));
+    if (nchunk == 1) {
+        OC_HIP_TRY(hipMemcpyAsync(stage, pois, bytes, hipMemcpyHostToDevice, e->stream));
+        const float* d_off = nullptr;
+        if (offsets) {
+            OC_HIP_TRY(hipMemcpyAsync(e->off_stage.p, offsets, count * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+            d_off = e->off_stage.as<float>();
+        }
+        OC_TRY(run_compute_device(e, reinterpret_cast<float*>(stage), stride_f, count, d_off));
+        OC_HIP_TRY(hipMemcpyAsync(pois, stage, bytes, hipMemcpyDeviceToHost, e->stream));
+        OC_HIP_TRY(hipStreamSynchronize(e->stream));
+        return OC_HIP_OK;
+    }
+    // A copy between pageable host memory and the device blocks the calling thread, so the two directions get a thread
+    // each (PCIe is full duplex): this thread feeds chunks in and launches their kernels, the helper waits for each
+    // chunk's event and copies its records back.
+    const int device = e->device;
+    hipError_t out_err = hipSuccess;
+    e->chunks_fed.store(0, std::memory_order_release);
+    std::thread out_thread([&] {
+        if (hipSetDevice(device) != hipSuccess) {
+            out_err = hipErrorInvalidDevice;
+            return;
+        }
+        for (size_t c = 0; c < nchunk && out_err == hipSuccess; c++) {
+            const size_t first = c * chunk, n = std::min(chunk, count - first);
+            // the event is recorded by the feeding thread after chunk c's kernels were enqueued; until then
+            // hipStreamWaitEvent would see the event of an earlier call, so wait for the hand-off first
+            while (e->chunks_fed.load(std::memory_order_acquire) <= c) std::this_thread::yield();
+            if (e->chunks_fed.load(std::memory_order_acquire) == (size_t)-1) return;  // the feeder failed
+            out_err = hipStreamWaitEvent(e->copy_stream, e->chunk_done[c], 0);
+            if (out_err == hipSuccess)
+                out_err = hipMemcpyAsync(pois + first * stride_bytes, stage + first * stride_bytes, n * stride_bytes, hipMemcpyDeviceToHost,
+                                         e->copy_stream);
+        }
+        if (out_err == hipSuccess) out_err = hipStreamSynchronize(e->copy_stream);
+    });
+    int rc = OC_HIP_OK;
+    auto feed = [&]() -> int {
+        // the staging buffer may still be read by kernels of an earlier call on the engine's stream
+        OC_HIP_TRY(hipEventRecord(e->chunk_in[0], e->stream));
+        OC_HIP_TRY(hipStreamWaitEvent(e->copy_in_stream, e->chunk_in[0], 0));
+        for (size_t c = 0; c < nchunk; c++) {
+            const size_t first = c * chunk, n = std::min(chunk, count - first);
+            // copies in travel on their own stream: on the kernels' stream a pageable copy would queue behind the
+            // previous chunk's kernels and nothing would overlap
+            OC_HIP_TRY(hipMemcpyAsync(stage + first * stride_bytes, pois + first * stride_bytes, n * stride_bytes, hipMemcpyHostToDevice,
+                                      e->copy_in_stream));
+            const float* d_off = nullptr;
+            if (offsets) {
+                float* o = e->off_stage.as<float>() + 2 * first;
+                OC_HIP_TRY(hipMemcpyAsync(o, offsets + 2 * first, n * 2 * sizeof(float), hipMemcpyHostToDevice, e->copy_in_stream));
+                d_off = o;
+            }
+            OC_HIP_TRY(hipEventRecord(e->chunk_in[c], e->copy_in_stream));
+            OC_HIP_TRY(hipStreamWaitEvent(e->stream, e->chunk_in[c], 0));
+            OC_TRY(run_compute_device(e, reinterpret_cast<float*>(stage + first * stride_bytes), stride_f, n, d_off));
+            OC_HIP_TRY(hipEventRecord(e->chunk_done[c], e->stream));
+            e->chunks_fed.store(c + 1, std::memory_order_release);
         }
         return OC_HIP_OK;
     };
-    for (size_t c = 0; c < nchunk; c++) {
-        const size_t first = c * chunk, n = std::min(chunk, count - first);
-        OC_HIP_TRY(hipMemcpyAsync(stage + first * stride_bytes, pois + first * stride_bytes, n * stride_bytes, hipMemcpyHostToDevice, e->stream));
-        const float* d_off = nullptr;
-        if (offsets) {
-            float* o = e->off_stage.as<float>() + 2 * first;
-            OC_HIP_TRY(hipMemcpyAsync(o, offsets + 2 * first, n * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
-            d_off = o;
-        }
-        OC_TRY(run_compute_device(e, reinterpret_cast<float*>(stage + first * stride_bytes), stride_f, n, d_off));
-        if (nchunk > 1) OC_HIP_TRY(hipEventRecord(e->chunk_done[c], e->stream));
-        if (c > 0) OC_TRY(copy_out(c - 1));
-    }
-    OC_TRY(copy_out(nchunk - 1));
-    if (nchunk > 1) OC_HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    rc = feed();
+    if (rc != OC_HIP_OK) e->chunks_fed.store((size_t)-1, std::memory_order_release);
+    out_thread.join();
+    const std::string feed_error = g_last_error;
     OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (rc != OC_HIP_OK) return fail(rc, "%s", feed_error.c_str());
+    if (out_err != hipSuccess) return fail(OC_HIP_ERR_HIP, "copying results back failed: %s", hipGetErrorString(out_err));
     return OC_HIP_OK;
 }
 

@@ -163,9 +163,9 @@ def run_3d(name, dim, r, nside, oracle_sample):
     prepare_s = time.perf_counter() - t0
     pristine = torch.from_numpy(oc.make_pois3d(xs, ys, zs)).to(dev)
     pois = pristine.clone()
-    t_f = timed(lambda: (pois.copy_(pristine), f.compute(pois)), torch.cuda.synchronize, reps=1)
+    t_f = timed(lambda: (pois.copy_(pristine), f.compute(pois)), torch.cuda.synchronize, reps=3)
     guess = pois.clone()
-    t_g = timed(lambda: (pois.copy_(guess), g.compute(pois)), torch.cuda.synchronize, reps=1)
+    t_g = timed(lambda: (pois.copy_(guess), g.compute(pois)), torch.cuda.synchronize, reps=3)
     after = pois.cpu().numpy()
     P = oracle.P3
     conv = after[:, P["zncc"]] >= 0
