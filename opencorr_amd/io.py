@@ -45,11 +45,15 @@ def _load(path, columns, floats, delimiter):
     with open(path) as f:
         f.readline()  # header (the reference skips it without looking at it, src/oc_io.cpp:257-258)
         rows = [[float(tok) for tok in line.strip().split(delimiter) if tok != ""] for line in f if line.strip()]
-    width = min(len(r) for r in rows) if rows else 0
+    # every row fills the fields it has (a short or truncated line leaves ITS remaining fields at 0, like the C++ twin
+    # include/opencorr_compat/oc_io.h does; it must not cost the other rows their columns); rows without a position
+    # (fewer than 2 / 3 values) are skipped there as well
+    need = 2 if floats == 25 else 3
+    rows = [r for r in rows if len(r) >= need]
     pois = np.zeros((len(rows), floats), dtype=np.float32)
-    data = np.asarray([r[:width] for r in rows], dtype=np.float32).reshape(len(rows), width)
-    for j, (_, off) in enumerate(columns[:width]):
-        pois[:, off] = data[:, j]
+    for i, r in enumerate(rows):
+        for value, (_, off) in zip(r, columns):
+            pois[i, off] = value
     return pois
 
 

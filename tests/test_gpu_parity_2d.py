@@ -512,3 +512,31 @@ def test_candidate_batching_and_select_best(eng, speckle_small):
     d = icgn.select_best(torch.from_numpy(cand).cuda(), torch.from_numpy(starts.astype(np.int32)).cuda(),
                          torch.from_numpy(pois.copy()).cuda())
     assert np.array_equal(_bits(d.cpu().numpy()), _bits(want))
+
+
+def test_oversized_images_are_refused_not_wrapped():
+    """The 2D solvers address image-sized arrays with 32-bit byte offsets: an image beyond the limits must come back as
+    OC_HIP_ERR_UNSUPPORTED from prepare() (and compute()), never as silently wrong table look-ups."""
+    import torch
+    import opencorr_amd
+    from opencorr_amd import capi
+    dev = torch.device("cuda", 0)
+    # width >= 2^22: the row offset (row * width * 4) no longer fits the 24-bit multiply
+    wide = torch.zeros((5, 1 << 22), dtype=torch.float32, device=dev)
+    icgn = opencorr_amd.ICGN2D1(2, 2, 0.001, 10)
+    icgn.set_images(wide, wide)
+    with pytest.raises(capi.OpenCorrHipError) as e:
+        icgn.prepare()
+    assert e.value.status == capi.ERR_UNSUPPORTED
+    # NR2D1 reads three tables through one descriptor each: 2^26 pixels is its limit (8192 x 8192 passes, one row more does not)
+    big = torch.zeros((8193, 8192), dtype=torch.float32, device=dev)
+    nr = opencorr_amd.NR2D1(16, 16, 0.001, 10)
+    nr.set_images(big, big)
+    with pytest.raises(capi.OpenCorrHipError) as e:
+        nr.prepare()
+    assert e.value.status == capi.ERR_UNSUPPORTED
+    # ... while ICGN2D1 (one descriptor per table plane) accepts that image
+    icgn2 = opencorr_amd.ICGN2D1(16, 16, 0.001, 10)
+    icgn2.set_images(big, big)
+    icgn2.prepare()
+    icgn2.synchronize()

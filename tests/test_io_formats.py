@@ -91,3 +91,23 @@ def test_cpp_io_header_exchanges_files_with_the_python_twin(tmp_path):
     for row in back:
         assert abs(m[int(row[1]), int(row[0])] - row[21]) < 1e-6
     assert np.count_nonzero(m) == 6
+
+
+def test_ragged_rows_keep_their_own_width(tmp_path):
+    """A truncated line must cost only itself its missing columns (the C++ loader works row by row too)."""
+    from opencorr_amd import io
+    pois = np.zeros((3, 25), np.float32)
+    pois[:, 0] = [10, 20, 30]
+    pois[:, 1] = [11, 21, 31]
+    pois[:, 2] = [0.5, 0.25, 0.125]     # u
+    pois[:, 16] = [0.9, 0.8, 0.7]       # zncc
+    path = tmp_path / "t.csv"
+    io.save_table2d(str(path), pois)
+    lines = open(path).read().splitlines()
+    lines[2] = ",".join(lines[2].split(",")[:3]) + ","   # second POI: only x, y, u survive
+    lines.append("42,")                                      # a row without a position: skipped
+    open(path, "w").write("\n".join(lines) + "\n")
+    got = io.load_table2d(str(path))
+    assert got.shape == (3, 25)
+    assert np.array_equal(got[[0, 2]], pois[[0, 2]])
+    assert got[1, 0] == 20 and got[1, 1] == 21 and got[1, 2] == 0.25 and got[1, 16] == 0
