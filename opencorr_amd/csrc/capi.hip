@@ -429,6 +429,7 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
     const long long N = (2LL * rx + 1) * (2LL * ry + 1);
     // fall back to the LDS-light single-wave variant when the tuned one cannot hold the subset
     int variant = e->icgn2d_variant;
+    if (e->self_adaptive && ochip::icgn2d_variant_uses_table(variant)) variant = 2;  // per-POI radii: no shared coordinate table
     if (lm) variant = 1;  // the IC-LM launch shape has the LDS footprint of variant 1
     if (N > ochip::icgn2d_max_samples(variant)) variant = 1;
     if (N > ochip::icgn2d_max_samples(variant))

@@ -31,9 +31,14 @@ namespace ochip {
 //   MODE 0 (floats per wave): rs[NT*64] | ts[NT*64] | gx[NT*64] | gy[NT*64]
 //   MODE 1:                   rs[NT*64] | ts[NT*64]       (gx, gy re-read from the gradient
 //                             images in the numerator pass: half the LDS, twice the waves)
+//   MODE 3 = MODE 1 + TAB, MODE 4 = TAB + ts[NT*64] only (the zero-mean reference value is re-formed from the image in
+//                             the numerator pass as well).
+//   TAB: one table per WORKGROUP of what depends on (lane, pass) only -- the sample's local coordinates as a float
+//        pair and its byte offset from the subset origin -- filled once by the workgroup's waves: the per-sample
+//        walk (wrap test, selects) and the int -> float conversions of every pass become one or two LDS reads.
+//        Needs one radius per launch, i.e. not available with self-adaptive subsets.
 // G    = samples whose LUT gathers are issued back to back.
-// PIPE = software-pipelined sweep: the gathers of group g+1 are in flight while the
-//        polynomials of group g are evaluated (two register buffers).
+// PIPE = (retired) software-pipelined sweep of round 1; the parameter stays 0.
 // OCC  = minimum waves per SIMD the register allocation must allow.
 // Wave-uniform small matrices are kept one COLUMN per lane (lane j < n holds column j):
 // the inverse Hessian, and for 2D2 also the 6x6 warp matrix.
@@ -62,10 +67,26 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                                                                Icgn2dLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NH = DOF * (DOF + 1) / 2;
-    constexpr int ARRAYS = MODE == 0 ? 4 : 2;
+    constexpr bool TAB = MODE >= 3;
+    constexpr bool KEEP_RS = MODE != 4;  // the zero-mean reference subset is parked in LDS
+    constexpr int ARRAYS = MODE == 0 ? 4 : (MODE == 4 ? 1 : 2);
     const int NTA = L.nt;  // passes the LDS arrays are sized for (>= the passes of any POI)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // TAB: [NTA*64] float pairs (x_local, y_local), then [NTA*64] byte offsets; the waves' own arrays follow
+    f2* __restrict__ tab_xy = reinterpret_cast<f2*>(lds);
+    unsigned* __restrict__ tab_off = reinterpret_cast<unsigned*>(lds + 2 * NTA * kWave);
+    float* const wave_lds = lds + (TAB ? 3 * NTA * kWave : 0);
+    if constexpr (TAB) {
+        const int Wt = 2 * P.rx + 1;
+        const unsigned w4t = (unsigned)P.width * 4u;
+        for (int s = threadIdx.x; s < NTA * kWave; s += kWave * WPB) {
+            const int r = s / Wt, c = s - r * Wt;
+            tab_xy[s] = mk2((float)(c - P.rx), (float)(r - P.ry));
+            tab_off[s] = (unsigned)r * w4t + ((unsigned)c << 2);
+        }
+        __syncthreads();  // the only barrier of the kernel; waves that leave early below are past it
+    }
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD a
     // contiguous range of the queue so POIs that share LUT lines meet in the same L2.
     unsigned long long grp = blockIdx.x;
@@ -74,8 +95,10 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     if (slot >= L.count) return;
     // the k-th wave of the launch solves POI perm[k] (a locality schedule) or simply POI k
     const unsigned long long idx = P.perm ? (unsigned long long)__builtin_amdgcn_readfirstlane((int)P.perm[slot]) : slot;
-    float* __restrict__ l_rs = lds + (size_t)wave * ARRAYS * NTA * kWave + lane;
-    float* __restrict__ l_ts = l_rs + NTA * kWave;
+    // (no __restrict__: in MODE 4 the two names denote one array -- the reference values pass through it before the
+    // first sweep overwrites them)
+    float* l_rs = wave_lds + (size_t)wave * ARRAYS * NTA * kWave + lane;
+    float* l_ts = KEEP_RS ? l_rs + NTA * kWave : l_rs;
     float* __restrict__ l_gx = l_ts + NTA * kWave;  // MODE 0 only
     float* __restrict__ l_gy = l_gx + NTA * kWave;
 
@@ -120,41 +143,47 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     // subset origin as a wave-uniform byte offset (images are <= 2^28 bytes)
     const unsigned goff = (unsigned)__builtin_amdgcn_readfirstlane((((int)py - ry) * width + ((int)px - rx)) * 4);
     const __amdgpu_buffer_rsrc_t r_gx = make_rsrc(P.gx), r_gy = make_rsrc(P.gy), r_ref = make_rsrc(P.ref);
-    const LutPlanesS r_lut(P.lut, height, width);
+    const LutPlanes4 r_lut(P.lut, height, width);
     const unsigned w4 = (unsigned)width * 4u;
     // byte offset of sample (r, c) from the subset origin
     auto soff = [&](const SampleWalk& w) { return __umul24((unsigned)w.r, w4) + ((unsigned)w.c << 2); };
 
+    // per-pass sample coordinates: from the workgroup's table, or walked
+    auto tab_at = [&](int t) { return tab_xy[t * kWave + lane]; };
+    auto off_at = [&](int t) { return tab_off[t * kWave + lane]; };
+
     // ---- reference subset, zero-mean + norm (src/oc_icgn.cpp:174-176, src/oc_subset.cpp:39-53)
-    float ref_norm;
+    float ref_norm, ref_mean;
+    const int x0r = (int)(px - rx), y0r = (int)(py - ry);
+    const unsigned roff = (unsigned)__builtin_amdgcn_readfirstlane((y0r * width + x0r) * 4);
     {
-        const int x0 = (int)(px - rx), y0 = (int)(py - ry);
-        const unsigned roff = (unsigned)__builtin_amdgcn_readfirstlane((y0 * width + x0) * 4);
         float acc = 0.f;
         SampleWalk w(lane, r0, c0, W, q64, r64);
+        // (MODE 4 parks the raw values in the target array, which is idle until the first sweep)
 #pragma unroll 3
         for (int t = 0; t < NF; t++, w.next()) {
-            const float v = buf_f32(r_ref, soff(w), roff);
+            const float v = buf_f32(r_ref, TAB ? off_at(t) : soff(w), roff);
             acc = acc + v;
             l_rs[t * kWave] = v;
         }
         if (NF < NT) {
-            const bool valid = w.s < N;
-            const float v = valid ? buf_f32(r_ref, soff(w), roff) : 0.f;
+            const bool valid = (NF * kWave + lane) < N;
+            const float v = valid ? buf_f32(r_ref, TAB ? off_at(NF) : soff(w), roff) : 0.f;
             acc = valid ? acc + v : acc;
             l_rs[NF * kWave] = v;
         }
         const float mean = wave_allreduce_sum(acc) / fN;
+        ref_mean = uni(mean);
         acc = 0.f;
 #pragma unroll 3
         for (int t = 0; t < NF; t++) {
             const float d = l_rs[t * kWave] - mean;
-            l_rs[t * kWave] = d;
+            if constexpr (KEEP_RS) l_rs[t * kWave] = d;
             acc = acc + d * d;
         }
         if (NF < NT) {
             const float d = l_rs[NF * kWave] - mean;
-            l_rs[NF * kWave] = d;
+            if constexpr (KEEP_RS) l_rs[NF * kWave] = d;
             acc = (NF * kWave + lane) < N ? acc + d * d : acc;
         }
         ref_norm = uni(sqrtf(wave_allreduce_sum(acc)));
@@ -175,14 +204,14 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             f2 hAA = mk2(0.f, 0.f), hBB = hAA, hAB = hAA, hAs = hAA, hxA = hAA, hyA = hAA, hxB = hAA, hyB = hAA;
             float h00 = 0.f, h33 = 0.f, h30 = 0.f, h21 = 0.f, h54 = 0.f;
             auto sample = [&](int t, bool valid) {
-                const unsigned off = soff(w);
+                const unsigned off = TAB ? off_at(t) : soff(w);
                 const float g_x = valid ? buf_f32(r_gx, off, goff) : 0.f;
                 const float g_y = valid ? buf_f32(r_gy, off, goff) : 0.f;
                 if constexpr (MODE == 0) {
                     l_gx[t * kWave] = g_x;
                     l_gy[t * kWave] = g_y;
                 }
-                const f2 xy = mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
+                const f2 xy = TAB ? tab_at(t) - mk2(offx, offy) : mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
                 const f2 A = g_x * xy, B = g_y * xy;
                 const f2 nAA = hAA + A * A, nBB = hBB + B * B, nAB = hAB + A * B, nAs = hAs + A * B.yx;
                 const f2 nxA = hxA + g_x * A, nyA = hyA + g_y * A, nxB = hxB + g_x * B, nyB = hyB + g_y * B;
@@ -195,7 +224,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             };
 #pragma unroll 1
             for (int t = 0; t < NF; t++, w.next()) sample(t, true);
-            if (NF < NT) sample(NF, w.s < N);
+            if (NF < NT) sample(NF, (NF * kWave + lane) < N);
             // back to the row-major lower triangle h[i*(i+1)/2 + j]
             h[0] = h00;                                                           // (0,0)
             h[1] = hxA.x; h[2] = hAA.x;                                           // (1,0) (1,1)
@@ -216,14 +245,15 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 for (int q = 0; q < 6; q++) hp[r][q] = mk2(0.f, 0.f);
             }
             auto sample = [&](int t, bool valid) {
-                const unsigned off = soff(w);
+                const unsigned off = TAB ? off_at(t) : soff(w);
                 const float g_x = valid ? buf_f32(r_gx, off, goff) : 0.f;
                 const float g_y = valid ? buf_f32(r_gy, off, goff) : 0.f;
                 if constexpr (MODE == 0) {
                     l_gx[t * kWave] = g_x;
                     l_gy[t * kWave] = g_y;
                 }
-                const float fxl = (float)(w.c - rx) - offx, fyl = (float)(w.r - ry) - offy;
+                const f2 lxy = TAB ? tab_at(t) - mk2(offx, offy) : mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
+                const float fxl = lxy.x, fyl = lxy.y;
                 const float xx = (fxl * fxl) * 0.5f, xy = fxl * fyl, yy = (fyl * fyl) * 0.5f;
                 const f2 m01 = mk2(1.f, fxl), m23 = mk2(fyl, xx), m45 = mk2(xy, yy);  // g * 1.f is exact
                 const f2 sdp[6] = {g_x * m01, g_x * m23, g_x * m45, g_y * m01, g_y * m23, g_y * m45};
@@ -240,7 +270,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             };
 #pragma unroll 1
             for (int t = 0; t < NF; t++, w.next()) sample(t, true);
-            if (NF < NT) sample(NF, w.s < N);
+            if (NF < NT) sample(NF, (NF * kWave + lane) < N);
             int k = 0;
 #pragma unroll
             for (int r = 0; r < 12; r++)
@@ -268,6 +298,21 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         } else {
             lu_inverse_lanes<DOF>(col, hinv_col, lane);
         }
+    }
+    // IC-GN: H^-1 stays fixed, so it is transposed once -- lane i (< DOF) gets ROW i of H^-1 -- and every iteration's
+    // dp[i] = sum_j H^-1(i,j) * num[j] is formed inside lane i (ascending j, as the reference's loop) and handed round
+    // with DOF broadcasts, instead of DOF x DOF v_readlane per iteration (6.2 cycles each on gfx950).
+    float hinv_row[LM ? 1 : DOF];
+    if constexpr (!LM) {
+#pragma unroll
+        for (int j = 0; j < DOF; j++) hinv_row[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < DOF; i++)
+#pragma unroll
+            for (int j = 0; j < DOF; j++) {
+                const float v = wave_bcast(hinv_col[i], j);  // H^-1(i, j)
+                hinv_row[j] = lane == i ? v : hinv_row[j];
+            }
     }
 
     // ---- IC-GN loop (src/oc_icgn.cpp:216-307; 2D2: 762-858)
@@ -324,13 +369,22 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             // !LM: a sample outside the interpolatable range makes the reference abandon the POI (:251-255: -1.f is
             // the only way out of range shows, and any negative value aborts), so "outside" is folded into `negative`
             // right here and the sample's value is never looked at; LM keeps the -1.f sentinel as a value (MARK).
-            auto issue = [&](LutFetch(&f)[G], bool(&valid)[G], auto checked) {
+            auto issue = [&](LutFetch(&f)[G], bool(&valid)[G], int t0, auto checked) {
                 constexpr bool CHECKED = decltype(checked)::value;
 #pragma unroll
                 for (int g = 0; g < G; g++, w.next()) {
                     valid[g] = CHECKED ? w.s < N : true;
                     // local_coor = (c - rx) - center_offset (src/oc_icgn.cpp:447-450); "- 0.f" is exact
-                    const float xl = (float)(w.c - rx) - offx, yl = (float)(w.r - ry) - offy;
+                    float xl, yl;
+                    if constexpr (TAB) {
+                        // a pass past the table's end (only in the CHECKED tail) reads the last pass: its value is unused
+                        const f2 lxy = tab_at(CHECKED ? min(t0 + g, NT - 1) : t0 + g);
+                        xl = lxy.x - offx;
+                        yl = lxy.y - offy;
+                    } else {
+                        xl = (float)(w.c - rx) - offx;
+                        yl = (float)(w.r - ry) - offy;
+                    }
                     float wx, wy;
                     if constexpr (DOF == 6) {
                         // Deformation2D1::warp, src/oc_deformation.cpp:94-105: (W0 x + W1 y) + W2 * 1 (the product
@@ -378,34 +432,20 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             };
             // groups of G passes in which every lane owns a sample need no validity logic
             const int full_groups = NF / G;
-            if constexpr (PIPE == 0) {
-                int t0 = 0;
+            int t0 = 0;
 #pragma nounroll
-                for (int q = 0; q < full_groups; q++, t0 += G) {
-                    LutFetch f[G];
-                    bool valid[G];
-                    issue(f, valid, std::false_type{});
-                    consume(f, valid, t0, std::false_type{});
-                }
+            for (int q = 0; q < full_groups; q++, t0 += G) {
+                LutFetch f[G];
+                bool valid[G];
+                issue(f, valid, t0, std::false_type{});
+                consume(f, valid, t0, std::false_type{});
+            }
 #pragma nounroll
-                for (; t0 < NT; t0 += G) {
-                    LutFetch f[G];
-                    bool valid[G];
-                    issue(f, valid, std::true_type{});
-                    consume(f, valid, t0, std::true_type{});
-                }
-            } else {
-                LutFetch fa[G], fb[G];
-                bool va[G], vb[G];
-                issue(fa, va, std::true_type{});
-#pragma nounroll
-                for (int t0 = 0; t0 < NT; t0 += 2 * G) {
-                    const bool more_b = t0 + G < NT, more_a = t0 + 2 * G < NT;
-                    if (more_b) issue(fb, vb, std::true_type{});
-                    consume(fa, va, t0, std::true_type{});
-                    if (more_a) issue(fa, va, std::true_type{});
-                    if (more_b) consume(fb, vb, t0 + G, std::true_type{});
-                }
+            for (; t0 < NT; t0 += G) {
+                LutFetch f[G];
+                bool valid[G];
+                issue(f, valid, t0, std::true_type{});
+                consume(f, valid, t0, std::true_type{});
             }
         }
         // src/oc_icgn.cpp:251-255 (the IC-LM classes have no such check)
@@ -437,27 +477,32 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         {
             SampleWalk w(lane, r0, c0, W, q64, r64);
             FloatWalk fw(r0, c0, rx, ry, W, q64, r64, w4);  // DOF 6 without centre offsets
-            constexpr bool kFloatWalk = DOF == 6 && !OFFS;
+            constexpr bool kFloatWalk = DOF == 6 && !OFFS && !TAB;
             f2 nA = mk2(0.f, 0.f), nB = nA;  // DOF 6: (num1, num2) and (num4, num5) as packed pairs
             f2 np12[6];                       // DOF 12: (num0, num1) .. (num10, num11)
 #pragma unroll
             for (int q = 0; q < 6; q++) np12[q] = mk2(0.f, 0.f);
             auto sample = [&](int t, bool valid) {
                 float g_x, g_y;
+                [[maybe_unused]] float ref_v = 0.f;
                 if constexpr (MODE == 0) {
                     g_x = l_gx[t * kWave];
                     g_y = l_gy[t * kWave];
                 } else {
-                    const unsigned off = kFloatWalk ? fw.off : soff(w);
+                    const unsigned off = TAB ? off_at(t) : (kFloatWalk ? fw.off : soff(w));
                     g_x = valid ? buf_f32(r_gx, off, goff) : 0.f;
                     g_y = valid ? buf_f32(r_gy, off, goff) : 0.f;
+                    if constexpr (!KEEP_RS) ref_v = valid ? buf_f32(r_ref, off, roff) : 0.f;
                 }
                 const float tz = l_ts[t * kWave] - tmean;  // same bits as in the norm pass
-                const float e = tz * factor - l_rs[t * kWave];
+                // the zero-mean reference value: parked in LDS, or re-formed from the image (same subtraction, same bits)
+                const float rsv = KEEP_RS ? l_rs[t * kWave] : ref_v - ref_mean;
+                const float e = tz * factor - rsv;
                 const float e2 = e * e;
                 ssd = valid ? ssd + e2 : ssd;
                 if constexpr (DOF == 6) {
-                    const f2 xy = kFloatWalk ? fw.xy : mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
+                    const f2 xy = TAB ? tab_at(t) - mk2(offx, offy)
+                                      : (kFloatWalk ? fw.xy : mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy));
                     const f2 A = g_x * xy, B = g_y * xy;  // (sd1, sd2), (sd4, sd5)
                     const f2 mA = nA + A * e, mB = nB + B * e;
                     const float m0 = num[0] + g_x * e, m3 = num[3] + g_y * e;
@@ -465,7 +510,8 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                         nA = mA; nB = mB; num[0] = m0; num[3] = m3;
                     }
                 } else {
-                    const float fxl = (float)(w.c - rx) - offx, fyl = (float)(w.r - ry) - offy;
+                    const f2 lxy = TAB ? tab_at(t) - mk2(offx, offy) : mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
+                    const float fxl = lxy.x, fyl = lxy.y;
                     const float xx = (fxl * fxl) * 0.5f, xy = fxl * fyl, yy = (fyl * fyl) * 0.5f;
                     const f2 m01 = mk2(1.f, fxl), m23 = mk2(fyl, xx), m45 = mk2(xy, yy);
                     const f2 sdp[6] = {g_x * m01, g_x * m23, g_x * m45, g_y * m01, g_y * m23, g_y * m45};
@@ -483,7 +529,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             } else {
 #pragma unroll 3
                 for (int t = 0; t < NF; t++, w.next()) sample(t, true);
-                if (NF < NT) sample(NF, w.s < N);
+                if (NF < NT) sample(NF, (NF * kWave + lane) < N);
             }
             if constexpr (DOF == 6) {
                 num[1] = nA.x; num[2] = nA.y; num[4] = nB.x; num[5] = nB.y;
@@ -512,17 +558,25 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         }
         // dp = H^-1 * numerator (src/oc_icgn.cpp:279-286): lane j forms H^-1(i,j) * num[j], the
         // products of row i are then added in ascending j exactly like the reference loop
-        float numj = 0.f;
-#pragma unroll
-        for (int j = 0; j < DOF; j++) numj = lane == j ? red[j] : numj;
         float dp[DOF];
+        if constexpr (LM) {
+            float numj = 0.f;
 #pragma unroll
-        for (int i = 0; i < DOF; i++) {
-            const float prod = hinv_col[i] * numj;
-            float v = 0.f;
+            for (int j = 0; j < DOF; j++) numj = lane == j ? red[j] : numj;
 #pragma unroll
-            for (int j = 0; j < DOF; j++) v += wave_bcast(prod, j);
-            dp[i] = v;
+            for (int i = 0; i < DOF; i++) {
+                const float prod = hinv_col[i] * numj;
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < DOF; j++) v += wave_bcast(prod, j);
+                dp[i] = v;
+            }
+        } else {
+            float mine = 0.f;  // lane i < DOF: dp[i]
+#pragma unroll
+            for (int j = 0; j < DOF; j++) mine += hinv_row[j] * red[j];
+#pragma unroll
+            for (int i = 0; i < DOF; i++) dp[i] = wave_bcast(mine, i);
         }
         // IC-LM applies the step only when the ZNSSD went down (src/oc_iclm.cpp:283-300); wave-uniform
         const bool accept = !LM || znssd < znssd0;
@@ -651,8 +705,8 @@ struct VariantInfo {
 template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC, int OFFS, int LM = 0>
 static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int nt, bool xcd,
                            hipStream_t stream) {
-    constexpr int arrays = MODE == 0 ? 4 : 2;
-    const size_t lds = (size_t)arrays * nt * kWave * sizeof(float) * WPB;
+    constexpr int arrays = MODE == 0 ? 4 : (MODE == 4 ? 1 : 2);
+    const size_t lds = ((size_t)arrays * WPB + (MODE >= 3 ? 3 : 0)) * nt * kWave * sizeof(float);
     if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
     auto kern = icgn2d_kernel<DOF, G, MODE, PIPE, WPB, OCC, OFFS, LM>;
     // the dynamic-LDS limit is a per-device property of the loaded function: raise it once on every
@@ -680,17 +734,20 @@ static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, siz
     return hipGetLastError();
 }
 
+// 0: everything per sample parked in LDS, one wave per workgroup (the first design; kept as the reference point of the
+//    sweeps), 1: LDS-light single wave (the fallback for large subsets and the IC-LM launch shape), 2: the ICGN2D1
+//    default, 3: the ICGN2D2 default (deeper gathers, fewer registers per wave budget), 4: per-workgroup coordinate
+//    table, target array only (measured within 2 % of variant 2 on config B: LDS reads are not free either).
+// Round 1's G = 2 and software-pipelined variants never won a sweep and are gone.
 //        id  G mode pipe wpb occ
 #define OC_ICGN2D_VARIANTS(X) \
     X(0, 3, 0, 0, 1, 1)       \
     X(1, 3, 1, 0, 1, 4)       \
     X(2, 3, 1, 0, 4, 4)       \
     X(3, 4, 1, 0, 1, 3)       \
-    X(4, 2, 1, 0, 1, 4)       \
-    X(5, 2, 1, 0, 4, 4)       \
-    X(6, 2, 0, 1, 1, 1)
+    X(4, 3, 4, 0, 8, 4)
 
-constexpr int kIcgn2dVariants = 7;
+constexpr int kIcgn2dVariants = 5;
 
 int icgn2d_variant_count() { return kIcgn2dVariants; }
 
@@ -708,8 +765,8 @@ int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int
 int icgn2d_max_samples(int variant) {
     int g, mode, pipe, wpb, occ;
     if (icgn2d_variant_info(variant, &g, &mode, &pipe, &wpb, &occ)) return 0;
-    const int arrays = mode == 0 ? 4 : 2;
-    return kLdsBudget / (arrays * wpb * (int)sizeof(float) * kWave) * kWave;
+    const int arrays = mode == 0 ? 4 : (mode == 4 ? 1 : 2);
+    return kLdsBudget / ((arrays * wpb + (mode >= 3 ? 3 : 0)) * (int)sizeof(float) * kWave) * kWave;
 }
 
 template <int DOF>

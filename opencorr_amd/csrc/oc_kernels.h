@@ -43,6 +43,11 @@ hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_floats,
                           hipStream_t stream);
 int icgn2d_variant_count();
 int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int* occ);
+// variants with a per-workgroup coordinate table (mode >= 3) need one subset radius per launch
+inline bool icgn2d_variant_uses_table(int variant) {
+    int g, mode, pipe, wpb, occ;
+    return icgn2d_variant_info(variant, &g, &mode, &pipe, &wpb, &occ) == 0 && mode >= 3;
+}
 // largest (2rx+1)*(2ry+1) a variant accepts
 int icgn2d_max_samples(int variant);
 

@@ -111,7 +111,7 @@ def test_fftcc2d_fused_kernel_matches_rocfft_pipeline(eng, speckle_small, r):
     assert (fused[:-3, 16] > 0.5).mean() > 0.9
 
 
-@pytest.mark.parametrize("variant,xcd", [(0, 0), (1, 1), (2, 1), (5, 0), (6, 1), (3, 0), (4, 1)])
+@pytest.mark.parametrize("variant,xcd", [(0, 0), (1, 1), (2, 1), (3, 0), (4, 1), (4, 0)])
 def test_icgn2d1_variants_identical_bits(eng, speckle_small, variant, xcd):
     """Every kernel variant / workgroup mapping of oc_hip_set_tuning computes the same bits."""
     import oracle
@@ -130,6 +130,51 @@ def test_icgn2d1_variants_identical_bits(eng, speckle_small, variant, xcd):
     icgn.set_tuning("icgn2d_xcd", xcd)
     got = icgn.compute(pois.copy())
     assert np.array_equal(_bits(got), _bits(want))
+
+
+@pytest.mark.parametrize("variant", [4])
+@pytest.mark.parametrize("dof", [6, 12])
+def test_icgn2d_coordinate_table_variants(eng, speckle_small, variant, dof):
+    """The variants with a per-workgroup coordinate table (one barrier, then waves may leave early): guard trippers,
+    rejected and NaN POIs, a queue length that fills neither the last workgroup nor its last wave's table share, a
+    non-square subset, centre offsets, and the fallback to a table-free variant under self-adaptive radii -- all
+    bit-identical to the oracle."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    rx, ry = (13, 9) if dof == 6 else (10, 12)
+    xs, ys = synth.poi_grid_2d(h, w, 11, 9, 24)   # 99 POIs
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, 12, 12, pois)
+    P = oracle.P2
+    extra = oracle.make_pois2d([3.0, 90.0, 90.0, 90.0, w - 12.0], [80.0, 80.0, 80.0, 80.0, 100.0])
+    extra[1, P["u"]] = 200.0
+    extra[2, P["zncc"]] = -1.0
+    extra[3, P["v"]] = np.nan
+    extra[4, P["u"]], extra[4, P["ux"]] = 1.0, 0.4
+    pois = np.concatenate([extra[:2], pois, extra[2:]]).astype(np.float32)   # 104 POIs, the trippers spread over workgroups
+    prep = oracle.Prepared2D(ref, tar)
+    fn = oracle.icgn2d1 if dof == 6 else oracle.icgn2d2
+    icgn = (eng.ICGN2D1 if dof == 6 else eng.ICGN2D2)(rx, ry, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    icgn.set_tuning("icgn2d_variant", variant)
+    want = pois.copy()
+    fn(prep, rx, ry, 0.001, 10, want, order=oracle.ORDER_LANES, lanes=64)
+    assert np.array_equal(_bits(icgn.compute(pois.copy())), _bits(want))
+    off = np.random.default_rng(variant).uniform(-2, 2, (len(pois), 2)).astype(np.float32)
+    want = pois.copy()
+    fn(prep, rx, ry, 0.001, 10, want, order=oracle.ORDER_LANES, lanes=64, center_offsets=off)
+    assert np.array_equal(_bits(icgn.compute_with_offsets(pois.copy(), off)), _bits(want))
+    # self-adaptive radii cannot share a table: the engine falls back to a table-free variant by itself
+    sa = pois.copy()
+    sa[:, P["srx"]] = np.random.default_rng(1).integers(6, rx + 1, len(sa))
+    sa[:, P["sry"]] = np.random.default_rng(2).integers(6, ry + 1, len(sa))
+    want = sa.copy()
+    fn(prep, rx, ry, 0.001, 10, want, order=oracle.ORDER_LANES, lanes=64, self_adaptive=True)
+    icgn.set_self_adaptive(True)
+    assert np.array_equal(_bits(icgn.compute(sa.copy())), _bits(want))
 
 
 def test_icgn2d_tile_schedule_changes_no_bits(eng, speckle_small):
