@@ -118,11 +118,20 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    # OC_BENCH_ONE_DEVICE=1 (tests only): every rank uses GPU 0 and the collective runs over gloo, so that the N > 1
+    # control flow (sharding, double-buffered queues, overlapped gathers, barriers) can be exercised on a one-GPU box.
+    # Numbers of such a run mean nothing.
+    one_device = os.environ.get("OC_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import opencorr_amd
     from opencorr_amd import synth
