@@ -38,6 +38,27 @@ def test_prepare3d_fields_bit_exact(volumes):
     assert np.array_equal(_bits(icgn.read_field("coef")), _bits(coef))
 
 
+@pytest.mark.parametrize("shape", [(37, 41, 43), (20, 130, 17), (65, 16, 520), (37, 41, 44), (16, 18, 16), (61, 15, 260)])
+def test_prepare3d_odd_shapes_bit_exact(shape):
+    """The walking prepare kernels on shapes that exercise their tails: runs that are no multiple of 15 / 64, rows that
+    are not 16-byte aligned (scalar kernels) and rows that are (16-byte kernels), more than one x block / row segment,
+    dimensions barely above the 15-voxel minimum of the engine."""
+    import opencorr_amd
+    import oracle
+    rng = np.random.default_rng(sum(shape))
+    ref = rng.uniform(0, 255, shape).astype(np.float32)
+    tar = rng.uniform(0, 255, shape).astype(np.float32)
+    icgn = opencorr_amd.ICGN3D1(4, 4, 4, 0.001, 20)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    gx, gy, gz = oracle.gradient3d(ref)
+    coef = oracle.bspline3d_prefilter(tar)
+    assert np.array_equal(_bits(icgn.read_field("gx")), _bits(gx))
+    assert np.array_equal(_bits(icgn.read_field("gy")), _bits(gy))
+    assert np.array_equal(_bits(icgn.read_field("gz")), _bits(gz))
+    assert np.array_equal(_bits(icgn.read_field("coef")), _bits(coef))
+
+
 @pytest.mark.parametrize("r", [(8, 8, 8), (6, 8, 10)])
 def test_fftcc3d_matches_oracle(volumes, r):
     import opencorr_amd

@@ -25,7 +25,9 @@ def main(db_path, out_path, top=40):
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_us", "avg_us", "median_us", "min_us", "max_us", "percent", "vgpr", "sgpr", "lds_bytes",
                     "scratch_bytes"])
-        for r in rows[:top]:
+        # the top kernels by time, plus every kernel of this library however small (torch's synthetic-data kernels can crowd
+        # them out of the top rows)
+        for r in [r for i, r in enumerate(rows) if i < top or "ochip::" in r[0]]:
             name = r[0] if len(r[0]) < 160 else r[0][:157] + "..."
             w.writerow([name, r[1], "%.3f" % (r[2] / 1e3), "%.3f" % (r[3] / 1e3), "%.3f" % (median[r[0]] / 1e3), "%.3f" % (r[4] / 1e3),
                         "%.3f" % (r[5] / 1e3), "%.2f" % (100.0 * r[2] / total), r[6], r[7], r[8], r[9]])
