@@ -215,7 +215,7 @@ int oc_hip_group_queue(const oc_hip_engine* engine, int member, const void** dev
 
 /* Performance knobs; every setting computes bit-identical results.
  *   "icgn2d_variant"  index into the ICGN2D kernel-variant table (gather depth, LDS footprint, per-workgroup
- *                     coordinate table, waves per workgroup)
+ *                     coordinate table, waves per workgroup); -1 (the default) lets the engine choose by subset size
  *   "icgn2d_xcd"      1: workgroups of one XCD serve a contiguous range of the POI queue
  *   "icgn2d_tile_px"  side of the square image tiles the ICGN2D queue is visited by (L2 locality; 0 = queue order)
  *   "fftcc2d_fused"   1: single-kernel FFTCC2D (LDS / register FFT) for square windows of side 20, 24, 30, 32,

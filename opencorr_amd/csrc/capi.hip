@@ -149,7 +149,7 @@ struct oc_hip_engine {
     FftPlans fft;
     DevBuf win, freq, norms, flags;
     // kernel selection (oc_hip_set_tuning); every choice computes the same bits
-    int icgn2d_variant = 2;   // G = 3, LDS-light, 4 waves per workgroup (MI355X sweep)
+    int icgn2d_variant = -1;  // -1 = automatic (run_icgn2d; MI355X sweeps), else the variant oc_hip_set_tuning chose
     bool self_adaptive = false;  // DIC::setSelfAdaptive
     int icgn2d_xcd = 1;
     int fftcc2d_fused = 1;    // single-kernel FFTCC2D when the window is 32 x 32
@@ -219,7 +219,6 @@ int create_engine(int kind, int rx, int ry, int rz, float conv, float stop, int 
     e->stop = stop;
     // MI355X sweep (profiles/r01b_icgn2d*_variant_sweep.json): 12 DoF keeps more registers live, so
     // the single-wave G = 4 variant wins there
-    if (kind == OC_HIP_ICGN2D2) e->icgn2d_variant = 3;
     OC_HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     *out = e.release();
@@ -429,6 +428,12 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
     const long long N = (2LL * rx + 1) * (2LL * ry + 1);
     // fall back to the LDS-light single-wave variant when the tuned one cannot hold the subset
     int variant = e->icgn2d_variant;
+    if (variant < 0) {
+        // ICGN2D1: the coordinate-table variant at 6 waves per SIMD while three of its workgroups fit a CU's LDS (subsets up
+        // to 19 passes of 64 samples, i.e. 35 x 34), the LDS-light 4-wave workgroups beyond; ICGN2D2: deeper gathers
+        const long long passes = ((2LL * rx + 1) * (2LL * ry + 1) + 63) / 64;
+        variant = dof == 12 ? 3 : (passes <= 19 ? 5 : 2);
+    }
     if (e->self_adaptive && ochip::icgn2d_variant_uses_table(variant)) variant = 2;  // per-POI radii: no shared coordinate table
     if (lm) variant = 1;  // the IC-LM launch shape has the LDS footprint of variant 1
     if (N > ochip::icgn2d_max_samples(variant)) variant = 1;
@@ -1158,8 +1163,8 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
     std::lock_guard<std::mutex> lock(e->mu);
     const std::string k(key);
     if (k == "icgn2d_variant") {
-        if (value < 0 || value >= ochip::icgn2d_variant_count())
-            return fail(OC_HIP_ERR_INVALID, "icgn2d_variant %d out of range [0,%d)", value, ochip::icgn2d_variant_count());
+        if (value < -1 || value >= ochip::icgn2d_variant_count())
+            return fail(OC_HIP_ERR_INVALID, "icgn2d_variant %d out of range [-1 (automatic), %d)", value, ochip::icgn2d_variant_count());
         e->icgn2d_variant = value;
     } else if (k == "icgn2d_xcd" || k == "xcd") {
         e->icgn2d_xcd = value != 0;

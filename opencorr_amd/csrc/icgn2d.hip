@@ -21,6 +21,14 @@
 
 #include "dic2d_device.h"
 #include "oc_kernels.h"
+// OC_ABLATE2D (experiments only, tools/ablate_icgn2d.sh; the shipped library is built without it): 1 = every POI runs
+// exactly three iterations (no convergence test, no abort) so that builds can be compared; 2 = from the second iteration
+// on the table gathers are confined to a 16 KB window per plane (L1 hits); 4 = from the second iteration on the gathers
+// are not issued at all (stale registers) -- what a register-resident coefficient cache could save at best.
+#ifndef OC_ABLATE2D
+#define OC_ABLATE2D 0
+#endif
+
 namespace ochip {
 
 // ---------------------------------------------------------------------------
@@ -349,6 +357,9 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         cur[0] = u_in; cur[1] = ux_in; cur[2] = uy_in;
         cur[6] = v_in; cur[7] = vx_in; cur[8] = vy_in;
     }
+#if OC_ABLATE2D & 4
+    LutFetch f_stale[G] = {};  // coefficients survive from the first iteration
+#endif
 #pragma nounroll
     do {
         iter++;
@@ -410,7 +421,13 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                         ay = valid[g] ? ay : 1.f;
                     }
                     bool out;
-                    lut_fetch<LM != 0>(f[g], r_lut, height, width, ax, ay, out);
+                    if constexpr ((OC_ABLATE2D & 6) != 0) {
+                        unsigned off = lut_locate<LM != 0>(f[g], height, width, ax, ay, out);
+                        if (OC_ABLATE2D & 2) off = iter > 1 ? (off & 0x3ff0u) : off;
+                        if (!(OC_ABLATE2D & 4) || iter == 1) r_lut.load(f[g], off);
+                    } else {
+                        lut_fetch<LM != 0>(f[g], r_lut, height, width, ax, ay, out);
+                    }
                     if constexpr (!LM) negative = negative || out;
                 }
             };
@@ -435,14 +452,22 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             int t0 = 0;
 #pragma nounroll
             for (int q = 0; q < full_groups; q++, t0 += G) {
+#if OC_ABLATE2D & 4
+                LutFetch(&f)[G] = f_stale;
+#else
                 LutFetch f[G];
+#endif
                 bool valid[G];
                 issue(f, valid, t0, std::false_type{});
                 consume(f, valid, t0, std::false_type{});
             }
 #pragma nounroll
             for (; t0 < NT; t0 += G) {
+#if OC_ABLATE2D & 4
+                LutFetch(&f)[G] = f_stale;
+#else
                 LutFetch f[G];
+#endif
                 bool valid[G];
                 issue(f, valid, t0, std::true_type{});
                 consume(f, valid, t0, std::true_type{});
@@ -450,7 +475,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         }
         // src/oc_icgn.cpp:251-255 (the IC-LM classes have no such check)
         if constexpr (!LM) {
-            if (wave_any(negative)) {
+            if (!(OC_ABLATE2D & 1) && wave_any(negative)) {
                 if (lane == 0) poi[poi2d::ZNCC] = -3.f;
                 return;
             }
@@ -654,7 +679,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             }
             dp_norm = uni(sqrtf(d));
         }
-    } while (iter < P.stop && dp_norm >= P.conv);
+    } while ((OC_ABLATE2D & 1) ? iter < 3 : (iter < P.stop && dp_norm >= P.conv));
 
     // ---- outputs (src/oc_icgn.cpp:310-340; 2D2: 860-897)
     if (lane == 0) {
@@ -737,7 +762,10 @@ static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, siz
 // 0: everything per sample parked in LDS, one wave per workgroup (the first design; kept as the reference point of the
 //    sweeps), 1: LDS-light single wave (the fallback for large subsets and the IC-LM launch shape), 2: the ICGN2D1
 //    default, 3: the ICGN2D2 default (deeper gathers, fewer registers per wave budget), 4: per-workgroup coordinate
-//    table, target array only (measured within 2 % of variant 2 on config B: LDS reads are not free either).
+//    table, target array only, 5: the same with G = 2 inside 80 VGPRs, i.e. three 8-wave workgroups (6 waves per SIMD)
+//    per CU -- the ICGN2D1 default.  Interleaved A/B timing on config B (tools/variant_ab.py,
+//    profiles/r02w_icgn2d1_variant_ab.json): 2: 3.71 ms, 4: 3.65, 5: 3.64; G = 3 at 6 waves per SIMD spills (4.29 ms),
+//    G = 4 / G = 1 / 5 waves per SIMD lose 1 - 4 %.  The kernel is VALU-issue bound: occupancy barely matters.
 // Round 1's G = 2 and software-pipelined variants never won a sweep and are gone.
 //        id  G mode pipe wpb occ
 #define OC_ICGN2D_VARIANTS(X) \
@@ -745,9 +773,10 @@ static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, siz
     X(1, 3, 1, 0, 1, 4)       \
     X(2, 3, 1, 0, 4, 4)       \
     X(3, 4, 1, 0, 1, 3)       \
-    X(4, 3, 4, 0, 8, 4)
+    X(4, 3, 4, 0, 8, 4)       \
+    X(5, 2, 4, 0, 8, 6)
 
-constexpr int kIcgn2dVariants = 5;
+constexpr int kIcgn2dVariants = 6;
 
 int icgn2d_variant_count() { return kIcgn2dVariants; }
 

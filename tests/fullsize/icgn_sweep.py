@@ -63,7 +63,7 @@ def main():
     torch.cuda.synchronize()
     pois = start.clone()
 
-    nvar = 5
+    nvar = 6
     variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(nvar))
     xcds = [int(v) for v in args.xcd.split(",")]
     tiles = [int(v) for v in args.tile_px.split(",")] if args.tile_px else [None]

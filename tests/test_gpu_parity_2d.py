@@ -111,7 +111,7 @@ def test_fftcc2d_fused_kernel_matches_rocfft_pipeline(eng, speckle_small, r):
     assert (fused[:-3, 16] > 0.5).mean() > 0.9
 
 
-@pytest.mark.parametrize("variant,xcd", [(0, 0), (1, 1), (2, 1), (3, 0), (4, 1), (4, 0)])
+@pytest.mark.parametrize("variant,xcd", [(0, 0), (1, 1), (2, 1), (2, 0), (3, 0), (4, 1), (4, 0), (5, 1), (5, 0)])
 def test_icgn2d1_variants_identical_bits(eng, speckle_small, variant, xcd):
     """Every kernel variant / workgroup mapping of oc_hip_set_tuning computes the same bits."""
     import oracle
@@ -132,7 +132,7 @@ def test_icgn2d1_variants_identical_bits(eng, speckle_small, variant, xcd):
     assert np.array_equal(_bits(got), _bits(want))
 
 
-@pytest.mark.parametrize("variant", [4])
+@pytest.mark.parametrize("variant", [4, 5])
 @pytest.mark.parametrize("dof", [6, 12])
 def test_icgn2d_coordinate_table_variants(eng, speckle_small, variant, dof):
     """The variants with a per-workgroup coordinate table (one barrier, then waves may leave early): guard trippers,

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""A/B timing of ICGN2D kernel variants on config B with HIP events, variants interleaved round by round so that clock
+drift hits all of them alike.  usage: python tools/variant_ab.py 2,7,9 [rounds] [launches]   (GPU box)"""
+import json
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import opencorr_amd as oc
+from opencorr_amd import synth
+
+variants = [int(v) for v in sys.argv[1].split(",")]
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+launches = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+dev = torch.device("cuda", 0)
+side, r, ns = 4096, 16, 500
+ref, tar = synth.speckle_pair_2d(side, side, seed=20260925, device=dev)
+xs, ys = synth.poi_grid_2d(side, side, ns, ns, r + 8)
+stream = torch.cuda.current_stream().cuda_stream
+f = oc.FFTCC2D(r, r); f.set_stream(stream); f.set_images(ref, tar)
+g = oc.ICGN2D1(r, r, 0.001, 10.0); g.set_stream(stream); g.share_images(f); g.prepare()
+guess = torch.from_numpy(oc.make_pois2d(xs, ys)).to(dev)
+f.compute(guess)
+q = guess.clone()
+times = {v: [] for v in variants}
+bits = {}
+for rd in range(rounds + 1):
+    for v in variants:
+        g.set_tuning("icgn2d_variant", v)
+        tot = 0.0
+        for _ in range(launches):
+            q.copy_(guess)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); g.compute(q); b.record(); b.synchronize()
+            tot += a.elapsed_time(b)
+        if rd:  # round 0 warms up
+            times[v].append(tot / launches)
+        bits[v] = q.cpu().numpy().view(np.uint32)
+first = bits[variants[0]]
+print(json.dumps({"workload": "config B, ICGN2D1 compute() incl. the tile-order kernels, HIP events", "launches_per_round": launches,
+                  "ms": {str(v): [round(t, 4) for t in ts] for v, ts in times.items()},
+                  "mean_ms": {str(v): round(float(np.mean(ts)), 4) for v, ts in times.items()},
+                  "same_bits": {str(v): bool(np.array_equal(bits[v], first)) for v in variants}}))
