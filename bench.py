@@ -29,9 +29,10 @@ complete inside the timed region.
 blocks); the default is weak scaling as described above.
 
 Besides the contract fields the JSON line carries
-  roofline     -- ICGN2D1 kernel, judged against the roof that BINDS it.  The kernel is fp32-VALU-issue bound
-                  (SQ_ACTIVE_INST_VALU covers ~90 % of its cycles, HBM traffic is 5 % of peak, the
-                  L2 -> L1 gather ~45 % of the L2 figure), so `achieved` = the reference algorithm's own floating
+  roofline     -- ICGN2D1 kernel, judged against the roof it sits closest to: fp32 VALU issue (71 % of
+                  the SIMDs' issue slots carry a VALU instruction; HBM traffic is <= 9 % of peak, the L2 -> L1 gather
+                  ~45 % of the L2 figure; ablations show that no single resource binds alone), so `achieved` = the
+                  reference algorithm's own floating
                   point operations (50*N2 + 75*N2*k per POI with that POI's iteration count k, every multiply, add,
                   subtract counted once: the parity contract forbids FMA contraction) / the hipEvent-timed kernel
                   duration, `peak` = the chip's fp32 vector rate for separately rounded operations

@@ -23,19 +23,32 @@ __device__ __forceinline__ float uni(float v) {
 // choice, multipliers f = a_rk / a_kk, eliminations a_rc -= f * a_kc, the two
 // triangular solves) is the one the sequential algorithm performs on that element, so
 // the result is bit-identical to oracle lu_inverse(); only the element -> lane
-// placement differs.  Multipliers and pivots are broadcast with v_readlane (SGPRs).
-template <int n>
-__device__ __forceinline__ void lu_inverse_lanes(float (&col)[n], float (&inv)[n], int lane) {
+// placement differs.  Multipliers and pivots are broadcast lane to lane (`bcast`).
+// `bcast(v, k)` hands every lane the value lane k of ITS matrix holds: v_readlane for one matrix per wave
+// (WaveBcast), a ds_bpermute inside 8-lane groups when a wave factors eight matrices at once (GroupBcast8; pivots and
+// the row permutation are then per-lane values, uniform inside a group).
+struct WaveBcast {
+    __device__ __forceinline__ float operator()(float v, int k) const { return wave_bcast(v, k); }
+};
+struct GroupBcast8 {
+    int base;  // byte address of the group's lane 0 in ds_bpermute terms
+    __device__ __forceinline__ explicit GroupBcast8(int lane) : base((lane & ~7) << 2) {}
+    __device__ __forceinline__ float operator()(float v, int k) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(base + (k << 2), __builtin_bit_cast(int, v)));
+    }
+};
+template <int n, class Bcast = WaveBcast>
+__device__ __forceinline__ void lu_inverse_lanes(float (&col)[n], float (&inv)[n], int lane, const Bcast& bcast = Bcast()) {
     int perm[n];  // wave-uniform row permutation
 #pragma unroll
     for (int i = 0; i < n; i++) perm[i] = i;
 #pragma unroll
     for (int k = 0; k < n; k++) {
         int piv = k;
-        float best = fabsf(wave_bcast(col[k], k));
+        float best = fabsf(bcast(col[k], k));
 #pragma unroll
         for (int r = k + 1; r < n; r++) {
-            const float v = fabsf(wave_bcast(col[r], k));
+            const float v = fabsf(bcast(col[r], k));
             if (v > best) { best = v; piv = r; }
         }
 #pragma unroll
@@ -48,10 +61,10 @@ __device__ __forceinline__ void lu_inverse_lanes(float (&col)[n], float (&inv)[n
             perm[k] = sw ? pb : pa;
             perm[r] = sw ? pa : pb;
         }
-        const float d = wave_bcast(col[k], k);
+        const float d = bcast(col[k], k);
 #pragma unroll
         for (int r = k + 1; r < n; r++) {
-            const float f = wave_bcast(col[r], k) / d;
+            const float f = bcast(col[r], k) / d;
             const float upd = col[r] - f * col[k];
             col[r] = lane == k ? f : (lane > k ? upd : col[r]);
         }
@@ -62,18 +75,40 @@ __device__ __forceinline__ void lu_inverse_lanes(float (&col)[n], float (&inv)[n
     for (int i = 0; i < n; i++) {
         float v = (perm[i] == lane) ? 1.f : 0.f;
 #pragma unroll
-        for (int j = 0; j < i; j++) v = v - wave_bcast(col[i], j) * y[j];
+        for (int j = 0; j < i; j++) v = v - bcast(col[i], j) * y[j];
         y[i] = v;
     }
 #pragma unroll
     for (int i = n - 1; i >= 0; i--) {
         float v = y[i];
 #pragma unroll
-        for (int j = i + 1; j < n; j++) v = v - wave_bcast(col[i], j) * y[j];
-        y[i] = v / wave_bcast(col[i], i);
+        for (int j = i + 1; j < n; j++) v = v - bcast(col[i], j) * y[j];
+        y[i] = v / bcast(col[i], i);
     }
 #pragma unroll
     for (int i = 0; i < n; i++) inv[i] = y[i];
+}
+
+// Cooperative inverse of the eight 6 x 6 Hessians of an 8-wave workgroup (icgn2d.hip, ICGN2D1): every wave has filed the
+// 21 totals of its lower triangle (row-major, h[i(i+1)/2 + j]) at area[64 w .. 64 w + 20]; ONE wave factors all eight
+// matrices in a single instruction stream -- matrix g in lanes 8g .. 8g+5, lane 8g+j holding column j -- and leaves
+// H^-1 of matrix g row-major at area[64 g + 24 .. 64 g + 59].  Per matrix the operations are those of lu_inverse_lanes,
+// so the bits are the oracle's; the other seven waves do not spend their ~900 VALU instructions (128 v_readlane, 21
+// divisions) on a computation that uses six lanes.
+__device__ __forceinline__ void coop_inverse6_x8(float* __restrict__ area, int lane) {
+    const int g = lane >> 3, j = min(lane & 7, 5);  // lanes 6, 7 of a group shadow lane 5
+    float* __restrict__ mine = area + g * 64;
+    float col[6], inv[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const int r = max(i, j), c = min(i, j);
+        col[i] = mine[(r * (r + 1)) / 2 + c];  // H(i, j) = H(j, i)
+    }
+    lu_inverse_lanes<6, GroupBcast8>(col, inv, j, GroupBcast8(lane));
+    if ((lane & 7) < 6) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) mine[24 + i * 6 + j] = inv[i];  // H^-1(i, j)
+    }
 }
 
 template <int n>

@@ -24,7 +24,9 @@
 // OC_ABLATE2D (experiments only, tools/ablate_icgn2d.sh; the shipped library is built without it): 1 = every POI runs
 // exactly three iterations (no convergence test, no abort) so that builds can be compared; 2 = from the second iteration
 // on the table gathers are confined to a 16 KB window per plane (L1 hits); 4 = from the second iteration on the gathers
-// are not issued at all (stale registers) -- what a register-resident coefficient cache could save at best.
+// are not issued at all (stale registers) -- what a register-resident coefficient cache could save at best; 8 = from the
+// second iteration on the 43-operation polynomial is replaced by 6 operations on four of the fetched coefficients (the
+// gathers stay): how much of the kernel's time is VALU issue.
 #ifndef OC_ABLATE2D
 #define OC_ABLATE2D 0
 #endif
@@ -78,9 +80,21 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     constexpr bool TAB = MODE >= 3;
     constexpr bool KEEP_RS = MODE != 4;  // the zero-mean reference subset is parked in LDS
     constexpr int ARRAYS = MODE == 0 ? 4 : (MODE == 4 ? 1 : 2);
+    // ICGN2D1 in 8-wave workgroups: the eight 6 x 6 Hessians are inverted by ONE wave (coop_inverse6_x8); two more
+    // barriers, which every wave passes exactly once -- also the ones that abandon their POI early (leave())
+    constexpr bool COOP = MODE == 4 && DOF == 6 && LM == 0 && WPB == 8;
+    __shared__ float coop_area[COOP ? WPB * 64 : 1];
     const int NTA = L.nt;  // passes the LDS arrays are sized for (>= the passes of any POI)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto leave = [&]() {
+        if constexpr (COOP) {
+            if (lane < 24) coop_area[wave * 64 + lane] = 0.f;
+            __syncthreads();
+            if (wave == 0) coop_inverse6_x8(coop_area, lane);
+            __syncthreads();
+        }
+    };
     // TAB: [NTA*64] float pairs (x_local, y_local), then [NTA*64] byte offsets; the waves' own arrays follow
     f2* __restrict__ tab_xy = reinterpret_cast<f2*>(lds);
     unsigned* __restrict__ tab_off = reinterpret_cast<unsigned*>(lds + 2 * NTA * kWave);
@@ -93,14 +107,17 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             tab_xy[s] = mk2((float)(c - P.rx), (float)(r - P.ry));
             tab_off[s] = (unsigned)r * w4t + ((unsigned)c << 2);
         }
-        __syncthreads();  // the only barrier of the kernel; waves that leave early below are past it
+        __syncthreads();  // waves that leave early below are past this barrier (and pass COOP's two in leave())
     }
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD a
     // contiguous range of the queue so POIs that share LUT lines meet in the same L2.
     unsigned long long grp = blockIdx.x;
     if (L.xcd_chunk > 0) grp = (unsigned long long)(blockIdx.x & 7u) * L.xcd_chunk + (blockIdx.x >> 3);
     const unsigned long long slot = grp * WPB + wave;
-    if (slot >= L.count) return;
+    if (slot >= L.count) {
+        leave();
+        return;
+    }
     // the k-th wave of the launch solves POI perm[k] (a locality schedule) or simply POI k
     const unsigned long long idx = P.perm ? (unsigned long long)__builtin_amdgcn_readfirstlane((int)P.perm[slot]) : slot;
     // (no __restrict__: in MODE 4 the two names denote one array -- the reference values pass through it before the
@@ -126,6 +143,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         // reference would reallocate; here the POI is rejected like any other unusable POI
         if (rx < 0 || ry < 0 || (2 * rx + 1) * (2 * ry + 1) > NTA * kWave) {
             if (lane == 0) poi[poi2d::ZNCC] = zncc_in >= 0 ? -3.f : zncc_in;
+            leave();
             return;
         }
     }
@@ -139,6 +157,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     if (py - ry < 0 || px - rx < 0 || py + ry > height - 1 || px + rx > width - 1 || fabsf(u_in) >= width ||
         fabsf(v_in) >= height || zncc_in < 0 || isnan(u_in) || isnan(v_in)) {
         if (lane == 0) poi[poi2d::ZNCC] = zncc_in >= 0 ? -3.f : zncc_in;
+        leave();
         return;
     }
     const int W = 2 * rx + 1, N = W * (2 * ry + 1);
@@ -286,32 +305,44 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 for (int c = 0; c <= r; c++, k++)
                     h[k % NH] = (c == r && (r & 1) == 0) ? hd[r] : ((c & 1) ? hp[r][c / 2].y : hp[r][c / 2].x);
         }
-        // lane j < DOF assembles column j of the symmetric Hessian
-        float col[DOF];
-#pragma unroll
-        for (int i = 0; i < DOF; i++) col[i] = 0.f;
-        wave_allreduce_sum_multi<NH>(h, lane);  // all NH sums in one transposing butterfly (oc_device.h)
-        int k = 0;
-#pragma unroll
-        for (int i = 0; i < DOF; i++)
-#pragma unroll
-            for (int j = 0; j <= i; j++) {
-                const float v = h[k++];
-                if (lane == j) col[i] = v;  // H(i,j)
-                if (lane == i) col[j] = v;  // H(j,i)
-            }
-        if constexpr (LM) {
-#pragma unroll
-            for (int i = 0; i < DOF; i++) hcol[i] = col[i];
+        if constexpr (COOP) {
+            // the totals go to LDS, wave 0 inverts the workgroup's eight Hessians at once
+            wave_reduce_sum_multi_to_lds<NH>(h, lane, coop_area + wave * 64);
+            __syncthreads();
+            if (wave == 0) coop_inverse6_x8(coop_area, lane);
+            __syncthreads();
         } else {
-            lu_inverse_lanes<DOF>(col, hinv_col, lane);
+            // lane j < DOF assembles column j of the symmetric Hessian
+            float col[DOF];
+#pragma unroll
+            for (int i = 0; i < DOF; i++) col[i] = 0.f;
+            wave_allreduce_sum_multi<NH>(h, lane);  // all NH sums in one transposing butterfly (oc_device.h)
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < DOF; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) {
+                    const float v = h[k++];
+                    if (lane == j) col[i] = v;  // H(i,j)
+                    if (lane == i) col[j] = v;  // H(j,i)
+                }
+            if constexpr (LM) {
+#pragma unroll
+                for (int i = 0; i < DOF; i++) hcol[i] = col[i];
+            } else {
+                lu_inverse_lanes<DOF>(col, hinv_col, lane);
+            }
         }
     }
     // IC-GN: H^-1 stays fixed, so it is transposed once -- lane i (< DOF) gets ROW i of H^-1 -- and every iteration's
     // dp[i] = sum_j H^-1(i,j) * num[j] is formed inside lane i (ascending j, as the reference's loop) and handed round
     // with DOF broadcasts, instead of DOF x DOF v_readlane per iteration (6.2 cycles each on gfx950).
     float hinv_row[LM ? 1 : DOF];
-    if constexpr (!LM) {
+    if constexpr (COOP) {
+        const float* __restrict__ row = coop_area + wave * 64 + 24 + min(lane, DOF - 1) * DOF;
+#pragma unroll
+        for (int j = 0; j < DOF; j++) hinv_row[j] = lane < DOF ? row[j] : 0.f;
+    } else if constexpr (!LM) {
 #pragma unroll
         for (int j = 0; j < DOF; j++) hinv_row[j] = 0.f;
 #pragma unroll
@@ -435,7 +466,11 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 constexpr bool CHECKED = decltype(checked)::value;
 #pragma unroll
                 for (int g = 0; g < G; g++) {
+#if OC_ABLATE2D & 8
+                    const float v = iter > 1 ? f[g].c0.x + f[g].c1.y * f[g].dx + f[g].c2.z * f[g].dy + f[g].c3.w : lut_poly(f[g]);
+#else
                     const float v = LM ? lut_eval(f[g]) : lut_poly(f[g]);
+#endif
                     if constexpr (CHECKED) {
                         negative = negative || (valid[g] && v < 0.f);
                         acc = valid[g] ? acc + v : acc;
@@ -721,7 +756,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
 // oc_hip_set_tuning("icgn2d_variant", i) / ("icgn2d_xcd", 0|1); defaults chosen from the
 // MI355X sweep in DESIGN.md section 4.
 // ---------------------------------------------------------------------------
-constexpr int kLdsBudget = 160 * 1024;
+constexpr int kLdsBudget = 160 * 1024 - 2048;  // dynamic LDS; 2 KB stay free for the static area of the cooperative inverse
 
 struct VariantInfo {
     int g, mode, pipe, wpb, occ;

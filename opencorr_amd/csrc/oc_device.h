@@ -99,6 +99,45 @@ __device__ __forceinline__ void wave_allreduce_sum_multi(float (&v)[K], int lane
     }
 }
 
+// The same reduction, but the K totals are filed into LDS (dst[0..K)) by the four lanes that hold them after the row
+// levels instead of being broadcast to the wave: for a consumer in another wave (icgn2d.hip, cooperative inverse).
+template <int K>
+__device__ __forceinline__ void wave_reduce_sum_multi_to_lds(float (&v)[K], int lane, float* __restrict__ dst) {
+    constexpr int H = (K + 1) / 2, H2 = (H + 1) / 2;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        v[k] = v[k] + dpp_perm<0xB1>(v[k]);  // xor 1
+        v[k] = v[k] + dpp_perm<0x4E>(v[k]);  // xor 2
+    }
+    const bool odd_quad = (lane & 4) != 0, high8 = (lane & 8) != 0;
+    float d[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+        const float a = v[i], b = (i + H < K) ? v[(i + H) % K] : 0.f;
+        const float keep = odd_quad ? b : a, give = odd_quad ? a : b;
+        d[i] = keep + dpp_perm<0x141>(give);
+    }
+    float e[H2];
+#pragma unroll
+    for (int j = 0; j < H2; j++) {
+        const float a = d[j], b = (j + H2 < H) ? d[(j + H2) % H] : 0.f;
+        const float keep = high8 ? b : a, give = high8 ? a : b;
+        e[j] = keep + dpp_perm<0x128>(give);
+    }
+#pragma unroll
+    for (int j = 0; j < H2; j++) {
+        e[j] = e[j] + __shfl_xor(e[j], 16, kWave);
+        e[j] = e[j] + __shfl_xor(e[j], 32, kWave);
+    }
+    // lane 0 holds values 0 .. H2-1, lane 8 values H2 .. H-1, lane 4 values H .. H+H2-1, lane 12 the rest
+    const int i0 = high8 ? H2 : 0, k0 = (odd_quad ? H : 0) + i0;
+    if ((lane & ~12) == 0) {
+#pragma unroll
+        for (int j = 0; j < H2; j++)
+            if (i0 + j < H && k0 + j < K) dst[k0 + j] = e[j];
+    }
+}
+
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
 }  // namespace ochip
