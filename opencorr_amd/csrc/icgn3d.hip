@@ -32,6 +32,7 @@
 // -DOC_ABLATE=<mask> leaves a phase out and runs a fixed number of iterations, so that timing differences price the
 // phases.  Results of such a build are garbage; the product is always built with the mask at 0.
 //   1 = no coefficient staging (global -> LDS)   2 = no tap evaluation   4 = no Hessian sweep   8 = no numerator sweep
+//   32 = taps addressed with a row pitch of 33 floats (wrong rows, but no LDS bank conflicts: what a conflict-free layout is worth)
 //   16 = timeline: results stay valid, and the six strain floats of every POI record receive the shader-clock
 //        kilocycles its workgroup spent in  reference stats | Hessian sweep + reduction | LU inverse | warped-subvolume
 //        sweeps (boxes, staging, taps) | mean / norm / numerator sweeps + reductions | solve + warp update
@@ -259,7 +260,7 @@ __device__ __forceinline__ float bspline3d_eval(const float* __restrict__ coef, 
 template <int PX>
 __device__ __forceinline__ float bspline3d_eval_lds(const float* __restrict__ win, int ox, int oy, int oz, int nx_rt, int nxy,
                                                     int dz, int dy, int dx, float x, float y, float z) {
-    const int nx = PX ? PX : nx_rt;
+    const int nx = (OC_ABLATE & 32) ? 33 : (PX ? PX : nx_rt);  // ablation 32: a pitch of 33 reads garbage, but free of bank conflicts
     const bool out = (x < 1 || y < 1 || z < 1 || x >= dx - 2 || y >= dy - 2 || z >= dz - 2 || isnan(x) || isnan(y) ||
                       isnan(z));
     const int xi = out ? ox + 1 : (int)floorf(x), yi = out ? oy + 1 : (int)floorf(y), zi = out ? oz + 1 : (int)floorf(z);
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
             }
             lap(3);
             // src/oc_icgn.cpp:1396-1400
-            if (__syncthreads_or(out_of_range && !(OC_ABLATE & 15) ? 1 : 0)) {
+            if (__syncthreads_or(out_of_range && !(OC_ABLATE & 47) ? 1 : 0)) {
                 failed = true;
                 break;
             }
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
             // src/oc_icgn.cpp:1445
             dp_norm = uni3(sqrtf(dp[0] * dp[0] + dp[4] * dp[4] + dp[8] * dp[8]));
             lap(5);
-        } while (iter < P.stop && ((OC_ABLATE & 15) ? iter < 3 : dp_norm >= P.conv));
+        } while (iter < P.stop && ((OC_ABLATE & 47) ? iter < 3 : dp_norm >= P.conv));
 
         if (failed) {
             if (tid == 0) poi[poi3d::ZNCC] = -3.f;
