@@ -35,6 +35,6 @@ PY
 for mask in ${MASKS:-0 1 3 5}; do
   hipcc --offload-arch=gfx950 -c opencorr_amd/csrc/icgn2d.hip -o /tmp/icgn2d_ab.o $FLAGS -DOC_ABLATE2D=$mask || exit 1
   hipcc --offload-arch=gfx950 -shared -o /tmp/libablate2d_$mask.so $OBJS /tmp/icgn2d_ab.o -L/opt/rocm/lib -lrocfft -ldl -lpthread || exit 1
-  echo -n "mask $mask: "
+  echo -n "mask $mask: " | tee -a $OUT/ablate2d.txt
   OPENCORR_HIP_LIB=/tmp/libablate2d_$mask.so timeout 300 python /tmp/time2d.py 2>&1 | tail -1 | tee -a $OUT/ablate2d.txt
 done

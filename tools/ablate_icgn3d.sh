@@ -34,6 +34,6 @@ PY
 for mask in ${MASKS:-0 16}; do
   hipcc --offload-arch=gfx950 -c opencorr_amd/csrc/icgn3d.hip -o /tmp/icgn3d_ab.o $FLAGS -DOC_ABLATE=$mask || exit 1
   hipcc --offload-arch=gfx950 -shared -o /tmp/libablate_$mask.so $OBJS /tmp/icgn3d_ab.o -L/opt/rocm/lib -lrocfft -ldl -lpthread || exit 1
-  echo -n "mask $mask: "
+  echo -n "mask $mask: " | tee -a $OUT/ablate.txt
   OPENCORR_HIP_LIB=/tmp/libablate_$mask.so timeout 300 python /tmp/time3d.py 2>&1 | tail -1 | tee -a $OUT/ablate.txt
 done
