@@ -111,6 +111,31 @@ def test_fftcc2d_fused_kernel_matches_rocfft_pipeline(eng, speckle_small, r):
     assert (fused[:-3, 16] > 0.5).mean() > 0.9
 
 
+def test_fftcc2d_setsubset_replans(eng, speckle_small):
+    """FFTCC2D::setSubset between computes (examples/test_3d_dic_epipolar_sift.cpp:188-190): the engine drops its FFT
+    plans / picks another kernel for the new window -- fused 32 -> rocFFT pipeline (rx != ry) -> fused 40 -> fused 32
+    again, each pass equal to a fresh engine of that radius and to the oracle."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    xs, ys = synth.poi_grid_2d(h, w, 17, 13, 30)
+    base = eng.make_pois2d(xs, ys)
+    f = eng.FFTCC2D(16, 16)
+    f.set_images(ref, tar)
+    for rx, ry in [(16, 16), (9, 13), (20, 20), (16, 16)]:
+        f.set_subset(rx, ry)
+        got = f.compute(base.copy())
+        fresh = eng.FFTCC2D(rx, ry)
+        fresh.set_images(ref, tar)
+        assert np.array_equal(_bits(got), _bits(fresh.compute(base.copy()))), (rx, ry)
+        want = base.copy()
+        oracle.fftcc2d(ref, tar, rx, ry, want)
+        for col in (2, 8, 14, 15):
+            assert np.array_equal(got[:, col], want[:, col]), (rx, ry, col)
+        assert np.abs(got[:, 16] - want[:, 16]).max() <= 3e-5
+
+
 @pytest.mark.parametrize("variant,xcd", [(0, 0), (1, 1), (2, 1), (2, 0), (3, 0), (4, 1), (4, 0), (5, 1), (5, 0)])
 def test_icgn2d1_variants_identical_bits(eng, speckle_small, variant, xcd):
     """Every kernel variant / workgroup mapping of oc_hip_set_tuning computes the same bits."""

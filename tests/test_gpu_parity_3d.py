@@ -81,6 +81,33 @@ def test_fftcc3d_matches_oracle(volumes, r):
     assert np.array_equal(_bits(got[:, untouched]), _bits(want[:, untouched]))
 
 
+def test_fftcc3d_setsubset_replans(volumes):
+    """FFTCC3D::setSubset between computes: the rocFFT plans are rebuilt for the new window, every pass equal to a fresh
+    engine and (integer results) to the oracle."""
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = volumes
+    xs, ys, zs = synth.poi_grid_3d(*SHAPE, 3, 3, 2, 26)
+    base = oracle.make_pois3d(xs, ys, zs)
+    f = opencorr_amd.FFTCC3D(8, 8, 8)
+    f.set_images(ref, tar)
+    P = oracle.P3
+    for r in [(8, 8, 8), (6, 9, 7), (10, 10, 10), (8, 8, 8)]:
+        f.set_subset(*r)
+        got = base.copy()
+        f.compute(got)
+        fresh = opencorr_amd.FFTCC3D(*r)
+        fresh.set_images(ref, tar)
+        again = base.copy()
+        fresh.compute(again)
+        assert np.array_equal(_bits(got), _bits(again)), r
+        want = base.copy()
+        oracle.fftcc3d(ref, tar, r[0], r[1], r[2], want)
+        for key in ("u", "v", "w", "u0", "v0", "w0"):
+            assert np.array_equal(got[:, P[key]], want[:, P[key]]), (r, key)
+
+
 def test_fftcc3d_fused_kernel_matches_oracle_and_rocfft_pipeline(volumes):
     """r = 16: the single-kernel FFTCC3D (fftcc3d_fused.hip).  Same integer peak as the oracle and as the rocFFT
     pipeline; ZNCC within 2e-6 of the pipeline and within north_star's 1e-4 of the oracle -- at 32^3 voxels the
