@@ -193,6 +193,38 @@ struct FloatWalk {
     }
 };
 
+// Passes 0 .. NT-1 of a lane's samples with the global loads of up to B passes in flight: `load(t, valid)` issues the
+// loads of pass t (and captures whatever the walk says about it), `use(t, valid, v)` consumes them -- in pass order, so
+// every running sum keeps its association.  A timeline of the one-wave-per-POI kernels showed the
+// passes of the set-up phase waiting ~2 k cycles each for ONE dependent round trip; with B passes per round trip the
+// phase shrinks accordingly.  Passes [0, NF) are full, pass NF (if NF < NT) holds the lanes with `tail_valid`.
+template <int B, class Load, class Use>
+__device__ __forceinline__ void passes_batched(int NF, int NT, bool tail_valid, Load&& load, Use&& use) {
+    int t = 0;
+#pragma unroll 1
+    for (; t + B <= NF; t += B) {
+        decltype(load(0, true)) v[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) v[u] = load(t + u, true);
+#pragma unroll
+        for (int u = 0; u < B; u++) use(t + u, true, v[u]);
+    }
+    // the remaining full passes and the partial one as a last, shorter batch (B - 1 full passes at most + the tail)
+    {
+        decltype(load(0, true)) v[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            if (t + u < NF) v[u] = load(t + u, true);
+            else if (t + u < NT) v[u] = load(t + u, tail_valid);
+        }
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            if (t + u < NF) use(t + u, true, v[u]);  // (a literal `true` folds the validity selects away)
+            else if (t + u < NT) use(t + u, tail_valid, v[u]);
+        }
+    }
+}
+
 // One LUT entry in flight: address generation and the four 16-byte loads are issued for a
 // whole group of G samples before any polynomial is evaluated, so each lane keeps G*64 B
 // of gathers outstanding (the interpolation sweep is latency/L1-bandwidth bound).  Only the

@@ -26,7 +26,10 @@
 // on the table gathers are confined to a 16 KB window per plane (L1 hits); 4 = from the second iteration on the gathers
 // are not issued at all (stale registers) -- what a register-resident coefficient cache could save at best; 8 = from the
 // second iteration on the 43-operation polynomial is replaced by 6 operations on four of the fetched coefficients (the
-// gathers stay): how much of the kernel's time is VALU issue.
+// gathers stay): how much of the kernel's time is VALU issue; 16 = timeline: results stay valid, and exx / eyy / exy / feature of
+// every POI record receive the kilocycles (s_memtime) its wave spent in  reference subset + Hessian sweep | Hessian
+// reduction + inverse (incl. the barriers of the cooperative form) | interpolation sweeps, all iterations | everything
+// else inside the iterations (norms, numerator pass, solve, warp update).
 #ifndef OC_ABLATE2D
 #define OC_ABLATE2D 0
 #endif
@@ -72,6 +75,13 @@ struct Icgn2dLaunch {
     unsigned long long count;  // POIs
 };
 
+// what a pass of the Hessian sweep / the numerator pass fetches for one sample (passes_batched): the reference gradients,
+// the reference value where it is not parked in LDS, and -- for the walking variants -- the sample's local coordinates
+struct GradSample {
+    float gx, gy, ref = 0.f;
+    f2 xy = {0.f, 0.f};
+};
+
 template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC, int OFFS, int LM = 0>
 __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, float* __restrict__ pois,
                                                                Icgn2dLaunch L) {
@@ -83,10 +93,25 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     // ICGN2D1 in 8-wave workgroups: the eight 6 x 6 Hessians are inverted by ONE wave (coop_inverse6_x8); two more
     // barriers, which every wave passes exactly once -- also the ones that abandon their POI early (leave())
     constexpr bool COOP = MODE == 4 && DOF == 6 && LM == 0 && WPB == 8;
+    // passes whose global loads are issued together in the load-then-use loops outside the interpolation sweep
+    // (reference subset, Hessian sweep, numerator pass): one dependent round trip per batch instead of one per pass
+    constexpr int kSetupBatch = 6;
+    constexpr int kHessBatch = DOF == 6 ? 6 : 1;  // the 78 running sums of the 12-DoF Hessian leave no room for a batch
+    constexpr int kNumBatch = DOF == 6 ? 6 : 4;
     __shared__ float coop_area[COOP ? WPB * 64 : 1];
     const int NTA = L.nt;  // passes the LDS arrays are sized for (>= the passes of any POI)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    [[maybe_unused]] unsigned long long tl_mark = __builtin_readcyclecounter();
+    [[maybe_unused]] unsigned long long tl[4] = {0, 0, 0, 0};
+    auto lap = [&](int slot) {
+        if constexpr ((OC_ABLATE2D & 16) != 0) {
+            __builtin_amdgcn_sched_barrier(0);  // keep the surrounding arithmetic on its side of the stamp
+            const unsigned long long now = __builtin_readcyclecounter();
+            tl[slot] += now - tl_mark;
+            tl_mark = now;
+        }
+    };
     auto leave = [&]() {
         if constexpr (COOP) {
             if (lane < 24) coop_area[wave * 64 + lane] = 0.f;
@@ -187,18 +212,17 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         float acc = 0.f;
         SampleWalk w(lane, r0, c0, W, q64, r64);
         // (MODE 4 parks the raw values in the target array, which is idle until the first sweep)
-#pragma unroll 3
-        for (int t = 0; t < NF; t++, w.next()) {
-            const float v = buf_f32(r_ref, TAB ? off_at(t) : soff(w), roff);
-            acc = acc + v;
-            l_rs[t * kWave] = v;
-        }
-        if (NF < NT) {
-            const bool valid = (NF * kWave + lane) < N;
-            const float v = valid ? buf_f32(r_ref, TAB ? off_at(NF) : soff(w), roff) : 0.f;
-            acc = valid ? acc + v : acc;
-            l_rs[NF * kWave] = v;
-        }
+        passes_batched<kSetupBatch>(
+            NF, NT, (NF * kWave + lane) < N,
+            [&](int t, bool valid) {
+                const unsigned off = TAB ? off_at(t) : soff(w);
+                w.next();
+                return valid ? buf_f32(r_ref, off, roff) : 0.f;
+            },
+            [&](int t, bool valid, float v) {
+                acc = valid ? acc + v : acc;
+                l_rs[t * kWave] = v;
+            });
         const float mean = wave_allreduce_sum(acc) / fN;
         ref_mean = uni(mean);
         acc = 0.f;
@@ -230,15 +254,24 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             // products in the same order).  With A = (sd1, sd2) = g_x*(x, y), B = (sd4, sd5) = g_y*(x, y):
             f2 hAA = mk2(0.f, 0.f), hBB = hAA, hAB = hAA, hAs = hAA, hxA = hAA, hyA = hAA, hxB = hAA, hyB = hAA;
             float h00 = 0.f, h33 = 0.f, h30 = 0.f, h21 = 0.f, h54 = 0.f;
-            auto sample = [&](int t, bool valid) {
+            auto fetch = [&](int t, bool valid) {
+                GradSample v;
                 const unsigned off = TAB ? off_at(t) : soff(w);
-                const float g_x = valid ? buf_f32(r_gx, off, goff) : 0.f;
-                const float g_y = valid ? buf_f32(r_gy, off, goff) : 0.f;
+                v.gx = valid ? buf_f32(r_gx, off, goff) : 0.f;
+                v.gy = valid ? buf_f32(r_gy, off, goff) : 0.f;
+                if constexpr (!TAB) v.xy = mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
+                w.next();
+                return v;
+            };
+            auto sample = [&](int t, bool valid, const GradSample& v) {
+                const float g_x = v.gx, g_y = v.gy;
                 if constexpr (MODE == 0) {
                     l_gx[t * kWave] = g_x;
                     l_gy[t * kWave] = g_y;
                 }
-                const f2 xy = TAB ? tab_at(t) - mk2(offx, offy) : mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
+                f2 xy;
+                if constexpr (TAB) xy = tab_at(t) - mk2(offx, offy);
+                else xy = v.xy;
                 const f2 A = g_x * xy, B = g_y * xy;
                 const f2 nAA = hAA + A * A, nBB = hBB + B * B, nAB = hAB + A * B, nAs = hAs + A * B.yx;
                 const f2 nxA = hxA + g_x * A, nyA = hyA + g_y * A, nxB = hxB + g_x * B, nyB = hyB + g_y * B;
@@ -249,9 +282,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     h00 = n00; h33 = n33; h30 = n30; h21 = n21; h54 = n54;
                 }
             };
-#pragma unroll 1
-            for (int t = 0; t < NF; t++, w.next()) sample(t, true);
-            if (NF < NT) sample(NF, (NF * kWave + lane) < N);
+            passes_batched<kHessBatch>(NF, NT, (NF * kWave + lane) < N, fetch, sample);
             // back to the row-major lower triangle h[i*(i+1)/2 + j]
             h[0] = h00;                                                           // (0,0)
             h[1] = hxA.x; h[2] = hAA.x;                                           // (1,0) (1,1)
@@ -271,15 +302,24 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
 #pragma unroll
                 for (int q = 0; q < 6; q++) hp[r][q] = mk2(0.f, 0.f);
             }
-            auto sample = [&](int t, bool valid) {
+            auto fetch = [&](int t, bool valid) {
+                GradSample v;
                 const unsigned off = TAB ? off_at(t) : soff(w);
-                const float g_x = valid ? buf_f32(r_gx, off, goff) : 0.f;
-                const float g_y = valid ? buf_f32(r_gy, off, goff) : 0.f;
+                v.gx = valid ? buf_f32(r_gx, off, goff) : 0.f;
+                v.gy = valid ? buf_f32(r_gy, off, goff) : 0.f;
+                if constexpr (!TAB) v.xy = mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
+                w.next();
+                return v;
+            };
+            auto sample = [&](int t, bool valid, const GradSample& v) {
+                const float g_x = v.gx, g_y = v.gy;
                 if constexpr (MODE == 0) {
                     l_gx[t * kWave] = g_x;
                     l_gy[t * kWave] = g_y;
                 }
-                const f2 lxy = TAB ? tab_at(t) - mk2(offx, offy) : mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
+                f2 lxy;
+                if constexpr (TAB) lxy = tab_at(t) - mk2(offx, offy);
+                else lxy = v.xy;
                 const float fxl = lxy.x, fyl = lxy.y;
                 const float xx = (fxl * fxl) * 0.5f, xy = fxl * fyl, yy = (fyl * fyl) * 0.5f;
                 const f2 m01 = mk2(1.f, fxl), m23 = mk2(fyl, xx), m45 = mk2(xy, yy);  // g * 1.f is exact
@@ -295,9 +335,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     if ((r & 1) == 0) hd[r] = valid ? hd[r] + sr * sr : hd[r];
                 }
             };
-#pragma unroll 1
-            for (int t = 0; t < NF; t++, w.next()) sample(t, true);
-            if (NF < NT) sample(NF, (NF * kWave + lane) < N);
+            passes_batched<kHessBatch>(NF, NT, (NF * kWave + lane) < N, fetch, sample);
             int k = 0;
 #pragma unroll
             for (int r = 0; r < 12; r++)
@@ -305,6 +343,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 for (int c = 0; c <= r; c++, k++)
                     h[k % NH] = (c == r && (r & 1) == 0) ? hd[r] : ((c & 1) ? hp[r][c / 2].y : hp[r][c / 2].x);
         }
+        lap(0);
         if constexpr (COOP) {
             // the totals go to LDS, wave 0 inverts the workgroup's eight Hessians at once
             wave_reduce_sum_multi_to_lds<NH>(h, lane, coop_area + wave * 64);
@@ -354,6 +393,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             }
     }
 
+    lap(1);
     // ---- IC-GN loop (src/oc_icgn.cpp:216-307; 2D2: 762-858)
     // 2D1: 3x3 warp matrix, wave-uniform in SGPRs.  2D2: 6x6 warp matrix, column j in lane j;
     // rows 3 and 4 (the ones Deformation2D2::warp needs) are broadcast once per iteration.
@@ -401,6 +441,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 row4[k] = wave_bcast(Wcol[4], k);
             }
         }
+        lap(3);
         // warped target subset (src/oc_icgn.cpp:230-242; 2D2: 784-796)
         bool negative = false;
         float acc = 0.f;
@@ -508,6 +549,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 consume(f, valid, t0, std::true_type{});
             }
         }
+        lap(2);
         // src/oc_icgn.cpp:251-255 (the IC-LM classes have no such check)
         if constexpr (!LM) {
             if (!(OC_ABLATE2D & 1) && wave_any(negative)) {
@@ -542,18 +584,25 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             f2 np12[6];                       // DOF 12: (num0, num1) .. (num10, num11)
 #pragma unroll
             for (int q = 0; q < 6; q++) np12[q] = mk2(0.f, 0.f);
-            auto sample = [&](int t, bool valid) {
-                float g_x, g_y;
-                [[maybe_unused]] float ref_v = 0.f;
+            auto fetch = [&](int t, bool valid) {
+                GradSample v;
                 if constexpr (MODE == 0) {
-                    g_x = l_gx[t * kWave];
-                    g_y = l_gy[t * kWave];
+                    v.gx = l_gx[t * kWave];
+                    v.gy = l_gy[t * kWave];
                 } else {
                     const unsigned off = TAB ? off_at(t) : (kFloatWalk ? fw.off : soff(w));
-                    g_x = valid ? buf_f32(r_gx, off, goff) : 0.f;
-                    g_y = valid ? buf_f32(r_gy, off, goff) : 0.f;
-                    if constexpr (!KEEP_RS) ref_v = valid ? buf_f32(r_ref, off, roff) : 0.f;
+                    v.gx = valid ? buf_f32(r_gx, off, goff) : 0.f;
+                    v.gy = valid ? buf_f32(r_gy, off, goff) : 0.f;
+                    if constexpr (!KEEP_RS) v.ref = valid ? buf_f32(r_ref, off, roff) : 0.f;
                 }
+                if constexpr (!TAB) v.xy = kFloatWalk ? fw.xy : mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
+                if constexpr (kFloatWalk) fw.next();
+                else w.next();
+                return v;
+            };
+            auto sample = [&](int t, bool valid, const GradSample& v) {
+                const float g_x = v.gx, g_y = v.gy;
+                [[maybe_unused]] const float ref_v = v.ref;
                 const float tz = l_ts[t * kWave] - tmean;  // same bits as in the norm pass
                 // the zero-mean reference value: parked in LDS, or re-formed from the image (same subtraction, same bits)
                 const float rsv = KEEP_RS ? l_rs[t * kWave] : ref_v - ref_mean;
@@ -561,8 +610,9 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 const float e2 = e * e;
                 ssd = valid ? ssd + e2 : ssd;
                 if constexpr (DOF == 6) {
-                    const f2 xy = TAB ? tab_at(t) - mk2(offx, offy)
-                                      : (kFloatWalk ? fw.xy : mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy));
+                    f2 xy;
+                    if constexpr (TAB) xy = tab_at(t) - mk2(offx, offy);
+                    else xy = v.xy;
                     const f2 A = g_x * xy, B = g_y * xy;  // (sd1, sd2), (sd4, sd5)
                     const f2 mA = nA + A * e, mB = nB + B * e;
                     const float m0 = num[0] + g_x * e, m3 = num[3] + g_y * e;
@@ -570,7 +620,9 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                         nA = mA; nB = mB; num[0] = m0; num[3] = m3;
                     }
                 } else {
-                    const f2 lxy = TAB ? tab_at(t) - mk2(offx, offy) : mk2((float)(w.c - rx) - offx, (float)(w.r - ry) - offy);
+                    f2 lxy;
+                    if constexpr (TAB) lxy = tab_at(t) - mk2(offx, offy);
+                    else lxy = v.xy;
                     const float fxl = lxy.x, fyl = lxy.y;
                     const float xx = (fxl * fxl) * 0.5f, xy = fxl * fyl, yy = (fyl * fyl) * 0.5f;
                     const f2 m01 = mk2(1.f, fxl), m23 = mk2(fyl, xx), m45 = mk2(xy, yy);
@@ -582,15 +634,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     }
                 }
             };
-            if constexpr (kFloatWalk) {
-#pragma unroll 3
-                for (int t = 0; t < NF; t++, fw.next()) sample(t, true);
-                if (NF < NT) sample(NF, (NF * kWave + lane) < N);
-            } else {
-#pragma unroll 3
-                for (int t = 0; t < NF; t++, w.next()) sample(t, true);
-                if (NF < NT) sample(NF, (NF * kWave + lane) < N);
-            }
+            passes_batched<kNumBatch>(NF, NT, (NF * kWave + lane) < N, fetch, sample);
             if constexpr (DOF == 6) {
                 num[1] = nA.x; num[2] = nA.y; num[4] = nB.x; num[5] = nB.y;
             } else {
@@ -716,8 +760,15 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         }
     } while ((OC_ABLATE2D & 1) ? iter < 3 : (iter < P.stop && dp_norm >= P.conv));
 
+    lap(3);
     // ---- outputs (src/oc_icgn.cpp:310-340; 2D2: 860-897)
     if (lane == 0) {
+        if constexpr ((OC_ABLATE2D & 16) != 0) {
+            poi[20] = (float)tl[0] * 1e-3f;  // strain exx, eyy, exy and result.feature (src/oc_poi.h:102-136)
+            poi[21] = (float)tl[1] * 1e-3f;
+            poi[22] = (float)tl[2] * 1e-3f;
+            poi[19] = (float)tl[3] * 1e-3f;
+        }
         float zncc = 0.5f * (2 - znssd);
         const float fiter = (float)iter;
         if (dp_norm >= P.conv && fiter >= P.stop) zncc = -4.f;

@@ -30,7 +30,9 @@ for _ in range(6):
     q.copy_(pristine); torch.cuda.synchronize(); t0 = time.perf_counter(); g.compute(q); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 res = q.cpu().numpy()
 print(json.dumps(dict(ms_best=min(ts) * 1e3, ms_median=sorted(ts)[len(ts) // 2] * 1e3, pois=len(xs), mean_iter=float(res[:, 17].mean()),
-                      converged=int((res[:, 16] >= 0).sum()))))
+                      converged=int((res[:, 16] >= 0).sum()),
+                      timeline_kcycles=dict(zip(['ref_and_hessian_sweep', 'hessian_reduce_inverse', 'interpolation_sweeps', 'rest_of_iterations'],
+                                                [float(v) for v in res[:, [20, 21, 22, 19]].astype(np.float64).mean(0)])))))
 PY
 for mask in ${MASKS:-0 1 3 5}; do
   hipcc --offload-arch=gfx950 -c opencorr_amd/csrc/icgn2d.hip -o /tmp/icgn2d_ab.o $FLAGS -DOC_ABLATE2D=$mask || exit 1
