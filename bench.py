@@ -29,17 +29,18 @@ complete inside the timed region.
 blocks); the default is weak scaling as described above.
 
 Besides the contract fields the JSON line carries
-  roofline     -- ICGN2D1 kernel, judged against the roof it sits closest to: fp32 VALU issue (71 % of
-                  the SIMDs' issue slots carry a VALU instruction; HBM traffic is <= 9 % of peak, the L2 -> L1 gather
-                  ~45 % of the L2 figure; ablations show that no single resource binds alone), so `achieved` = the
-                  reference algorithm's own floating
-                  point operations (50*N2 + 75*N2*k per POI with that POI's iteration count k, every multiply, add,
-                  subtract counted once: the parity contract forbids FMA contraction) / the hipEvent-timed kernel
-                  duration, `peak` = the chip's fp32 vector rate for separately rounded operations
-                  (256 CUs x 4 SIMD32 x 2.4 GHz = 78.6 Tflop/s, half the 157.3 Tflop/s FMA figure of
-                  MI355X_MICROARCH.md).  The SURVEY 8(d) byte count (3*N2*4 + k*N2*64 + 200 per POI) is kept as
-                  `algorithmic_rate` (bytes are served by L2/L1, so it may exceed the HBM peak) next to the HBM
-                  traffic measured with PMC counters in a separate, committed profiling run,
+  roofline     -- ICGN2D1 kernel, judged against the roof it sits closest to.  HBM is not it (traffic <= 9 % of peak:
+                  neighbouring subsets share their table entries in L1/L2, so the SURVEY 8(d) byte count / time exceeds
+                  the HBM peak); ablations show the gather path of the 64-byte table entries to be the
+                  larger limiter (-13 % without two thirds of the gathers, -3 % without two thirds of the polynomials),
+                  so `achieved` = the SURVEY 8(d) bytes (3*N2*4 + k*N2*64 + 200 per POI, k = that POI's iteration
+                  count) / the hipEvent-timed kernel duration against `peak` = the guide's aggregate L2 figure
+                  (34.5 TB/s); `gather_ubench` sets the same rate against a compute-free gather of the same pattern,
+                  `valu` the reference's own floating point operations (50*N2 + 75*N2*k per POI, every multiply, add,
+                  subtract counted once: the parity contract forbids FMA contraction) against the chip's fp32 vector
+                  rate for separately rounded operations (256 CUs x 4 SIMD32 x 2.4 GHz = 78.6 Tflop/s, half the
+                  157.3 Tflop/s FMA figure of MI355X_MICROARCH.md); HBM traffic measured with PMC counters in a
+                  separate, committed profiling run is attached as `hbm_traffic_profiled`,
   cpu_baseline -- the CPU oracle (float32 restatement of the reference, OpenMP; pinned bit for bit on the reference's
                   own sources, tests/test_oracle_vs_ref.py) timed on a bounded sample of the same workload on this
                   box's host cores (rank 0, N = 1), built -O3 -march=native for timing,
@@ -62,6 +63,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # fp32 vector peak for separately rounded multiplies / adds: 256 CUs x 4 SIMD32 x 32 lanes x 2.4 GHz (the guide's
 # 157.3 Tflop/s counts an FMA as two operations; FMA contraction is excluded by the parity contract)
 VALU_PEAK_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+L2_PEAK_GBS = 34500.0       # aggregate L2 bandwidth, MI355X_MICROARCH.md ("4 MiB per XCD ... ~34.5 TB/s")
+GATHER_UBENCH_GBS = 20350.0  # compute-free gather of the kernel's own access pattern, profiles/r02a_gather_ubench.txt
 # HBM bytes per ICGN2D1 launch of THIS workload from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in their
 # own runs, corrected as the guide prescribes); written by tools/pmc_traffic.py, see tools/gpu_round.sh
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "icgn2d1_hbm_traffic_configB.json")
@@ -287,21 +290,28 @@ def main():
                 "all_gather_alone_ms": gather_alone_ms,
             },
             "roofline": {
+                # the roof the kernel sits closest to: the L1 / L2 gather of the 64-byte table entries (ablations in
+                # -13 % without two thirds of the gathers, -3 % without two thirds of the polynomials)
                 "kernel": "icgn2d_kernel<6,...> (ICGN2D1)",
-                "bound": "valu",
-                "achieved": achieved,
-                "peak": VALU_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / VALU_PEAK_TFLOPS,
+                "bound": "l2",
+                "achieved": alg_rate,
+                "peak": L2_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": alg_rate / L2_PEAK_GBS,
                 "traffic": None,  # HBM bytes are not collected inside a bench run: see hbm_traffic_profiled
-                "algorithmic_flops_per_launch": alg_flops,
+                "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": icgn_avg_ms,
                 "launches_timed": icgn_launches,
-                "why_not_hbm": "the 64 B/sample table gather is served by L2/L1 (neighbouring subsets overlap): HBM sees ~3 % "
-                               "of the algorithmic bytes, so bytes / time exceeds the HBM peak and says nothing",
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "algorithmic_rate": {"value": alg_rate, "unit": "GB/s", "vs_hbm_peak": alg_rate / HBM_PEAK_GBS,
-                                     "vs_l2_peak_34.5TBs": alg_rate / 34500.0},
+                "why_not_hbm": "the 64 B/sample table gather is served by L1/L2 (neighbouring subsets overlap): HBM sees ~4 % "
+                               "of the algorithmic bytes, so bytes / time exceeds the HBM peak (%.1fx) and says nothing"
+                               % (alg_rate / HBM_PEAK_GBS),
+                "gather_ubench": {"value": GATHER_UBENCH_GBS, "unit": "GB/s", "frac": alg_rate / GATHER_UBENCH_GBS,
+                                  "source": "profiles/r02a_gather_ubench.txt",
+                                  "note": "the same gather pattern with no arithmetic at all (tools/ubench/gather_ubench.hip, "
+                                          "planar table): the kernel's gather rate as a fraction of that ceiling"},
+                "valu": {"achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / VALU_PEAK_TFLOPS,
+                         "algorithmic_flops_per_launch": alg_flops,
+                         "note": "the reference's own fp32 operations over the chip's rate for separately rounded operations"},
                 "hbm_traffic_profiled": prof,
             },
             "stage_ms": {

@@ -51,7 +51,9 @@ namespace ochip {
 //        walk (wrap test, selects) and the int -> float conversions of every pass become one or two LDS reads.
 //        Needs one radius per launch, i.e. not available with self-adaptive subsets.
 // G    = samples whose LUT gathers are issued back to back.
-// PIPE = (retired) software-pipelined sweep of round 1; the parameter stays 0.
+// PIPE = (retired) software-pipelined sweep: the gathers of the next group in flight while this group's polynomials are
+//        evaluated lost in round 1 and again in round 2 (+3.5 % at G = 2 / 4 waves per SIMD, +4 % at G = 1 / 6 waves:
+//        profiles/r03f_icgn2d1_variant_ab_pipelined.json); the parameter stays 0.
 // OCC  = minimum waves per SIMD the register allocation must allow.
 // Wave-uniform small matrices are kept one COLUMN per lane (lane j < n holds column j):
 // the inverse Hessian, and for 2D2 also the 6x6 warp matrix.

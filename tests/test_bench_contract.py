@@ -32,9 +32,10 @@ def test_bench_prints_the_contract_keys():
     assert 'out["cpu_baseline"]' in src and "--no-cpu-baseline" in src
 
 
-def test_algorithmic_flops_formula_and_roofline_fraction_is_bounded():
-    """roofline.frac must be a fraction: flops of the reference's arithmetic over the fp32 vector peak for separately
-    rounded operations.  At the measured 3.7 ms per 250 000-POI launch that is ~0.27."""
+def test_algorithmic_flops_formula_and_roofline_fractions_are_bounded():
+    """roofline.frac must be a fraction.  Main roof: SURVEY 8(d) bytes over the guide's L2 figure (~0.48 at the measured
+    3.5 ms per 250 000-POI launch); `valu`: flops of the reference's arithmetic over the fp32 vector peak for separately
+    rounded operations (~0.28)."""
     import bench
     pois = np.zeros((3, 25), np.float32)
     pois[:, 17] = [3, 0, 5]
@@ -42,5 +43,9 @@ def test_algorithmic_flops_formula_and_roofline_fraction_is_bounded():
     assert bench.algorithmic_flops_icgn2d1(pois, 16, 16) == 2 * 50 * n2 + 8 * 75 * n2
     assert abs(bench.VALU_PEAK_TFLOPS - 78.6432) < 1e-3
     per_poi = 50 * n2 + 75 * n2 * 3.105
-    frac = per_poi * 250000 / 3.7e-3 / 1e12 / bench.VALU_PEAK_TFLOPS
+    frac = per_poi * 250000 / 3.5e-3 / 1e12 / bench.VALU_PEAK_TFLOPS
     assert 0.2 < frac < 0.35
+    bytes_per_poi = 3 * n2 * 4 + 200 + 3.105 * n2 * 64
+    rate = bytes_per_poi * 250000 / 3.5e-3 / 1e9
+    assert 0.3 < rate / bench.L2_PEAK_GBS < 0.6
+    assert 0.6 < rate / bench.GATHER_UBENCH_GBS < 1.0
