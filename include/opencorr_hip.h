@@ -19,6 +19,9 @@
  *     POI2D = 25 floats / 100 B (src/oc_poi.h:102-136), POI3D = 31 floats / 124 B
  *     (src/oc_poi.h:187-222).  `stride_bytes` lets a caller embed them in a
  *     larger struct (must be a multiple of 4).
+ *   - An engine lives on the device named at creation.  Every entry point makes that
+ *     device current for its own duration and hands the calling thread's current
+ *     device back on return.
  *   - `memory` says where a buffer lives: OC_HIP_HOST buffers are copied by the
  *     engine (pageable or pinned), OC_HIP_DEVICE buffers are used in place on the
  *     engine's device and stream (no copy).  On a stream the caller chose with

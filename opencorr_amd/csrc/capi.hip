@@ -198,6 +198,25 @@ int activate(const oc_hip_engine* e) {
     return OC_HIP_OK;
 }
 
+// Entry points make the engine's device current for the calling thread and give the caller's device back on the way
+// out (a host that drives several GPUs from one thread -- torch with more than one device, say -- must not find its
+// current device changed by a library call).
+struct DeviceScope {
+    int saved = -1;
+    DeviceScope() {
+        if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+    }
+    ~DeviceScope() {
+        int now = -1;
+        if (saved >= 0 && hipGetDevice(&now) == hipSuccess && now != saved) (void)hipSetDevice(saved);
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define OC_ACTIVATE(e)        \
+    DeviceScope device_scope; \
+    OC_TRY(activate(e))
+
 int create_engine(int kind, int rx, int ry, int rz, float conv, float stop, int device, oc_hip_engine** out) {
     if (!out) return fail(OC_HIP_ERR_INVALID, "null output handle");
     *out = nullptr;
@@ -208,6 +227,7 @@ int create_engine(int kind, int rx, int ry, int rz, float conv, float stop, int 
     if (err != hipSuccess || ndev <= 0)
         return fail(OC_HIP_ERR_HIP, "no usable HIP device: %s", err == hipSuccess ? "device count is 0" : hipGetErrorString(err));
     if (device < 0 || device >= ndev) return fail(OC_HIP_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    DeviceScope device_scope;
     OC_HIP_TRY(hipSetDevice(device));
     std::unique_ptr<oc_hip_engine> e(new oc_hip_engine);
     e->kind = kind;
@@ -723,7 +743,7 @@ static int strain_stage(oc_hip_engine* e, const void* pois, size_t count, size_t
 // neighbour search over a queue's coordinates; gather_records: also snapshot the fit records (RegionFit's cloud)
 static int plane_prepare(oc_hip_engine* e, int kind, const void* pois, size_t count, size_t stride_bytes, int ndim, int memory,
                          bool gather_records) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     if (e->kind != kind) return fail(OC_HIP_ERR_INVALID, "prepare: wrong engine kind for this entry point");
     std::lock_guard<std::mutex> lock(e->mu);
     e->st_count = 0;
@@ -772,7 +792,7 @@ int oc_hip_region_fit_prepare(oc_hip_engine* e, const void* reliable_pois, size_
 }
 
 int oc_hip_region_fit_compute(oc_hip_engine* e, void* pois, size_t count, size_t stride_bytes, int ndim, int memory) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     if (count == 0) return OC_HIP_OK;
     std::lock_guard<std::mutex> lock(e->mu);
     if (e->kind != OC_HIP_REGION_FIT) return fail(OC_HIP_ERR_INVALID, "not a RegionFit engine");
@@ -800,7 +820,7 @@ int oc_hip_region_fit_compute(oc_hip_engine* e, void* pois, size_t count, size_t
 }
 
 int oc_hip_strain_compute(oc_hip_engine* e, void* pois, size_t count, size_t stride_bytes, int ndim, int memory) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     if (count == 0) return OC_HIP_OK;
     std::lock_guard<std::mutex> lock(e->mu);
     if (e->kind != OC_HIP_STRAIN) return fail(OC_HIP_ERR_INVALID, "not a Strain engine");
@@ -840,6 +860,7 @@ int oc_hip_icgn3d1_create(int rx, int ry, int rz, float conv, float stop, int de
 
 int oc_hip_destroy(oc_hip_engine* e) {
     if (!e) return OC_HIP_OK;
+    DeviceScope device_scope;
     group_drop_comms(e);
     for (oc_hip_engine* r : e->replicas) {
         r->is_replica = false;
@@ -902,7 +923,7 @@ static int upload_image(oc_hip_engine* e, const float* src, size_t count, int me
 
 int oc_hip_set_images2d(oc_hip_engine* e, const float* ref, const float* tar, int height, int width, int layout,
                         int memory) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     if (e->is3d()) return fail(OC_HIP_ERR_INVALID, "set_images2d called on a 3D engine");
     if (!ref || !tar) return fail(OC_HIP_ERR_INVALID, "null image pointer");
     if (height < 5 || width < 5) return fail(OC_HIP_ERR_INVALID, "image too small: %d x %d", width, height);
@@ -939,7 +960,7 @@ int oc_hip_set_images2d(oc_hip_engine* e, const float* ref, const float* tar, in
 
 int oc_hip_set_images3d(oc_hip_engine* e, const float* ref, const float* tar, int dim_x, int dim_y, int dim_z,
                         int memory) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     if (!e->is3d()) return fail(OC_HIP_ERR_INVALID, "set_images3d called on a 2D engine");
     if (!ref || !tar) return fail(OC_HIP_ERR_INVALID, "null volume pointer");
     if (dim_x < 15 || dim_y < 15 || dim_z < 15)
@@ -967,7 +988,7 @@ int oc_hip_set_images3d(oc_hip_engine* e, const float* ref, const float* tar, in
 }
 
 int oc_hip_share_images(oc_hip_engine* e, oc_hip_engine* donor) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     OC_TRY(check_engine(donor));
     if (donor->device != e->device) return fail(OC_HIP_ERR_INVALID, "share_images: engines live on different devices");
     if (!donor->img) return fail(OC_HIP_ERR_INVALID, "share_images: donor has no images");
@@ -1051,6 +1072,7 @@ static int rehome(oc_hip_engine* e, int device) {
 
 int oc_hip_set_devices(oc_hip_engine* e, const int* device_ids, int n_devices) {
     OC_TRY(check_engine(e));
+    DeviceScope device_scope;
     if (e->is_replica) return fail(OC_HIP_ERR_INVALID, "set_devices: this handle is a group member");
     if (!device_ids || n_devices < 1) return fail(OC_HIP_ERR_INVALID, "set_devices: need at least one device id");
     if (n_devices > 1 && (e->kind == OC_HIP_STRAIN || e->kind == OC_HIP_REGION_FIT))
@@ -1143,7 +1165,7 @@ int oc_hip_set_iteration(oc_hip_engine* e, float conv, float stop) {
 // Switching streams: work already enqueued on the old stream (prepare()'s gradient and table kernels, a layout
 // conversion) must not race with computes on the new one, so the old stream is drained first.
 int oc_hip_set_stream(oc_hip_engine* e, void* hip_stream) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     std::lock_guard<std::mutex> lock(e->mu);
     const hipStream_t next = reinterpret_cast<hipStream_t>(hip_stream);
     if (next != e->stream) OC_HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1152,7 +1174,7 @@ int oc_hip_set_stream(oc_hip_engine* e, void* hip_stream) {
 }
 
 int oc_hip_reset_stream(oc_hip_engine* e) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     std::lock_guard<std::mutex> lock(e->mu);
     if (e->stream != e->own_stream) OC_HIP_TRY(hipStreamSynchronize(e->stream));
     e->stream = e->own_stream;
@@ -1190,7 +1212,7 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
 }
 
 int oc_hip_prepare_ref(oc_hip_engine* e) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     if (!e->is_icgn()) return OC_HIP_OK;  // FFTCC::prepare() is empty in the reference
     if (!e->img) return fail(OC_HIP_ERR_INVALID, "prepare: set_images has not been called");
     std::lock_guard<std::mutex> lock(e->mu);
@@ -1220,7 +1242,7 @@ int oc_hip_prepare_ref(oc_hip_engine* e) {
 }
 
 int oc_hip_prepare_tar(oc_hip_engine* e) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     if (!e->is_icgn()) return OC_HIP_OK;
     if (!e->img) return fail(OC_HIP_ERR_INVALID, "prepare: set_images has not been called");
     std::lock_guard<std::mutex> lock(e->mu);
@@ -1573,7 +1595,7 @@ int compute_group_host(oc_hip_engine* e, char* pois, const float* offsets, size_
 extern "C" {
 
 static int compute_impl(oc_hip_engine* e, void* pois, const float* offsets, size_t count, size_t stride_bytes, int memory) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     if (count == 0) return OC_HIP_OK;
     if (!pois) return fail(OC_HIP_ERR_INVALID, "null POI buffer");
     if (stride_bytes < e->poi_bytes() || (stride_bytes & 3))
@@ -1619,7 +1641,7 @@ int oc_hip_compute_one_with_offset(oc_hip_engine* e, void* poi, const float* cen
 
 int oc_hip_select_best(oc_hip_engine* e, const void* candidates, size_t n_candidates, size_t candidate_stride_bytes,
                        const unsigned* segment_starts, size_t n_segments, void* pois, size_t stride_bytes, int memory) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     if (n_segments == 0) return OC_HIP_OK;
     if (!candidates || !segment_starts || !pois) return fail(OC_HIP_ERR_INVALID, "select_best: null argument");
     if (candidate_stride_bytes < OC_HIP_POI2D_BYTES || (candidate_stride_bytes & 3) || stride_bytes < OC_HIP_POI2D_BYTES ||
@@ -1666,7 +1688,7 @@ int oc_hip_set_self_adaptive(oc_hip_engine* e, int enable) {
 }
 
 int oc_hip_synchronize(oc_hip_engine* e) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     OC_HIP_TRY(hipStreamSynchronize(e->stream));
     return OC_HIP_OK;
 }
@@ -1700,7 +1722,7 @@ int oc_hip_get_field(const oc_hip_engine* e, const char* name, const float** ptr
 }
 
 int oc_hip_read_field(oc_hip_engine* e, const char* name, float* host_dst, size_t count) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     const float* p = nullptr;
     size_t n = 0;
     OC_TRY(oc_hip_get_field(e, name, &p, &n));
@@ -1718,7 +1740,7 @@ int oc_hip_profile_enable(oc_hip_engine* e, int enable) {
 }
 
 int oc_hip_profile_reset(oc_hip_engine* e) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     std::lock_guard<std::mutex> lock(e->mu);
     OC_HIP_TRY(hipStreamSynchronize(e->stream));
     clear_events(e);
@@ -1726,7 +1748,7 @@ int oc_hip_profile_reset(oc_hip_engine* e) {
 }
 
 int oc_hip_profile_read(oc_hip_engine* e, double* total_ms, long* launches) {
-    OC_TRY(activate(e));
+    OC_ACTIVATE(e);
     if (!total_ms || !launches) return fail(OC_HIP_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lock(e->mu);
     OC_HIP_TRY(hipStreamSynchronize(e->stream));
