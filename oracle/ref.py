@@ -34,6 +34,17 @@ def build(force=False):
     return _LIB_PATH
 
 
+def build_examples(force=False):
+    """``make -C oracle examples``: the reference's own example mains compiled unmodified against the drop-in headers and
+    linked with libopencorr_hip.so (tests/test_gpu_reference_examples.py runs them on the GPU box).  Needs the reference
+    tree and the built HIP library; returns the list of binaries that exist afterwards."""
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, "examples")):
+        cmd = ["make", "-C", _HERE, "examples", "REF=" + REFERENCE_ROOT] + (["-B"] if force else ["-s"])
+        subprocess.check_call(cmd)
+    out = os.path.join(_HERE, "_ref")
+    return sorted(os.path.join(out, f) for f in os.listdir(out) if f.startswith("example_")) if os.path.isdir(out) else []
+
+
 def available():
     try:
         return lib() is not None

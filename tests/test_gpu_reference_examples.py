@@ -1,0 +1,177 @@
+"""The reference's OWN example mains on the MI355X.
+
+`make -C oracle examples` (run by __graft_entry__.build() wherever the reference tree is mounted) compiles
+examples/test_2d_dic_fftcc_icgn1.cpp, test_2d_dic_fftcc_nr1.cpp and test_2d_dic_strain.cpp UNMODIFIED, where they lie,
+against the drop-in headers of include/opencorr_compat and links them with libopencorr_hip.so; the binaries land in
+oracle/_ref/ (git-ignored build output that travels to the GPU box, like oracle/_ref/liboc_ref.so).  Here they run the way
+a user would run them: in a directory that holds the image pair under the path the examples hard-code
+("d:/dic_tests/2d_dic/...", a relative path on Linux), and the CSV files they write are checked against the reference's
+own result tables (tests/golden/*.npz) with the acceptance of the other golden tests.  No reference source is read or
+needed at run time; without the binaries (no reference tree at build time) the tests skip.
+"""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+DATA = os.path.join("d:", "dic_tests", "2d_dic")
+
+
+def _exe(name):
+    path = os.path.join(REFDIR, "example_" + name)
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/example_%s was not built (needs the reference tree at build time)" % name)
+    return path
+
+
+def _write_bmp8(path, img):
+    """8-bit BMP with a grey palette, rows bottom-up, padded to 4 bytes (what the fixture files are)."""
+    img = np.asarray(img, dtype=np.uint8)
+    h, w = img.shape
+    row = (w + 3) // 4 * 4
+    body = np.zeros((h, row), np.uint8)
+    body[:, :w] = img[::-1]
+    palette = b"".join(struct.pack("<4B", i, i, i, 0) for i in range(256))
+    off = 14 + 40 + len(palette)
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", off + body.size, 0, 0, off))
+        f.write(struct.pack("<IiiHHIIiiII", 40, w, h, 1, 8, 0, body.size, 2835, 2835, 256, 0))
+        f.write(palette)
+        f.write(body.tobytes())
+
+
+def _workdir(tmp_path, golden):
+    d = tmp_path / DATA
+    os.makedirs(d)
+    _write_bmp8(d / "oht_cfrp_0.bmp", golden["ref"])
+    _write_bmp8(d / "oht_cfrp_4.bmp", golden["tar"])
+    return d
+
+
+def _run(exe, cwd):
+    # the examples end with cin.get(): give them an empty stdin
+    out = subprocess.run([exe], cwd=cwd, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0, out.stdout.decode(errors="replace")[-2000:]
+    return out.stdout.decode(errors="replace")
+
+
+def _table(path, ncols):
+    return np.genfromtxt(path, delimiter=",", skip_header=1, usecols=range(ncols))
+
+
+@pytest.mark.gpu
+def test_reference_example_fftcc_icgn1_runs_unmodified(tmp_path, golden):
+    """examples/test_2d_dic_fftcc_icgn1.cpp: Image2D(path) -> FFTCC2D -> ICGN2D1 -> IO2D::saveTable2D /
+    saveDeformationTable2D / saveMap2D, 30 000 POIs on the OHT pair; its CSVs against the reference's own CSVs."""
+    exe = _exe("test_2d_dic_fftcc_icgn1")
+    d = _workdir(tmp_path, golden)
+    log = _run(exe, tmp_path)
+    assert "30000 POIs" in log
+    got = _table(d / "oht_cfrp_4_fftcc_icgn1_r16.csv", 9)   # x y u v u0 v0 zncc iteration convergence
+    # x y u ux uy uxx uxy uyy v vx vy vxx vxy vyy subset_rx subset_ry (src/oc_io.cpp:375-421; the fixture predates the
+    # second-order and radius columns: x y u ux uy v vx vy)
+    de = _table(d / "oht_cfrp_4_fftcc_icgn1_r16_deformation.csv", 16)
+    tab, gde = golden["table"].astype(np.float64), golden["deformation"].astype(np.float64)
+    assert got.shape == tab.shape and np.array_equal(got[:, :2], tab[:, :2])
+    same = (got[:, 4] == tab[:, 4]) & (got[:, 5] == tab[:, 5])
+    assert same.mean() >= 0.999
+    m = (tab[:, 7] < golden["stop"]) & same
+    assert m.sum() > 28000
+    assert np.abs(got[m, 2] - tab[m, 2]).max() <= 2e-4 and np.abs(got[m, 3] - tab[m, 3]).max() <= 2e-4
+    assert np.abs(got[m, 6] - tab[m, 6]).max() <= 1e-5
+    assert (got[m, 7] == tab[m, 7]).mean() >= 0.99
+    assert np.abs(de[m][:, [3, 4, 9, 10]] - gde[m][:, [3, 4, 6, 7]]).max() <= 5e-5
+    assert (de[:, 14] == golden["rx"]).all() and (de[:, 15] == golden["ry"]).all()
+    # the maps and the timing table are written too
+    for name in ("oht_cfrp_4_fftcc_icgn1_r16_u.csv", "oht_cfrp_4_fftcc_icgn1_r16_v.csv", "oht_cfrp_4_fftcc_icgn1_r16_time.csv"):
+        assert os.path.getsize(d / name) > 0
+
+
+@pytest.mark.gpu
+def test_reference_example_fftcc_nr1_runs_unmodified(tmp_path, golden, golden_nr1):
+    """examples/test_2d_dic_fftcc_nr1.cpp (FFTCC2D -> NR2D1) against examples/2d_dic/oht_cfrp_4_fftcc_nr1_r16.csv."""
+    exe = _exe("test_2d_dic_fftcc_nr1")
+    d = _workdir(tmp_path, golden)
+    _run(exe, tmp_path)
+    got = _table(d / "oht_cfrp_4_fftcc_nr1_r16.csv", 9)
+    tab = golden_nr1.astype(np.float64)
+    assert got.shape == tab.shape and np.array_equal(got[:, :2], tab[:, :2])
+    same = (got[:, 4] == tab[:, 4]) & (got[:, 5] == tab[:, 5])
+    assert same.mean() >= 0.999
+    m = (tab[:, 7] < golden["stop"]) & same & (tab[:, 6] > 0)
+    assert m.sum() > 28000
+    assert np.abs(got[m, 2] - tab[m, 2]).max() <= 2e-4 and np.abs(got[m, 3] - tab[m, 3]).max() <= 2e-4
+    assert np.abs(got[m, 6] - tab[m, 6]).max() <= 1e-5
+    assert (got[m, 7] == tab[m, 7]).mean() >= 0.99
+
+
+@pytest.mark.gpu
+def test_reference_example_strain_runs_unmodified(tmp_path, golden, golden_strain):
+    """examples/test_2d_dic_strain.cpp: IO2D::loadTable2D of the ICGN table -> Strain(20, 5) -> saveTable2D.  The input
+    table is the reference's own (written here in its CSV format from the fixture), so that the strains can be held
+    against the reference's own strain columns at the print resolution."""
+    exe = _exe("test_2d_dic_strain")
+    d = _workdir(tmp_path, golden)
+    t = golden_strain["table"]   # x y u v zncc exx eyy exy
+    path = d / "oht_cfrp_4_fftcc_icgn1_r16.csv"
+    with open(path, "w") as f:
+        f.write("x,y,u,v,u0,v0,ZNCC,iteration,convergence,feature,exx,eyy,exy,\n")
+        for r in t:
+            f.write("%.8f,%.8f,%.8f,%.8f,0.00000000,0.00000000,%.8f,3.00000000,0.00010000,0.00000000,0.00000000,0.00000000,0.00000000,\n"
+                    % (r[0], r[1], r[2], r[3], r[4]))
+    _run(exe, tmp_path)
+    got = _table(path, 13)
+    assert got.shape[0] == t.shape[0] and np.array_equal(got[:, :2], t[:, :2])
+    m = t[:, 4] >= golden_strain["zncc_threshold"]
+    for name, c, gc in (("exx", 10, 5), ("eyy", 11, 6), ("exy", 12, 7)):
+        dlt = np.abs(got[m, c] - t[m, gc])
+        assert dlt.max() <= 3e-7, (name, dlt.max())
+        assert np.median(dlt) <= 6e-9, (name, np.median(dlt))
+    assert not got[~m][:, 10:13].any()
+
+
+@pytest.mark.gpu
+def test_reference_example_dvc_fftcc_icgn1_runs_unmodified(tmp_path):
+    """examples/test_dvc_fftcc_icgn1.cpp: Image3D(path) of two `.bin` volumes -> FFTCC3D -> ICGN3D1 (r = 30, 7 x 7 x 117
+    POIs) -> IO3D::saveTable3D.  The reference ships no volumes, so the pair is synthetic (written under the file names
+    the example hard-codes); the CSV must hold what the Python mirror computes from the same files, to the print
+    resolution, and recover the analytic displacement field."""
+    import torch
+    import opencorr_amd
+    from opencorr_amd import synth
+    exe = _exe("test_dvc_fftcc_icgn1")
+    dz, dy, dx = 704, 104, 104
+    ref, tar = synth.speckle_pair_3d(dz, dy, dx, seed=41, device=torch.device("cuda", 0))
+    ref, tar = ref.cpu().numpy(), tar.cpu().numpy()
+    d = tmp_path / "d:" / "dic_tests" / "dvc"
+    os.makedirs(d)
+    for name, vol in (("al_foam4_0.bin", ref), ("al_foam4_1.bin", tar)):
+        with open(d / name, "wb") as f:
+            f.write(struct.pack("<3i", dx, dy, dz))
+            f.write(np.ascontiguousarray(vol, np.float32).tobytes())
+    log = _run(exe, tmp_path)
+    assert "5733 POIs" in log
+    got = _table(d / "al_foam4_1_fftcc_icgn1_r30.csv", 13)   # x y z u v w u0 v0 w0 zncc iteration convergence feature
+    # the same queue through the Python mirror
+    k, j, i = np.meshgrid(np.arange(7), np.arange(7), np.arange(117), indexing="ij")   # x fastest in the example's loops
+    xs = (35 + 5 * k).transpose(2, 1, 0).ravel().astype(np.float32)
+    ys = (35 + 5 * j).transpose(2, 1, 0).ravel().astype(np.float32)
+    zs = (60 + 5 * i).transpose(2, 1, 0).ravel().astype(np.float32)
+    assert np.array_equal(got[:, 0], xs) and np.array_equal(got[:, 1], ys) and np.array_equal(got[:, 2], zs)
+    want = opencorr_amd.make_pois3d(xs, ys, zs)
+    f3 = opencorr_amd.FFTCC3D(30, 30, 30)
+    f3.set_images(ref, tar)
+    f3.compute(want)
+    g3 = opencorr_amd.ICGN3D1(30, 30, 30, 0.001, 20.0)
+    g3.share_images(f3)
+    g3.prepare()
+    g3.compute(want)
+    # columns of POI3D: x y z | u ux uy uz v vx vy vz w wx wy wz | u0 v0 w0 zncc iteration convergence feature
+    for col, idx in ((3, 3), (4, 7), (5, 11), (6, 15), (7, 16), (8, 17), (9, 18), (11, 20)):
+        assert np.abs(got[:, col] - want[:, idx].astype(np.float64)).max() <= 1e-6, col
+    assert np.array_equal(got[:, 10], want[:, 19])   # iterations
+    assert (got[:, 9] > 0.9).mean() > 0.99
