@@ -44,6 +44,21 @@ def _write_bmp8(path, img):
         f.write(body.tobytes())
 
 
+def _dvc_workdir(tmp_path, seed=41, dz=704, dy=104, dx=104):
+    """The synthetic volume pair under the names the DVC examples hard-code; returns (directory, ref, tar)."""
+    import torch
+    from opencorr_amd import synth
+    ref, tar = synth.speckle_pair_3d(dz, dy, dx, seed=seed, device=torch.device("cuda", 0))
+    ref, tar = ref.cpu().numpy(), tar.cpu().numpy()
+    d = tmp_path / "d:" / "dic_tests" / "dvc"
+    os.makedirs(d)
+    for name, vol in (("al_foam4_0.bin", ref), ("al_foam4_1.bin", tar)):
+        with open(d / name, "wb") as f:
+            f.write(struct.pack("<3i", dx, dy, dz))
+            f.write(np.ascontiguousarray(vol, np.float32).tobytes())
+    return d, ref, tar
+
+
 def _workdir(tmp_path, golden):
     d = tmp_path / DATA
     os.makedirs(d)
@@ -140,19 +155,9 @@ def test_reference_example_dvc_fftcc_icgn1_runs_unmodified(tmp_path):
     POIs) -> IO3D::saveTable3D.  The reference ships no volumes, so the pair is synthetic (written under the file names
     the example hard-codes); the CSV must hold what the Python mirror computes from the same files, to the print
     resolution, and recover the analytic displacement field."""
-    import torch
     import opencorr_amd
-    from opencorr_amd import synth
     exe = _exe("test_dvc_fftcc_icgn1")
-    dz, dy, dx = 704, 104, 104
-    ref, tar = synth.speckle_pair_3d(dz, dy, dx, seed=41, device=torch.device("cuda", 0))
-    ref, tar = ref.cpu().numpy(), tar.cpu().numpy()
-    d = tmp_path / "d:" / "dic_tests" / "dvc"
-    os.makedirs(d)
-    for name, vol in (("al_foam4_0.bin", ref), ("al_foam4_1.bin", tar)):
-        with open(d / name, "wb") as f:
-            f.write(struct.pack("<3i", dx, dy, dz))
-            f.write(np.ascontiguousarray(vol, np.float32).tobytes())
+    d, ref, tar = _dvc_workdir(tmp_path)
     log = _run(exe, tmp_path)
     assert "5733 POIs" in log
     got = _table(d / "al_foam4_1_fftcc_icgn1_r30.csv", 13)   # x y z u v w u0 v0 w0 zncc iteration convergence feature
@@ -175,3 +180,45 @@ def test_reference_example_dvc_fftcc_icgn1_runs_unmodified(tmp_path):
         assert np.abs(got[:, col] - want[:, idx].astype(np.float64)).max() <= 1e-6, col
     assert np.array_equal(got[:, 10], want[:, 19])   # iterations
     assert (got[:, 9] > 0.9).mean() > 0.99
+
+
+@pytest.mark.gpu
+def test_reference_example_fftcc_iclm1_runs_unmodified(tmp_path, golden):
+    """examples/test_2d_dic_fftcc_iclm1.cpp (FFTCC2D -> ICLM2D1 with setDamping(10, 0.1, 10)).  The reference ships no result
+    table for it, so the CSV is held against the Python mirror (itself bit-exact vs the oracle, which is pinned on the
+    reference's own ICLM source) and against the converged ICGN2D1 table."""
+    import opencorr_amd
+    exe = _exe("test_2d_dic_fftcc_iclm1")
+    d = _workdir(tmp_path, golden)
+    _run(exe, tmp_path)
+    got = _table(d / "oht_cfrp_4_fftcc_iclm1_r16.csv", 9)
+    tab = golden["table"]
+    want = opencorr_amd.make_pois2d(tab[:, 0], tab[:, 1])
+    f = opencorr_amd.FFTCC2D(16, 16)
+    f.set_images(golden["ref"], golden["tar"])
+    f.compute(want)
+    lm = opencorr_amd.ICLM2D1(16, 16, 0.001, 10.0)
+    lm.share_images(f)
+    lm.set_damping(10.0, 0.1, 10.0)
+    lm.prepare()
+    lm.compute(want)
+    for col, idx in ((2, 2), (3, 8), (4, 14), (5, 15), (6, 16), (8, 18)):
+        assert np.abs(got[:, col] - want[:, idx].astype(np.float64)).max() <= 1e-6, col
+    assert np.array_equal(got[:, 7], want[:, 17])
+    m = (tab[:, 7] < golden["stop"]) & (got[:, 6] > 0.9)
+    assert m.sum() > 27000 and np.median(np.abs(got[m, 2] - tab[m, 2])) <= 5e-4
+
+
+@pytest.mark.gpu
+def test_reference_example_dvc_gpu_icgn_runs_unmodified(tmp_path):
+    """examples/test_dvc_gpu_icgn.cpp, written for the reference's binary CUDA module (`#include "opencorr_gpu.h"`:
+    Img3D + ICGN3D1GPU beside the ICGN3D1 class): both classes end in the same HIP engine, so the "(cpu)" and "(gpu)" tables
+    it writes must be the same text."""
+    exe = _exe("test_dvc_gpu_icgn")
+    d, _, _ = _dvc_workdir(tmp_path, seed=43)
+    _run(exe, tmp_path)
+    a = open(d / "al_foam4_1_fftcc_icgn1(cpu)_r30.csv").read()
+    b = open(d / "al_foam4_1_fftcc_icgn1(gpu)_r30.csv").read()
+    assert a == b and a.count("\n") == 5734
+    got = _table(d / "al_foam4_1_fftcc_icgn1(gpu)_r30.csv", 13)
+    assert (got[:, 9] > 0.9).mean() > 0.99 and (got[:, 10] <= 10).all()

@@ -17,7 +17,7 @@ LIBDIR = os.path.join(ROOT, "opencorr_amd", "lib")
 REF = "/root/reference"
 
 EXAMPLES = ["test_2d_dic_fftcc_icgn1", "test_2d_dic_fftcc_iclm1", "test_2d_dic_fftcc_nr1", "test_2d_dic_strain",
-            "test_dvc_fftcc_icgn1", "test_dvc_strain"]
+            "test_dvc_fftcc_icgn1", "test_dvc_strain", "test_dvc_gpu_icgn"]
 
 
 @pytest.mark.parametrize("name", EXAMPLES)
