@@ -200,7 +200,8 @@ hipError_t launch_n(const Fftcc2dParams& p, float* pois, int stride_f, size_t co
 }  // namespace
 
 bool fftcc2d_fusedn_supported(int rx, int ry) {
-    return rx == ry && (rx == 10 || rx == 12 || rx == 15 || rx == 18 || rx == 20 || rx == 24);
+    return rx == ry && (rx == 8 || rx == 9 || rx == 10 || rx == 12 || rx == 15 || rx == 18 || rx == 20 || rx == 24 || rx == 25 || rx == 30 ||
+                        rx == 32);
 }
 
 hipError_t launch_fftcc2d_fusedn(const Fftcc2dParams& p, float* pois, int stride_f, size_t count, bool xcd,
@@ -208,6 +209,11 @@ hipError_t launch_fftcc2d_fusedn(const Fftcc2dParams& p, float* pois, int stride
     if (count == 0) return hipSuccess;
     if (!fftcc2d_fusedn_supported(p.rx, p.ry)) return hipErrorInvalidValue;
     switch (2 * p.rx) {
+        case 16: return launch_n<16>(p, pois, stride_f, count, xcd, stream);
+        case 18: return launch_n<18>(p, pois, stride_f, count, xcd, stream);
+        case 50: return launch_n<50>(p, pois, stride_f, count, xcd, stream);
+        case 60: return launch_n<60>(p, pois, stride_f, count, xcd, stream);
+        case 64: return launch_n<64>(p, pois, stride_f, count, xcd, stream);
         case 20: return launch_n<20>(p, pois, stride_f, count, xcd, stream);
         case 24: return launch_n<24>(p, pois, stride_f, count, xcd, stream);
         case 36: return launch_n<36>(p, pois, stride_f, count, xcd, stream);

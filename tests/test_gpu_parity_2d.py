@@ -76,9 +76,9 @@ def test_fftcc2d_matches_oracle(eng, speckle_small, rx, ry):
     assert np.array_equal(_bits(got[:, untouched]), _bits(want[:, untouched]))
 
 
-@pytest.mark.parametrize("r", [16, 10, 12, 15, 18, 20, 24])
+@pytest.mark.parametrize("r", [16, 8, 9, 10, 12, 15, 18, 20, 24, 25, 30, 32])
 def test_fftcc2d_fused_kernel_matches_rocfft_pipeline(eng, speckle_small, r):
-    """Square windows of side 20, 24, 30, 32, 36, 40, 48 run a single-kernel FFT (fftcc2d_fused.hip for 32, the mixed-radix
+    """Square windows of side 16, 18, 20, 24, 30, 32, 36, 40, 48, 50, 60, 64 run a single-kernel FFT (fftcc2d_fused.hip for 32, the mixed-radix
     fftcc2d_fusedn.hip otherwise) by default; the rocFFT pipeline and the oracle must agree: identical integer
     results, ZNCC to float rounding, guarded POIs untouched."""
     import oracle
