@@ -1,6 +1,7 @@
 #!/bin/bash
+# 3D parity tests + rocprofv3 kernel trace of BASELINE config E (prepare kernels, FFTCC3D, ICGN3D1): bash tools/gpu_configE_profile.sh <tag>
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r02s}
+TAG=${1:-configE}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
