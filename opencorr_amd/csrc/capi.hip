@@ -450,11 +450,13 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
     int variant = e->icgn2d_variant;
     if (variant < 0) {
         // ICGN2D1: the coordinate-table variant at 6 waves per SIMD while three of its workgroups fit a CU's LDS (subsets up
-        // to 19 passes of 64 samples, i.e. 35 x 34), the LDS-light 4-wave workgroups beyond; ICGN2D2: deeper gathers
+        // to 19 passes of 64 samples, i.e. 35 x 34), the LDS-light 4-wave workgroups beyond; ICGN2D2: see below
         // (queues that fill the chip only a couple of times over finish sooner in the finer-grained 4-wave workgroups:
         // config A, 10 000 POIs, 0.33 against 0.38 ms)
         const long long passes = ((2LL * rx + 1) * (2LL * ry + 1) + 63) / 64;
-        variant = dof == 12 ? 3 : (passes <= 19 && count >= 32768 ? 5 : 2);
+        // ICGN2D2: the table variant in 8-wave workgroups while two of them fit a CU (up to 28 passes: 41 x 41), measured
+        // 3.65 against 3.81 ms on config C (profiles/r03q_icgn2d2_variant_ab_configC.json)
+        variant = dof == 12 ? (passes <= 28 && count >= 32768 ? 4 : 3) : (passes <= 19 && count >= 32768 ? 5 : 2);
     }
     if (e->self_adaptive && ochip::icgn2d_variant_uses_table(variant)) variant = 2;  // per-POI radii: no shared coordinate table
     if (lm) variant = 1;  // the IC-LM launch shape has the LDS footprint of variant 1

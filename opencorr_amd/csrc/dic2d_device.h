@@ -225,6 +225,24 @@ __device__ __forceinline__ void passes_batched(int NF, int NT, bool tail_valid, 
     }
 }
 
+// The same walk for bodies that are too register-hungry to be unrolled (the 78 running sums of the 12-DoF Hessian): the
+// loads of pass t + 1 are issued before pass t is consumed, so the round trip of one pass hides behind the arithmetic
+// of the previous one at the price of one more set of loaded values.
+template <class Load, class Use>
+__device__ __forceinline__ void passes_prefetched(int NF, int NT, bool tail_valid, Load&& load, Use&& use) {
+    if (NT <= 0) return;
+    auto cur = NF > 0 ? load(0, true) : load(0, tail_valid);
+#pragma unroll 1
+    for (int t = 0; t < NF; t++) {
+        decltype(cur) nxt = cur;
+        if (t + 1 < NF) nxt = load(t + 1, true);
+        else if (t + 1 < NT) nxt = load(t + 1, tail_valid);
+        use(t, true, cur);
+        cur = nxt;
+    }
+    if (NF < NT) use(NF, tail_valid, cur);
+}
+
 // One LUT entry in flight: address generation and the four 16-byte loads are issued for a
 // whole group of G samples before any polynomial is evaluated, so each lane keeps G*64 B
 // of gathers outstanding (the interpolation sweep is latency/L1-bandwidth bound).  Only the

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     // passes whose global loads are issued together in the load-then-use loops outside the interpolation sweep
     // (reference subset, Hessian sweep, numerator pass): one dependent round trip per batch instead of one per pass
     constexpr int kSetupBatch = 6;
-    constexpr int kHessBatch = DOF == 6 ? 6 : 1;  // the 78 running sums of the 12-DoF Hessian leave no room for a batch
+    constexpr int kHessBatch = 6;  // (6 DoF; the 78 running sums of the 12-DoF Hessian leave no room: passes_prefetched)
     constexpr int kNumBatch = DOF == 6 ? 6 : 4;
     __shared__ float coop_area[COOP ? WPB * 64 : 1];
     const int NTA = L.nt;  // passes the LDS arrays are sized for (>= the passes of any POI)
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     if ((r & 1) == 0) hd[r] = valid ? hd[r] + sr * sr : hd[r];
                 }
             };
-            passes_batched<kHessBatch>(NF, NT, (NF * kWave + lane) < N, fetch, sample);
+            passes_prefetched(NF, NT, (NF * kWave + lane) < N, fetch, sample);
             int k = 0;
 #pragma unroll
             for (int r = 0; r < 12; r++)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Ablation of icgn2d_kernel on the GPU box: builds the library with -DOC_ABLATE2D=<mask> (icgn2d.hip) and times ICGN2D1 on
-# config B (4096^2, r = 16, 500 x 500 POIs).  usage: MASKS="1 3 5" bash tools/ablate_icgn2d.sh <tag>
+# config B (4096^2, r = 16, 500 x 500 POIs; ENGINE=2 R=20 NS=316 = config C).  usage: MASKS="1 3 5" bash tools/ablate_icgn2d.sh <tag>
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-ablate2d}
 OUT=$ROOT/gpurun_out/$TAG
@@ -15,11 +15,13 @@ sys.path.insert(0, ".")
 import opencorr_amd as oc
 from opencorr_amd import synth
 dev = torch.device("cuda", 0)
-side, r, ns = 4096, 16, 500
-ref, tar = synth.speckle_pair_2d(side, side, seed=20260925, device=dev)
+side, r, ns = 4096, int(os.environ.get('R', 16)), int(os.environ.get('NS', 500))
+engine = int(os.environ.get('ENGINE', 1))  # 1 = ICGN2D1, 2 = ICGN2D2 (config C: ENGINE=2 R=20 NS=316)
+so = dict(uxx=2e-6, vyy=-1e-6) if engine == 2 else None
+ref, tar = synth.speckle_pair_2d(side, side, seed=20260925, device=dev, second_order=so)
 xs, ys = synth.poi_grid_2d(side, side, ns, ns, r + 8)
 f = oc.FFTCC2D(r, r); f.set_images(ref, tar)
-g = oc.ICGN2D1(r, r, 0.001, 10.0); g.share_images(f); g.prepare()
+g = (oc.ICGN2D1 if engine == 1 else oc.ICGN2D2)(r, r, 0.001, 10.0); g.share_images(f); g.prepare()
 for k, v in [kv.split("=") for kv in os.environ.get("TUNING", "").split(",") if kv]:
     g.set_tuning(k, int(v))
 pristine = torch.from_numpy(oc.make_pois2d(xs, ys)).to(dev)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """A/B timing of ICGN2D kernel variants on config B with HIP events, variants interleaved round by round so that clock
-drift hits all of them alike.  usage: python tools/variant_ab.py 2,7,9 [rounds] [launches]   (GPU box)"""
+drift hits all of them alike.  usage: [ENGINE=2 R=20 NS=316] python tools/variant_ab.py 2,4,5 [rounds] [launches]   (GPU box;
+ENGINE=2 R=20 NS=316 is config C: ICGN2D2)"""
 import json
+import os
 import sys
 
 import numpy as np
@@ -15,12 +17,14 @@ variants = [int(v) for v in sys.argv[1].split(",")]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 launches = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 dev = torch.device("cuda", 0)
-side, r, ns = 4096, 16, 500
-ref, tar = synth.speckle_pair_2d(side, side, seed=20260925, device=dev)
+side, r, ns = 4096, int(os.environ.get("R", 16)), int(os.environ.get("NS", 500))
+engine = int(os.environ.get("ENGINE", 1))
+so = dict(uxx=2e-6, vyy=-1e-6) if engine == 2 else None
+ref, tar = synth.speckle_pair_2d(side, side, seed=20260925, device=dev, second_order=so)
 xs, ys = synth.poi_grid_2d(side, side, ns, ns, r + 8)
 stream = torch.cuda.current_stream().cuda_stream
 f = oc.FFTCC2D(r, r); f.set_stream(stream); f.set_images(ref, tar)
-g = oc.ICGN2D1(r, r, 0.001, 10.0); g.set_stream(stream); g.share_images(f); g.prepare()
+g = (oc.ICGN2D1 if engine == 1 else oc.ICGN2D2)(r, r, 0.001, 10.0); g.set_stream(stream); g.share_images(f); g.prepare()
 guess = torch.from_numpy(oc.make_pois2d(xs, ys)).to(dev)
 f.compute(guess)
 q = guess.clone()
@@ -39,7 +43,7 @@ for rd in range(rounds + 1):
             times[v].append(tot / launches)
         bits[v] = q.cpu().numpy().view(np.uint32)
 first = bits[variants[0]]
-print(json.dumps({"workload": "config B, ICGN2D1 compute() incl. the tile-order kernels, HIP events", "launches_per_round": launches,
+print(json.dumps({"workload": "4096^2, r = %d, %d x %d POIs, ICGN2D%d compute() incl. the tile-order kernels, HIP events" % (r, ns, ns, engine), "launches_per_round": launches,
                   "ms": {str(v): [round(t, 4) for t in ts] for v, ts in times.items()},
                   "mean_ms": {str(v): round(float(np.mean(ts)), 4) for v, ts in times.items()},
                   "same_bits": {str(v): bool(np.array_equal(bits[v], first)) for v in variants}}))
