@@ -111,6 +111,38 @@ def algorithmic_flops_icgn2d1(pois_np, rx, ry):
     return float(ran.sum() * 50 * n2 + it[ran].sum() * 75 * n2)
 
 
+def roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof):
+    """The `roofline` object of the JSON line (a function so that the CPU tests can exercise it)."""
+    secs = icgn_avg_ms * 1e-3
+    alg_rate = alg_bytes / secs / 1e9 if secs > 0 else 0.0      # GB/s
+    achieved = alg_flops / secs / 1e12 if secs > 0 else 0.0     # Tflop/s
+    return {
+        # the roof the kernel sits closest to: the L1 / L2 gather of the 64-byte table entries (ablations in
+        # DESIGN.md 4.1: -13 % without two thirds of the gathers, -3 % without two thirds of the polynomials)
+        "kernel": "icgn2d_kernel<6,...> (ICGN2D1)",
+        "bound": "l2",
+        "achieved": alg_rate,
+        "peak": L2_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": alg_rate / L2_PEAK_GBS,
+        "traffic": None,  # HBM bytes are not collected inside a bench run: see hbm_traffic_profiled
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "avg_launch_ms": icgn_avg_ms,
+        "launches_timed": icgn_launches,
+        "why_not_hbm": ("the 64 B/sample table gather is served by L1/L2 (neighbouring subsets overlap): HBM sees a few percent "
+                        "of the algorithmic bytes, so bytes / time exceeds the HBM peak ({:.1f}x) and says nothing"
+                        .format(alg_rate / HBM_PEAK_GBS)),
+        "gather_ubench": {"value": GATHER_UBENCH_GBS, "unit": "GB/s", "frac": alg_rate / GATHER_UBENCH_GBS,
+                          "source": "profiles/r02a_gather_ubench.txt",
+                          "note": "the same gather pattern with no arithmetic at all (tools/ubench/gather_ubench.hip, "
+                                  "planar table): the kernel's gather rate as a fraction of that ceiling"},
+        "valu": {"achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / VALU_PEAK_TFLOPS,
+                 "algorithmic_flops_per_launch": alg_flops,
+                 "note": "the reference's own fp32 operations over the chip's rate for separately rounded operations"},
+        "hbm_traffic_profiled": prof,
+    }
+
+
 def main():
     args = parse()
     import torch
@@ -263,8 +295,6 @@ def main():
         alg_bytes, mean_iter = algorithmic_bytes_icgn2d1(local_np, RX, RY)
         alg_flops = algorithmic_flops_icgn2d1(local_np, RX, RY)
         icgn_avg_ms = icgn_ms / max(icgn_launches, 1)
-        alg_rate = alg_bytes / (icgn_avg_ms * 1e-3) / 1e9 if icgn_avg_ms > 0 else 0.0
-        achieved = alg_flops / (icgn_avg_ms * 1e-3) / 1e12 if icgn_avg_ms > 0 else 0.0
         prof = pmc_profile(world)
         out = {
             "metric": "converged POIs/sec (FFTCC+ICGN2D1, 33x33 subset)",
@@ -289,31 +319,7 @@ def main():
                                if world > 1 else "none"),
                 "all_gather_alone_ms": gather_alone_ms,
             },
-            "roofline": {
-                # the roof the kernel sits closest to: the L1 / L2 gather of the 64-byte table entries (ablations in
-                # -13 % without two thirds of the gathers, -3 % without two thirds of the polynomials)
-                "kernel": "icgn2d_kernel<6,...> (ICGN2D1)",
-                "bound": "l2",
-                "achieved": alg_rate,
-                "peak": L2_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": alg_rate / L2_PEAK_GBS,
-                "traffic": None,  # HBM bytes are not collected inside a bench run: see hbm_traffic_profiled
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_launch_ms": icgn_avg_ms,
-                "launches_timed": icgn_launches,
-                "why_not_hbm": "the 64 B/sample table gather is served by L1/L2 (neighbouring subsets overlap): HBM sees ~4 % "
-                               "of the algorithmic bytes, so bytes / time exceeds the HBM peak (%.1fx) and says nothing"
-                               % (alg_rate / HBM_PEAK_GBS),
-                "gather_ubench": {"value": GATHER_UBENCH_GBS, "unit": "GB/s", "frac": alg_rate / GATHER_UBENCH_GBS,
-                                  "source": "profiles/r02a_gather_ubench.txt",
-                                  "note": "the same gather pattern with no arithmetic at all (tools/ubench/gather_ubench.hip, "
-                                          "planar table): the kernel's gather rate as a fraction of that ceiling"},
-                "valu": {"achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / VALU_PEAK_TFLOPS,
-                         "algorithmic_flops_per_launch": alg_flops,
-                         "note": "the reference's own fp32 operations over the chip's rate for separately rounded operations"},
-                "hbm_traffic_profiled": prof,
-            },
+            "roofline": roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof),
             "stage_ms": {
                 "fftcc_pipeline_avg": fftcc_ms / max(fftcc_launches, 1),
                 "icgn_kernel_avg": icgn_avg_ms,

@@ -49,3 +49,21 @@ def test_algorithmic_flops_formula_and_roofline_fractions_are_bounded():
     rate = bytes_per_poi * 250000 / 3.5e-3 / 1e9
     assert 0.3 < rate / bench.L2_PEAK_GBS < 0.6
     assert 0.6 < rate / bench.GATHER_UBENCH_GBS < 1.0
+
+
+def test_roofline_block_is_well_formed():
+    """The roofline object is built by a plain function: exercise it with the measured figures (a stray '%' in one of
+    its strings once crashed the bench at the very end of a run)."""
+    import json
+    import bench
+    n2 = 33 * 33
+    alg_bytes = (3 * n2 * 4 + 200 + 3.105 * n2 * 64) * 250000
+    alg_flops = (50 * n2 + 75 * n2 * 3.105) * 250000
+    r = bench.roofline_block(alg_bytes, alg_flops, 3.47, 10, {"hbm_bytes_per_launch": 2.4e9})
+    json.dumps(r)
+    assert r["bound"] == "l2" and r["unit"] == "GB/s" and r["traffic"] is None
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.4 < r["frac"] < 0.55
+    assert 0.7 < r["gather_ubench"]["frac"] < 0.9 and 0.25 < r["valu"]["frac"] < 0.31
+    assert "2.1x" in r["why_not_hbm"]
+    z = bench.roofline_block(alg_bytes, alg_flops, 0.0, 0, None)   # nothing timed: no division by zero
+    assert z["achieved"] == 0.0 and z["frac"] == 0.0
