@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--settle", type=int, default=25,
+                    help="untimed steps run BEFORE the W warm-up steps so that clocks, allocators and lazily created handles "
+                         "have settled (a cold first run once showed one 13 ms stall inside 10 timed steps); not part of W or K")
     ap.add_argument("--size", type=int, default=0, help="override image side (debug)")
     ap.add_argument("--pois", type=int, default=0, help="override POIs per GPU side (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
@@ -249,6 +252,10 @@ def main():
                 pending[b].wait()
                 pending[b] = None
 
+    for _ in range(max(args.settle, 0)):
+        step()
+    drain()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     drain()
