@@ -31,6 +31,14 @@ struct Nr2dLaunch {
 
 constexpr int kNrWaves = 4;  // POIs (waves) per workgroup
 
+// passes whose 12 gathers per lane (192 bytes) are issued together.  Measured on config B (FFTCC2D + NR2D1): 9.7 ms with 1,
+// 2 or 3 passes per batch at 109 / 174 / 228 VGPRs -- the engine moves three table entries per sample and iteration and
+// is bound by that gather throughput (2.6 x ICGN2D1's time for 3 x its gather bytes), not by their latency.
+#ifndef OC_NR_BATCH
+#define OC_NR_BATCH 1
+#endif
+constexpr int kNrBatch = OC_NR_BATCH;
+
 __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, float* __restrict__ pois, Nr2dLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NT = L.nt;
@@ -136,7 +144,13 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
         float h00 = 0.f, h33 = 0.f, h30 = 0.f, h21 = 0.f, h54 = 0.f;
         {
             SampleWalk w(lane, r0, c0, W, q64, r64);
-            auto sample = [&](int t, bool valid) {
+            struct NrFetch {
+                LutFetch ft, fgx, fgy;
+                f2 xy;
+            };
+            // the gathers of kNrBatch passes (12 x 16 bytes per lane and pass) are in flight before the first is used
+            auto fetch = [&](int t, bool valid) {
+                NrFetch q;
                 const float xl = (float)(w.c - rx), yl = (float)(w.r - ry);
                 // Deformation2D1::warp, src/oc_deformation.cpp:94-105
                 const float wx = (Wm[0] * xl + Wm[1] * yl) + Wm[2] * 1.f;
@@ -144,19 +158,23 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
                 const float x = valid ? px + wx : 1.f, y = valid ? py + wy : 1.f;
                 // one range test and one entry offset serve the three tables
                 // (BicubicBspline::compute, src/oc_cubic_bspline.cpp:134-181; rule explained at lut_fetch)
-                LutFetch ft, fgx, fgy;
                 bool out;
-                const unsigned e = lut_locate<true>(ft, height, width, x, y, out);
-                fgx.dx = fgy.dx = ft.dx;
-                fgx.dy = fgy.dy = ft.dy;
-                r_lut.load(ft, e);
-                r_lgx.load(fgx, e);
-                r_lgy.load(fgy, e);
-                const float tv = lut_eval(ft), g_x = lut_eval(fgx), g_y = lut_eval(fgy);
+                const unsigned e = lut_locate<true>(q.ft, height, width, x, y, out);
+                q.fgx.dx = q.fgy.dx = q.ft.dx;
+                q.fgx.dy = q.fgy.dy = q.ft.dy;
+                r_lut.load(q.ft, e);
+                r_lgx.load(q.fgx, e);
+                r_lgy.load(q.fgy, e);
+                q.xy = mk2(xl, yl);
+                w.next();
+                return q;
+            };
+            auto sample = [&](int t, bool valid, const NrFetch& q) {
+                const float tv = lut_eval(q.ft), g_x = lut_eval(q.fgx), g_y = lut_eval(q.fgy);
                 l_ts[t * kWave] = tv;
                 l_gx[t * kWave] = g_x;
                 l_gy[t * kWave] = g_y;
-                const f2 xy = mk2(xl, yl);
+                const f2 xy = q.xy;
                 const f2 A = g_x * xy, B = g_y * xy;
                 const f2 nAA = hAA + A * A, nBB = hBB + B * B, nAB = hAB + A * B, nAs = hAs + A * B.yx;
                 const f2 nxA = hxA + g_x * A, nyA = hyA + g_y * A, nxB = hxB + g_x * B, nyB = hyB + g_y * B;
@@ -169,9 +187,7 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
                     acc = nacc;
                 }
             };
-#pragma unroll 1
-            for (int t = 0; t < NF; t++, w.next()) sample(t, true);
-            if (NF < NT) sample(NF, w.s < N);
+            passes_batched<kNrBatch>(NF, NT, (NF * kWave + lane) < N, fetch, sample);
         }
         // (2) zeroMeanNorm of the target subset (:210)
         const float tmean = wave_allreduce_sum(acc) / fN;
