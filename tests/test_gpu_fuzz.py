@@ -1,0 +1,157 @@
+"""Randomised differential parity: HIP engines vs the oracle on queues nobody tuned for.
+
+Every case draws its own image size, subset radii (rx != ry included), iteration limits and a queue of POIs at
+NON-INTEGER positions (the reference truncates `(int)(x - rx)` for the subset origin and compares floats in its guards,
+src/oc_icgn.cpp:160-188), with initial guesses from "exact" to "far off", first-order gradients, borders, NaN and
+rejected records mixed in.  The bar is the usual one: every float of every record identical to the oracle's
+(ORDER_LANES), whatever the POI did -- converge, hit the iteration limit (-4), leave the image (-3), turn NaN (-5).
+Seeds are fixed: the cases are the same on every run.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _queue2d(rng, h, w, rx, ry, n):
+    import oracle
+    P = oracle.P2
+    m = max(rx, ry) + 3
+    xs = rng.uniform(m, w - 1 - m, n).astype(np.float32)
+    ys = rng.uniform(m, h - 1 - m, n).astype(np.float32)
+    xs[: n // 4] = np.round(xs[: n // 4])          # a quarter on the integer grid
+    ys[: n // 4] = np.round(ys[: n // 4])
+    # a few on / over the border of what the guard accepts
+    xs[-6:] = np.array([rx - 0.5, rx, rx + 0.25, w - 1 - rx, w - 1 - rx + 0.5, w - 0.75 - rx], np.float32)
+    ys[-6:] = np.array([ry + 2, ry - 0.25, ry, h - 1 - ry, h - 2 - ry, h - 1 - ry + 0.001], np.float32)
+    pois = oracle.make_pois2d(xs, ys)
+    return pois, P
+
+
+def _guess2d(rng, pois, P, true_u, true_v, spread):
+    n = len(pois)
+    pois[:, P["u"]] = true_u + rng.normal(0, spread, n)
+    pois[:, P["v"]] = true_v + rng.normal(0, spread, n)
+    for k in ("ux", "uy", "vx", "vy"):
+        pois[:, P[k]] = rng.normal(0, 0.01, n)
+    pois[:, P["zncc"]] = rng.uniform(0, 1, n)
+    bad = rng.choice(n - 6, 8, replace=False)
+    pois[bad[0], P["u"]] = np.nan
+    pois[bad[1], P["v"]] = np.nan
+    pois[bad[2], P["zncc"]] = -1.0
+    pois[bad[3], P["u"]] = 1e6
+    pois[bad[4], P["u"]] += 9.0       # a guess far off: runs into the iteration limit or out of the image
+    pois[bad[5], P["ux"]] = 0.5
+    pois[bad[6], P["vy"]] = -0.4
+    pois[bad[7], P["zncc"]] = np.nan
+    return pois.astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_icgn2d1_icgn2d2_nr2d1_iclm(seed):
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    rng = np.random.default_rng(1000 + seed)
+    h, w = int(rng.integers(150, 260)), int(rng.integers(150, 260))
+    warp = dict(u=float(rng.uniform(-3, 3)), ux=float(rng.uniform(-4e-3, 4e-3)), uy=float(rng.uniform(-4e-3, 4e-3)),
+                v=float(rng.uniform(-3, 3)), vx=float(rng.uniform(-4e-3, 4e-3)), vy=float(rng.uniform(-4e-3, 4e-3)))
+    ref, tar = synth.speckle_pair_2d(h, w, seed=500 + seed, warp=warp)
+    rx, ry = int(rng.integers(4, 22)), int(rng.integers(4, 22))
+    conv = float(rng.choice([1e-3, 1e-4, 5e-3]))
+    stop = float(rng.choice([10, 6, 15]))
+    pois, P = _queue2d(rng, h, w, rx, ry, 150)
+    pois = _guess2d(rng, pois, P, warp["u"], warp["v"], spread=[0.05, 0.4, 1.0][seed % 3])
+    prep = oracle.Prepared2D(ref, tar)
+    for name, Engine, solve in (("ICGN2D1", opencorr_amd.ICGN2D1, oracle.icgn2d1), ("ICGN2D2", opencorr_amd.ICGN2D2, oracle.icgn2d2),
+                                ("ICLM2D1", opencorr_amd.ICLM2D1, oracle.iclm2d1), ("ICLM2D2", opencorr_amd.ICLM2D2, oracle.iclm2d2)):
+        eng = Engine(rx, ry, conv, stop)
+        eng.set_images(ref, tar)
+        eng.prepare()
+        got = eng.compute(pois.copy())
+        want = pois.copy()
+        solve(prep, rx, ry, conv, stop, want, order=oracle.ORDER_LANES, lanes=64)
+        same = (_bits(got) == _bits(want)).all(axis=1)
+        assert same.all(), (name, seed, rx, ry, np.flatnonzero(~same)[:5], got[~same][:2], want[~same][:2])
+        # the cases are not all trivial: some POIs converge, some do not
+        z = got[:, P["zncc"]]
+        assert (z > 0.5).sum() > 40 and (z < 0).sum() >= 3, (name, seed)
+    nr = opencorr_amd.NR2D1(rx, ry, conv, stop)
+    nr.set_images(ref, tar)
+    nr.prepare()
+    got = nr.compute(pois.copy())
+    want = pois.copy()
+    oracle.nr2d1(oracle.PreparedNR2D(ref, tar), rx, ry, conv, stop, want, order=oracle.ORDER_LANES, lanes=64)
+    same = (_bits(got) == _bits(want)).all(axis=1)
+    assert same.all(), ("NR2D1", seed, rx, ry, np.flatnonzero(~same)[:5])
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_fftcc2d(seed):
+    """FFTCC2D with float POI positions and float initial guesses (truncating casts, src/oc_fftcc.cpp:190-216): fused
+    sizes and rocFFT-pipeline sizes, rx != ry."""
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    rng = np.random.default_rng(2000 + seed)
+    h, w = int(rng.integers(170, 260)), int(rng.integers(170, 260))
+    ref, tar = synth.speckle_pair_2d(h, w, seed=700 + seed)
+    for rx, ry in [(int(rng.choice([8, 9, 10, 12, 15, 16, 18, 20, 24])),) * 2, (int(rng.integers(5, 20)), int(rng.integers(5, 20)))]:
+        pois, P = _queue2d(rng, h, w, rx + 4, ry + 4, 120)
+        pois[:, P["u"]] = rng.uniform(-3, 3, len(pois))
+        pois[:, P["v"]] = rng.uniform(-3, 3, len(pois))
+        pois[5, P["u"]] = 500.0     # target window outside: the guard leaves the record untouched
+        pois[6, P["v"]] = -500.0
+        pois = pois.astype(np.float32)
+        want = pois.copy()
+        oracle.fftcc2d(ref, tar, rx, ry, want)
+        f = opencorr_amd.FFTCC2D(rx, ry)
+        f.set_images(ref, tar)
+        got = f.compute(pois.copy())
+        for k in ("u", "v", "u0", "v0"):
+            assert np.array_equal(got[:, P[k]], want[:, P[k]]), (seed, rx, ry, k)
+        assert np.abs(got[:, P["zncc"]] - want[:, P["zncc"]]).max() <= 3e-5
+        other = [c for c in range(25) if c not in (P["u"], P["v"], P["u0"], P["v0"], P["zncc"])]
+        assert np.array_equal(_bits(got[:, other]), _bits(want[:, other]))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_icgn3d1(seed):
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    rng = np.random.default_rng(3000 + seed)
+    dz, dy, dx = (int(rng.integers(44, 60)) for _ in range(3))
+    ref, tar = synth.speckle_pair_3d(dz, dy, dx, seed=900 + seed)
+    rx, ry, rz = (int(rng.integers(3, 9)) for _ in range(3))
+    P = oracle.P3
+    n = 60
+    m = max(rx, ry, rz) + 4
+    xs = rng.uniform(m, dx - 1 - m, n).astype(np.float32)
+    ys = rng.uniform(m, dy - 1 - m, n).astype(np.float32)
+    zs = rng.uniform(m, dz - 1 - m, n).astype(np.float32)
+    xs[:20], ys[:20], zs[:20] = np.round(xs[:20]), np.round(ys[:20]), np.round(zs[:20])
+    pois = oracle.make_pois3d(xs, ys, zs)
+    w3 = synth.DEFAULT_WARP_3D
+    pois[:, P["u"]] = w3["u"] + rng.normal(0, 0.3, n)
+    pois[:, P["v"]] = w3["v"] + rng.normal(0, 0.3, n)
+    pois[:, P["w"]] = w3["w"] + rng.normal(0, 0.3, n)
+    pois[3, P["u"]] = np.nan
+    pois[4, P["zncc"]] = -2.0
+    pois[5, P["w"]] += 7.0
+    pois[6, P["x"]] = rx - 0.5
+    pois = pois.astype(np.float32)
+    conv, stop = 1e-3, float(rng.choice([20, 8]))
+    g = opencorr_amd.ICGN3D1(rx, ry, rz, conv, stop)
+    g.set_images(ref, tar)
+    g.prepare()
+    got = g.compute(pois.copy())
+    want = pois.copy()
+    oracle.icgn3d1(oracle.Prepared3D(ref, tar), rx, ry, rz, conv, stop, want, order=oracle.ORDER_LANES, lanes=512)
+    same = (_bits(got) == _bits(want)).all(axis=1)
+    assert same.all(), (seed, rx, ry, rz, np.flatnonzero(~same)[:5], got[~same][:2], want[~same][:2])
+    assert (got[:, P["zncc"]] > 0.5).sum() > 20
