@@ -155,3 +155,66 @@ def test_fuzz_icgn3d1(seed):
     same = (_bits(got) == _bits(want)).all(axis=1)
     assert same.all(), (seed, rx, ry, rz, np.flatnonzero(~same)[:5], got[~same][:2], want[~same][:2])
     assert (got[:, P["zncc"]] > 0.5).sum() > 20
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_offsets_and_self_adaptive(seed):
+    """ICGN2D1 / ICGN2D2 with per-POI centre offsets (src/oc_icgn.cpp:353-557, 910-1136) and with per-POI subset radii
+    (setSelfAdaptive, :152-158), separately and together, on float POI positions."""
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    rng = np.random.default_rng(4000 + seed)
+    h, w = int(rng.integers(170, 240)), int(rng.integers(170, 240))
+    ref, tar = synth.speckle_pair_2d(h, w, seed=1100 + seed)
+    rx, ry = int(rng.integers(6, 16)), int(rng.integers(6, 16))
+    pois, P = _queue2d(rng, h, w, rx + 6, ry + 6, 120)
+    pois = _guess2d(rng, pois, P, 2.3, -1.7, spread=0.3)
+    n = len(pois)
+    off = rng.uniform(-2.5, 2.5, (n, 2)).astype(np.float32)
+    off[: n // 3] = np.round(off[: n // 3])
+    radii = np.stack([rng.integers(3, rx + 1, n), rng.integers(3, ry + 1, n)], 1).astype(np.float32)
+    prep = oracle.Prepared2D(ref, tar)
+    for Engine, solve in ((opencorr_amd.ICGN2D1, oracle.icgn2d1), (opencorr_amd.ICGN2D2, oracle.icgn2d2)):
+        eng = Engine(rx, ry, 1e-3, 10)
+        eng.set_images(ref, tar)
+        eng.prepare()
+        want = pois.copy()
+        solve(prep, rx, ry, 1e-3, 10, want, order=oracle.ORDER_LANES, lanes=64, center_offsets=off)
+        assert np.array_equal(_bits(eng.compute_with_offsets(pois.copy(), off)), _bits(want)), (seed, "offsets")
+        eng.set_self_adaptive(True)
+        q = pois.copy()
+        q[:, 23:25] = radii
+        want = q.copy()
+        solve(prep, rx, ry, 1e-3, 10, want, order=oracle.ORDER_LANES, lanes=64, self_adaptive=True)
+        assert np.array_equal(_bits(eng.compute(q.copy())), _bits(want)), (seed, "self-adaptive")
+        want = q.copy()
+        solve(prep, rx, ry, 1e-3, 10, want, order=oracle.ORDER_LANES, lanes=64, center_offsets=off, self_adaptive=True)
+        assert np.array_equal(_bits(eng.compute_with_offsets(q.copy(), off)), _bits(want)), (seed, "both")
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_fftcc3d(seed):
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    rng = np.random.default_rng(5000 + seed)
+    dz, dy, dx = (int(rng.integers(52, 70)) for _ in range(3))
+    ref, tar = synth.speckle_pair_3d(dz, dy, dx, seed=1300 + seed)
+    rx, ry, rz = (int(rng.integers(4, 11)) for _ in range(3))
+    P = oracle.P3
+    n = 40
+    m = max(rx, ry, rz) + 6
+    pois = oracle.make_pois3d(rng.uniform(m, dx - 1 - m, n).astype(np.float32), rng.uniform(m, dy - 1 - m, n).astype(np.float32),
+                              rng.uniform(m, dz - 1 - m, n).astype(np.float32))
+    for k in ("u", "v", "w"):
+        pois[:, P[k]] = rng.uniform(-2.5, 2.5, n)
+    pois = pois.astype(np.float32)
+    want = pois.copy()
+    oracle.fftcc3d(ref, tar, rx, ry, rz, want)
+    f = opencorr_amd.FFTCC3D(rx, ry, rz)
+    f.set_images(ref, tar)
+    got = f.compute(pois.copy())
+    for k in ("u", "v", "w", "u0", "v0", "w0"):
+        assert np.array_equal(got[:, P[k]], want[:, P[k]]), (seed, k)
+    assert np.abs(got[:, P["zncc"]] - want[:, P["zncc"]]).max() <= 3e-5
