@@ -229,3 +229,82 @@ def test_icgn3d1_bit_exact_against_reference(volumes, r):
     oracle.icgn3d1(prep, rx, ry, rz, 0.001, 20, got, order=oracle.ORDER_SEQ)
     _same(got, want)
     assert (want[:12, P["zncc"]] > 0.9).all()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_2d_solvers_against_reference(seed):
+    """Randomised: image size, rx != ry, limits, POIs at NON-INTEGER positions, on the guard's borders, with first-order
+    guesses, NaN / rejected / far-off records -- the reference's own sources and the oracle (sequential order) must agree
+    on every bit of every record, for all five 2D solvers."""
+    from opencorr_amd import synth
+    rng = np.random.default_rng(7000 + seed)
+    h, w = int(rng.integers(120, 180)), int(rng.integers(120, 180))
+    warp = dict(u=float(rng.uniform(-2, 2)), ux=float(rng.uniform(-3e-3, 3e-3)), uy=float(rng.uniform(-3e-3, 3e-3)),
+                v=float(rng.uniform(-2, 2)), vx=float(rng.uniform(-3e-3, 3e-3)), vy=float(rng.uniform(-3e-3, 3e-3)))
+    ref, tar = synth.speckle_pair_2d(h, w, seed=800 + seed, warp=warp)
+    rx, ry = int(rng.integers(4, 14)), int(rng.integers(4, 14))
+    conv, stop = float(rng.choice([1e-3, 1e-4])), float(rng.choice([10, 5]))
+    P = oracle.P2
+    n = 60
+    m = max(rx, ry) + 3
+    xs = rng.uniform(m, w - 1 - m, n).astype(np.float32)
+    ys = rng.uniform(m, h - 1 - m, n).astype(np.float32)
+    xs[:15], ys[:15] = np.round(xs[:15]), np.round(ys[:15])
+    xs[-4:] = np.array([rx - 0.5, rx, w - 1 - rx, w - 1 - rx + 0.5], np.float32)
+    ys[-4:] = np.array([ry + 2, ry - 0.25, h - 1 - ry, h - 2 - ry], np.float32)
+    pois = oracle.make_pois2d(xs, ys)
+    pois[:, P["u"]] = warp["u"] + rng.normal(0, 0.4, n)
+    pois[:, P["v"]] = warp["v"] + rng.normal(0, 0.4, n)
+    for k in ("ux", "uy", "vx", "vy"):
+        pois[:, P[k]] = rng.normal(0, 0.01, n)
+    pois[:, P["zncc"]] = rng.uniform(0, 1, n)
+    pois[20, P["u"]] = np.nan
+    pois[21, P["zncc"]] = -1.0
+    pois[22, P["u"]] += 8.0
+    pois[23, P["v"]] = 1e6
+    pois = pois.astype(np.float32)
+    prep = oracle.Prepared2D(ref, tar)
+    for eng, fn in ((oref.ICGN2D1, oracle.icgn2d1), (oref.ICGN2D2, oracle.icgn2d2)):
+        want, got = pois.copy(), pois.copy()
+        oref.solve2d(eng, ref, tar, rx, ry, conv, stop, want)
+        fn(prep, rx, ry, conv, stop, got, order=oracle.ORDER_SEQ)
+        _same(got, want)
+    dmp = (100.0, 0.1, 10.0)
+    for eng, fn in ((oref.ICLM2D1, oracle.iclm2d1), (oref.ICLM2D2, oracle.iclm2d2)):
+        want, got = pois.copy(), pois.copy()
+        oref.solve2d(eng, ref, tar, rx, ry, conv, stop, want, damping=dmp)
+        fn(prep, rx, ry, conv, stop, got, damping=dmp, order=oracle.ORDER_SEQ)
+        _same(got, want)
+    want, got = pois.copy(), pois.copy()
+    oref.solve2d(oref.NR2D1, ref, tar, rx, ry, conv, stop, want)
+    oracle.nr2d1(oracle.PreparedNR2D(ref, tar), rx, ry, conv, stop, got, order=oracle.ORDER_SEQ)
+    _same(got, want)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_fuzz_icgn3d1_against_reference(seed):
+    """Randomised DVC case: volume shape, rx != ry != rz, float POI positions, noisy guesses, NaN / rejected records."""
+    from opencorr_amd import synth
+    rng = np.random.default_rng(7100 + seed)
+    dz, dy, dx = (int(rng.integers(36, 46)) for _ in range(3))
+    ref, tar = synth.speckle_pair_3d(dz, dy, dx, seed=850 + seed)
+    rx, ry, rz = (int(rng.integers(3, 7)) for _ in range(3))
+    P = oracle.P3
+    n = 24
+    m = max(rx, ry, rz) + 4
+    pois = oracle.make_pois3d(rng.uniform(m, dx - 1 - m, n).astype(np.float32), rng.uniform(m, dy - 1 - m, n).astype(np.float32),
+                              rng.uniform(m, dz - 1 - m, n).astype(np.float32))
+    w3 = synth.DEFAULT_WARP_3D
+    for k in ("u", "v", "w"):
+        pois[:, P[k]] = w3[k] + rng.normal(0, 0.3, n)
+    pois[2, P["u"]] = np.nan
+    pois[3, P["zncc"]] = -2.0
+    pois[4, P["w"]] += 6.0
+    pois[5, P["x"]] = rx - 0.5
+    pois = pois.astype(np.float32)
+    stop = float(rng.choice([20, 6]))
+    want, got = pois.copy(), pois.copy()
+    oref.icgn3d1(ref, tar, rx, ry, rz, 0.001, stop, want)
+    oracle.icgn3d1(oracle.Prepared3D(ref, tar), rx, ry, rz, 0.001, stop, got, order=oracle.ORDER_SEQ)
+    _same(got, want)
+    assert (want[:, P["zncc"]] > 0.5).sum() > 8
