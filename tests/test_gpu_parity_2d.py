@@ -610,3 +610,41 @@ def test_oversized_images_are_refused_not_wrapped():
     icgn2.set_images(big, big)
     icgn2.prepare()
     icgn2.synchronize()
+
+
+def test_engine_lifecycle_does_not_leak(eng, speckle_small):
+    """create -> setImages -> prepare -> compute -> destroy, many times, with every engine kind: the device's free memory
+    comes back (the engines allocate with hipMalloc, so torch's mem_get_info sees it)."""
+    import gc
+    import torch
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 9, 9, 30)
+    pois = eng.make_pois2d(xs, ys)
+
+    def cycle():
+        f = eng.FFTCC2D(16, 16)
+        f.set_images(ref, tar)
+        q = f.compute(pois.copy())
+        for cls in (eng.ICGN2D1, eng.ICGN2D2, eng.NR2D1, eng.ICLM2D1):
+            g = cls(16, 16, 0.001, 10)
+            g.share_images(f) if cls is not eng.NR2D1 else g.set_images(ref, tar)
+            g.prepare()
+            g.compute(q.copy())
+            del g
+        st = eng.Strain(30.0, 5)
+        st.prepare(q)
+        st.compute(q)
+        del st, f
+
+    for _ in range(3):
+        cycle()
+    gc.collect()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(25):
+        cycle()
+    gc.collect()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, (free0, free1)
