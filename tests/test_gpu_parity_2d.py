@@ -648,3 +648,48 @@ def test_engine_lifecycle_does_not_leak(eng, speckle_small):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 << 20, (free0, free1)
+
+
+def test_engines_are_usable_from_several_host_threads(eng, speckle_small):
+    """Four host threads, each with its own FFTCC2D + ICGN2D1 pair, plus two more threads that share ONE pair (the library
+    serialises calls on an engine; the reference's compute(POI2D*) is called from OpenMP regions,
+    src/oc_epipolar_search.cpp:184-188): every thread gets the bits a lone run produces."""
+    import threading
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 13, 11, 30)
+    base = eng.make_pois2d(xs, ys)
+
+    def make():
+        f = eng.FFTCC2D(16, 16)
+        f.set_images(ref, tar)
+        g = eng.ICGN2D1(16, 16, 0.001, 10)
+        g.share_images(f)
+        g.prepare()
+        return f, g
+
+    f0, g0 = make()
+    want = g0.compute(f0.compute(base.copy()))
+    shared = make()
+    results, errors = {}, []
+
+    def work(k, pair):
+        try:
+            f, g = pair if pair is not None else make()
+            for rep in range(6):
+                q = base[k % 3:].copy()      # different queue lengths per thread
+                q = g.compute(f.compute(q))
+                results[(k, rep)] = q
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k, None)) for k in range(4)]
+    threads += [threading.Thread(target=work, args=(k, shared)) for k in (4, 5)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 36
+    for (k, rep), q in results.items():
+        assert np.array_equal(_bits(q), _bits(want[k % 3:])), (k, rep)
