@@ -29,7 +29,10 @@
 // gathers stay): how much of the kernel's time is VALU issue; 16 = timeline: results stay valid, and exx / eyy / exy / feature of
 // every POI record receive the kilocycles (s_memtime) its wave spent in  reference subset + Hessian sweep | Hessian
 // reduction + inverse (incl. the barriers of the cooperative form) | interpolation sweeps, all iterations | everything
-// else inside the iterations (norms, numerator pass, solve, warp update).
+// else inside the iterations (norms, numerator pass, solve, warp update); 32 = the Hessian is not inverted (with 1: what the
+// per-wave inverse costs -- 14 % of ICGN2D2 on config C.  Sharing it inside the workgroup was built and measured: two waves
+// inverting four 12 x 12 matrices each in 16-lane groups, ds_bpermute broadcasts, the totals filed through the idle target
+// arrays; 3.69 against 3.65 ms -- the barrier wait for ~300 dependent LDS round trips eats what the other waves save).
 #ifndef OC_ABLATE2D
 #define OC_ABLATE2D 0
 #endif
@@ -371,7 +374,12 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
 #pragma unroll
                 for (int i = 0; i < DOF; i++) hcol[i] = col[i];
             } else {
-                lu_inverse_lanes<DOF>(col, hinv_col, lane);
+                if constexpr ((OC_ABLATE2D & 32) != 0) {
+#pragma unroll
+                    for (int i = 0; i < DOF; i++) hinv_col[i] = col[i] * 1e-9f;  // ablation: no inverse at all
+                } else {
+                    lu_inverse_lanes<DOF>(col, hinv_col, lane);
+                }
             }
         }
     }

@@ -637,17 +637,17 @@ def test_engine_lifecycle_does_not_leak(eng, speckle_small):
         st.compute(q)
         del st, f
 
-    for _ in range(3):
-        cycle()
-    gc.collect()
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
-    for _ in range(25):
-        cycle()
-    gc.collect()
-    torch.cuda.synchronize()
-    free1 = torch.cuda.mem_get_info()[0]
-    assert free0 - free1 < 8 << 20, (free0, free1)
+    def free_after(n):
+        for _ in range(n):
+            cycle()
+        gc.collect()
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    free_after(5)            # one-off allocations of the runtime (code objects, scratch, pools) happen here
+    f1 = free_after(10)
+    f2 = free_after(15)
+    assert f1 - f2 < 4 << 20, (f1, f2)   # steady state: 15 more cycles of every engine kind cost nothing
 
 
 def test_engines_are_usable_from_several_host_threads(eng, speckle_small):
