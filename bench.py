@@ -28,7 +28,19 @@ complete inside the timed region.
 `--scaling strong` fixes the total work instead (BASELINE config D: 8192 x 8192 pair, 1414 x 1414 POIs, cut into N
 blocks); the default is weak scaling as described above.
 
+Warm-up is exactly W steps: nothing else runs the hot path before the timed region (round 2 ran 25 extra "settle"
+steps first; `--settle` still exists for experiments, defaults to 0, and is reported in the line when used).
+
 Besides the contract fields the JSON line carries
+  value_pcie_inclusive -- SURVEY 8(d)'s own definition of the metric (host POI queue: H2D + D2H of the AoS inside the
+                  timed region) as a top-level scalar next to `value` (which the bench contract defines on HBM-resident
+                  inputs); details in `pcie_inclusive`,
+  roofline_secondary -- the same kind of statement for the dominant kernels of the other BASELINE configs
+                  (fftcc2d_fused32 on B, icgn2d_kernel<12> on C, fftcc3d_fused32 and icgn3d1_kernel on E), each with the
+                  SURVEY 8(d) byte formula, hipEvent-timed on the engines' stream in this run,
+  multi_gpu_check -- N > 1 only: world size and device distinctness asserted, rank 0 re-solves a strided sample of every
+                  other rank's block and compares it bit for bit with the gathered records, and the step is timed once more
+                  with the all-gather NOT overlapped,
   roofline     -- ICGN2D1 kernel, judged against the roof it sits closest to.  HBM is not it (traffic <= 9 % of peak:
                   neighbouring subsets share their table entries in L1/L2, so the SURVEY 8(d) byte count / time exceeds
                   the HBM peak); ablations show the gather path of the 64-byte table entries to be the
@@ -39,8 +51,11 @@ Besides the contract fields the JSON line carries
                   `valu` the reference's own floating point operations (50*N2 + 75*N2*k per POI, every multiply, add,
                   subtract counted once: the parity contract forbids FMA contraction) against the chip's fp32 vector
                   rate for separately rounded operations (256 CUs x 4 SIMD32 x 2.4 GHz = 78.6 Tflop/s, half the
-                  157.3 Tflop/s FMA figure of MI355X_MICROARCH.md); HBM traffic measured with PMC counters in a
-                  separate, committed profiling run is attached as `hbm_traffic_profiled`,
+                  157.3 Tflop/s FMA figure of MI355X_MICROARCH.md); `traffic` = HBM bytes per launch from PMC counters
+                  (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) and `traffic_l2` = L2-side bytes (TCC_REQ x a request
+                  size calibrated on a gather of known byte count), both collected by tools/gpu_traffic.sh over THIS
+                  command and committed as profiles/icgn2d1_traffic_configB.json (counters cannot be read from inside
+                  the process; `traffic_source` names the file and its age),
   cpu_baseline -- the CPU oracle (float32 restatement of the reference, OpenMP; pinned bit for bit on the reference's
                   own sources, tests/test_oracle_vs_ref.py) timed on a bounded sample of the same workload on this
                   box's host cores (rank 0, N = 1), built -O3 -march=native for timing,
@@ -67,7 +82,11 @@ L2_PEAK_GBS = 34500.0       # aggregate L2 bandwidth, MI355X_MICROARCH.md ("4 Mi
 GATHER_UBENCH_GBS = 20350.0  # compute-free gather of the kernel's own access pattern, profiles/r02a_gather_ubench.txt
 # HBM bytes per ICGN2D1 launch of THIS workload from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in their
 # own runs, corrected as the guide prescribes); written by tools/pmc_traffic.py, see tools/gpu_round.sh
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "icgn2d1_hbm_traffic_configB.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "icgn2d1_traffic_configB.json")
+TRAFFIC_JSON_OLD = os.path.join(ROOT, "profiles", "icgn2d1_hbm_traffic_configB.json")  # rounds 1-2: HBM side only
+# ds_read2_b32 serves 128 B per clock and CU (MI355X_MICROARCH.md, LDS table): 256 CUs x 128 B x 2.4 GHz
+LDS_READ2_PEAK_GBS = 256 * 128 * 2.4
+CLOCK_GHZ = 2.4
 RX = RY = 16
 CONV, STOP = 0.001, 10.0
 POIS_PER_GPU_SIDE = 500
@@ -78,9 +97,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--settle", type=int, default=25,
-                    help="untimed steps run BEFORE the W warm-up steps so that clocks, allocators and lazily created handles "
-                         "have settled (a cold first run once showed one 13 ms stall inside 10 timed steps); not part of W or K")
+    ap.add_argument("--settle", type=int, default=0,
+                    help="extra untimed steps BEFORE the W warm-up steps (experiments only: the default run warms up with exactly "
+                         "W steps, as the bench contract says; a non-zero value is reported in the JSON line)")
     ap.add_argument("--size", type=int, default=0, help="override image side (debug)")
     ap.add_argument("--pois", type=int, default=0, help="override POIs per GPU side (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
@@ -128,7 +147,12 @@ def roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof):
         "peak": L2_PEAK_GBS,
         "unit": "GB/s",
         "frac": alg_rate / L2_PEAK_GBS,
-        "traffic": None,  # HBM bytes are not collected inside a bench run: see hbm_traffic_profiled
+        # HBM bytes per launch by PMC counters -- collected over this very command by tools/gpu_traffic.sh in separate
+        # rocprofv3 passes (a process cannot read them itself) and committed; None when no record exists for the workload
+        "traffic": (prof or {}).get("hbm_bytes_per_launch"),
+        "traffic_l2": (prof or {}).get("l2_bytes_per_launch"),
+        "traffic_source": (prof or {}).get("source"),
+        "l2_counter_frac": ((prof or {}).get("l2_bytes_per_launch") or 0.0) / secs / 1e9 / L2_PEAK_GBS if secs > 0 else 0.0,
         "algorithmic_bytes_per_launch": alg_bytes,
         "avg_launch_ms": icgn_avg_ms,
         "launches_timed": icgn_launches,
@@ -155,22 +179,31 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+        # the driver launches N ranks for --gpus N; anything else is a mis-launch, and a number from it would be mislabelled
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (launch with torch.distributed.run --nproc-per-node %d)"
+                         % (args.gpus, world, args.gpus))
     # OC_BENCH_ONE_DEVICE=1 (tests only): every rank uses GPU 0 and the collective runs over gloo, so that the N > 1
     # control flow (sharding, double-buffered queues, overlapped gathers, barriers) can be exercised on a one-GPU box.
     # Numbers of such a run mean nothing.
     one_device = os.environ.get("OC_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
+    # OC_BENCH_FORCE_DIST=1 (tests only): the N > 1 control flow -- process group, all-gather, barriers -- also at
+    # WORLD_SIZE = 1, so that torch.distributed's RCCL backend executes on a one-GPU box
+    force_dist = os.environ.get("OC_BENCH_FORCE_DIST") == "1"
+    dist_on = world > 1 or force_dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    backend = None
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "gloo" if one_device else "nccl"
         if one_device:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     import opencorr_amd
     from opencorr_amd import synth
@@ -208,10 +241,10 @@ def main():
     lo, hi = shard_bounds(n_total, world, rank)
     pristine = torch.from_numpy(opencorr_amd.make_pois2d(xs[lo:hi], ys[lo:hi])).to(dev)
     # two queues (and two gather buffers): step k+1 fills one while the all-gather of step k reads the other
-    queues = [pristine.clone(), pristine.clone()] if world > 1 else [pristine.clone()]
+    queues = [pristine.clone(), pristine.clone()] if dist_on else [pristine.clone()]
     per_rank = -(-n_total // world)
     gather_bufs = [torch.empty((world * per_rank, pristine.shape[1]), dtype=pristine.dtype, device=dev)
-                   for _ in queues] if world > 1 else []
+                   for _ in queues] if dist_on else []
     pending = [None] * len(queues)
     pois = queues[0]
     gen_s = time.time() - t0
@@ -243,7 +276,7 @@ def main():
         pois.copy_(pristine)
         fftcc.compute(pois)
         icgn.compute(pois)
-        if world > 1:
+        if dist_on:
             gathered, pending[b] = allgather_pois(pois, n_total, out=gather_bufs[b], async_op=True)
 
     def drain():
@@ -262,7 +295,7 @@ def main():
     torch.cuda.synchronize()
     icgn.profile_enable(True)
     fftcc.profile_enable(True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -270,15 +303,29 @@ def main():
         step()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     icgn_ms, icgn_launches = icgn.profile_read()
     fftcc_ms, fftcc_launches = fftcc.profile_read()
+    icgn.profile_enable(False)
+    fftcc.profile_enable(False)
     # one all-gather on its own, nothing overlapping it (what a caller that needs the field at once would wait for)
     gather_alone_ms = None
-    if world > 1:
+    serial_ms = None
+    if dist_on:
+        # the same K steps with the all-gather NOT overlapped: every step waits for its own gather before the next starts
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            drain()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
         dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -288,14 +335,17 @@ def main():
         torch.cuda.synchronize()
         gather_alone_ms = (time.perf_counter() - t1) / 3 * 1e3
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    full = gathered if world > 1 else pois
-    if world > 1:
+    t = torch.tensor([elapsed, serial_ms or 0.0], dtype=torch.float64, device=dev)
+    full = gathered if dist_on else pois
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = float(t[0].item())
+    serial_ms = float(t[1].item()) if dist_on else None
     full_np = full.cpu().numpy()
     converged = int((full_np[:, 16] >= 0).sum())
     local_np = pois.cpu().numpy()
+    check = multi_gpu_check(args, dist, torch, dev, rank, world, local_rank, one_device, backend, fftcc, icgn, xs, ys, n_total,
+                            full_np, local_np, lo, hi, serial_ms) if dist_on else None
 
     if rank == 0:
         value = converged * args.steps / elapsed
@@ -309,7 +359,7 @@ def main():
             "unit": "POI/s",
             "n_gpus": world,
             "steps": args.steps,
-            "warmup": args.warmup,
+            "warmup": args.warmup + max(args.settle, 0),
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling,
@@ -323,7 +373,7 @@ def main():
                 "converged_pois": converged,
                 "mean_iterations": mean_iter,
                 "collective": ("RCCL all_gather of POI records, overlapped with the next step's kernels"
-                               if world > 1 else "none"),
+                               if dist_on else "none"),
                 "all_gather_alone_ms": gather_alone_ms,
             },
             "roofline": roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof),
@@ -334,14 +384,160 @@ def main():
                 "generate_inputs_s": gen_s,
             },
         }
+        if args.settle > 0:
+            out["settle_steps"] = args.settle
+        if check is not None:
+            out["multi_gpu_check"] = check
         # side measurements, skipped with --no-cpu-baseline so that a profiler sees only warm-up + timed steps
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not dist_on and not args.no_cpu_baseline:
             out["pcie_inclusive"] = host_queue_rate(fftcc, icgn, pristine, converged)
+            out["value_pcie_inclusive"] = out["pcie_inclusive"]["value"]
+            fftcc_block = secondary_block(
+                "fftcc2d_fused32_kernel (FFTCC2D, 32x32 window)", "B: 4096^2, r=16, 250 000 POIs",
+                (2 * (2 * RX) * (2 * RY) * 4 + 20) * float(hi - lo), fftcc_ms / max(fftcc_launches, 1), fftcc_launches,
+                "hbm", HBM_PEAK_GBS, "SURVEY 8(d): 2*M2*4 B in + 20 B out = 8 212 B per POI; the kernel itself is VALU-bound "
+                "(about 2 k wave-instructions per POI, DESIGN.md 4.2)")
+            del queues, gather_bufs
+            out["roofline_secondary"] = [fftcc_block] + secondary_rooflines(dev, local_rank)
             out["cpu_baseline"] = cpu_baseline(ref, tar, xs, ys, args.cpu_sample)
             out["oht_pair"] = oht_pair(local_rank)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
+
+
+def multi_gpu_check(args, dist, torch, dev, rank, world, local_rank, one_device, backend, fftcc, icgn, xs, ys, n_total, full_np,
+                    local_np, lo, hi, serial_ms, sample_per_rank=512):
+    """N > 1 self-check (results for G in {1, 2, 4, 8} must be bitwise identical).  Every rank: its own block of
+    the gathered queue equals what it computed.  Rank 0 additionally RE-SOLVES a strided sample of every other rank's block
+    on its own GPU (same images, same engines) and compares with the gathered records bit for bit -- a rank that computed on
+    a stale image, a mis-cut block or a gather that landed records in the wrong slot cannot pass.  Ranks must sit on
+    distinct devices (PCI bus ids gathered over the process group)."""
+    import opencorr_amd
+    assert dist.get_world_size() == world == args.gpus
+    props = torch.cuda.get_device_properties(dev)
+    ident = "%s/%s" % (getattr(props, "pci_bus_id", "?"), getattr(props, "uuid", local_rank))
+    idents = [None] * world
+    dist.all_gather_object(idents, (rank, local_rank, ident))
+    distinct = len({i[2] for i in idents}) == world
+    if not one_device:
+        assert distinct, "ranks share a device: %r" % (idents,)
+    own_ok = bool(np.array_equal(full_np[lo:hi].view(np.uint32), local_np.view(np.uint32)))
+    assert own_ok, "rank %d: its block of the gathered queue differs from what it computed" % rank
+    checked, ok = 0, True
+    if rank == 0:
+        per = -(-n_total // world)
+        for r in range(1, world):
+            rlo, rhi = min(r * per, n_total), min((r + 1) * per, n_total)
+            if rhi <= rlo:
+                continue
+            stride = max(1, (rhi - rlo) // sample_per_rank)
+            idx = np.arange(rlo, rhi, stride)
+            q = torch.from_numpy(opencorr_amd.make_pois2d(xs[idx], ys[idx])).to(dev)
+            fftcc.compute(q)
+            icgn.compute(q)
+            torch.cuda.synchronize()
+            same = bool(np.array_equal(q.cpu().numpy().view(np.uint32), full_np[idx].view(np.uint32)))
+            assert same, "records gathered from rank %d differ from rank 0's own solution of the same POIs" % r
+            ok = ok and same
+            checked += len(idx)
+    flag = torch.tensor([1 if (ok and own_ok) else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    assert int(flag.item()) == 1
+    return {"world_size": dist.get_world_size(), "backend": backend, "devices": [i[2] for i in idents],
+            "devices_distinct": distinct, "gathered_equals_local_bits": own_ok,
+            "resolved_sample_of_other_ranks": checked, "resolved_sample_bit_identical": ok,
+            "ms_per_step_gather_not_overlapped": serial_ms}
+
+
+def secondary_block(kernel, config, alg_bytes, avg_ms, launches, bound, peak_gbs, note, extra=None):
+    secs = avg_ms * 1e-3
+    rate = alg_bytes / secs / 1e9 if secs > 0 else 0.0
+    blk = {"kernel": kernel, "config": config, "bound": bound, "achieved": rate, "peak": peak_gbs, "unit": "GB/s",
+           "frac": rate / peak_gbs, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+           "launches_timed": launches, "hbm_frac_of_algorithmic_bytes": rate / HBM_PEAK_GBS, "note": note}
+    if extra:
+        blk.update(extra)
+    return blk
+
+
+def _timed_launches(torch, eng, fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    ms, n = eng.profile_read()
+    eng.profile_enable(False)
+    return ms / max(n, 1), n
+
+
+def secondary_rooflines(dev, device, reps=3):
+    """Dominant kernels of BASELINE configs C and E on this GPU, each against the SURVEY 8(d) byte formula (hipEvents on the
+    engines' stream around every launch, like the main block).  Side measurement: runs after the timed region."""
+    import torch
+    import opencorr_amd
+    from opencorr_amd import synth
+    out = []
+    stream = torch.cuda.current_stream().cuda_stream
+    # ---- C: 4096^2, r = 20, ICGN2D2, 316 x 316 POIs
+    r = 20
+    ref, tar = synth.speckle_pair_2d(4096, 4096, seed=20260925, device=dev, second_order=dict(uxx=2e-6, vyy=-1e-6))
+    xs, ys = synth.poi_grid_2d(4096, 4096, 316, 316, r + 8)
+    f = opencorr_amd.FFTCC2D(r, r, device=device)
+    f.set_stream(stream)
+    f.set_images(ref, tar)
+    g = opencorr_amd.ICGN2D2(r, r, CONV, STOP, device=device)
+    g.set_stream(stream)
+    g.share_images(f)
+    g.prepare()
+    guess = torch.from_numpy(opencorr_amd.make_pois2d(xs, ys)).to(dev)
+    f.compute(guess)
+    q = guess.clone()
+    avg, n = _timed_launches(torch, g, lambda: (q.copy_(guess), g.compute(q)), reps)
+    res = q.cpu().numpy()
+    it = res[:, 17].astype(np.float64)
+    ran = it > 0
+    n2 = (2 * r + 1) ** 2
+    alg = float(ran.sum() * (3 * n2 * 4 + 200) + it[ran].sum() * n2 * 64 + (~ran).sum() * 200)
+    out.append(secondary_block("icgn2d_kernel<12,...> (ICGN2D2)", "C: 4096^2, r=20 (41x41), %d POIs" % len(xs), alg, avg, n, "l2",
+                               L2_PEAK_GBS, "SURVEY 8(d): 3*N2*4 + k*N2*64 + 200 B per POI, N2 = 1681; same L1/L2 table gather as ICGN2D1",
+                               {"mean_iterations": float(it[ran].mean()), "converged": int((res[:, 16] >= 0).sum())}))
+    del f, g, ref, tar, guess, q
+    # ---- E: 512^3, r = 16, FFTCC3D + ICGN3D1, 37^3 POIs
+    r = 16
+    ref, tar = synth.speckle_pair_3d(512, 512, 512, seed=20260927, device=dev)
+    xs, ys, zs = synth.poi_grid_3d(512, 512, 512, 37, 37, 37, r + 8)
+    f = opencorr_amd.FFTCC3D(r, r, r, device=device)
+    f.set_stream(stream)
+    f.set_images(ref, tar)
+    g = opencorr_amd.ICGN3D1(r, r, r, CONV, 20.0, device=device)
+    g.set_stream(stream)
+    g.share_images(f)
+    g.prepare()
+    pristine = torch.from_numpy(opencorr_amd.make_pois3d(xs, ys, zs)).to(dev)
+    guess = pristine.clone()
+    avg_f, n_f = _timed_launches(torch, f, lambda: (guess.copy_(pristine), f.compute(guess)), reps)
+    m3 = (2 * r) ** 3
+    out.append(secondary_block("fftcc3d_fused32_kernel (FFTCC3D, 32^3 window)", "E: 512^3, r=16, %d POIs" % len(xs),
+                               (2 * m3 * 4 + 28) * float(len(xs)), avg_f, n_f, "hbm", HBM_PEAK_GBS,
+                               "SURVEY 8(d): 2*M3*4 B in + 28 B out = 262 172 B per POI; the kernel is VALU + LDS-exchange bound "
+                               "(six 32-point FFT passes per thread, DESIGN.md 4.2b)"))
+    q = guess.clone()
+    avg, n = _timed_launches(torch, g, lambda: (q.copy_(guess), g.compute(q)), reps)
+    res = q.cpu().numpy()
+    it = res[:, 19].astype(np.float64)   # POI3D: result.iteration (float 19; zncc is float 18)
+    ran = it > 0
+    n3 = (2 * r + 1) ** 3
+    alg = float(ran.sum() * (4 * n3 * 4 + 248) + it[ran].sum() * n3 * 256 + (~ran).sum() * 248)
+    out.append(secondary_block("icgn3d1_kernel (ICGN3D1)", "E: 512^3, r=16 (33^3), %d POIs" % len(xs), alg, avg, n, "lds",
+                               LDS_READ2_PEAK_GBS, "SURVEY 8(d): 4*N3*4 + k*N3*256 + 248 B per POI; the 256 B per sample and iteration are "
+                               "the 64 tricubic taps, served from the LDS-staged coefficient box: judged against the LDS read rate "
+                               "(ds_read2_b32: 128 B per clock and CU)",
+                               {"mean_iterations": float(it[ran].mean()), "converged": int((res[:, 18] >= 0).sum())}))
+    return out
 
 
 def host_queue_rate(fftcc, icgn, pristine, converged, reps=3):
@@ -364,13 +560,20 @@ def host_queue_rate(fftcc, icgn, pristine, converged, reps=3):
 def pmc_profile(world):
     """HBM bytes per ICGN launch from the COMMITTED PMC record of this workload (separate rocprofv3 --pmc passes,
     tools/gpu_round.sh); a constant read from profiles/, not something measured in this run."""
-    if world != 1 or not os.path.exists(TRAFFIC_JSON):
+    if world != 1:
         return None
-    with open(TRAFFIC_JSON) as f:
+    path = TRAFFIC_JSON if os.path.exists(TRAFFIC_JSON) else TRAFFIC_JSON_OLD
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
         rec = json.load(f)
-    b = float(rec["hbm_bytes_per_launch"])
-    return {"hbm_bytes_per_launch": b, "source": os.path.relpath(TRAFFIC_JSON, ROOT),
-            "note": "PMC FETCH_SIZE x2 + WRITE_SIZE, collected in their own runs; compulsory traffic (images + table once) is 1.27 GB"}
+    return {"hbm_bytes_per_launch": float(rec["hbm_bytes_per_launch"]),
+            "l2_bytes_per_launch": (float(rec["l2_bytes_per_launch"]) if rec.get("l2_bytes_per_launch") else None),
+            "l2_request_bytes_calibrated": rec.get("l2_request_bytes"), "l2_hit_rate": rec.get("l2_hit_rate"),
+            "source": os.path.relpath(path, ROOT) + (" (%s)" % rec["collected"] if rec.get("collected") else ""),
+            "note": "PMC counters over `python bench.py --no-cpu-baseline`, one counter set per rocprofv3 run (tools/gpu_traffic.sh): "
+                    "HBM = FETCH_SIZE x 2 + WRITE_SIZE; L2 side = TCC_REQ_sum x a request size calibrated on a gather of known byte "
+                    "count; compulsory HBM traffic (images + table once) is 1.27 GB"}
 
 
 def cpu_baseline(ref, tar, xs, ys, sample):

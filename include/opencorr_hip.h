@@ -184,10 +184,15 @@ int oc_hip_set_iteration(oc_hip_engine* engine, float conv_criterion, float stop
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of
  * the engine's own stream.  The handle is used as given: NULL is HIP's default
  * (null) stream, which is what torch.cuda.current_stream().cuda_stream returns
- * for torch's default stream.  The stream in use so far is drained first, so work
- * already enqueued (prepare()'s kernels) cannot race with calls on the new stream. */
+ * for torch's default stream.  The new stream is ordered behind the work already
+ * enqueued on the stream in use so far (prepare()'s kernels, say) ON THE DEVICE --
+ * an event, no host-side wait -- so switching never blocks and never races.  The
+ * outgoing stream may already have been destroyed by its owner (destroy, then
+ * set_stream(other) is a valid sequence): a dead stream has nothing left to order
+ * behind, the new one is installed regardless.  Fails only if the NEW handle is
+ * unusable. */
 int oc_hip_set_stream(oc_hip_engine* engine, void* hip_stream);
-/* Go back to the engine's own (non-blocking) stream. */
+/* Go back to the engine's own (non-blocking) stream; ordered like set_stream, always succeeds. */
 int oc_hip_reset_stream(oc_hip_engine* engine);
 
 /* ---- device groups: one engine, several GPUs of the node -------------------------------
@@ -226,7 +231,12 @@ int oc_hip_group_queue(const oc_hip_engine* engine, int member, const void** dev
  *   "fftcc3d_fused"   1: single-kernel FFTCC3D (register/LDS FFT) for 32 x 32 x 32 windows; 0: rocFFT pipeline
  *   "host_chunk"      POIs per chunk of the host-queue pipeline (copies of one chunk overlap the kernels of its
  *                     neighbours); 0 = whole queue at once; default 65536
- *   "group_allgather" 1: device groups leave the complete result queue on every member (see oc_hip_set_devices) */
+ *   "group_allgather" 1: device groups leave the complete result queue on every member (see oc_hip_set_devices)
+ *   "group_force_rccl" 1 (with "group_allgather"): an engine WITHOUT a group sends its DEVICE queues down the group path
+ *                     as a group of one, whose all-gather is an ncclAllGather on a one-rank communicator (queue ->
+ *                     oc_hip_group_queue(engine, 0)); fails instead of falling back when librccl is unusable.  Exists
+ *                     so that the RCCL binding (dlopen, version check, ncclCommInitAll, ncclAllGather) can be executed
+ *                     on a one-GPU machine */
 int oc_hip_set_tuning(oc_hip_engine* engine, const char* key, int value);
 
 /* ---- precompute ----------------------------------------------------------- */

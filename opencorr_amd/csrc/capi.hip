@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <rccl/rccl.h>  // types and enumerators only: the library itself is loaded with dlopen on first use (struct Rccl)
 
 #include "oc_kernels.h"
 
@@ -129,6 +132,7 @@ struct oc_hip_engine {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t order_ev = nullptr;  // orders the private stream behind the caller's default-stream work
+    hipEvent_t switch_ev = nullptr; // orders a newly chosen stream behind the work left on the previous one
     std::shared_ptr<ImagePair> img;
     DevBuf gx, gy, gz, coef;  // coef: 2D LUT (16 floats / px) or 3D coefficient volume
     DevBuf coef_gx, coef_gy;  // NR2D1: LUTs of the target gradients
@@ -158,7 +162,9 @@ struct oc_hip_engine {
     // its neighbours; one event per chunk orders the copy-out stream behind the kernels
     hipStream_t copy_stream = nullptr, copy_in_stream = nullptr;
     std::vector<hipEvent_t> chunk_done, chunk_in;
-    std::atomic<size_t> chunks_fed{0};  // chunks whose kernels (and event) are enqueued, for the copy-out thread
+    size_t chunks_fed = 0;  // chunks whose kernels (and event) are enqueued; (size_t)-1: the feeder failed.  Guarded by feed_mu
+    std::mutex feed_mu;
+    std::condition_variable feed_cv;  // the copy-out thread sleeps here until the next chunk has been handed over
     int host_chunk = 65536;  // POIs per chunk ("host_chunk" tuning key; 0 = the whole queue at once)
     // device group (oc_hip_set_devices): this engine leads, replicas[i] is a full engine of the same kind on
     // group_devices[i + 1]; every setter, set_images, prepare and compute fans out
@@ -166,6 +172,7 @@ struct oc_hip_engine {
     std::vector<int> group_devices;
     bool is_replica = false;
     int group_allgather = 0;     // DEVICE queues: leave the complete result queue in every member's mirror
+    int group_force_rccl = 0;    // the all-gather goes through RCCL even for a group of ONE (a one-rank communicator)
     DevBuf group_mirror;         // full-size copy of a DEVICE queue (members other than the leader work in theirs)
     DevBuf group_off_mirror;
     size_t group_mirror_block = 0;  // bytes per member block of the last all-gathered queue
@@ -174,7 +181,7 @@ struct oc_hip_engine {
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    std::mutex mu;
+    mutable std::mutex mu;
 
     bool is3d() const { return kind == OC_HIP_FFTCC3D || kind == OC_HIP_ICGN3D1; }
     bool is_iclm() const { return kind == OC_HIP_ICLM2D1 || kind == OC_HIP_ICLM2D2; }
@@ -871,12 +878,14 @@ int oc_hip_destroy(oc_hip_engine* e) {
     e->replicas.clear();
     (void)hipSetDevice(e->device);
     if (e->own_stream) {
-        (void)hipStreamSynchronize(e->stream);
+        // the caller may already have destroyed a stream it once named: an invalid handle means nothing is left to drain
+        if (hipStreamSynchronize(e->stream) != hipSuccess) (void)hipGetLastError();
         if (e->stream != e->own_stream) (void)hipStreamSynchronize(e->own_stream);
     }
     clear_events(e);
     e->fft.destroy();
     if (e->order_ev) (void)hipEventDestroy(e->order_ev);
+    if (e->switch_ev) (void)hipEventDestroy(e->switch_ev);
     if (e->group_ev) (void)hipEventDestroy(e->group_ev);
     for (hipEvent_t ev : e->chunk_done) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->chunk_in) (void)hipEventDestroy(ev);
@@ -1031,6 +1040,8 @@ static int clone_engine(const oc_hip_engine* e, int device, oc_hip_engine** out)
     r->fftcc2d_fused = e->fftcc2d_fused;
     r->fftcc3d_fused = e->fftcc3d_fused;
     r->host_chunk = e->host_chunk;
+    r->group_allgather = e->group_allgather;
+    r->group_force_rccl = e->group_force_rccl;
     return OC_HIP_OK;
 }
 
@@ -1056,6 +1067,7 @@ static int rehome(oc_hip_engine* e, int device) {
     e->ref_ready = e->tar_ready = false;
     e->st_count = 0;
     if (e->order_ev) { (void)hipEventDestroy(e->order_ev); e->order_ev = nullptr; }
+    if (e->switch_ev) { (void)hipEventDestroy(e->switch_ev); e->switch_ev = nullptr; }
     if (e->group_ev) { (void)hipEventDestroy(e->group_ev); e->group_ev = nullptr; }
     for (hipEvent_t ev : e->chunk_done) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->chunk_in) (void)hipEventDestroy(ev);
@@ -1094,24 +1106,42 @@ int oc_hip_set_devices(oc_hip_engine* e, const int* device_ids, int n_devices) {
     e->group_devices.clear();
     if (device_ids[0] != e->device) OC_TRY(rehome(e, device_ids[0]));
     OC_HIP_TRY(hipSetDevice(e->device));
-    for (int i = 1; i < n_devices; i++) {
-        oc_hip_engine* r = nullptr;
-        OC_TRY(clone_engine(e, device_ids[i], &r));
-        e->replicas.push_back(r);
-        if (device_ids[i] != e->device) {
-            // direct xGMI copies between the members (ignored when the platform has no peer path: copies are then staged)
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, e->device, device_ids[i]) == hipSuccess && can) {
-                (void)hipSetDevice(e->device);
-                (void)hipDeviceEnablePeerAccess(device_ids[i], 0);
-                (void)hipSetDevice(device_ids[i]);
-                (void)hipDeviceEnablePeerAccess(e->device, 0);
+    // The new members are built aside and committed as a whole: a failure half way (allocation on member 3 of 8, say)
+    // destroys what was built and leaves a plain single-device engine, never a handle that fans out over a partial group.
+    std::vector<oc_hip_engine*> fresh;
+    auto build = [&]() -> int {
+        for (int i = 1; i < n_devices; i++) {
+            oc_hip_engine* r = nullptr;
+            OC_TRY(clone_engine(e, device_ids[i], &r));
+            fresh.push_back(r);
+            if (device_ids[i] != e->device) {
+                // direct xGMI copies between the members (ignored when the platform has no peer path: copies are then staged)
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, e->device, device_ids[i]) == hipSuccess && can) {
+                    (void)hipSetDevice(e->device);
+                    (void)hipDeviceEnablePeerAccess(device_ids[i], 0);
+                    (void)hipSetDevice(device_ids[i]);
+                    (void)hipDeviceEnablePeerAccess(e->device, 0);
+                }
+                (void)hipGetLastError();  // "already enabled" is fine
             }
-            (void)hipGetLastError();  // "already enabled" is fine
+            if (e->img) OC_TRY(replicate_images(e, r));
         }
-        if (e->img) OC_TRY(replicate_images(e, r));
+        return OC_HIP_OK;
+    };
+    const int rc = build();
+    (void)hipSetDevice(e->device);
+    if (rc != OC_HIP_OK) {
+        const std::string why = g_last_error;
+        for (oc_hip_engine* r : fresh) {
+            r->is_replica = false;
+            (void)oc_hip_destroy(r);
+        }
+        (void)hipSetDevice(e->device);
+        e->group_devices.assign(1, e->device);
+        return fail(rc, "set_devices: %s (the engine stays on device %d alone)", why.c_str(), e->device);
     }
-    OC_HIP_TRY(hipSetDevice(e->device));
+    e->replicas.swap(fresh);
     e->group_devices.assign(device_ids, device_ids + n_devices);
     // precomputed fields exist on the leader only: prepare() again
     if (n_devices > 1) e->ref_ready = e->tar_ready = false;
@@ -1121,6 +1151,7 @@ int oc_hip_set_devices(oc_hip_engine* e, const int* device_ids, int n_devices) {
 int oc_hip_get_devices(const oc_hip_engine* e, int* device_ids, int capacity, int* n_devices) {
     OC_TRY(check_engine(e));
     if (!n_devices) return fail(OC_HIP_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lock(e->mu);
     *n_devices = (int)e->replicas.size() + 1;
     if (device_ids) {
         if (capacity > 0) device_ids[0] = e->device;
@@ -1134,6 +1165,7 @@ int oc_hip_group_queue(const oc_hip_engine* e, int member, const void** device_p
     if (!device_ptr || !block_bytes) return fail(OC_HIP_ERR_INVALID, "null argument");
     *device_ptr = nullptr;
     *block_bytes = 0;
+    std::lock_guard<std::mutex> lock(e->mu);
     if (member < 0 || member > (int)e->replicas.size()) return fail(OC_HIP_ERR_INVALID, "group_queue: member %d out of range", member);
     const oc_hip_engine* m = member == 0 ? e : e->replicas[member - 1];
     if (!m->group_mirror.p || m->group_mirror_block == 0)
@@ -1165,22 +1197,50 @@ int oc_hip_set_iteration(oc_hip_engine* e, float conv, float stop) {
 }
 
 // Switching streams: work already enqueued on the old stream (prepare()'s gradient and table kernels, a layout
-// conversion) must not race with computes on the new one, so the old stream is drained first.
+// conversion) must not race with computes on the new one.  The two streams are ordered ON THE DEVICE: an event recorded
+// on the outgoing stream, a wait for it on the incoming one -- no host-side wait, so a caller that hops between
+// streams (torch's current stream changing from call to call) stays asynchronous.  The outgoing handle may be dead
+// already (destroy the stream, then name another one, is a normal C-API sequence): a stream that no longer exists has
+// nothing left to drain, so failing to record on it is not an error; the new stream is installed regardless.
+static int switch_stream(oc_hip_engine* e, hipStream_t next, bool must_succeed) {
+    if (next == e->stream) return OC_HIP_OK;
+    if (!e->switch_ev && hipEventCreateWithFlags(&e->switch_ev, hipEventDisableTiming) != hipSuccess) {
+        e->switch_ev = nullptr;
+        (void)hipGetLastError();
+    }
+    bool recorded = false;
+    if (e->switch_ev) {
+        recorded = hipEventRecord(e->switch_ev, e->stream) == hipSuccess;
+        if (!recorded) (void)hipGetLastError();  // invalid handle / destroyed context: nothing to drain
+    } else {
+        // no event to order with: drain the outgoing stream from the host instead (an invalid handle again is fine)
+        if (hipStreamSynchronize(e->stream) != hipSuccess) (void)hipGetLastError();
+    }
+    if (recorded) {
+        const hipError_t err = hipStreamWaitEvent(next, e->switch_ev, 0);
+        if (err != hipSuccess) {
+            (void)hipGetLastError();
+            // the INCOMING handle is unusable.  reset_stream() goes back to the engine's own stream and must always
+            // succeed: drain the outgoing stream from the host instead and carry on
+            if (!must_succeed)
+                return fail(OC_HIP_ERR_HIP, "set_stream: cannot enqueue on the new stream: %s", hipGetErrorString(err));
+            if (hipStreamSynchronize(e->stream) != hipSuccess) (void)hipGetLastError();
+        }
+    }
+    e->stream = next;
+    return OC_HIP_OK;
+}
+
 int oc_hip_set_stream(oc_hip_engine* e, void* hip_stream) {
     OC_ACTIVATE(e);
     std::lock_guard<std::mutex> lock(e->mu);
-    const hipStream_t next = reinterpret_cast<hipStream_t>(hip_stream);
-    if (next != e->stream) OC_HIP_TRY(hipStreamSynchronize(e->stream));
-    e->stream = next;
-    return OC_HIP_OK;
+    return switch_stream(e, reinterpret_cast<hipStream_t>(hip_stream), false);
 }
 
 int oc_hip_reset_stream(oc_hip_engine* e) {
     OC_ACTIVATE(e);
     std::lock_guard<std::mutex> lock(e->mu);
-    if (e->stream != e->own_stream) OC_HIP_TRY(hipStreamSynchronize(e->stream));
-    e->stream = e->own_stream;
-    return OC_HIP_OK;
+    return switch_stream(e, e->own_stream, true);
 }
 
 int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
@@ -1206,6 +1266,8 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
         e->host_chunk = value;
     } else if (k == "group_allgather") {
         e->group_allgather = value != 0;
+    } else if (k == "group_force_rccl") {
+        e->group_force_rccl = value != 0;
     } else {
         return fail(OC_HIP_ERR_INVALID, "unknown tuning key '%s'", key);
     }
@@ -1334,8 +1396,18 @@ int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t coun
     // chunk's event and copies its records back.
     const int device = e->device;
     hipError_t out_err = hipSuccess;
-    e->chunks_fed.store(0, std::memory_order_release);
-    std::thread out_thread([&] {
+    {
+        std::lock_guard<std::mutex> hand(e->feed_mu);
+        e->chunks_fed = 0;
+    }
+    auto hand_over = [&](size_t fed) {
+        {
+            std::lock_guard<std::mutex> hand(e->feed_mu);
+            e->chunks_fed = fed;
+        }
+        e->feed_cv.notify_one();
+    };
+    auto copy_out = [&] {
         if (hipSetDevice(device) != hipSuccess) {
             out_err = hipErrorInvalidDevice;
             return;
@@ -1343,16 +1415,28 @@ int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t coun
         for (size_t c = 0; c < nchunk && out_err == hipSuccess; c++) {
             const size_t first = c * chunk, n = std::min(chunk, count - first);
             // the event is recorded by the feeding thread after chunk c's kernels were enqueued; until then
-            // hipStreamWaitEvent would see the event of an earlier call, so wait for the hand-off first
-            while (e->chunks_fed.load(std::memory_order_acquire) <= c) std::this_thread::yield();
-            if (e->chunks_fed.load(std::memory_order_acquire) == (size_t)-1) return;  // the feeder failed
+            // hipStreamWaitEvent would see the event of an earlier call, so sleep until the hand-off
+            {
+                std::unique_lock<std::mutex> hand(e->feed_mu);
+                e->feed_cv.wait(hand, [&] { return e->chunks_fed > c; });
+                if (e->chunks_fed == (size_t)-1) return;  // the feeder failed
+            }
             out_err = hipStreamWaitEvent(e->copy_stream, e->chunk_done[c], 0);
             if (out_err == hipSuccess)
                 out_err = hipMemcpyAsync(pois + first * stride_bytes, stage + first * stride_bytes, n * stride_bytes, hipMemcpyDeviceToHost,
                                          e->copy_stream);
         }
         if (out_err == hipSuccess) out_err = hipStreamSynchronize(e->copy_stream);
-    });
+    };
+    // std::thread's constructor throws std::system_error when the process is out of threads; nothing may unwind through
+    // the extern "C" boundary, so the helper is optional: without it this thread copies out after feeding
+    std::thread out_thread;
+    bool helper = true;
+    try {
+        out_thread = std::thread(copy_out);
+    } catch (...) {
+        helper = false;
+    }
     int rc = OC_HIP_OK;
     auto feed = [&]() -> int {
         // the staging buffer may still be read by kernels of an earlier call on the engine's stream
@@ -1374,14 +1458,15 @@ int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t coun
             OC_HIP_TRY(hipStreamWaitEvent(e->stream, e->chunk_in[c], 0));
             OC_TRY(run_compute_device(e, reinterpret_cast<float*>(stage + first * stride_bytes), stride_f, n, d_off));
             OC_HIP_TRY(hipEventRecord(e->chunk_done[c], e->stream));
-            e->chunks_fed.store(c + 1, std::memory_order_release);
+            hand_over(c + 1);
         }
         return OC_HIP_OK;
     };
     rc = feed();
-    if (rc != OC_HIP_OK) e->chunks_fed.store((size_t)-1, std::memory_order_release);
-    out_thread.join();
     const std::string feed_error = g_last_error;
+    if (rc != OC_HIP_OK) hand_over((size_t)-1);
+    if (helper) out_thread.join();
+    else copy_out();
     OC_HIP_TRY(hipStreamSynchronize(e->stream));
     if (rc != OC_HIP_OK) return fail(rc, "%s", feed_error.c_str());
     if (out_err != hipSuccess) return fail(OC_HIP_ERR_HIP, "copying results back failed: %s", hipGetErrorString(out_err));
@@ -1407,38 +1492,56 @@ std::vector<GroupBlock> group_blocks(oc_hip_engine* e, size_t count) {
     return b;
 }
 
-// RCCL, loaded on first use: the single-GPU path never needs it and should not pay for loading it
+// RCCL, loaded on first use: the single-GPU path never needs it and should not pay for loading it (nor fail to start
+// on a machine without it).  Types and enumerators come from <rccl/rccl.h> at compile time -- the datatype passed to
+// ncclAllGather is the header's ncclUint8, not a number typed in here -- and the loaded library must report the same
+// major version as that header.
 struct Rccl {
-    typedef int (*CommInitAll)(void**, int, const int*);
-    typedef int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t);
-    typedef int (*Group)();
-    typedef int (*CommDestroy)(void*);
-    typedef const char* (*ErrStr)(int);
-    CommInitAll comm_init_all = nullptr;
-    AllGather all_gather = nullptr;
-    Group group_start = nullptr, group_end = nullptr;
-    CommDestroy comm_destroy = nullptr;
-    ErrStr err = nullptr;
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclGetErrorString) err = nullptr;
+    decltype(&ncclGetVersion) get_version = nullptr;
+    int version = 0;
+    std::string why;  // why the library is unusable
     bool ok = false;
+    const char* text(ncclResult_t rc) const { return err ? err(rc) : "?"; }
     static Rccl& get() {
         static Rccl r;
         static std::once_flag once;
         std::call_once(once, [] {
-            void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-            if (!h) return;
-            r.comm_init_all = (CommInitAll)dlsym(h, "ncclCommInitAll");
-            r.all_gather = (AllGather)dlsym(h, "ncclAllGather");
-            r.group_start = (Group)dlsym(h, "ncclGroupStart");
-            r.group_end = (Group)dlsym(h, "ncclGroupEnd");
-            r.comm_destroy = (CommDestroy)dlsym(h, "ncclCommDestroy");
-            r.err = (ErrStr)dlsym(h, "ncclGetErrorString");
-            r.ok = r.comm_init_all && r.all_gather && r.group_start && r.group_end && r.comm_destroy;
+            // OC_HIP_RCCL_LIB names a specific build; otherwise the ROCm soname, then the unversioned name
+            const char* names[3] = {getenv("OC_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so"};
+            void* h = nullptr;
+            for (const char* name : names)
+                if (!h && name && *name) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) {
+                const char* d = dlerror();
+                r.why = std::string("librccl.so.1 could not be loaded: ") + (d ? d : "?");
+                return;
+            }
+            r.comm_init_all = (decltype(r.comm_init_all))dlsym(h, "ncclCommInitAll");
+            r.all_gather = (decltype(r.all_gather))dlsym(h, "ncclAllGather");
+            r.group_start = (decltype(r.group_start))dlsym(h, "ncclGroupStart");
+            r.group_end = (decltype(r.group_end))dlsym(h, "ncclGroupEnd");
+            r.comm_destroy = (decltype(r.comm_destroy))dlsym(h, "ncclCommDestroy");
+            r.err = (decltype(r.err))dlsym(h, "ncclGetErrorString");
+            r.get_version = (decltype(r.get_version))dlsym(h, "ncclGetVersion");
+            if (!(r.comm_init_all && r.all_gather && r.group_start && r.group_end && r.comm_destroy && r.get_version)) {
+                r.why = "librccl lacks one of ncclCommInitAll / ncclAllGather / ncclGroupStart / ncclGroupEnd / ncclCommDestroy / ncclGetVersion";
+                return;
+            }
+            if (r.get_version(&r.version) != ncclSuccess || r.version / 10000 != NCCL_MAJOR) {
+                r.why = "librccl reports version " + std::to_string(r.version) + ", built against major " + std::to_string(NCCL_MAJOR);
+                return;
+            }
+            r.ok = true;
         });
         return r;
     }
 };
-constexpr int kNcclUint8 = 1;  // ncclUint8 / ncclChar family: ncclInt8 = 0, ncclUint8 = 1 (rccl.h)
 
 void group_drop_comms(oc_hip_engine* e) {
     bool any = e->rccl_comm != nullptr;
@@ -1448,7 +1551,7 @@ void group_drop_comms(oc_hip_engine* e) {
     auto drop = [&](oc_hip_engine* m) {
         if (m->rccl_comm && R.ok) {
             (void)hipSetDevice(m->device);
-            (void)R.comm_destroy(m->rccl_comm);
+            (void)R.comm_destroy((ncclComm_t)m->rccl_comm);
         }
         m->rccl_comm = nullptr;
     };
@@ -1456,37 +1559,66 @@ void group_drop_comms(oc_hip_engine* e) {
     for (oc_hip_engine* r : e->replicas) drop(r);
 }
 
+// Can this group's all-gather be ONE ncclAllGather?  Yes when its members sit on distinct devices (a communicator
+// cannot hold a device twice) and there is more than one of them -- or exactly one and "group_force_rccl" is set, which
+// runs the identical code (ncclCommInitAll over one device, ncclAllGather on a one-rank communicator) so that the RCCL
+// binding executes on a one-GPU machine.
+bool group_uses_rccl(oc_hip_engine* e, const std::vector<GroupBlock>& blocks) {
+    const int G = (int)blocks.size();
+    for (int a = 0; a < G; a++)
+        for (int b = a + 1; b < G; b++)
+            if (blocks[a].e->device == blocks[b].e->device) return false;
+    if (G == 1 && !e->group_force_rccl) return false;
+    return true;
+}
+
 // Every member's mirror ends up holding the whole queue (blocks of `block` bytes, the last one padded): ONE
 // ncclAllGather over xGMI when the members sit on distinct devices, peer copies otherwise (a group may name a device
-// twice -- that is how the sharding logic is exercised on a one-GPU box).
-int group_allgather(oc_hip_engine* e, const std::vector<GroupBlock>& blocks, size_t block) {
+// twice -- that is how the sharding logic is exercised on a one-GPU box).  RCCL: every member sends its own block from
+// where it lies -- the leader straight from the caller's queue (`leader_block`), the others from their slot of their
+// mirror (an in-place all-gather for them).
+int group_allgather(oc_hip_engine* e, const std::vector<GroupBlock>& blocks, size_t block, const char* leader_block) {
     const int G = (int)blocks.size();
-    bool distinct = true;
-    for (int a = 0; a < G; a++)
-        for (int b = a + 1; b < G; b++) distinct = distinct && blocks[a].e->device != blocks[b].e->device;
-    Rccl& R = Rccl::get();
-    if (distinct && R.ok && G > 1) {
-        if (!e->rccl_comm) {
-            std::vector<void*> comms(G, nullptr);
-            std::vector<int> devs;
-            for (const GroupBlock& b : blocks) devs.push_back(b.e->device);
-            const int rc = R.comm_init_all(comms.data(), G, devs.data());
-            if (rc != 0) return fail(OC_HIP_ERR_HIP, "ncclCommInitAll over %d devices failed: %s", G, R.err ? R.err(rc) : "?");
-            for (int g = 0; g < G; g++) blocks[g].e->rccl_comm = comms[g];
+    if (group_uses_rccl(e, blocks)) {
+        Rccl& R = Rccl::get();
+        if (!R.ok) {
+            if (e->group_force_rccl) return fail(OC_HIP_ERR_HIP, "group_force_rccl: %s", R.why.c_str());
+        } else {
+            if (!e->rccl_comm) {
+                std::vector<ncclComm_t> comms(G, nullptr);
+                std::vector<int> devs;
+                for (const GroupBlock& b : blocks) devs.push_back(b.e->device);
+                const ncclResult_t rc = R.comm_init_all(comms.data(), G, devs.data());
+                (void)hipSetDevice(e->device);
+                if (rc != ncclSuccess) return fail(OC_HIP_ERR_HIP, "ncclCommInitAll over %d devices failed: %s", G, R.text(rc));
+                for (int g = 0; g < G; g++) blocks[g].e->rccl_comm = comms[g];
+            }
+            // whatever happens between ncclGroupStart and ncclGroupEnd, ncclGroupEnd is reached: an open group would
+            // poison this thread's later RCCL calls and the cached communicators
+            ncclResult_t rc = R.group_start();
+            hipError_t herr = hipSuccess;
+            if (rc == ncclSuccess) {
+                for (int g = 0; g < G && rc == ncclSuccess && herr == hipSuccess; g++) {
+                    oc_hip_engine* m = blocks[g].e;
+                    herr = hipSetDevice(m->device);
+                    if (herr != hipSuccess) break;
+                    char* mirror = m->group_mirror.as<char>();
+                    const char* mine = g == 0 ? leader_block : mirror + (size_t)g * block;
+                    rc = R.all_gather(mine, mirror, block, ncclUint8, (ncclComm_t)m->rccl_comm, m->stream);
+                }
+                const ncclResult_t rc2 = R.group_end();
+                if (rc == ncclSuccess) rc = rc2;
+            }
+            (void)hipSetDevice(e->device);
+            if (herr != hipSuccess) return fail(OC_HIP_ERR_HIP, "hipSetDevice inside the all-gather failed: %s", hipGetErrorString(herr));
+            if (rc != ncclSuccess) return fail(OC_HIP_ERR_HIP, "ncclAllGather failed: %s", R.text(rc));
+            return OC_HIP_OK;
         }
-        int rc = R.group_start();
-        for (int g = 0; g < G && rc == 0; g++) {
-            oc_hip_engine* m = blocks[g].e;
-            OC_HIP_TRY(hipSetDevice(m->device));
-            char* mirror = m->group_mirror.as<char>();
-            rc = R.all_gather(mirror + (size_t)g * block, mirror, block, kNcclUint8, m->rccl_comm, m->stream);
-        }
-        const int rc2 = R.group_end();
-        OC_HIP_TRY(hipSetDevice(e->device));
-        if (rc != 0 || rc2 != 0) return fail(OC_HIP_ERR_HIP, "ncclAllGather failed: %s", R.err ? R.err(rc ? rc : rc2) : "?");
-        return OC_HIP_OK;
     }
-    // peer copies: member g fetches every other member's block once that member is done (its event)
+    // peer copies: the leader's block joins its mirror, then member g fetches every other member's block once that
+    // member is done (its event)
+    OC_HIP_TRY(hipMemcpyAsync(e->group_mirror.p, leader_block, block, hipMemcpyDeviceToDevice, e->stream));  // blocks[0] is a full block
+    OC_HIP_TRY(hipEventRecord(e->group_ev, e->stream));
     for (int g = 0; g < G; g++) {
         oc_hip_engine* m = blocks[g].e;
         OC_HIP_TRY(hipSetDevice(m->device));
@@ -1543,11 +1675,9 @@ int compute_group_device(oc_hip_engine* e, char* pois, const float* offsets, siz
     // the members are busy; now the leader's own block, in place
     if (blocks[0].n) OC_TRY(run_compute_device(e, reinterpret_cast<float*>(pois), stride_f, blocks[0].n, offsets));
     if (e->group_allgather) {
-        // the leader's block joins the mirrors, then one all-gather
+        // one all-gather: every member ends up with every block
         OC_TRY(e->group_mirror.reserve(blocks.size() * block));
-        OC_HIP_TRY(hipMemcpyAsync(e->group_mirror.p, pois, blocks[0].n * stride_bytes, hipMemcpyDeviceToDevice, e->stream));
-        OC_HIP_TRY(hipEventRecord(e->group_ev, e->stream));
-        OC_TRY(group_allgather(e, blocks, block));
+        OC_TRY(group_allgather(e, blocks, block, pois));
         for (const GroupBlock& b : blocks) {
             b.e->group_mirror_block = block;
             if (b.e != e) {
@@ -1606,8 +1736,10 @@ static int compute_impl(oc_hip_engine* e, void* pois, const float* offsets, size
     if (offsets && e->kind != OC_HIP_ICGN2D1 && e->kind != OC_HIP_ICGN2D2)
         return fail(OC_HIP_ERR_INVALID, "center offsets are an ICGN2D1/ICGN2D2 feature (src/oc_icgn.h:75-76,130-131)");
     std::lock_guard<std::mutex> lock(e->mu);
-    // a queue of a few POIs is not worth waking the other devices for
-    const bool grouped = !e->replicas.empty() && count >= 64 * (e->replicas.size() + 1);
+    // a queue of a few POIs is not worth waking the other devices for; "group_force_rccl" sends a lone engine's DEVICE
+    // queue down the group path as well (a group of one, whose all-gather is a one-rank ncclAllGather)
+    const bool lone_rccl = e->replicas.empty() && e->group_allgather && e->group_force_rccl && memory == OC_HIP_DEVICE;
+    const bool grouped = (!e->replicas.empty() && count >= 64 * (e->replicas.size() + 1)) || lone_rccl;
     if (memory == OC_HIP_DEVICE) {
         OC_TRY(order_after_default_stream(e));
         if (grouped) OC_TRY(compute_group_device(e, static_cast<char*>(pois), offsets, count, stride_bytes));

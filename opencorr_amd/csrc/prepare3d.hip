@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256) void bspline3d_prefilter_x_kernel(const float*
     const float* __restrict__ row = in + ((size_t)i * dy + j) * dx;
     float* __restrict__ orow = out + ((size_t)i * dy + j) * dx;
     float v[24];  // v[t] = row[clamp(x0 - 8 + t)]
-    if (x0 >= 8 && x0 + 16 <= dx && (dx & 3) == 0) {
+    // 16-byte loads only from 16-byte-aligned addresses: this kernel is also the fallback for volumes whose base pointer is
+    // merely 4-byte aligned (a view into a larger device allocation), where dx % 4 == 0 says nothing about the rows
+    if (x0 >= 8 && x0 + 16 <= dx && (dx & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
 #pragma unroll
         for (int t = 0; t < 6; t++) {
             const float4 q = *reinterpret_cast<const float4*>(row + x0 - 8 + 4 * t);

@@ -38,11 +38,13 @@ def _buf(x, floats_per_row=None):
 class _Engine:
     _ndim = 2
 
-    def __init__(self):
+    def __init__(self, device=0):
         self._h = ctypes.c_void_p()
         self._keep = []
+        self._device = int(device)   # where the engine lives (set_devices()[0] moves it)
         self._stream_pinned = False  # set_stream() was called by the user
         self._auto_stream = None     # torch stream adopted for CUDA-tensor arguments
+        self._on_private_stream = True  # False once any caller-owned stream (pinned or adopted) is in use
 
     # -- lifecycle ---------------------------------------------------------
     def close(self):
@@ -85,9 +87,18 @@ class _Engine:
         self.shape = shape
 
     def share_images(self, donor):
+        """Use the donor's device-resident image pair (one upload for an FFTCC + ICGN pair).  The borrower also joins the
+        stream the donor runs on (pinned with ``set_stream`` or adopted from a CUDA tensor), unless it was given a
+        stream of its own: the donor's images may still be in flight on that stream, and ``prepare()`` receives no tensor
+        it could take the stream from -- on its private stream it would read them too early."""
         capi.check(capi.lib().oc_hip_share_images(self._h, donor._h))
         self._keep = [donor]
         self.shape = donor.shape
+        if not self._stream_pinned and not getattr(donor, "_on_private_stream", True):
+            s = donor._auto_stream
+            capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(s or None)))
+            self._auto_stream = s
+            self._on_private_stream = False
 
     def set_subset(self, rx, ry, rz=0):
         capi.check(capi.lib().oc_hip_set_subset(self._h, rx, ry, rz))
@@ -96,18 +107,28 @@ class _Engine:
         """Run on a caller-owned hipStream_t (0 / None = HIP's default stream, as torch reports it)."""
         capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(stream_handle or None)))
         self._stream_pinned = True
+        self._auto_stream = stream_handle or None
+        self._on_private_stream = False
 
     def _adopt_stream_of(self, x):
         """CUDA torch tensors are produced on torch's current stream: unless the user pinned a stream, the engine
         runs on that stream too, so the tensor is read after whatever wrote it and torch ops that follow see the
-        results (stream order instead of timing)."""
-        if self._stream_pinned or not _is_torch(x) or not x.is_cuda:
+        results (stream order instead of timing).  From then on the engine STAYS on that stream (until
+        ``reset_stream``): DEVICE-queue computes are asynchronous, and later NumPy / host-queue calls run on it too.
+        A tensor that lives on another GPU than the engine is refused (its stream belongs to that device)."""
+        if not _is_torch(x) or not x.is_cuda:
+            return
+        dev = getattr(self, "_device", None)
+        if dev is not None and x.device.index is not None and x.device.index != dev:
+            raise ValueError("tensor lives on cuda:%d but the engine on device %d" % (x.device.index, dev))
+        if self._stream_pinned:
             return
         import torch
-        s = torch.cuda.current_stream(x.device).cuda_stream
-        if s != self._auto_stream:
-            capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(s or None)))
+        s = torch.cuda.current_stream(x.device).cuda_stream or None
+        if getattr(self, "_on_private_stream", True) or s != self._auto_stream:
+            capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(s)))
             self._auto_stream = s
+            self._on_private_stream = False
 
     def set_devices(self, device_ids):
         """Spread this engine over several GPUs of the node (``oc_hip_set_devices``): contiguous blocks of every
@@ -115,6 +136,12 @@ class _Engine:
         own device (it moves there if needed -- set the images again).  Results do not depend on the group size."""
         ids = (ctypes.c_int * len(device_ids))(*[int(d) for d in device_ids])
         capi.check(capi.lib().oc_hip_set_devices(self._h, ids, len(device_ids)))
+        if int(device_ids[0]) != self._device:
+            # the engine moved: it is back on a fresh private stream of the new device
+            self._device = int(device_ids[0])
+            self._stream_pinned = False
+            self._auto_stream = None
+            self._on_private_stream = True
 
     def devices(self):
         n = ctypes.c_int()
@@ -138,6 +165,7 @@ class _Engine:
         capi.check(capi.lib().oc_hip_reset_stream(self._h))
         self._stream_pinned = False
         self._auto_stream = None
+        self._on_private_stream = True
 
     def prepare(self):
         capi.check(capi.lib().oc_hip_prepare(self._h))
@@ -260,7 +288,7 @@ class FFTCC2D(_Engine):
     """FFTCC2D(subset_radius_x, subset_radius_y, thread_number) -- src/oc_fftcc.h:54-68."""
 
     def __init__(self, subset_radius_x, subset_radius_y, thread_number=1, device=0):
-        super().__init__()
+        super().__init__(device)
         self.thread_number = thread_number  # kept for signature compatibility
         capi.check(capi.lib().oc_hip_fftcc2d_create(subset_radius_x, subset_radius_y, device, ctypes.byref(self._h)))
 
@@ -269,7 +297,7 @@ class ICGN2D1(_Engine, _IcgnMixin):
     """ICGN2D1(rx, ry, conv_criterion, stop_condition, thread_number) -- src/oc_icgn.h:45-77."""
 
     def __init__(self, subset_radius_x, subset_radius_y, conv_criterion, stop_condition, thread_number=1, device=0):
-        super().__init__()
+        super().__init__(device)
         self.thread_number = thread_number
         capi.check(capi.lib().oc_hip_icgn2d1_create(subset_radius_x, subset_radius_y, conv_criterion, stop_condition,
                                                     device, ctypes.byref(self._h)))
@@ -279,7 +307,7 @@ class ICGN2D2(_Engine, _IcgnMixin):
     """ICGN2D2(rx, ry, conv_criterion, stop_condition, thread_number) -- src/oc_icgn.h:100-132."""
 
     def __init__(self, subset_radius_x, subset_radius_y, conv_criterion, stop_condition, thread_number=1, device=0):
-        super().__init__()
+        super().__init__(device)
         self.thread_number = thread_number
         capi.check(capi.lib().oc_hip_icgn2d2_create(subset_radius_x, subset_radius_y, conv_criterion, stop_condition,
                                                     device, ctypes.byref(self._h)))
@@ -289,7 +317,7 @@ class NR2D1(_Engine, _IcgnMixin):
     """NR2D1(rx, ry, conv_criterion, stop_condition, thread_number) -- src/oc_nr.h, src/oc_nr.cpp:75-91."""
 
     def __init__(self, subset_radius_x, subset_radius_y, conv_criterion, stop_condition, thread_number=1, device=0):
-        super().__init__()
+        super().__init__(device)
         self.thread_number = thread_number
         capi.check(capi.lib().oc_hip_nr2d1_create(subset_radius_x, subset_radius_y, conv_criterion, stop_condition,
                                                   device, ctypes.byref(self._h)))
@@ -305,7 +333,7 @@ class ICLM2D1(_Engine, _IclmMixin):
     """ICLM2D1(rx, ry, conv_criterion, stop_condition, thread_number) -- src/oc_iclm.h:56-85."""
 
     def __init__(self, subset_radius_x, subset_radius_y, conv_criterion, stop_condition, thread_number=1, device=0):
-        super().__init__()
+        super().__init__(device)
         self.thread_number = thread_number
         capi.check(capi.lib().oc_hip_iclm2d1_create(subset_radius_x, subset_radius_y, conv_criterion, stop_condition,
                                                     device, ctypes.byref(self._h)))
@@ -315,7 +343,7 @@ class ICLM2D2(_Engine, _IclmMixin):
     """ICLM2D2(rx, ry, conv_criterion, stop_condition, thread_number) -- src/oc_iclm.h:104-133."""
 
     def __init__(self, subset_radius_x, subset_radius_y, conv_criterion, stop_condition, thread_number=1, device=0):
-        super().__init__()
+        super().__init__(device)
         self.thread_number = thread_number
         capi.check(capi.lib().oc_hip_iclm2d2_create(subset_radius_x, subset_radius_y, conv_criterion, stop_condition,
                                                     device, ctypes.byref(self._h)))
@@ -331,6 +359,7 @@ class Strain:
     def __init__(self, subregion_radius, neighbor_number_min, thread_number=1, device=0):
         self._h = ctypes.c_void_p()
         self.thread_number = thread_number
+        self._device = int(device)
         self._p = dict(radius=float(subregion_radius), nmin=int(neighbor_number_min), zncc=0.9, approx=1)
         capi.check(capi.lib().oc_hip_strain_create(self._p["radius"], self._p["nmin"], device, ctypes.byref(self._h)))
 
@@ -364,13 +393,11 @@ class Strain:
         """1 = Cauchy strain, 2 = Green strain."""
         self._push(approx=int(approximation))
 
-    def set_stream(self, stream_handle):
-        capi.check(capi.lib().oc_hip_set_stream(self._h, ctypes.c_void_p(stream_handle or None)))
-        self._stream_pinned = True
-
+    set_stream = _Engine.set_stream
     _adopt_stream_of = _Engine._adopt_stream_of
     _stream_pinned = False
     _auto_stream = None
+    _on_private_stream = True
 
     def synchronize(self):
         capi.check(capi.lib().oc_hip_synchronize(self._h))
@@ -424,6 +451,7 @@ class RegionFit:
     def __init__(self, neighbor_search_radius, neighbor_number_min, thread_number=1, device=0):
         self._h = ctypes.c_void_p()
         self.thread_number = thread_number
+        self._device = int(device)
         self._radius, self._nmin = float(neighbor_search_radius), int(neighbor_number_min)
         self._reliable = None
         capi.check(capi.lib().oc_hip_region_fit_create(self._radius, self._nmin, device, ctypes.byref(self._h)))
@@ -434,6 +462,7 @@ class RegionFit:
     _adopt_stream_of = _Engine._adopt_stream_of
     _stream_pinned = False
     _auto_stream = None
+    _on_private_stream = True
     synchronize = Strain.synchronize
     profile_enable = Strain.profile_enable
     profile_reset = Strain.profile_reset
@@ -469,7 +498,7 @@ class FFTCC3D(_Engine):
     _ndim = 3
 
     def __init__(self, subset_radius_x, subset_radius_y, subset_radius_z, thread_number=1, device=0):
-        super().__init__()
+        super().__init__(device)
         self.thread_number = thread_number
         capi.check(capi.lib().oc_hip_fftcc3d_create(subset_radius_x, subset_radius_y, subset_radius_z, device,
                                                     ctypes.byref(self._h)))
@@ -481,7 +510,7 @@ class ICGN3D1(_Engine, _IcgnMixin):
 
     def __init__(self, subset_radius_x, subset_radius_y, subset_radius_z, conv_criterion, stop_condition,
                  thread_number=1, device=0):
-        super().__init__()
+        super().__init__(device)
         self.thread_number = thread_number
         capi.check(capi.lib().oc_hip_icgn3d1_create(subset_radius_x, subset_radius_y, subset_radius_z, conv_criterion,
                                                     stop_condition, device, ctypes.byref(self._h)))

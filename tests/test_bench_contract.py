@@ -59,11 +59,41 @@ def test_roofline_block_is_well_formed():
     n2 = 33 * 33
     alg_bytes = (3 * n2 * 4 + 200 + 3.105 * n2 * 64) * 250000
     alg_flops = (50 * n2 + 75 * n2 * 3.105) * 250000
-    r = bench.roofline_block(alg_bytes, alg_flops, 3.47, 10, {"hbm_bytes_per_launch": 2.4e9})
+    r = bench.roofline_block(alg_bytes, alg_flops, 3.47, 10, {"hbm_bytes_per_launch": 2.4e9, "l2_bytes_per_launch": 5.5e10,
+                                                              "source": "profiles/icgn2d1_traffic_configB.json"})
     json.dumps(r)
-    assert r["bound"] == "l2" and r["unit"] == "GB/s" and r["traffic"] is None
+    assert r["bound"] == "l2" and r["unit"] == "GB/s"
+    # traffic is the PMC record of the committed profiling run over the same command (HBM side and L2 side)
+    assert r["traffic"] == 2.4e9 and r["traffic_l2"] == 5.5e10 and r["traffic_source"].startswith("profiles/")
+    assert abs(r["l2_counter_frac"] - 5.5e10 / 3.47e-3 / 1e9 / bench.L2_PEAK_GBS) < 1e-9
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.4 < r["frac"] < 0.55
     assert 0.7 < r["gather_ubench"]["frac"] < 0.9 and 0.25 < r["valu"]["frac"] < 0.31
     assert "2.1x" in r["why_not_hbm"]
     z = bench.roofline_block(alg_bytes, alg_flops, 0.0, 0, None)   # nothing timed: no division by zero
-    assert z["achieved"] == 0.0 and z["frac"] == 0.0
+    assert z["achieved"] == 0.0 and z["frac"] == 0.0 and z["traffic"] is None
+
+
+def test_secondary_roofline_blocks():
+    """One block per dominant kernel of the other BASELINE configs, each recomputable from its own fields."""
+    import json
+    import bench
+    n3 = 33 ** 3
+    alg = (4 * n3 * 4 + 248 + 2.906 * n3 * 256) * 50653   # SURVEY 8(d): 4*N3*4 + k*N3*256 + 248 B per POI
+    b = bench.secondary_block("icgn3d1_kernel (ICGN3D1)", "E", alg, 80.7, 3, "lds", bench.LDS_READ2_PEAK_GBS, "note")
+    json.dumps(b)
+    assert abs(bench.LDS_READ2_PEAK_GBS - 78643.2) < 1e-6
+    assert abs(b["achieved"] - alg / 80.7e-3 / 1e9) < 1e-6 and abs(b["frac"] - b["achieved"] / b["peak"]) < 1e-12
+    assert 0.18 < b["frac"] < 0.25    # the round-2 kernel: 0.21 of the ds_read2_b32 rate (VERDICT round 2)
+    z = bench.secondary_block("k", "c", 1.0, 0.0, 0, "hbm", bench.HBM_PEAK_GBS, "")
+    assert z["achieved"] == 0.0
+
+
+def test_the_default_run_has_no_hidden_warmup():
+    import bench
+    import sys
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = argv
+    assert a.settle == 0 and a.gpus == 1

@@ -1,8 +1,11 @@
-"""BASELINE.json's configurations at their FULL sizes on one MI355X (configs A, B, C; E's shape lives in
-tests/test_gpu_parity_3d.py because the oracle needs a small volume).
+"""ALL FIVE of BASELINE.json's configurations at their FULL sizes on one MI355X: A, B, C, D (the 8-GPU config's whole
+2 M-POI queue on one device: 8192^2 pair, 4.3 GB table -- right at the 32-bit-offset limits check_image2d_limits guards)
+and E (512^3 volume pair, 37^3 = 50 653 POIs, FFTCC3D + ICGN3D1).
 
 Size-independent properties + a strided oracle sample, the checks of tests/fullsize/run_configs.py:
-  * GPU == oracle(OC_ORDER_LANES) bit for bit on every k-th POI of the queue (FFTCC by the GPU, ICGN by the oracle),
+  * FFTCC: the oracle's FFTCC on every k-th POI gives the GPU's integer displacement and guess exactly, ZNCC within 1e-5
+    (1e-4 for 32^3 windows),
+  * GPU == oracle(OC_ORDER_LANES) bit for bit on every k-th POI of the queue (ICGN by the oracle on the GPU's FFTCC output),
   * split queue == whole queue bit for bit (what multi-GPU sharding relies on: a POI's result does not depend on
     which block of the queue it travels in),
   * the analytic displacement field the synthetic pair was rendered with is recovered,
@@ -27,6 +30,7 @@ def _configs():
 
 def _check(rec, min_converged, max_err):
     assert rec["oracle_bit_exact"], rec
+    assert rec["fftcc_oracle_same_integers"] and rec["fftcc_oracle_max_zncc_diff"] <= 1e-5, rec
     assert rec["split_queue_same_bits"], rec
     assert rec["converged"] >= min_converged * rec["pois"], rec
     assert rec["median_abs_err_u"] < 0.01 and rec["max_abs_err_u"] < max_err and rec["max_abs_err_v"] < max_err, rec
@@ -51,3 +55,22 @@ def test_config_c_full_size():
     rec = _configs().run_2d("C", 4096, 20, 316, 2, 1000, so=dict(uxx=2e-6, vyy=-1e-6))
     _check(rec, 0.99, 0.1)
     assert rec["pois"] == 99856
+
+
+def test_config_d_full_size_on_one_gpu():
+    """D (BASELINE configs[3], the 8-GPU config) as ONE queue on one MI355X: 8192^2 pair, r = 16, 1414 x 1414 = 1 999 396
+    POIs, 4.3 GB bicubic table; every 1000th POI against the oracle, halves of the queue == whole queue."""
+    rec = _configs().run_2d("D1", 8192, 16, 1414, 1, 2000)
+    _check(rec, 0.995, 0.05)
+    assert rec["pois"] == 1999396 and rec["oracle_sample"] >= 2000
+
+
+def test_config_e_full_size():
+    """E (BASELINE configs[4]) on one MI355X: 512^3 volume pair, r = 16 (33^3 subvolume, 32^3 FFTCC window), 37^3 = 50 653
+    POIs, FFTCC3D -> ICGN3D1 (stop 20); >= 96 strided POIs against the oracle, 3D-affine field recovered."""
+    rec = _configs().run_3d("E", 512, 16, 37, 96)
+    assert rec["pois"] == 50653 and rec["oracle_sample"] >= 96
+    assert rec["oracle_bit_exact"], rec
+    assert rec["fftcc_oracle_same_integers"] and rec["fftcc_oracle_max_zncc_diff"] <= 1e-4, rec
+    assert rec["converged"] >= 0.999 * rec["pois"], rec
+    assert rec["median_abs_err"] < 0.01 and rec["max_abs_err"] < 0.05, rec

@@ -201,6 +201,80 @@ def test_group_on_distinct_devices(case2d):
         assert np.array_equal(_bits(host.reshape(-1, floats)[:n]), _bits(want)), member
 
 
+def test_rccl_allgather_on_a_one_rank_communicator(case2d):
+    """The RCCL binding itself -- dlopen of librccl, the version check, ncclCommInitAll, ncclGroupStart/End and an
+    ncclAllGather of ncclUint8 blocks -- executed on ONE GPU: with "group_force_rccl" a lone engine's DEVICE queue goes
+    down the group path as a group of one, whose all-gather is a one-rank ncclAllGather (queue -> mirror).  The mirror
+    is written by RCCL alone (no copy of the leader's block precedes it), so equal bits prove the call moved the
+    records.  The peer-copy emulation used by the [0, 0, 0] groups is NOT involved here."""
+    import torch
+    import opencorr_amd
+    ref, tar, pois, want = case2d
+    dev = torch.device("cuda", 0)
+    g = opencorr_amd.ICGN2D1(16, 16, 0.001, 10)
+    g.set_images(torch.from_numpy(ref).to(dev), torch.from_numpy(tar).to(dev))
+    g.prepare()
+    g.set_tuning("group_allgather", 1)
+    g.set_tuning("group_force_rccl", 1)
+    n, floats = pois.shape
+    for rep in range(2):  # the second call reuses the cached communicator
+        q = torch.from_numpy(pois).to(dev)
+        g.compute(q)
+        torch.cuda.synchronize()
+        assert np.array_equal(_bits(q.cpu().numpy()), _bits(want))
+        ptr, block = g.group_queue(0)
+        assert block == n * floats * 4
+        assert np.array_equal(_bits(_download(ptr, block).reshape(n, floats)), _bits(want)), rep
+    # 3D records (124 B, not a multiple of 8) through the same call
+    from opencorr_amd import synth
+    ref3, tar3 = synth.speckle_pair_3d(64, 72, 80, seed=3)
+    xs, ys, zs = synth.poi_grid_3d(64, 72, 80, 4, 4, 4, 22)
+    p3 = opencorr_amd.make_pois3d(xs, ys, zs)
+    f3 = opencorr_amd.FFTCC3D(8, 8, 8)
+    f3.set_images(ref3, tar3)
+    want3 = f3.compute(p3.copy())
+    g3 = opencorr_amd.FFTCC3D(8, 8, 8)
+    g3.set_images(ref3, tar3)
+    g3.set_tuning("group_allgather", 1)
+    g3.set_tuning("group_force_rccl", 1)
+    q3 = torch.from_numpy(p3).to(dev)
+    g3.compute(q3)
+    torch.cuda.synchronize()
+    ptr, block = g3.group_queue(0)
+    assert block == p3.size * 4
+    assert np.array_equal(_bits(_download(ptr, block).reshape(p3.shape)), _bits(want3))
+    # dissolving / destroying drops the communicator without complaint
+    g.set_devices([0])
+    g.close()
+    g3.close()
+
+
+def test_bench_nccl_backend_at_world_size_one():
+    """bench.py's N > 1 control flow (init_process_group(backend="nccl"), double-buffered queues, async all-gather,
+    barriers, max-over-ranks) with WORLD_SIZE = 1 and OC_BENCH_FORCE_DIST=1: torch.distributed's RCCL backend executes
+    on the one GPU of this box.  Small workload; the numbers mean nothing."""
+    import json
+    import socket
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, OC_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--size", "1024", "--pois", "64", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["config"]["collective"].startswith("RCCL")
+    assert rec["config"]["all_gather_alone_ms"] is not None and rec["config"]["all_gather_alone_ms"] > 0
+    assert rec["multi_gpu_check"]["backend"] == "nccl" and rec["multi_gpu_check"]["gathered_equals_local_bits"]
+    assert rec["config"]["converged_pois"] >= 0.99 * rec["config"]["total_pois"]
+
+
 def test_host_pipeline_chunks_change_no_bits():
     """Host queues travel in chunks (H2D / kernels / D2H of neighbouring chunks overlap): same bits as one piece and as
     the device-resident queue."""

@@ -693,3 +693,107 @@ def test_engines_are_usable_from_several_host_threads(eng, speckle_small):
     assert len(results) == 36
     for (k, rep), q in results.items():
         assert np.array_equal(_bits(q), _bits(want[k % 3:])), (k, rep)
+
+
+def test_stream_switches_are_device_ordered_and_survive_a_dead_stream(eng, speckle_small):
+    """oc_hip_set_stream / oc_hip_reset_stream: the outgoing stream is ordered before the incoming one on
+    the DEVICE (event), not drained from the host; a stream the caller has ALREADY DESTROYED has nothing left to drain, so
+    naming another stream -- or going back to the engine's own -- succeeds and the engine keeps working.  Results are the
+    bits a lone engine produces, whichever stream each call ran on."""
+    import ctypes
+    import torch
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 11, 9, 30)
+    base = eng.make_pois2d(xs, ys)
+    f0 = eng.FFTCC2D(16, 16)
+    f0.set_images(ref, tar)
+    g0 = eng.ICGN2D1(16, 16, 0.001, 10)
+    g0.share_images(f0)
+    g0.prepare()
+    want = g0.compute(f0.compute(base.copy()))
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+
+    def new_stream():
+        h = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(h)) == 0
+        return h
+
+    dev = torch.device("cuda", 0)
+    f = eng.FFTCC2D(16, 16)
+    g = eng.ICGN2D1(16, 16, 0.001, 10)
+    s1 = new_stream()
+    f.set_stream(s1.value)
+    g.set_stream(s1.value)
+    f.set_images(ref, tar)
+    g.share_images(f)
+    g.prepare()                    # gradients + table are still in flight on s1 ...
+    s2 = new_stream()
+    f.set_stream(s2.value)         # ... when both engines hop to s2: ordered by an event, no host wait
+    g.set_stream(s2.value)
+    q = torch.from_numpy(base).to(dev)
+    torch.cuda.synchronize()
+    g.compute(f.compute(q))
+    assert hip.hipStreamSynchronize(s2) == 0
+    assert np.array_equal(_bits(q.cpu().numpy()), _bits(want))
+    # destroy s1 (no longer in use), then s2 WHILE the engines still name it; set_stream(new) must install the new one
+    assert hip.hipStreamSynchronize(s1) == 0 and hip.hipStreamDestroy(s1) == 0
+    assert hip.hipStreamDestroy(s2) == 0
+    s3 = new_stream()
+    f.set_stream(s3.value)
+    g.set_stream(s3.value)
+    q = torch.from_numpy(base).to(dev)
+    torch.cuda.synchronize()
+    g.compute(f.compute(q))
+    assert hip.hipStreamSynchronize(s3) == 0
+    assert np.array_equal(_bits(q.cpu().numpy()), _bits(want))
+    # and reset_stream always succeeds, dead outgoing stream or not
+    assert hip.hipStreamDestroy(s3) == 0
+    f.reset_stream()
+    g.reset_stream()
+    got = g.compute(f.compute(base.copy()))
+    assert np.array_equal(_bits(got), _bits(want))
+
+
+def test_share_images_joins_the_donors_stream(eng, speckle_small):
+    """`icgn.share_images(fftcc); icgn.prepare()` -- prepare() receives no tensor to take a stream from, so
+    the borrower joins the donor's (adopted) stream; the in-place device images produced on a NON-default torch stream are
+    then read in order.  A tensor on the wrong device is refused."""
+    import torch
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 9, 9, 30)
+    base = eng.make_pois2d(xs, ys)
+    f0 = eng.FFTCC2D(16, 16)
+    f0.set_images(ref, tar)
+    g0 = eng.ICGN2D1(16, 16, 0.001, 10)
+    g0.share_images(f0)
+    g0.prepare()
+    want = g0.compute(f0.compute(base.copy()))
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
+    ref_h, tar_h = torch.from_numpy(ref).pin_memory(), torch.from_numpy(tar).pin_memory()
+    with torch.cuda.stream(side):
+        # a long chain of work on the side stream ends in the images: anything not ordered behind it reads garbage
+        junk = torch.zeros((4096, 4096), device=dev)
+        for _ in range(20):
+            junk = junk @ junk
+        d_ref = torch.empty(ref.shape, device=dev).copy_(ref_h, non_blocking=True)
+        d_tar = torch.empty(tar.shape, device=dev).copy_(tar_h, non_blocking=True)
+        f = eng.FFTCC2D(16, 16)
+        f.set_images(d_ref, d_tar)        # adopts `side`
+        g = eng.ICGN2D1(16, 16, 0.001, 10)
+        g.share_images(f)                  # joins `side` too
+        assert g._auto_stream == side.cuda_stream and not g._on_private_stream
+        g.prepare()
+        q = torch.from_numpy(base).to(dev, non_blocking=False)
+        g.compute(f.compute(q))
+    side.synchronize()
+    assert np.array_equal(_bits(q.cpu().numpy()), _bits(want))
+    if torch.cuda.device_count() > 1:
+        with pytest.raises(ValueError):
+            f.compute(torch.zeros((4, 25), device=torch.device("cuda", 1)))

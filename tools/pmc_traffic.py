@@ -8,7 +8,12 @@ Units and corrections (/opt/skills/guides/MI355X_MICROARCH.md, section HBM): FET
 WRITE_SIZE are kilobytes summed over the L2 channels; on gfx950 FETCH_SIZE counts 128-byte fabric
 requests as 64 bytes, so it is doubled.  WRITE_SIZE is taken as reported (uncalibrated on gfx950).
 Warm-up launches are dropped: only the last `--launches` dispatches of the kernel are averaged.
+
+L2 side (when <dir> also holds pmc_tcc/ and pmc_calib/, tools/gpu_traffic.sh): TCC_REQ_sum of the kernel x the request
+size measured on tools/ubench/l2_req_calib (a read-once stream of 2^30 bytes with the same 16-byte-per-lane loads:
+bytes / TCC_REQ_sum); FETCH_SIZE of that stream checks the x2 correction of the HBM side on this box.
 """
+import datetime
 import argparse
 import csv
 import glob
@@ -34,6 +39,7 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--launches", type=int, default=5)
     ap.add_argument("--note", default="")
+    ap.add_argument("--command", default="", help="the profiled command, recorded in the output")
     a = ap.parse_args()
     rx = re.compile(a.kernel)
     fetch = per_dispatch(glob.glob(os.path.join(a.root, "pmc_fetch", "*_counter_collection.csv"))[0], "FETCH_SIZE", rx)
@@ -50,6 +56,31 @@ def main():
         "hbm_bytes_per_launch": 2.0 * f_kb * 1024.0 + w_kb * 1024.0,
         "note": a.note or "FETCH_SIZE x2 (gfx950 counts 128 B fabric requests as 64 B); WRITE_SIZE as reported",
     }
+    rec["collected"] = datetime.date.today().isoformat()
+    if a.command:
+        rec["command"] = a.command
+    tcc = glob.glob(os.path.join(a.root, "pmc_tcc", "*_counter_collection.csv"))
+    cal = glob.glob(os.path.join(a.root, "pmc_calib", "*_counter_collection.csv"))
+    if tcc:
+        avg = lambda v: sum(v[-a.launches:]) / max(len(v[-a.launches:]), 1)
+        req = avg(per_dispatch(tcc[0], "TCC_REQ_sum", rx))
+        hit = avg(per_dispatch(tcc[0], "TCC_HIT_sum", rx))
+        miss = avg(per_dispatch(tcc[0], "TCC_MISS_sum", rx))
+        rd = avg(per_dispatch(tcc[0], "TCP_TCC_READ_REQ_sum", rx))
+        rec.update({"TCC_REQ_per_launch": req, "TCC_HIT_per_launch": hit, "TCC_MISS_per_launch": miss,
+                    "TCP_TCC_READ_REQ_per_launch": rd, "l2_hit_rate": hit / (hit + miss) if hit + miss else None})
+        if cal:
+            crx = re.compile("stream_read")
+            creq = per_dispatch(cal[0], "TCC_REQ_sum", crx)
+            cbytes = float(1 << 30)
+            per_req = cbytes / (sum(creq[1:]) / max(len(creq[1:]), 1))   # first launch dropped (cold)
+            rec.update({"l2_request_bytes": per_req, "l2_request_calibration": "tools/ubench/l2_req_calib: 2^30 bytes read once / TCC_REQ_sum",
+                        "l2_bytes_per_launch": req * per_req})
+            calf = glob.glob(os.path.join(a.root, "pmc_calib_fetch", "*_counter_collection.csv"))
+            if calf:
+                cf = per_dispatch(calf[0], "FETCH_SIZE", crx)
+                rec["fetch_size_kb_of_the_1GiB_stream"] = sum(cf[1:]) / max(len(cf[1:]), 1)
+                rec["fetch_correction_measured"] = cbytes / 1024.0 / rec["fetch_size_kb_of_the_1GiB_stream"]
     with open(a.out, "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec))
