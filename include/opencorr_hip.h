@@ -255,6 +255,14 @@ int oc_hip_prepare_tar(oc_hip_engine* engine);
  * With OC_HIP_HOST the call returns after the results are back in `pois` (the queue travels in chunks: H2D, kernels
  * and D2H of neighbouring chunks overlap); with OC_HIP_DEVICE it only enqueues work on the engine's stream. */
 int oc_hip_compute(oc_hip_engine* engine, void* pois, size_t count, size_t stride_bytes, int memory);
+/* Several engines over ONE queue, in the given order -- what examples/test_2d_dic_fftcc_icgn1.cpp:80-99 does with two
+ * calls (fftcc2d->compute(poi_queue); icgn2d1->compute(poi_queue);) as ONE: an OC_HIP_HOST queue then crosses PCIe once
+ * in each direction instead of once per engine (per chunk: one copy in, every engine's kernels, one copy out; config B:
+ * two crossings of the 25 MB AoS instead of four).  Results are bit-identical to the separate calls.  All engines live
+ * on one device and take the same record type (POI2D or POI3D); for the duration of the call they run on engines[0]'s
+ * stream (device-ordered behind whatever their own streams still hold, and handed back afterwards).  Centre offsets,
+ * device groups and Strain / RegionFit are not part of a chain. */
+int oc_hip_compute_chain(oc_hip_engine* const* engines, int n_engines, void* pois, size_t count, size_t stride_bytes, int memory);
 /* FFTCC2D::compute(POI2D*) / ICGN2D1::compute(POI2D*)  src/oc_fftcc.cpp:177, src/oc_icgn.cpp:144:
  * a mutex-guarded batch of one, safe to call from the caller's own OpenMP region
  * (src/oc_epipolar_search.cpp:184-188). */

@@ -6,6 +6,6 @@ speckle workloads), ``dist`` (POI sharding + RCCL all-gather).  Device side:
 ``csrc/*.hip`` built into ``lib/libopencorr_hip.so`` by ``python -m opencorr_amd.build``.
 """
 from . import capi  # noqa: F401
-from .engines import FFTCC2D, FFTCC3D, ICGN2D1, ICGN2D2, ICGN3D1, NR2D1, ICLM2D1, ICLM2D2, Strain, RegionFit, make_pois2d, make_pois3d  # noqa: F401
+from .engines import FFTCC2D, FFTCC3D, ICGN2D1, ICGN2D2, ICGN3D1, NR2D1, ICLM2D1, ICLM2D2, Strain, RegionFit, compute_chain, make_pois2d, make_pois3d  # noqa: F401
 
-__all__ = ["FFTCC2D", "FFTCC3D", "ICGN2D1", "ICGN2D2", "ICGN3D1", "NR2D1", "ICLM2D1", "ICLM2D2", "Strain", "RegionFit", "make_pois2d", "make_pois3d", "capi"]
+__all__ = ["FFTCC2D", "FFTCC3D", "ICGN2D1", "ICGN2D2", "ICGN3D1", "NR2D1", "ICLM2D1", "ICLM2D2", "Strain", "RegionFit", "compute_chain", "make_pois2d", "make_pois3d", "capi"]

@@ -5,7 +5,9 @@ HIP kernels for gfx950 + rocFFT).  If the library is missing the import fails
 loudly -- there is no CPU fallback anywhere in ``opencorr_amd``.
 """
 import ctypes
+import importlib.util
 import os
+import warnings
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # OPENCORR_HIP_LIB: developer override (tools/ablate_icgn3d.sh loads instrumented builds of the same library)
@@ -30,7 +32,7 @@ SYMBOLS = [
     "oc_hip_set_images2d", "oc_hip_set_images3d", "oc_hip_share_images", "oc_hip_set_subset",
     "oc_hip_set_iteration", "oc_hip_set_stream", "oc_hip_reset_stream", "oc_hip_set_tuning",
     "oc_hip_prepare", "oc_hip_prepare_ref", "oc_hip_prepare_tar",
-    "oc_hip_compute", "oc_hip_compute_one", "oc_hip_compute_with_offsets", "oc_hip_compute_one_with_offset",
+    "oc_hip_compute", "oc_hip_compute_chain", "oc_hip_compute_one", "oc_hip_compute_with_offsets", "oc_hip_compute_one_with_offset",
     "oc_hip_set_self_adaptive", "oc_hip_synchronize", "oc_hip_select_best",
     "oc_hip_get_kind", "oc_hip_get_field", "oc_hip_read_field",
     "oc_hip_profile_enable", "oc_hip_profile_read", "oc_hip_profile_reset",
@@ -45,6 +47,51 @@ class OpenCorrHipError(RuntimeError):
 
 
 _lib = None
+_hip = None
+
+
+def _mapped(name):
+    """Paths of the shared objects mapped into this process whose file name contains ``name``."""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({ln.split()[-1] for ln in f if name in ln and "/" in ln})
+    except OSError:
+        return []
+
+
+def _one_hip_runtime():
+    """A process must hold ONE HIP runtime: stream and event handles of one copy of libamdhip64 crash the other
+    (measured on the MI355X box: `std::bad_variant_access` inside hipStreamWaitEvent).  PyTorch wheels bundle their own
+    copy (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7); libopencorr_hip.so asks for "libamdhip64.so.7".  When torch
+    is imported FIRST the dynamic loader hands us torch's copy (SONAME match) and all is well; when this module is loaded
+    first it would bind /opt/rocm's copy and a later `import torch` would add a second runtime beside it.  So, if torch
+    is installed and no HIP runtime is mapped yet, torch's copy is loaded by path before our library -- without importing
+    torch.  C++ hosts (no Python, no torch) simply get the ROCm installation's runtime."""
+    if _mapped("libamdhip64"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
+def hip_runtime():
+    """ctypes handle of THE HIP runtime this process uses (the copy libopencorr_hip.so is bound to) -- for helpers that
+    need a raw hipMemcpy / hipStreamCreate next to the engines.  Never `ctypes.CDLL("libamdhip64.so")`: by name that may
+    load a second copy (see _one_hip_runtime)."""
+    global _hip
+    if _hip is None:
+        lib()
+        paths = _mapped("libamdhip64")
+        if not paths:
+            raise ImportError("no libamdhip64 is mapped into this process")
+        _hip = ctypes.CDLL(paths[0], mode=ctypes.RTLD_GLOBAL)
+    return _hip
 
 
 def lib():
@@ -56,7 +103,13 @@ def lib():
         raise ImportError(
             "%s is missing: build it with `python -m opencorr_amd.build` (hipcc, gfx950). "
             "opencorr_amd has no CPU fallback." % LIB_PATH)
+    _one_hip_runtime()
     L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    copies = _mapped("libamdhip64")
+    if len(copies) > 1:
+        warnings.warn("more than one HIP runtime is mapped into this process (%s): stream handles must not cross between "
+                      "them -- import opencorr_amd before anything that loads another libamdhip64, or torch first"
+                      % ", ".join(copies), RuntimeWarning)
     vp, i, f, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
     pp = ctypes.POINTER(vp)
     L.oc_hip_last_error.restype = ctypes.c_char_p
@@ -94,6 +147,7 @@ def lib():
     L.oc_hip_prepare_ref.argtypes = [vp]
     L.oc_hip_prepare_tar.argtypes = [vp]
     L.oc_hip_compute.argtypes = [vp, vp, sz, sz, i]
+    L.oc_hip_compute_chain.argtypes = [pp, i, vp, sz, sz, i]
     L.oc_hip_compute_one.argtypes = [vp, vp]
     L.oc_hip_compute_with_offsets.argtypes = [vp, vp, vp, sz, sz, i]
     L.oc_hip_compute_one_with_offset.argtypes = [vp, vp, vp]

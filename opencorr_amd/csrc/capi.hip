@@ -132,7 +132,13 @@ struct oc_hip_engine {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t order_ev = nullptr;  // orders the private stream behind the caller's default-stream work
-    hipEvent_t switch_ev = nullptr; // orders a newly chosen stream behind the work left on the previous one
+    // Orders a newly chosen stream behind the work this engine left on the previous one.  On a CALLER-owned stream the
+    // event is recorded at the end of every entry point that returns with work still enqueued (mark_tail): the caller may
+    // destroy its stream at any time afterwards, and HIP aborts the process when a destroyed stream is handed to ANY
+    // API call -- so a stream switch, destroy() and set_devices() never touch a caller's stream again, they wait for
+    // this event instead.
+    hipEvent_t switch_ev = nullptr;
+    bool tail_marked = false;  // switch_ev holds the tail of this engine's work on the current (caller-owned) stream
     std::shared_ptr<ImagePair> img;
     DevBuf gx, gy, gz, coef;  // coef: 2D LUT (16 floats / px) or 3D coefficient volume
     DevBuf coef_gx, coef_gy;  // NR2D1: LUTs of the target gradients
@@ -263,6 +269,26 @@ int order_after_default_stream(oc_hip_engine* e) {
     OC_HIP_TRY(hipEventRecord(e->order_ev, nullptr));
     OC_HIP_TRY(hipStreamWaitEvent(e->own_stream, e->order_ev, 0));
     return OC_HIP_OK;
+}
+
+// See oc_hip_engine::switch_ev.  Entry points that return with work enqueued on a caller-owned stream end with this.
+int mark_tail(oc_hip_engine* e) {
+    if (e->stream == e->own_stream) return OC_HIP_OK;  // the engine's own stream can always be asked later
+    if (!e->switch_ev) OC_HIP_TRY(hipEventCreateWithFlags(&e->switch_ev, hipEventDisableTiming));
+    OC_HIP_TRY(hipEventRecord(e->switch_ev, e->stream));
+    e->tail_marked = true;
+    return OC_HIP_OK;
+}
+
+// Host-side wait for everything this engine has enqueued, without ever touching a caller's (possibly destroyed) stream.
+void drain_engine(oc_hip_engine* e) {
+    if (e->stream == e->own_stream) {
+        if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+    } else {
+        if (e->tail_marked && e->switch_ev) (void)hipEventSynchronize(e->switch_ev);
+        if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+    }
+    (void)hipGetLastError();
 }
 
 void clear_events(oc_hip_engine* e) {
@@ -669,6 +695,7 @@ int oc_hip_set_damping(oc_hip_engine* e, float lambda, float alpha, float beta) 
 // else could order against it, so the call completes before it returns.
 static int finish_device_call(oc_hip_engine* e) {
     if (e->stream == e->own_stream) OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    else OC_TRY(mark_tail(e));
     return OC_HIP_OK;
 }
 
@@ -877,11 +904,7 @@ int oc_hip_destroy(oc_hip_engine* e) {
     }
     e->replicas.clear();
     (void)hipSetDevice(e->device);
-    if (e->own_stream) {
-        // the caller may already have destroyed a stream it once named: an invalid handle means nothing is left to drain
-        if (hipStreamSynchronize(e->stream) != hipSuccess) (void)hipGetLastError();
-        if (e->stream != e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-    }
+    drain_engine(e);  // never through a caller's stream handle: it may be gone already
     clear_events(e);
     e->fft.destroy();
     if (e->order_ev) (void)hipEventDestroy(e->order_ev);
@@ -1052,8 +1075,8 @@ static int rehome(oc_hip_engine* e, int device) {
     OC_HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(OC_HIP_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
     OC_HIP_TRY(hipSetDevice(e->device));
-    OC_HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->stream != e->own_stream) OC_HIP_TRY(hipStreamSynchronize(e->own_stream));
+    drain_engine(e);
+    e->tail_marked = false;
     clear_events(e);
     e->fft.destroy();
     e->fft.work_fwd.release();
@@ -1197,37 +1220,42 @@ int oc_hip_set_iteration(oc_hip_engine* e, float conv, float stop) {
 }
 
 // Switching streams: work already enqueued on the old stream (prepare()'s gradient and table kernels, a layout
-// conversion) must not race with computes on the new one.  The two streams are ordered ON THE DEVICE: an event recorded
-// on the outgoing stream, a wait for it on the incoming one -- no host-side wait, so a caller that hops between
-// streams (torch's current stream changing from call to call) stays asynchronous.  The outgoing handle may be dead
-// already (destroy the stream, then name another one, is a normal C-API sequence): a stream that no longer exists has
-// nothing left to drain, so failing to record on it is not an error; the new stream is installed regardless.
+// conversion) must not race with computes on the new one.  The two streams are ordered ON THE DEVICE: the incoming stream
+// waits for an event that marks the end of this engine's work on the outgoing one -- no host-side wait, so a caller that
+// hops between streams (torch's current stream changing from call to call) stays asynchronous.  The outgoing handle may
+// be dead already (destroy the stream, then name another one, is a normal C-API sequence) and HIP aborts on any call that
+// is handed a destroyed stream, so a caller-owned outgoing stream is never touched here: its event was recorded when the
+// work was enqueued (mark_tail).  The engine's own stream is recorded at switch time.
 static int switch_stream(oc_hip_engine* e, hipStream_t next, bool must_succeed) {
     if (next == e->stream) return OC_HIP_OK;
-    if (!e->switch_ev && hipEventCreateWithFlags(&e->switch_ev, hipEventDisableTiming) != hipSuccess) {
-        e->switch_ev = nullptr;
-        (void)hipGetLastError();
-    }
-    bool recorded = false;
-    if (e->switch_ev) {
-        recorded = hipEventRecord(e->switch_ev, e->stream) == hipSuccess;
-        if (!recorded) (void)hipGetLastError();  // invalid handle / destroyed context: nothing to drain
+    bool have_event = false;
+    if (e->stream == e->own_stream) {
+        if (!e->switch_ev && hipEventCreateWithFlags(&e->switch_ev, hipEventDisableTiming) != hipSuccess) {
+            e->switch_ev = nullptr;
+            (void)hipGetLastError();
+        }
+        if (e->switch_ev && hipEventRecord(e->switch_ev, e->own_stream) == hipSuccess) have_event = true;
+        else (void)hipStreamSynchronize(e->own_stream);  // no event to order with: drain the own stream from the host
     } else {
-        // no event to order with: drain the outgoing stream from the host instead (an invalid handle again is fine)
-        if (hipStreamSynchronize(e->stream) != hipSuccess) (void)hipGetLastError();
+        have_event = e->tail_marked && e->switch_ev;  // nothing marked: this engine left no work on that stream
     }
-    if (recorded) {
+    if (have_event && next != e->own_stream) {
         const hipError_t err = hipStreamWaitEvent(next, e->switch_ev, 0);
         if (err != hipSuccess) {
             (void)hipGetLastError();
-            // the INCOMING handle is unusable.  reset_stream() goes back to the engine's own stream and must always
-            // succeed: drain the outgoing stream from the host instead and carry on
-            if (!must_succeed)
-                return fail(OC_HIP_ERR_HIP, "set_stream: cannot enqueue on the new stream: %s", hipGetErrorString(err));
-            if (hipStreamSynchronize(e->stream) != hipSuccess) (void)hipGetLastError();
+            return fail(OC_HIP_ERR_HIP, "set_stream: cannot enqueue on the new stream: %s", hipGetErrorString(err));
+        }
+    } else if (have_event) {
+        // back to the engine's own stream: always possible; should even the wait fail, wait for the event on the host
+        if (hipStreamWaitEvent(e->own_stream, e->switch_ev, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipEventSynchronize(e->switch_ev);
+            (void)hipGetLastError();
         }
     }
+    (void)must_succeed;
     e->stream = next;
+    e->tail_marked = false;
     return OC_HIP_OK;
 }
 
@@ -1300,6 +1328,7 @@ int oc_hip_prepare_ref(oc_hip_engine* e) {
                                         e->gz.as<float>(), e->stream));
     }
     e->ref_ready = true;
+    OC_TRY(mark_tail(e));
     for (oc_hip_engine* r : e->replicas) OC_TRY(oc_hip_prepare_ref(r));
     OC_HIP_TRY(hipSetDevice(e->device));
     return OC_HIP_OK;
@@ -1336,6 +1365,7 @@ int oc_hip_prepare_tar(oc_hip_engine* e) {
         OC_HIP_TRY(hipStreamSynchronize(e->stream));  // before `pass` is freed
     }
     e->tar_ready = true;
+    OC_TRY(mark_tail(e));
     for (oc_hip_engine* r : e->replicas) OC_TRY(oc_hip_prepare_tar(r));
     OC_HIP_TRY(hipSetDevice(e->device));
     return OC_HIP_OK;
@@ -1359,8 +1389,17 @@ namespace {
 // engine's stream ahead of their kernels.  A POI's result does not depend on the chunk it travels in (tests: split
 // queue == whole queue), chunks are large enough for the ICGN2D tile schedule.
 // ---------------------------------------------------------------------------
-int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t count, size_t stride_bytes) {
+// `chain`: further engines that process the same records right after `e` (oc_hip_compute_chain: FFTCC then ICGN, say) --
+// per chunk ONE copy in, every engine's kernels in order on e's stream, ONE copy out, instead of a round trip per engine.
+// The callers have moved the chained engines onto e's stream for the duration of the call.
+int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t count, size_t stride_bytes,
+                 oc_hip_engine* const* chain = nullptr, int n_chain = 0) {
     const int stride_f = (int)(stride_bytes / 4);
+    auto run_all = [&](float* d_pois, size_t n, const float* d_off) -> int {
+        OC_TRY(run_compute_device(e, d_pois, stride_f, n, d_off));
+        for (int i = 0; i < n_chain; i++) OC_TRY(run_compute_device(chain[i], d_pois, stride_f, n, nullptr));
+        return OC_HIP_OK;
+    };
     const size_t bytes = count * stride_bytes;
     OC_TRY(e->poi_stage.reserve(bytes));
     if (offsets) OC_TRY(e->off_stage.reserve(count * 2 * sizeof(float)));
@@ -1386,7 +1425,7 @@ int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t coun
             OC_HIP_TRY(hipMemcpyAsync(e->off_stage.p, offsets, count * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
             d_off = e->off_stage.as<float>();
         }
-        OC_TRY(run_compute_device(e, reinterpret_cast<float*>(stage), stride_f, count, d_off));
+        OC_TRY(run_all(reinterpret_cast<float*>(stage), count, d_off));
         OC_HIP_TRY(hipMemcpyAsync(pois, stage, bytes, hipMemcpyDeviceToHost, e->stream));
         OC_HIP_TRY(hipStreamSynchronize(e->stream));
         return OC_HIP_OK;
@@ -1456,7 +1495,7 @@ int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t coun
             }
             OC_HIP_TRY(hipEventRecord(e->chunk_in[c], e->copy_in_stream));
             OC_HIP_TRY(hipStreamWaitEvent(e->stream, e->chunk_in[c], 0));
-            OC_TRY(run_compute_device(e, reinterpret_cast<float*>(stage + first * stride_bytes), stride_f, n, d_off));
+            OC_TRY(run_all(reinterpret_cast<float*>(stage + first * stride_bytes), n, d_off));
             OC_HIP_TRY(hipEventRecord(e->chunk_done[c], e->stream));
             hand_over(c + 1);
         }
@@ -1760,6 +1799,72 @@ int oc_hip_compute_with_offsets(oc_hip_engine* e, void* pois, const float* cente
     OC_TRY(check_engine(e));
     if (!center_offsets) return fail(OC_HIP_ERR_INVALID, "null center-offset buffer");
     return compute_impl(e, pois, center_offsets, count, stride_bytes, memory);
+}
+
+// Several engines over ONE queue, in order (FFTCC2D then ICGN2D1: examples/test_2d_dic_fftcc_icgn1.cpp:80-99 calls them
+// back to back on the same vector).  HOST queues make one round trip over PCIe instead of one per engine: per chunk one
+// copy in, every engine's kernels, one copy out.  All engines must live on one device and take the same record type;
+// they run on the FIRST engine's stream for the duration of the call (each is ordered behind what its own stream still
+// holds -- a prepare() in flight -- and handed back afterwards).
+int oc_hip_compute_chain(oc_hip_engine* const* engines, int n_engines, void* pois, size_t count, size_t stride_bytes, int memory) {
+    if (!engines || n_engines < 1) return fail(OC_HIP_ERR_INVALID, "compute_chain: need at least one engine");
+    for (int i = 0; i < n_engines; i++) OC_TRY(check_engine(engines[i]));
+    if (n_engines == 1) return compute_impl(engines[0], pois, nullptr, count, stride_bytes, memory);
+    oc_hip_engine* lead = engines[0];
+    for (int i = 1; i < n_engines; i++) {
+        oc_hip_engine* m = engines[i];
+        for (int j = 0; j < i; j++)
+            if (engines[j] == m) return fail(OC_HIP_ERR_INVALID, "compute_chain: engine %d is named twice", i);
+        if (m->device != lead->device) return fail(OC_HIP_ERR_INVALID, "compute_chain: engines live on different devices (%d, %d)", lead->device, m->device);
+        if (m->poi_bytes() != lead->poi_bytes()) return fail(OC_HIP_ERR_INVALID, "compute_chain: 2D and 3D engines cannot share a queue");
+        if (!m->replicas.empty() || !lead->replicas.empty() || m->is_replica || lead->is_replica)
+            return fail(OC_HIP_ERR_UNSUPPORTED, "compute_chain: device groups run their engines one by one (use oc_hip_compute per engine)");
+        if (m->kind == OC_HIP_STRAIN || m->kind == OC_HIP_REGION_FIT || lead->kind == OC_HIP_STRAIN || lead->kind == OC_HIP_REGION_FIT)
+            return fail(OC_HIP_ERR_UNSUPPORTED, "compute_chain: Strain / RegionFit have their own prepare / compute calls");
+    }
+    OC_ACTIVATE(lead);
+    if (count == 0) return OC_HIP_OK;
+    if (!pois) return fail(OC_HIP_ERR_INVALID, "null POI buffer");
+    if (stride_bytes < lead->poi_bytes() || (stride_bytes & 3))
+        return fail(OC_HIP_ERR_INVALID, "bad POI stride %zu (record is %zu bytes, stride must be a multiple of 4)", stride_bytes, lead->poi_bytes());
+    // every engine's mutex, in address order (two chains over the same engines in different order must not deadlock)
+    std::vector<oc_hip_engine*> order(engines, engines + n_engines);
+    std::sort(order.begin(), order.end());
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (oc_hip_engine* m : order) locks.emplace_back(m->mu);
+    // the followers join the lead's stream (device-ordered behind their own pending work) ...
+    std::vector<hipStream_t> home(n_engines, nullptr);
+    int rc = OC_HIP_OK;
+    int joined = 0;
+    for (int i = 1; i < n_engines && rc == OC_HIP_OK; i++) {
+        home[i] = engines[i]->stream;
+        rc = switch_stream(engines[i], lead->stream, false);
+        if (rc == OC_HIP_OK) joined = i;
+    }
+    if (rc == OC_HIP_OK) {
+        if (memory == OC_HIP_DEVICE) {
+            rc = order_after_default_stream(lead);
+            for (int i = 0; i < n_engines && rc == OC_HIP_OK; i++)
+                rc = run_compute_device(engines[i], static_cast<float*>(pois), (int)(stride_bytes / 4), count, nullptr);
+            if (rc == OC_HIP_OK) rc = finish_device_call(lead);
+        } else {
+            rc = compute_host(lead, static_cast<char*>(pois), nullptr, count, stride_bytes, engines + 1, n_engines - 1);
+        }
+    }
+    // ... and go home again, ordered behind what the chain enqueued
+    const std::string why = g_last_error;
+    for (int i = 1; i <= joined; i++) {
+        oc_hip_engine* m = engines[i];
+        // the end of the chain's work on the lead's stream is this engine's tail there: its home stream waits for it
+        if (!m->switch_ev && hipEventCreateWithFlags(&m->switch_ev, hipEventDisableTiming) != hipSuccess) m->switch_ev = nullptr;
+        m->tail_marked = m->switch_ev && hipEventRecord(m->switch_ev, lead->stream) == hipSuccess;
+        if (!m->tail_marked) (void)hipStreamSynchronize(lead->stream);
+        if (switch_stream(m, home[i], true) != OC_HIP_OK) m->stream = home[i];
+        (void)mark_tail(m);  // a caller-owned home stream: the chain's work is (transitively) this engine's tail there
+    }
+    (void)hipGetLastError();
+    if (rc != OC_HIP_OK) return fail(rc, "%s", why.c_str());
+    return OC_HIP_OK;
 }
 
 int oc_hip_compute_one(oc_hip_engine* e, void* poi) {

@@ -516,6 +516,31 @@ class ICGN3D1(_Engine, _IcgnMixin):
                                                     stop_condition, device, ctypes.byref(self._h)))
 
 
+def compute_chain(engines, pois):
+    """Several engines over ONE queue, in order (``oc_hip_compute_chain``): ``compute_chain([fftcc, icgn], pois)`` does what
+    ``fftcc.compute(pois); icgn.compute(pois)`` does -- same bits -- but a host (NumPy) queue crosses PCIe once in each
+    direction instead of once per engine."""
+    engines = list(engines)
+    if not engines:
+        raise ValueError("compute_chain needs at least one engine")
+    floats = capi.POI2D_FLOATS if engines[0]._ndim == 2 else capi.POI3D_FLOATS
+    for e in engines:
+        e._adopt_stream_of(pois)
+    if _is_torch(pois):
+        p, mem, _ = _buf(pois)
+        n, stride = pois.shape[0], pois.stride(0) * 4
+        if pois.shape[1] < floats:
+            raise ValueError("POI records need %d floats" % floats)
+    else:
+        if pois.dtype != np.float32 or not pois.flags.c_contiguous or pois.ndim != 2 or pois.shape[1] < floats:
+            raise ValueError("pois must be a C-contiguous float32 array of shape (n, >=%d)" % floats)
+        p, mem = ctypes.c_void_p(pois.ctypes.data), capi.HOST
+        n, stride = pois.shape[0], pois.strides[0]
+    handles = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+    capi.check(capi.lib().oc_hip_compute_chain(handles, len(engines), p, n, stride, mem))
+    return pois
+
+
 def make_pois2d(xs, ys):
     """Zero-initialised POI2D records (POI2D ctor, src/oc_poi.h:108-135)."""
     xs = np.asarray(xs, dtype=np.float32).ravel()

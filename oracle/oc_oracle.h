@@ -15,13 +15,20 @@
  *     oracle equals the reference bit for bit -- every float of every POI -- for ICGN2D1, ICGN2D2, both centre-offset
  *     overloads, self-adaptive subsets, ICLM2D1 / ICLM2D2, NR2D1, ICGN3D1, Gradient2D4 / 3D4, BicubicBspline and
  *     TricubicBspline; FFTCC2D / FFTCC3D give identical integer displacements and ZNCC within 1e-5 / 1e-4.
+ *     Since round 3 the same library also holds oc_strain.cpp, oc_region_fit.cpp and oc_nearest_neighbor.cpp (against a
+ *     stand-in nanoflann and a float colPivHouseholderQr in the stand-in Eigen): tests/test_oracle_vs_ref_strain.py --
+ *     Strain (2D and 3D) and RegionFit2D / RegionFit3D compute exactly the same POIs as the reference (ZNCC filters,
+ *     radius search, K-nearest fallback, minimum counts; untouched fields bit-identical) with strains / gradients
+ *     within 1e-6 and fitted displacements within 1e-5 (this file solves the plane fit in double, the reference by a
+ *     float QR).
  *   - Pinned on the reference's golden vectors (its authors' own runs, real Eigen + FFTW): FFTCC2D + ICGN2D1
  *     (examples/2d_dic/oht_cfrp_4_fftcc_icgn1_r16*.csv), NR2D1 (oht_cfrp_4_fftcc_nr1_r16.csv) and Strain (2D) in
  *     tests/test_oracle_golden.py, tests/test_oracle_strain.py; ICGN2D2 soft-anchored on the authors' CUDA results.
  *   - Still "parity unpinned": only what lives INSIDE the third-party libraries -- Eigen's association of mean() /
  *     squaredNorm() and of its LU / cofactor inverses, FFTW's butterflies (the stand-ins restate them the same way
- *     this file does), glibc vs MSVC powf in IC-LM's first damping value -- plus 3D strain and RegionFit2D/3D, whose
- *     reference code needs nanoflann and is not part of oracle/_ref.
+ *     this file does), glibc vs MSVC powf in IC-LM's first damping value, the rounding of Eigen's float Householder QR
+ *     in the plane fits, and nanoflann's choice among EQUIDISTANT K-nearest neighbours (tree-traversal order; the
+ *     reference has no defined result there).
  *
  * All images are row-major float32 (x fastest): img[y*width + x]; volumes are
  * vol[(z*dim_y + y)*dim_x + x] (same as Image3D::vol_mat, src/oc_array.h:57-74).

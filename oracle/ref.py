@@ -67,6 +67,8 @@ def lib():
         L.oc_ref_fftcc3d.argtypes = [fp, fp, i, i, i, i, i, i, fp, l, i]
         L.oc_ref_icgn3d1.argtypes = [fp, fp, i, i, i, i, i, i, f, f, fp, l, i]
         L.oc_ref_prepare3d.argtypes = [fp, fp, i, i, i, fp, fp, fp, fp, l, fp]
+        L.oc_ref_strain.argtypes = [i, fp, l, f, i, f, i, i]
+        L.oc_ref_region_fit.argtypes = [i, fp, l, fp, l, f, i, i]
         _lib = L
     return _lib
 
@@ -139,3 +141,24 @@ def prepare3d(ref, tar, xyz):
     _check(lib().oc_ref_prepare3d(_fp(ref), _fp(tar), dz, dy, dx, _fp(gx), _fp(gy), _fp(gz), _fp(xyz), len(xyz), _fp(out)),
            "Gradient3D4 / TricubicBspline")
     return gx, gy, gz, out
+
+
+def strain(pois, subregion_radius, neighbor_number_min, zncc_threshold=0.9, approximation=1, threads=0):
+    """Strain(radius, nmin, threads) + setZnccThreshold + setApproximation + prepare(queue) + compute(queue) of the
+    reference (src/oc_strain.cpp), in place; 2D or 3D by the record size (25 / 31 floats).  Built against the stand-in
+    nanoflann (brute-force radius / knn search) and the stand-in float colPivHouseholderQr."""
+    ndim = {25: 2, 31: 3}[pois.shape[1]]
+    assert pois.dtype == np.float32 and pois.flags.c_contiguous
+    _check(lib().oc_ref_strain(ndim, _fp(pois), pois.shape[0], float(subregion_radius), int(neighbor_number_min),
+                               float(zncc_threshold), int(approximation), threads), "Strain")
+
+
+def region_fit(reliable, pois, neighbor_search_radius, neighbor_number_min, threads=0):
+    """RegionFit2D / RegionFit3D: setNeighbor(reliable) + prepare() + compute(pois) of the reference
+    (src/oc_region_fit.cpp), ``pois`` in place."""
+    ndim = {25: 2, 31: 3}[pois.shape[1]]
+    assert reliable.shape[1] == pois.shape[1]
+    reliable = np.ascontiguousarray(reliable, dtype=np.float32)
+    assert pois.dtype == np.float32 and pois.flags.c_contiguous
+    _check(lib().oc_ref_region_fit(ndim, _fp(reliable), reliable.shape[0], _fp(pois), pois.shape[0],
+                                   float(neighbor_search_radius), int(neighbor_number_min), threads), "RegionFit")

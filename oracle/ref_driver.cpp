@@ -2,8 +2,9 @@
 //
 // TEST INFRASTRUCTURE ONLY.  oracle/Makefile (target `ref`) compiles the reference's sources UNMODIFIED, where they lie
 // under /root/reference/src -- oc_fftcc.cpp, oc_icgn.cpp, oc_iclm.cpp, oc_nr.cpp, oc_cubic_bspline.cpp,
-// oc_gradient.cpp, oc_subset.cpp, oc_deformation.cpp, oc_dic.cpp, oc_image.cpp -- against the stand-in headers of
-// oracle/ref_stubs (mini Eigen, FFTW and OpenCV), plus this file.  Nothing of the reference is copied into the
+// oc_gradient.cpp, oc_subset.cpp, oc_deformation.cpp, oc_dic.cpp, oc_image.cpp, and oc_strain.cpp,
+// oc_region_fit.cpp, oc_nearest_neighbor.cpp -- against the stand-in headers of oracle/ref_stubs (mini Eigen, FFTW,
+// OpenCV and nanoflann), plus this file.  Nothing of the reference is copied into the
 // repository; the library exists only where /root/reference does (this container) and is what pins the oracle's
 // reading of the reference's loops: tests/test_oracle_vs_ref.py asserts oracle(OC_ORDER_SEQ) == liboc_ref.
 //
@@ -18,6 +19,8 @@
 #include "oc_icgn.h"
 #include "oc_iclm.h"
 #include "oc_nr.h"
+#include "oc_region_fit.h"
+#include "oc_strain.h"
 
 using namespace opencorr;
 
@@ -222,6 +225,57 @@ int oc_ref_prepare3d(const float* ref, const float* tar, int dz, int dy, int dx,
         }
         ref_img.release();
         tar_img.release();
+    } catch (const std::string&) {
+        return 1;
+    }
+    return 0;
+}
+
+// Strain(subregion_radius, neighbor_number_min, threads); setZnccThreshold / setApproximation; prepare(poi_queue);
+// compute(poi_queue)  -- src/oc_strain.cpp:31-46, 72-107, 136-147, 236-247 (2D), 476-488 (3D)
+int oc_ref_strain(int ndim, float* pois, long n, float subregion_radius, int neighbor_number_min, float zncc_threshold,
+                  int approximation, int threads) {
+    try {
+        Strain strain(subregion_radius, neighbor_number_min, threads_or_all(threads));
+        strain.setZnccThreshold(zncc_threshold);
+        strain.setApproximation(approximation);
+        if (ndim == 2) {
+            std::vector<POI2D> q = load2d(pois, n);
+            strain.prepare(q);
+            strain.compute(q);
+            if (n) std::memcpy(pois, static_cast<void*>(q.data()), sizeof(POI2D) * (size_t)n);
+        } else {
+            std::vector<POI3D> q = load3d(pois, n);
+            strain.prepare(q);
+            strain.compute(q);
+            if (n) std::memcpy(pois, static_cast<void*>(q.data()), sizeof(POI3D) * (size_t)n);
+        }
+    } catch (const std::string&) {
+        return 1;
+    }
+    return 0;
+}
+
+// RegionFit2D / RegionFit3D(neighbor_search_radius, neighbor_number_min, threads); setNeighbor(reliable); prepare();
+// compute(poi_queue)  -- src/oc_region_fit.cpp:32-46, 75-92, 166-174 (2D), 189-203, 232-249, 334-342 (3D)
+int oc_ref_region_fit(int ndim, const float* reliable, long n_reliable, float* pois, long n, float neighbor_search_radius,
+                      int neighbor_number_min, int threads) {
+    try {
+        if (ndim == 2) {
+            std::vector<POI2D> rel = load2d(reliable, n_reliable), q = load2d(pois, n);
+            RegionFit2D fit(neighbor_search_radius, neighbor_number_min, threads_or_all(threads));
+            fit.setNeighbor(rel);
+            fit.prepare();
+            fit.compute(q);
+            if (n) std::memcpy(pois, static_cast<void*>(q.data()), sizeof(POI2D) * (size_t)n);
+        } else {
+            std::vector<POI3D> rel = load3d(reliable, n_reliable), q = load3d(pois, n);
+            RegionFit3D fit(neighbor_search_radius, neighbor_number_min, threads_or_all(threads));
+            fit.setNeighbor(rel);
+            fit.prepare();
+            fit.compute(q);
+            if (n) std::memcpy(pois, static_cast<void*>(q.data()), sizeof(POI3D) * (size_t)n);
+        }
     } catch (const std::string&) {
         return 1;
     }

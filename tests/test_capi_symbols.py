@@ -31,3 +31,21 @@ def test_abi_version_and_error_string():
     # a null handle is rejected with a readable message (no GPU needed for this path)
     assert L.oc_hip_prepare(None) == capi.ERR_INVALID
     assert b"null engine" in L.oc_hip_last_error()
+
+
+def test_one_hip_runtime_per_process():
+    """opencorr_amd loaded BEFORE torch must still end up on the HIP runtime torch uses (two copies of libamdhip64 in one
+    process crash as soon as a stream handle crosses, see capi._one_hip_runtime).  Runs in a fresh interpreter; no GPU
+    needed: only what gets mapped is looked at."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from opencorr_amd import capi\n"
+            "capi.lib()\n"
+            "before = capi._mapped('libamdhip64')\n"
+            "import torch\n"
+            "after = capi._mapped('libamdhip64')\n"
+            "print(len(before), len(after), after == before)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-W", "error::RuntimeWarning", "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert out.stdout.split() == ["1", "1", "True"], out.stdout

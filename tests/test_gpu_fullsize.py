@@ -3,8 +3,9 @@
 and E (512^3 volume pair, 37^3 = 50 653 POIs, FFTCC3D + ICGN3D1).
 
 Size-independent properties + a strided oracle sample, the checks of tests/fullsize/run_configs.py:
-  * FFTCC: the oracle's FFTCC on every k-th POI gives the GPU's integer displacement and guess exactly, ZNCC within 1e-5
-    (1e-4 for 32^3 windows),
+  * FFTCC: the oracle's FFTCC on every k-th POI gives the GPU's integer displacement and guess exactly, the ZNCC of the
+    peak within 5e-5 in 2D (measured maxima over a whole queue: 1.5e-5 at r = 15 -- the correlation surface passes through
+    a float32 FFT on the GPU and a double DFT in the oracle) and 1e-4 for 32^3 windows (north_star's tolerance),
   * GPU == oracle(OC_ORDER_LANES) bit for bit on every k-th POI of the queue (ICGN by the oracle on the GPU's FFTCC output),
   * split queue == whole queue bit for bit (what multi-GPU sharding relies on: a POI's result does not depend on
     which block of the queue it travels in),
@@ -30,7 +31,7 @@ def _configs():
 
 def _check(rec, min_converged, max_err):
     assert rec["oracle_bit_exact"], rec
-    assert rec["fftcc_oracle_same_integers"] and rec["fftcc_oracle_max_zncc_diff"] <= 1e-5, rec
+    assert rec["fftcc_oracle_same_integers"] and rec["fftcc_oracle_max_zncc_diff"] <= 5e-5, rec
     assert rec["split_queue_same_bits"], rec
     assert rec["converged"] >= min_converged * rec["pois"], rec
     assert rec["median_abs_err_u"] < 0.01 and rec["max_abs_err_u"] < max_err and rec["max_abs_err_v"] < max_err, rec

@@ -23,7 +23,8 @@ def _bits(a):
 def _download(ptr, nbytes, device=0):
     """hipMemcpy of a raw device pointer (a group member's mirror) to a float32 array."""
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    from opencorr_amd import capi
+    hip = capi.hip_runtime()  # THE runtime of this process, never a second copy by name
     hip.hipSetDevice.argtypes = [ctypes.c_int]
     hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     assert hip.hipSetDevice(device) == 0

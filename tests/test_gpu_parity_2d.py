@@ -713,7 +713,8 @@ def test_stream_switches_are_device_ordered_and_survive_a_dead_stream(eng, speck
     g0.prepare()
     want = g0.compute(f0.compute(base.copy()))
 
-    hip = ctypes.CDLL("libamdhip64.so")
+    from opencorr_amd import capi
+    hip = capi.hip_runtime()  # THE runtime of this process, never a second copy by name
     hip.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
     hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
     hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
