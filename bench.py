@@ -543,18 +543,27 @@ def secondary_rooflines(dev, device, reps=3):
 def host_queue_rate(fftcc, icgn, pristine, converged, reps=3):
     """The same step when the caller hands over a HOST queue (what the C++ shim's compute(std::vector<POI2D>&)
     does): every compute() then copies the 25 MB AoS to the GPU and back.  Reported beside `value`, never as it."""
+    import opencorr_amd
     host0 = pristine.cpu().numpy()
-    best = None
+    best, best2 = None, None
     for _ in range(reps + 1):
+        q = host0.copy()
+        t0 = time.perf_counter()
+        opencorr_amd.compute_chain([fftcc, icgn], q)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
         q = host0.copy()
         t0 = time.perf_counter()
         fftcc.compute(q)
         icgn.compute(q)
         dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+        best2 = dt if best2 is None else min(best2, dt)
     return {"ms_per_step": best * 1e3, "value": converged / best, "unit": "POI/s",
-            "note": "SURVEY 8(d)'s definition: pageable host POI queue (what compute(std::vector<POI2D>&) hands over), H2D + "
-                    "D2H of the AoS around FFTCC2D and around ICGN2D1, in chunks whose copies overlap the neighbours' kernels"}
+            "two_calls_ms_per_step": best2 * 1e3, "two_calls_value": converged / best2,
+            "note": "SURVEY 8(d)'s definition: pageable host POI queue (what a std::vector<POI2D> is), H2D and D2H of the AoS inside "
+                    "the timed region.  `value`: FFTCC2D + ICGN2D1 as ONE chain (oc_hip_compute_chain / computeChain in the C++ "
+                    "shim): one copy in, both engines' kernels, one copy out, chunk by chunk.  `two_calls_*`: the reference's "
+                    "unmodified call sequence fftcc->compute(q); icgn->compute(q); -- the queue crosses PCIe four times"}
 
 
 def pmc_profile(world):

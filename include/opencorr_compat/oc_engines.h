@@ -15,11 +15,15 @@
 //   * images are snapshotted to HBM when needed (first prepare()/compute() after setImages);
 //     editing the host image afterwards requires setImages() again, as with the reference's CUDA
 //     module (examples/test_2d_dic_gpu_icgn.cpp:99-136);
+//     engines that were given the SAME Image2D / Image3D pair share one device copy of it (the second engine's upload is
+//     skipped when the first one's snapshot was taken after the second engine's setImages() call -- a read of the host
+//     images "at some point after setImages()", which is all the contract above promises);
 //   * setSelfAdaptive(true) is honoured by ICGN2D1/ICGN2D2; a POI whose radius is negative is rejected
 //     with zncc = -3 (the reference would try to allocate a negative-sized subset).
 #pragma once
 
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -57,6 +61,62 @@ inline std::vector<int> default_devices() {
     }
     return ids;
 }
+// Device snapshots of host image pairs, so that an FFTCC and an ICGN engine working on one pair upload it once (config B:
+// 2 x 67 MB instead of 4 x 67 MB over PCIe; the reference shares the images the same way -- both engines hold pointers to
+// the caller's Image2D, src/oc_dic.cpp:22-26).  An engine that needs its images looks for a snapshot of the same pair
+// (same host pointers, same shape, same device) taken AFTER its own setImages() call (`seq` is a process-wide counter
+// stamped on both events) and borrows it with oc_hip_share_images -- the device copy is reference counted inside the
+// library, so the donor may be destroyed first.
+struct Snapshot {
+    const void* ref;
+    const void* tar;
+    int dims[3];
+    int device;
+    oc_hip_engine* donor;
+    unsigned long long seq;
+};
+struct SnapshotRegistry {
+    std::mutex mu;
+    std::vector<Snapshot> entries;
+    unsigned long long seq = 0;
+    static SnapshotRegistry& get() {
+        static SnapshotRegistry r;
+        return r;
+    }
+    unsigned long long stamp() {
+        std::lock_guard<std::mutex> lock(mu);
+        return ++seq;
+    }
+    // a snapshot of this pair newer than `after`, borrowed into `engine`; false: the caller uploads itself
+    bool borrow(oc_hip_engine* engine, const void* ref, const void* tar, int d0, int d1, int d2, int device, unsigned long long after) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Snapshot& s : entries)
+            if (s.ref == ref && s.tar == tar && s.dims[0] == d0 && s.dims[1] == d1 && s.dims[2] == d2 && s.device == device &&
+                s.donor != engine && s.seq > after)
+                return oc_hip_share_images(engine, s.donor) == OC_HIP_OK;
+        return false;
+    }
+    void publish(oc_hip_engine* engine, const void* ref, const void* tar, int d0, int d1, int d2, int device) {
+        std::lock_guard<std::mutex> lock(mu);
+        forget_locked(engine);
+        entries.push_back(Snapshot{ref, tar, {d0, d1, d2}, device, engine, ++seq});
+    }
+    void forget(oc_hip_engine* engine) {
+        std::lock_guard<std::mutex> lock(mu);
+        forget_locked(engine);
+    }
+
+private:
+    void forget_locked(oc_hip_engine* engine) {
+        for (size_t i = 0; i < entries.size();)
+            if (entries[i].donor == engine) entries.erase(entries.begin() + (long)i);
+            else i++;
+    }
+};
+inline bool single_device(oc_hip_engine* e) {
+    int n = 1;
+    return oc_hip_get_devices(e, nullptr, 0, &n) == OC_HIP_OK && n == 1;
+}
 // applied by every shim constructor right after the engine exists
 inline void apply_default_devices(oc_hip_engine* e) {
     const std::vector<int> ids = default_devices();
@@ -73,7 +133,12 @@ public:
     bool self_adaptive = false;
 
     DIC() {}
-    virtual ~DIC() { if (engine_) oc_hip_destroy(engine_); }
+    virtual ~DIC() {
+        if (engine_) {
+            hipdetail::SnapshotRegistry::get().forget(engine_);
+            oc_hip_destroy(engine_);
+        }
+    }
     DIC(const DIC&) = delete;
     DIC& operator=(const DIC&) = delete;
 
@@ -81,6 +146,8 @@ public:
         ref_img = &ref;
         tar_img = &tar;
         images_dirty_ = true;
+        images_seq_ = hipdetail::SnapshotRegistry::get().stamp();
+        if (engine_) hipdetail::SnapshotRegistry::get().forget(engine_);  // this engine's snapshot is of older content
     }
     void setSubset(int radius_x, int radius_y) {
         subset_radius_x = radius_x;
@@ -95,6 +162,7 @@ public:
     void setDevice(int device) { setDevices(std::vector<int>(1, device)); }
     void setDevices(const std::vector<int>& devices) {
         if (devices.empty()) throw std::string("setDevices: empty device list");
+        hipdetail::SnapshotRegistry::get().forget(engine_);
         hipdetail::check(oc_hip_set_devices(engine_, devices.data(), (int)devices.size()));
         device_ = devices[0];
         images_dirty_ = ref_img != nullptr;
@@ -105,11 +173,14 @@ public:
     virtual void compute(std::vector<POI2D>& poi_queue) = 0;
 
     oc_hip_engine* handle() { return engine_; }
+    // images on the device (uploaded, or borrowed from an engine that holds the same pair); what prepare() / compute() do first
+    void ensureImages() { uploadIfNeeded(); }
 
 protected:
     oc_hip_engine* engine_ = nullptr;
     int device_ = hipdetail::default_device();
     bool images_dirty_ = false;
+    unsigned long long images_seq_ = 0;
 
     void uploadIfNeeded() {
         if (!engine_) throw std::string("engine not created");
@@ -117,8 +188,14 @@ protected:
         if (!ref_img || !tar_img) throw std::string("setImages() has not been called");
         if (ref_img->height != tar_img->height || ref_img->width != tar_img->width)
             throw std::string("reference and target image sizes differ");
-        hipdetail::check(oc_hip_set_images2d(engine_, ref_img->eg_mat.data(), tar_img->eg_mat.data(), ref_img->height,
-                                             ref_img->width, OC_HIP_COL_MAJOR, OC_HIP_HOST));
+        hipdetail::SnapshotRegistry& reg = hipdetail::SnapshotRegistry::get();
+        const void* r = ref_img->eg_mat.data();
+        const void* t = tar_img->eg_mat.data();
+        if (!reg.borrow(engine_, r, t, ref_img->height, ref_img->width, 1, device_, images_seq_)) {
+            hipdetail::check(oc_hip_set_images2d(engine_, ref_img->eg_mat.data(), tar_img->eg_mat.data(), ref_img->height,
+                                                 ref_img->width, OC_HIP_COL_MAJOR, OC_HIP_HOST));
+            reg.publish(engine_, r, t, ref_img->height, ref_img->width, 1, device_);
+        }
         images_dirty_ = false;
     }
     void computeBatch(POI2D* pois, size_t n) {
@@ -135,7 +212,12 @@ public:
     int thread_number = 1;
 
     DVC() {}
-    virtual ~DVC() { if (engine_) oc_hip_destroy(engine_); }
+    virtual ~DVC() {
+        if (engine_) {
+            hipdetail::SnapshotRegistry::get().forget(engine_);
+            oc_hip_destroy(engine_);
+        }
+    }
     DVC(const DVC&) = delete;
     DVC& operator=(const DVC&) = delete;
 
@@ -143,6 +225,8 @@ public:
         ref_img = &ref;
         tar_img = &tar;
         images_dirty_ = true;
+        images_seq_ = hipdetail::SnapshotRegistry::get().stamp();
+        if (engine_) hipdetail::SnapshotRegistry::get().forget(engine_);
     }
     void setSubset(int radius_x, int radius_y, int radius_z) {
         subset_radius_x = radius_x;
@@ -153,6 +237,7 @@ public:
     void setDevice(int device) { setDevices(std::vector<int>(1, device)); }
     void setDevices(const std::vector<int>& devices) {
         if (devices.empty()) throw std::string("setDevices: empty device list");
+        hipdetail::SnapshotRegistry::get().forget(engine_);
         hipdetail::check(oc_hip_set_devices(engine_, devices.data(), (int)devices.size()));
         device_ = devices[0];
         images_dirty_ = ref_img != nullptr;
@@ -163,18 +248,26 @@ public:
     virtual void compute(std::vector<POI3D>& poi_queue) = 0;
 
     oc_hip_engine* handle() { return engine_; }
+    void ensureImages() { uploadIfNeeded(); }
 
 protected:
     oc_hip_engine* engine_ = nullptr;
     int device_ = hipdetail::default_device();
     bool images_dirty_ = false;
+    unsigned long long images_seq_ = 0;
 
     void uploadIfNeeded() {
         if (!engine_) throw std::string("engine not created");
         if (!images_dirty_) return;
         if (!ref_img || !tar_img) throw std::string("setImages() has not been called");
-        hipdetail::check(oc_hip_set_images3d(engine_, &ref_img->vol_mat[0][0][0], &tar_img->vol_mat[0][0][0],
-                                             ref_img->dim_x, ref_img->dim_y, ref_img->dim_z, OC_HIP_HOST));
+        hipdetail::SnapshotRegistry& reg = hipdetail::SnapshotRegistry::get();
+        const void* r = &ref_img->vol_mat[0][0][0];
+        const void* t = &tar_img->vol_mat[0][0][0];
+        if (!reg.borrow(engine_, r, t, ref_img->dim_x, ref_img->dim_y, ref_img->dim_z, device_, images_seq_)) {
+            hipdetail::check(oc_hip_set_images3d(engine_, &ref_img->vol_mat[0][0][0], &tar_img->vol_mat[0][0][0],
+                                                 ref_img->dim_x, ref_img->dim_y, ref_img->dim_z, OC_HIP_HOST));
+            reg.publish(engine_, r, t, ref_img->dim_x, ref_img->dim_y, ref_img->dim_z, device_);
+        }
         images_dirty_ = false;
     }
     void computeBatch(POI3D* pois, size_t n) {
@@ -240,6 +333,19 @@ public:
     }
     void compute(Poi* poi) override { this->computeBatch(poi, 1); }
     void compute(std::vector<Poi>& poi_queue) override { this->computeBatch(poi_queue.data(), poi_queue.size()); }
+    // initial guess and refinement in one call and ONE round trip of the queue over PCIe: `first` (an FFTCC engine, say)
+    // processes every POI, then this engine -- the same bits as first.compute(poi_queue); compute(poi_queue);
+    void compute(std::vector<Poi>& poi_queue, Base& first) {
+        this->ensureImages();
+        first.ensureImages();
+        if (!hipdetail::single_device(this->engine_) || !hipdetail::single_device(first.handle())) {
+            first.compute(poi_queue);
+            compute(poi_queue);
+            return;
+        }
+        oc_hip_engine* chain[2] = {first.handle(), this->engine_};
+        hipdetail::check(oc_hip_compute_chain(chain, 2, poi_queue.data(), poi_queue.size(), sizeof(Poi), OC_HIP_HOST));
+    }
 
 protected:
     float conv_criterion = 0.001f;
@@ -360,6 +466,35 @@ public:
         hipdetail::apply_default_devices(engine_);
     }
 };
+
+// ---- several engines, one queue, ONE round trip over PCIe --------------------------------------------------------
+// The reference's mains call fftcc->compute(poi_queue); icgn->compute(poi_queue); back to back
+// (examples/test_2d_dic_fftcc_icgn1.cpp:80-99, examples/test_dvc_fftcc_icgn1.cpp:87-106).  Through these shims each call
+// moves the whole POI vector to the GPU and back.  computeChain({fftcc, icgn}, poi_queue) is the same computation -- bit
+// for bit -- with one copy in and one copy out (oc_hip_compute_chain; 250 000 POIs: two crossings of 25 MB instead of
+// four).  Engines spread over several GPUs (setDevices / OC_HIP_DEVICES) run one after the other as before.
+namespace hipdetail {
+template <class Engine, class Poi>
+inline void compute_chain(const std::vector<Engine*>& engines, std::vector<Poi>& poi_queue) {
+    if (engines.empty()) throw std::string("computeChain: no engine given");
+    std::vector<oc_hip_engine*> handles;
+    bool plain = true;
+    for (Engine* e : engines) {
+        if (!e) throw std::string("computeChain: null engine");
+        e->ensureImages();
+        handles.push_back(e->handle());
+        plain = plain && single_device(e->handle());
+    }
+    if (!plain) {
+        for (Engine* e : engines) e->compute(poi_queue);
+        return;
+    }
+    check(oc_hip_compute_chain(handles.data(), (int)handles.size(), poi_queue.data(), poi_queue.size(), sizeof(Poi), OC_HIP_HOST));
+}
+}  // namespace hipdetail
+inline void computeChain(const std::vector<DIC*>& engines, std::vector<POI2D>& poi_queue) { hipdetail::compute_chain(engines, poi_queue); }
+inline void computeChain(const std::vector<DVC*>& engines, std::vector<POI3D>& poi_queue) { hipdetail::compute_chain(engines, poi_queue); }
+
 
 // Strain(float subregion_radius, int neighbor_number_min, int thread_number)  src/oc_strain.h:34-73.
 // prepare(poi_queue) builds the neighbour search over the queue's coordinates, compute(poi_queue) writes

@@ -1403,9 +1403,31 @@ int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t coun
     const size_t bytes = count * stride_bytes;
     OC_TRY(e->poi_stage.reserve(bytes));
     if (offsets) OC_TRY(e->off_stage.reserve(count * 2 * sizeof(float)));
-    size_t chunk = e->host_chunk > 0 ? (size_t)e->host_chunk : count;
-    if (count < 2 * chunk) chunk = count;  // not worth a pipeline
-    const size_t nchunk = (count + chunk - 1) / chunk;
+    // Chunk schedule.  What a pipeline cannot hide is the copy-in of its FIRST chunk and the copy-out of its LAST one, and
+    // every extra chunk costs a launch tail (the ICGN kernels' last workgroups run on a half-empty chip) plus an
+    // inter-stream hand-over.  So: small chunks at both ends (half of "host_chunk"), few large ones (three times
+    // "host_chunk") in between, whose copies hide behind the neighbours' kernels.  Measured on config B (250 000 POIs,
+    // chain of FFTCC2D + ICGN2D1): uniform chunks of 65 536: 4.76 ms, one piece: 5.36 ms, this schedule: see DESIGN 4.4.
+    std::vector<std::pair<size_t, size_t>> sched;  // (first POI, POIs)
+    {
+        const size_t unit = e->host_chunk > 0 ? (size_t)e->host_chunk : count;
+        if (count < 2 * unit) {
+            sched.emplace_back(0, count);  // not worth a pipeline
+        } else {
+            const size_t edge = std::max<size_t>(unit / 2, 1), mid_max = 3 * unit;
+            sched.emplace_back(0, edge);
+            size_t at = edge;
+            const size_t mid_total = count - 2 * edge;
+            const size_t nmid = (mid_total + mid_max - 1) / mid_max;
+            for (size_t i = 0; i < nmid; i++) {
+                const size_t n = mid_total / nmid + (i < mid_total % nmid ? 1 : 0);
+                sched.emplace_back(at, n);
+                at += n;
+            }
+            sched.emplace_back(at, count - at);
+        }
+    }
+    const size_t nchunk = sched.size();
     if (nchunk > 1) {
         if (!e->copy_stream) OC_HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
         if (!e->copy_in_stream) OC_HIP_TRY(hipStreamCreateWithFlags(&e->copy_in_stream, hipStreamNonBlocking));
@@ -1452,7 +1474,7 @@ int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t coun
             return;
         }
         for (size_t c = 0; c < nchunk && out_err == hipSuccess; c++) {
-            const size_t first = c * chunk, n = std::min(chunk, count - first);
+            const size_t first = sched[c].first, n = sched[c].second;
             // the event is recorded by the feeding thread after chunk c's kernels were enqueued; until then
             // hipStreamWaitEvent would see the event of an earlier call, so sleep until the hand-off
             {
@@ -1482,7 +1504,7 @@ int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t coun
         OC_HIP_TRY(hipEventRecord(e->chunk_in[0], e->stream));
         OC_HIP_TRY(hipStreamWaitEvent(e->copy_in_stream, e->chunk_in[0], 0));
         for (size_t c = 0; c < nchunk; c++) {
-            const size_t first = c * chunk, n = std::min(chunk, count - first);
+            const size_t first = sched[c].first, n = sched[c].second;
             // copies in travel on their own stream: on the kernels' stream a pageable copy would queue behind the
             // previous chunk's kernels and nothing would overlap
             OC_HIP_TRY(hipMemcpyAsync(stage + first * stride_bytes, pois + first * stride_bytes, n * stride_bytes, hipMemcpyHostToDevice,

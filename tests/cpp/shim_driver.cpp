@@ -78,6 +78,47 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        // FFTCC + ICGN as ONE round trip: computeChain({fftcc, icgn}, queue) and icgn->compute(queue, *fftcc) must give the
+        // bits of the two separate calls.  The engines were handed the same Image2D pair: the second one borrowed the
+        // first one's device snapshot instead of uploading again (nothing to observe here but the equal results).
+        {
+            std::vector<POI2D> q;
+            for (int i = 0; i < n; i++) q.push_back(POI2D(Point2D(xs[i], ys[i])));
+            std::vector<POI2D> q2 = q;
+            computeChain({fftcc, icgn1}, q);
+            icgn1->compute(q2, *fftcc);
+            if (std::memcmp(q.data(), poi_queue.data(), q.size() * sizeof(POI2D)) != 0 ||
+                std::memcmp(q2.data(), poi_queue.data(), q2.size() * sizeof(POI2D)) != 0) {
+                std::cerr << "computeChain differs from the two separate compute() calls" << std::endl;
+                return 17;
+            }
+            // a fresh target image in the SAME Image2D object (a main that loops over frames reloads tar_img): both
+            // engines are told with setImages(), the first to need the pair uploads it, the second borrows THAT snapshot
+            // -- never the older one
+            Image2D tar_shift(w, h);
+            std::vector<float> moved(tar.size());
+            for (int r = 0; r < h; r++)
+                for (int c = 0; c < w; c++) moved[(size_t)r * w + c] = tar[(size_t)r * w + (c + 1 < w ? c + 1 : c)];
+            tar_img.fromRowMajor(moved.data());
+            fftcc->setImages(ref_img, tar_img);
+            icgn1->setImages(ref_img, tar_img);
+            std::vector<POI2D> q3;
+            for (int i = 0; i < n; i++) q3.push_back(POI2D(Point2D(xs[i], ys[i])));
+            fftcc->compute(q3);
+            icgn1->prepare();
+            icgn1->compute(q3);
+            int moved_by_one = 0;
+            for (int i = 0; i < n; i++)
+                if (q3[i].result.zncc > 0.9f && std::fabs((q3[i].deformation.u + 1.f) - poi_queue[i].deformation.u) < 0.05f) moved_by_one++;
+            if (moved_by_one * 10 < n * 8) {
+                std::cerr << "after reloading the target image only " << moved_by_one << " of " << n << " POIs follow it" << std::endl;
+                return 18;
+            }
+            tar_img.fromRowMajor(tar.data());
+            fftcc->setImages(ref_img, tar_img);
+            icgn1->setImages(ref_img, tar_img);
+            icgn1->prepare();
+        }
         // single-POI entry point: recompute the first POI from its FFTCC state and check it agrees
         if (n > 0) {
             POI2D one(Point2D(xs[0], ys[0]));

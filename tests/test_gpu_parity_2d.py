@@ -798,3 +798,50 @@ def test_share_images_joins_the_donors_stream(eng, speckle_small):
     if torch.cuda.device_count() > 1:
         with pytest.raises(ValueError):
             f.compute(torch.zeros((4, 25), device=torch.device("cuda", 1)))
+
+
+def test_compute_chain_matches_separate_calls(eng, speckle_small):
+    """oc_hip_compute_chain (FFTCC2D -> ICGN2D1 over one queue, one PCIe round trip for host queues): the bits of the two
+    separate calls -- host queue in one piece, host queue in pipeline chunks, device queue; a follower whose prepare() is
+    still in flight on its own stream; bad chains are refused."""
+    import torch
+    from opencorr_amd import capi, synth
+    ref, tar = speckle_small
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 13, 11, 30)
+    base = eng.make_pois2d(xs, ys)
+    f = eng.FFTCC2D(16, 16)
+    f.set_images(ref, tar)
+    g = eng.ICGN2D1(16, 16, 0.001, 10)
+    g.share_images(f)
+    g.prepare()
+    want = g.compute(f.compute(base.copy()))
+    assert np.array_equal(_bits(eng.compute_chain([f, g], base.copy())), _bits(want))
+    q = torch.from_numpy(base).to("cuda:0")
+    eng.compute_chain([f, g], q)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(q.cpu().numpy()), _bits(want))
+    # three engines: FFTCC -> ICGN2D1 -> ICGN2D2 (refines the first-order result further)
+    g2 = eng.ICGN2D2(16, 16, 0.001, 10)
+    g2.share_images(f)
+    g2.prepare()                                   # no synchronisation: the chain orders itself behind it
+    got3 = eng.compute_chain([f, g, g2], base.copy())
+    want3 = g2.compute(want.copy())
+    assert np.array_equal(_bits(got3), _bits(want3))
+    # a queue long enough for the chunked pipeline (2 x 16384 POIs and a remainder)
+    rng = np.random.default_rng(3)
+    many = eng.make_pois2d(rng.uniform(30, ref.shape[1] - 31, 40000).astype(np.float32),
+                           rng.uniform(30, ref.shape[0] - 31, 40000).astype(np.float32))
+    for e in (f, g):
+        e.set_tuning("host_chunk", 16384)
+    want_many = g.compute(f.compute(many.copy()))
+    assert np.array_equal(_bits(eng.compute_chain([f, g], many.copy())), _bits(want_many))
+    # refused: an engine twice, 2D with 3D, nothing
+    with pytest.raises(capi.OpenCorrHipError):
+        eng.compute_chain([g, g], base.copy())
+    f3 = eng.FFTCC3D(8, 8, 8)
+    with pytest.raises(capi.OpenCorrHipError):
+        eng.compute_chain([f, f3], base.copy())
+    with pytest.raises(ValueError):
+        eng.compute_chain([], base.copy())
+    # the engines are still usable on their own afterwards
+    assert np.array_equal(_bits(g.compute(f.compute(base.copy()))), _bits(want))

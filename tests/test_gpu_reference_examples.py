@@ -104,6 +104,18 @@ def test_reference_example_fftcc_icgn1_runs_unmodified(tmp_path, golden):
     # the maps and the timing table are written too
     for name in ("oht_cfrp_4_fftcc_icgn1_r16_u.csv", "oht_cfrp_4_fftcc_icgn1_r16_v.csv", "oht_cfrp_4_fftcc_icgn1_r16_time.csv"):
         assert os.path.getsize(d / name) > 0
+    # the example's own timing table (POI number, Initialization, FFTCC, ICGN prepare + compute; seconds) -- the number a user
+    # of the unmodified main sees; the reference's own run is examples/2d_dic/oht_cfrp_4_fftcc_icgn1_r16_time.csv
+    # (30000, 0.0019, 0.0334, 0.5523).  OC_EXAMPLE_OUT=<dir> keeps a copy (tools/gpu_*.sh -> profiles/).
+    t = np.genfromtxt(d / "oht_cfrp_4_fftcc_icgn1_r16_time.csv", delimiter=",", skip_header=1)[:4]
+    assert t[0] == 30000 and 0 < t[2] < 5 and 0 < t[3] < 5
+    keep = os.environ.get("OC_EXAMPLE_OUT")
+    if keep:
+        import shutil
+        os.makedirs(keep, exist_ok=True)
+        shutil.copy(d / "oht_cfrp_4_fftcc_icgn1_r16_time.csv", os.path.join(keep, "example_test_2d_dic_fftcc_icgn1_time_mi355x.csv"))
+        with open(os.path.join(keep, "example_test_2d_dic_fftcc_icgn1_stdout.txt"), "w") as f:
+            f.write(log)
 
 
 @pytest.mark.gpu
