@@ -301,7 +301,13 @@ struct Walk3 {
     unsigned off;
     int doff, coff_k, coff_j;
     __device__ __forceinline__ Walk3(int tid, int SX_, int SY_, int first_pass = 0, int DX = 0, int DY = 0)
-        : s(tid + first_pass * kBlock3d), SX(SX_), SY(SY_) {
+        : SX(SX_), SY(SY_) {
+        // The walk's start state depends on the thread index and the subset shape only, so the optimiser computes ALL the
+        // walks of the kernel once, ahead of the POI loop, and keeps ~10 values per walk alive across everything -- which
+        // is where the kernel's scratch spills came from (78 dwords, round 2).  Hiding the thread index from it makes each
+        // sweep set its walk up on the spot (two small divisions) and frees those registers.
+        asm volatile("" : "+v"(tid));
+        s = tid + first_pass * kBlock3d;
         const int plane = SX_ * SY_;
         i = s / plane;
         int rem = s - i * plane;
