@@ -467,6 +467,48 @@ public:
     }
 };
 
+// ---- the two selections of the RegionFit -> re-ICGN loop -----------------------------------------------------------
+// examples/test_3d_reconstruction_sift_icgn2_regfit.cpp:214-260 sorts a finished queue into reliable / unreliable vectors
+// and, after every RegionFit + ICGN round, moves the POIs that now pass back.  splitReliable / mergeRecovered do the
+// classification and the order-preserving compactions on the GPU (oc_hip_split_reliable / oc_hip_merge_recovered);
+// `engine` is any engine of the matching dimension (it supplies the device and the stream).
+template <class Engine, class Poi>
+inline void splitReliable(Engine& engine, const std::vector<Poi>& poi_queue, float zncc_threshold_low, float zncc_threshold_high,
+                          float conv_criterion, std::vector<Poi>& pois_reliable, std::vector<Poi>& pois_unreliable,
+                          std::vector<unsigned>& pois_unreliable_idx) {
+    const size_t n = poi_queue.size(), r0 = pois_reliable.size();
+    pois_unreliable.clear();
+    pois_unreliable_idx.clear();
+    if (n == 0) return;
+    pois_reliable.resize(r0 + n, poi_queue[0]);  // (POI2D / POI3D have no default constructor, like the reference's)
+    pois_unreliable.assign(n, poi_queue[0]);
+    pois_unreliable_idx.assign(n, 0u);
+    size_t nr = 0, nu = 0;
+    hipdetail::check(oc_hip_split_reliable(engine.handle(), poi_queue.data(), n, sizeof(Poi), sizeof(Poi) == OC_HIP_POI2D_BYTES ? 2 : 3,
+                                           zncc_threshold_low, zncc_threshold_high, conv_criterion, pois_reliable.data(), r0,
+                                           pois_unreliable.data(), pois_unreliable_idx.data(), &nr, &nu, OC_HIP_HOST));
+    pois_reliable.resize(r0 + nr, poi_queue[0]);
+    pois_unreliable.resize(nu, poi_queue[0]);
+    pois_unreliable_idx.resize(nu);
+}
+// returns the number of POIs that became reliable in this round
+template <class Engine, class Poi>
+inline size_t mergeRecovered(Engine& engine, std::vector<Poi>& poi_queue, std::vector<Poi>& pois_unreliable,
+                             std::vector<unsigned>& pois_unreliable_idx, float zncc_threshold_high, float conv_criterion,
+                             std::vector<Poi>& pois_reliable) {
+    const size_t n = pois_unreliable.size(), r0 = pois_reliable.size();
+    if (n == 0) return 0;
+    pois_reliable.resize(r0 + n, pois_unreliable[0]);
+    size_t nrec = 0, nrem = 0;
+    hipdetail::check(oc_hip_merge_recovered(engine.handle(), poi_queue.data(), sizeof(Poi), sizeof(Poi) == OC_HIP_POI2D_BYTES ? 2 : 3,
+                                            pois_unreliable.data(), pois_unreliable_idx.data(), n, zncc_threshold_high, conv_criterion,
+                                            pois_reliable.data(), r0, &nrec, &nrem, OC_HIP_HOST));
+    pois_reliable.resize(r0 + nrec, pois_unreliable[0]);
+    pois_unreliable.resize(nrem, pois_unreliable[0]);
+    pois_unreliable_idx.resize(nrem);
+    return nrec;
+}
+
 // ---- several engines, one queue, ONE round trip over PCIe --------------------------------------------------------
 // The reference's mains call fftcc->compute(poi_queue); icgn->compute(poi_queue); back to back
 // (examples/test_2d_dic_fftcc_icgn1.cpp:80-99, examples/test_dvc_fftcc_icgn1.cpp:87-106).  Through these shims each call

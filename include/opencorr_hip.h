@@ -158,6 +158,30 @@ int oc_hip_region_fit_compute(oc_hip_engine* engine, void* pois, size_t count, s
  * engine handle supplies the device and stream. */
 int oc_hip_select_best(oc_hip_engine* engine, const void* candidates, size_t n_candidates, size_t candidate_stride_bytes,
                        const unsigned* segment_starts, size_t n_segments, void* pois, size_t stride_bytes, int memory);
+/* The two selections of the RegionFit -> re-ICGN loop (examples/test_3d_reconstruction_sift_icgn2_regfit.cpp:214-260), as
+ * order-preserving partitions ON THE DEVICE, so that a queue resident in HBM never travels to the host between ICGN,
+ * RegionFit and the next ICGN pass.  Any engine handle supplies the device and the stream; ndim = 2 (POI2D) / 3 (POI3D);
+ * all queues share `stride_bytes`; the counts come back to the host (the call completes before it returns).
+ *
+ * oc_hip_split_reliable: for every POI of `pois` in queue order (:216-229)
+ *     result.zncc < zncc_threshold_low || result.convergence > conv_criterion  -> appended to `unreliable`, its queue index to
+ *                                                                                 `unreliable_index`
+ *     else result.zncc >= zncc_threshold_high                                  -> appended to `reliable` (from record
+ *                                                                                 `reliable_offset` on)
+ *   (the example's own float comparisons: a NaN makes all of them false, the POI goes to neither set).  The caller's
+ *   buffers hold up to `count` records (reliable: reliable_offset + count). */
+int oc_hip_split_reliable(oc_hip_engine* engine, const void* pois, size_t count, size_t stride_bytes, int ndim,
+                          float zncc_threshold_low, float zncc_threshold_high, float conv_criterion, void* reliable,
+                          size_t reliable_offset, void* unreliable, unsigned* unreliable_index, size_t* n_reliable,
+                          size_t* n_unreliable, int memory);
+/* oc_hip_merge_recovered: after RegionFit + ICGN over `unreliable` (:236-256): every POI with result.zncc >=
+ * zncc_threshold_high && result.convergence <= conv_criterion is written back to pois[unreliable_index[j]] and appended to
+ * `reliable` (from record `reliable_offset` on); the others are moved to the front of `unreliable` / `unreliable_index`
+ * in their old order.  (The example erases inside its loop and thereby skips the POI after every success for one round;
+ * here every POI is looked at in every round.) */
+int oc_hip_merge_recovered(oc_hip_engine* engine, void* pois, size_t stride_bytes, int ndim, void* unreliable,
+                           unsigned* unreliable_index, size_t n_unreliable, float zncc_threshold_high, float conv_criterion,
+                           void* reliable, size_t reliable_offset, size_t* n_recovered, size_t* n_remaining, int memory);
 /* FFTCC3D(int rx, int ry, int rz, int thread_number)  src/oc_fftcc.cpp:300-313 */
 int oc_hip_fftcc3d_create(int radius_x, int radius_y, int radius_z, int device, oc_hip_engine** out);
 /* ICGN3D1(int rx, int ry, int rz, float conv, float stop, int thread_number)  src/oc_icgn.cpp:1197-1213 */

@@ -33,7 +33,7 @@ SYMBOLS = [
     "oc_hip_set_iteration", "oc_hip_set_stream", "oc_hip_reset_stream", "oc_hip_set_tuning",
     "oc_hip_prepare", "oc_hip_prepare_ref", "oc_hip_prepare_tar",
     "oc_hip_compute", "oc_hip_compute_chain", "oc_hip_compute_one", "oc_hip_compute_with_offsets", "oc_hip_compute_one_with_offset",
-    "oc_hip_set_self_adaptive", "oc_hip_synchronize", "oc_hip_select_best",
+    "oc_hip_set_self_adaptive", "oc_hip_synchronize", "oc_hip_select_best", "oc_hip_split_reliable", "oc_hip_merge_recovered",
     "oc_hip_get_kind", "oc_hip_get_field", "oc_hip_read_field",
     "oc_hip_profile_enable", "oc_hip_profile_read", "oc_hip_profile_reset",
     "oc_hip_set_devices", "oc_hip_get_devices", "oc_hip_group_queue",
@@ -124,6 +124,9 @@ def lib():
     L.oc_hip_iclm2d2_create.argtypes = [i, i, f, f, i, pp]
     L.oc_hip_set_damping.argtypes = [vp, f, f, f]
     L.oc_hip_select_best.argtypes = [vp, vp, sz, sz, vp, sz, vp, sz, i]
+    psz = ctypes.POINTER(sz)
+    L.oc_hip_split_reliable.argtypes = [vp, vp, sz, sz, i, f, f, f, vp, sz, vp, vp, psz, psz, i]
+    L.oc_hip_merge_recovered.argtypes = [vp, vp, sz, i, vp, vp, sz, f, f, vp, sz, psz, psz, i]
     L.oc_hip_strain_create.argtypes = [f, i, i, pp]
     L.oc_hip_strain_set.argtypes = [vp, f, i, f, i]
     L.oc_hip_strain_prepare.argtypes = [vp, vp, sz, sz, i, i]

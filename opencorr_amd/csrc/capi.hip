@@ -147,6 +147,7 @@ struct oc_hip_engine {
     DevBuf poi_stage, off_stage;
     DevBuf cursors;  // small device scratch (batch maxima)
     DevBuf perm, tiles, perm_slots;  // locality schedule of the ICGN2D queue (poi_order.hip)
+    DevBuf split_scratch, split_tmp; // oc_hip_split_reliable / oc_hip_merge_recovered (poi_split.hip)
     // Strain (src/oc_strain.cpp:31-46: radius, min neighbours; ZNCC threshold 0.9, Cauchy approximation)
     float st_radius = 0.f, st_zncc = 0.9f;
     int st_nmin = 0, st_approx = 1, st_ndim = 0;
@@ -1082,7 +1083,7 @@ static int rehome(oc_hip_engine* e, int device) {
     e->fft.work_fwd.release();
     e->fft.work_inv.release();
     for (DevBuf* b : {&e->gx, &e->gy, &e->gz, &e->coef, &e->coef_gx, &e->coef_gy, &e->tmp, &e->poi_stage, &e->off_stage, &e->cursors,
-                      &e->perm, &e->tiles, &e->perm_slots, &e->st_box, &e->st_counts, &e->st_start, &e->st_cursor, &e->st_slots,
+                      &e->perm, &e->tiles, &e->perm_slots, &e->split_scratch, &e->split_tmp, &e->st_box, &e->st_counts, &e->st_start, &e->st_cursor, &e->st_slots,
                       &e->st_order, &e->st_recs, &e->st_fallback, &e->win, &e->freq, &e->norms, &e->flags, &e->group_mirror,
                       &e->group_off_mirror})
         b->release();
@@ -1936,6 +1937,146 @@ int oc_hip_select_best(oc_hip_engine* e, const void* candidates, size_t n_candid
         return OC_HIP_OK;
     }
     return finish_device_call(e);
+}
+
+// ---------------------------------------------------------------------------
+// reliable / unreliable selection of the RegionFit -> re-ICGN loop (poi_split.hip)
+// ---------------------------------------------------------------------------
+static int split_params(int ndim, size_t stride_bytes, float low, float high, float conv, int mode, ochip::PoiSplitParams* P) {
+    if (ndim != 2 && ndim != 3) return fail(OC_HIP_ERR_INVALID, "ndim must be 2 (POI2D) or 3 (POI3D), got %d", ndim);
+    const size_t rec = ndim == 2 ? OC_HIP_POI2D_BYTES : OC_HIP_POI3D_BYTES;
+    if (stride_bytes < rec || (stride_bytes & 3)) return fail(OC_HIP_ERR_INVALID, "bad POI stride %zu (record is %zu bytes, stride must be a multiple of 4)", stride_bytes, rec);
+    P->mode = mode;
+    P->rec_floats = (int)(rec / 4);
+    P->zncc_at = ndim == 2 ? 16 : 18;  // result.zncc / result.convergence, src/oc_poi.h:102-136, 187-222
+    P->conv_at = ndim == 2 ? 18 : 20;
+    P->zncc_low = low;
+    P->zncc_high = high;
+    P->conv = conv;
+    return OC_HIP_OK;
+}
+
+static int read_split_totals(oc_hip_engine* e, size_t count, size_t totals[2]) {
+    unsigned host[2] = {0, 0};
+    const unsigned* d = e->split_scratch.as<unsigned>() + ochip::poi_split_scratch_words(count) - 2;
+    OC_HIP_TRY(hipMemcpyAsync(host, d, sizeof(host), hipMemcpyDeviceToHost, e->stream));
+    OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    totals[0] = host[0];
+    totals[1] = host[1];
+    return OC_HIP_OK;
+}
+
+int oc_hip_split_reliable(oc_hip_engine* e, const void* pois, size_t count, size_t stride_bytes, int ndim, float zncc_threshold_low,
+                          float zncc_threshold_high, float conv_criterion, void* reliable, size_t reliable_offset, void* unreliable,
+                          unsigned* unreliable_index, size_t* n_reliable, size_t* n_unreliable, int memory) {
+    OC_ACTIVATE(e);
+    if (!n_reliable || !n_unreliable) return fail(OC_HIP_ERR_INVALID, "split_reliable: null count pointer");
+    *n_reliable = *n_unreliable = 0;
+    if (count == 0) return OC_HIP_OK;
+    if (!pois || !reliable || !unreliable || !unreliable_index) return fail(OC_HIP_ERR_INVALID, "split_reliable: null buffer");
+    ochip::PoiSplitParams P;
+    OC_TRY(split_params(ndim, stride_bytes, zncc_threshold_low, zncc_threshold_high, conv_criterion, 0, &P));
+    std::lock_guard<std::mutex> lock(e->mu);
+    OC_TRY(order_after_default_stream(e));
+    OC_TRY(e->split_scratch.reserve(ochip::poi_split_scratch_words(count) * sizeof(unsigned)));
+    const int stride_f = (int)(stride_bytes / 4);
+    size_t totals[2];
+    if (memory == OC_HIP_DEVICE) {
+        OC_HIP_TRY(ochip::launch_poi_split(static_cast<const float*>(pois), stride_f, count, P, nullptr, static_cast<float*>(reliable),
+                                           reliable_offset, nullptr, static_cast<float*>(unreliable), unreliable_index, nullptr,
+                                           e->split_scratch.as<unsigned>(), e->stream));
+        OC_TRY(read_split_totals(e, count, totals));
+    } else {
+        const size_t qb = count * stride_bytes;
+        OC_TRY(e->poi_stage.reserve(3 * qb + count * sizeof(unsigned)));
+        char* base = e->poi_stage.as<char>();
+        float* d_in = reinterpret_cast<float*>(base);
+        float* d_rel = reinterpret_cast<float*>(base + qb);
+        float* d_unr = reinterpret_cast<float*>(base + 2 * qb);
+        unsigned* d_idx = reinterpret_cast<unsigned*>(base + 3 * qb);
+        OC_HIP_TRY(hipMemcpyAsync(d_in, pois, qb, hipMemcpyHostToDevice, e->stream));
+        OC_HIP_TRY(ochip::launch_poi_split(d_in, stride_f, count, P, nullptr, d_rel, 0, nullptr, d_unr, d_idx, nullptr,
+                                           e->split_scratch.as<unsigned>(), e->stream));
+        OC_TRY(read_split_totals(e, count, totals));
+        if (totals[0]) OC_HIP_TRY(hipMemcpyAsync(static_cast<char*>(reliable) + reliable_offset * stride_bytes, d_rel, totals[0] * stride_bytes, hipMemcpyDeviceToHost, e->stream));
+        if (totals[1]) {
+            OC_HIP_TRY(hipMemcpyAsync(unreliable, d_unr, totals[1] * stride_bytes, hipMemcpyDeviceToHost, e->stream));
+            OC_HIP_TRY(hipMemcpyAsync(unreliable_index, d_idx, totals[1] * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+        }
+        OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    *n_reliable = totals[0];
+    *n_unreliable = totals[1];
+    return OC_HIP_OK;
+}
+
+int oc_hip_merge_recovered(oc_hip_engine* e, void* pois, size_t stride_bytes, int ndim, void* unreliable, unsigned* unreliable_index,
+                           size_t n_unreliable, float zncc_threshold_high, float conv_criterion, void* reliable, size_t reliable_offset,
+                           size_t* n_recovered, size_t* n_remaining, int memory) {
+    OC_ACTIVATE(e);
+    if (!n_recovered || !n_remaining) return fail(OC_HIP_ERR_INVALID, "merge_recovered: null count pointer");
+    *n_recovered = 0;
+    *n_remaining = 0;
+    if (n_unreliable == 0) return OC_HIP_OK;
+    if (!pois || !reliable || !unreliable || !unreliable_index) return fail(OC_HIP_ERR_INVALID, "merge_recovered: null buffer");
+    ochip::PoiSplitParams P;
+    OC_TRY(split_params(ndim, stride_bytes, 0.f, zncc_threshold_high, conv_criterion, 1, &P));
+    std::lock_guard<std::mutex> lock(e->mu);
+    OC_TRY(order_after_default_stream(e));
+    OC_TRY(e->split_scratch.reserve(ochip::poi_split_scratch_words(n_unreliable) * sizeof(unsigned)));
+    const int stride_f = (int)(stride_bytes / 4);
+    const size_t qb = n_unreliable * stride_bytes, ib = n_unreliable * sizeof(unsigned);
+    size_t totals[2];
+    if (memory == OC_HIP_DEVICE) {
+        // the POIs that stay unreliable are compacted into a scratch copy first (an in-place compaction would overwrite
+        // records other threads still have to read), then moved back to the front of the caller's arrays
+        OC_TRY(e->split_tmp.reserve(qb + ib));
+        float* t_rec = e->split_tmp.as<float>();
+        unsigned* t_idx = reinterpret_cast<unsigned*>(e->split_tmp.as<char>() + qb);
+        OC_HIP_TRY(ochip::launch_poi_split(static_cast<const float*>(unreliable), stride_f, n_unreliable, P, unreliable_index,
+                                           static_cast<float*>(reliable), reliable_offset, nullptr, t_rec, t_idx, static_cast<float*>(pois),
+                                           e->split_scratch.as<unsigned>(), e->stream));
+        OC_TRY(read_split_totals(e, n_unreliable, totals));
+        if (totals[1]) {
+            OC_HIP_TRY(hipMemcpyAsync(unreliable, t_rec, totals[1] * stride_bytes, hipMemcpyDeviceToDevice, e->stream));
+            OC_HIP_TRY(hipMemcpyAsync(unreliable_index, t_idx, totals[1] * sizeof(unsigned), hipMemcpyDeviceToDevice, e->stream));
+        }
+        *n_recovered = totals[0];
+        *n_remaining = totals[1];
+        return finish_device_call(e);
+    }
+    // host queues: the classification and both compactions run on the device; the host only moves the recovered records to
+    // where the device's index list says they go
+    OC_TRY(e->poi_stage.reserve(3 * qb + 3 * ib));
+    char* base = e->poi_stage.as<char>();
+    float* d_in = reinterpret_cast<float*>(base);
+    float* d_rec = reinterpret_cast<float*>(base + qb);
+    float* d_rem = reinterpret_cast<float*>(base + 2 * qb);
+    unsigned* d_idx_in = reinterpret_cast<unsigned*>(base + 3 * qb);
+    unsigned* d_idx_rec = d_idx_in + n_unreliable;
+    unsigned* d_idx_rem = d_idx_rec + n_unreliable;
+    OC_HIP_TRY(hipMemcpyAsync(d_in, unreliable, qb, hipMemcpyHostToDevice, e->stream));
+    OC_HIP_TRY(hipMemcpyAsync(d_idx_in, unreliable_index, ib, hipMemcpyHostToDevice, e->stream));
+    OC_HIP_TRY(ochip::launch_poi_split(d_in, stride_f, n_unreliable, P, d_idx_in, d_rec, 0, d_idx_rec, d_rem, d_idx_rem, nullptr,
+                                       e->split_scratch.as<unsigned>(), e->stream));
+    OC_TRY(read_split_totals(e, n_unreliable, totals));
+    std::vector<unsigned> rec_idx(totals[0]);
+    char* rel_dst = static_cast<char*>(reliable) + reliable_offset * stride_bytes;
+    if (totals[0]) {
+        OC_HIP_TRY(hipMemcpyAsync(rel_dst, d_rec, totals[0] * stride_bytes, hipMemcpyDeviceToHost, e->stream));
+        OC_HIP_TRY(hipMemcpyAsync(rec_idx.data(), d_idx_rec, totals[0] * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    }
+    if (totals[1]) {
+        OC_HIP_TRY(hipMemcpyAsync(unreliable, d_rem, totals[1] * stride_bytes, hipMemcpyDeviceToHost, e->stream));
+        OC_HIP_TRY(hipMemcpyAsync(unreliable_index, d_idx_rem, totals[1] * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    }
+    OC_HIP_TRY(hipStreamSynchronize(e->stream));
+    const size_t rec_bytes = (size_t)P.rec_floats * 4;
+    for (size_t j = 0; j < totals[0]; j++)
+        std::memcpy(static_cast<char*>(pois) + (size_t)rec_idx[j] * stride_bytes, rel_dst + j * stride_bytes, rec_bytes);
+    *n_recovered = totals[0];
+    *n_remaining = totals[1];
+    return OC_HIP_OK;
 }
 
 int oc_hip_set_self_adaptive(oc_hip_engine* e, int enable) {

@@ -177,4 +177,17 @@ bool fftcc3d_fused_supported(int rx, int ry, int rz);
 hipError_t launch_fftcc3d_fused(const Fftcc3dParams& p, float* pois, int stride_floats, size_t count, bool xcd,
                                 hipStream_t stream);
 
+// ---- poi_split.hip ----------------------------------------------------------
+// order-preserving partition of a POI queue by result quality (oc_hip_split_reliable / oc_hip_merge_recovered)
+struct PoiSplitParams {
+    int mode;        // 0: reliable | unreliable | neither (first selection), 1: recovered | still unreliable (after a round)
+    int rec_floats;  // 25 (POI2D) or 31 (POI3D)
+    int zncc_at, conv_at;
+    float zncc_low, zncc_high, conv;
+};
+size_t poi_split_scratch_words(size_t count);  // unsigned words of device scratch: per-block counts + the two totals (last two words)
+hipError_t launch_poi_split(const float* pois, int stride_floats, size_t count, const PoiSplitParams& p, const unsigned* index_in,
+                            float* out0, size_t out0_offset, unsigned* index_out0, float* out1, unsigned* index_out,
+                            float* main_queue, unsigned* scratch, hipStream_t stream);
+
 }  // namespace ochip

@@ -241,6 +241,62 @@ class _Engine:
         capi.check(capi.lib().oc_hip_select_best(self._h, cp, nc, cs, sp, ns, pp_, ps, mem))
         return pois
 
+    # -- the two selections of the RegionFit -> re-ICGN loop, on the device --------------------------------------
+    def split_reliable(self, pois, zncc_threshold_low, zncc_threshold_high, conv_criterion, reliable=None, reliable_offset=0):
+        """``oc_hip_split_reliable``: order-preserving partition of a finished queue (examples/
+        test_3d_reconstruction_sift_icgn2_regfit.cpp:216-229).  Returns ``(reliable, n_reliable, unreliable, index,
+        n_unreliable)``: ``reliable[reliable_offset : reliable_offset + n_reliable]`` and ``unreliable[:n_unreliable]`` hold
+        the records, ``index[:n_unreliable]`` the queue positions of the unreliable ones.  CUDA tensors stay on the device
+        (the buffers are allocated with ``len(pois)`` records unless ``reliable`` is passed in)."""
+        self._adopt_stream_of(pois)
+        n, floats = pois.shape
+        ndim = 2 if floats == capi.POI2D_FLOATS else 3
+        if _is_torch(pois):
+            import torch
+            p, mem, _ = _buf(pois)
+            if reliable is None:
+                reliable = torch.empty((reliable_offset + n, floats), dtype=torch.float32, device=pois.device)
+            unreliable = torch.empty((n, floats), dtype=torch.float32, device=pois.device)
+            index = torch.empty((n,), dtype=torch.int32, device=pois.device)
+            rp, up, ip = (ctypes.c_void_p(t.data_ptr()) for t in (reliable, unreliable, index))
+            stride = pois.stride(0) * 4
+        else:
+            p, mem = ctypes.c_void_p(pois.ctypes.data), capi.HOST
+            if reliable is None:
+                reliable = np.zeros((reliable_offset + n, floats), dtype=np.float32)
+            unreliable = np.zeros((n, floats), dtype=np.float32)
+            index = np.zeros((n,), dtype=np.uint32)
+            rp, up, ip = (ctypes.c_void_p(a.ctypes.data) for a in (reliable, unreliable, index))
+            stride = pois.strides[0]
+        if reliable.shape[0] < reliable_offset + n:
+            raise ValueError("the reliable buffer needs room for reliable_offset + len(pois) records")
+        n_rel, n_unr = ctypes.c_size_t(), ctypes.c_size_t()
+        capi.check(capi.lib().oc_hip_split_reliable(self._h, p, n, stride, ndim, zncc_threshold_low, zncc_threshold_high, conv_criterion,
+                                                    rp, reliable_offset, up, ip, ctypes.byref(n_rel), ctypes.byref(n_unr), mem))
+        return reliable, n_rel.value, unreliable, index, n_unr.value
+
+    def merge_recovered(self, pois, unreliable, index, n_unreliable, zncc_threshold_high, conv_criterion, reliable, reliable_offset):
+        """``oc_hip_merge_recovered``: after RegionFit + ICGN over ``unreliable[:n_unreliable]`` -- the POIs that now pass go
+        back into ``pois`` (at their ``index``) and to ``reliable[reliable_offset:]``, the rest move to the front of
+        ``unreliable`` / ``index``.  Returns ``(n_recovered, n_remaining)``."""
+        self._adopt_stream_of(pois)
+        floats = pois.shape[1]
+        ndim = 2 if floats == capi.POI2D_FLOATS else 3
+        if _is_torch(pois):
+            mem = capi.DEVICE
+            pp_, up, ip, rp = (ctypes.c_void_p(t.data_ptr()) for t in (pois, unreliable, index, reliable))
+            stride = pois.stride(0) * 4
+        else:
+            mem = capi.HOST
+            pp_, up, ip, rp = (ctypes.c_void_p(a.ctypes.data) for a in (pois, unreliable, index, reliable))
+            stride = pois.strides[0]
+        if reliable.shape[0] < reliable_offset + n_unreliable:
+            raise ValueError("the reliable buffer needs room for reliable_offset + n_unreliable records")
+        n_rec, n_rem = ctypes.c_size_t(), ctypes.c_size_t()
+        capi.check(capi.lib().oc_hip_merge_recovered(self._h, pp_, stride, ndim, up, ip, n_unreliable, zncc_threshold_high, conv_criterion,
+                                                     rp, reliable_offset, ctypes.byref(n_rec), ctypes.byref(n_rem), mem))
+        return n_rec.value, n_rem.value
+
     def compute_one(self, poi):
         assert poi.dtype == np.float32 and poi.flags.c_contiguous
         capi.check(capi.lib().oc_hip_compute_one(self._h, ctypes.c_void_p(poi.ctypes.data)))

@@ -194,6 +194,43 @@ int main(int argc, char** argv) {
             strain.compute(&q2[q2.size() / 2], q2);
             if (q2[q2.size() / 2].strain.exy != probe.strain.exy) { std::cerr << "Strain::compute(POI*, queue) disagrees" << std::endl; return 15; }
         }
+        // reliable / unreliable selection and the merge after a RegionFit + ICGN round, against the reference example's host
+        // loops (examples/test_3d_reconstruction_sift_icgn2_regfit.cpp:214-260) written out here
+        {
+            std::vector<POI2D> q = poi_queue;
+            for (size_t i = 0; i < q.size(); i += 5) q[i].result.zncc = 0.3f;            // failed
+            for (size_t i = 2; i < q.size(); i += 7) q[i].result.convergence = 0.5f;     // did not converge
+            for (size_t i = 3; i < q.size(); i += 11) q[i].result.zncc = 0.8f;           // in between: neither set
+            const float low = 0.7f, high = 0.9f, crit = 0.001f;
+            std::vector<POI2D> rel, unr, rel_want, unr_want;
+            std::vector<unsigned> idx;
+            std::vector<int> idx_want;
+            for (int i = 0; i < (int)q.size(); i++) {
+                if (q[i].result.zncc < low || q[i].result.convergence > crit) { unr_want.push_back(q[i]); idx_want.push_back(i); }
+                else if (q[i].result.zncc >= high) rel_want.push_back(q[i]);
+            }
+            splitReliable(*icgn1, q, low, high, crit, rel, unr, idx);
+            bool same = rel.size() == rel_want.size() && unr.size() == unr_want.size() && idx.size() == idx_want.size() &&
+                        (rel.empty() || std::memcmp(rel.data(), rel_want.data(), rel.size() * sizeof(POI2D)) == 0) &&
+                        (unr.empty() || std::memcmp(unr.data(), unr_want.data(), unr.size() * sizeof(POI2D)) == 0);
+            for (size_t j = 0; same && j < idx.size(); j++) same = (int)idx[j] == idx_want[j];
+            if (!same || unr.empty() || rel.empty()) { std::cerr << "splitReliable differs from the host selection loop" << std::endl; return 19; }
+            // pretend a round repaired every second unreliable POI
+            for (size_t j = 0; j < unr.size(); j += 2) { unr[j].result.zncc = 0.95f; unr[j].result.convergence = 0.0005f; }
+            std::vector<POI2D> q_want = q, rel2_want = rel, unr2_want;
+            std::vector<unsigned> idx2_want;
+            for (size_t j = 0; j < unr.size(); j++) {
+                if (unr[j].result.zncc >= high && unr[j].result.convergence <= crit) { q_want[idx[j]] = unr[j]; rel2_want.push_back(unr[j]); }
+                else { unr2_want.push_back(unr[j]); idx2_want.push_back(idx[j]); }
+            }
+            const size_t rec = mergeRecovered(*icgn1, q, unr, idx, high, crit, rel);
+            same = rec == rel2_want.size() - rel_want.size() && rel.size() == rel2_want.size() && unr.size() == unr2_want.size() &&
+                   std::memcmp(q.data(), q_want.data(), q.size() * sizeof(POI2D)) == 0 &&
+                   std::memcmp(rel.data(), rel2_want.data(), rel.size() * sizeof(POI2D)) == 0 &&
+                   (unr.empty() || std::memcmp(unr.data(), unr2_want.data(), unr.size() * sizeof(POI2D)) == 0);
+            for (size_t j = 0; same && j < idx.size(); j++) same = idx[j] == idx2_want[j];
+            if (!same) { std::cerr << "mergeRecovered differs from the host merge loop" << std::endl; return 20; }
+        }
         // candidate batching (the EpipolarSearch pattern): three trial guesses per POI, the middle one is FFTCC's
         {
             std::vector<POI2D> cand;

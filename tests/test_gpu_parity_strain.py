@@ -207,3 +207,110 @@ def test_region_fit_then_icgn_recovers_bad_initial_guesses(speckle_small):
     rf.compute(unreliable)
     icgn.compute(unreliable)
     assert (unreliable[:, P["zncc"]] > 0.9).mean() > 0.95
+
+
+def _host_split(q, low, high, crit, P):
+    """The selection loop of examples/test_3d_reconstruction_sift_icgn2_regfit.cpp:216-229 in NumPy."""
+    z, c = q[:, P["zncc"]], q[:, P["convergence"]]
+    unr = (z < low) | (c > crit)
+    rel = ~unr & (z >= high)
+    return np.ascontiguousarray(q[rel]), np.ascontiguousarray(q[unr]), np.flatnonzero(unr).astype(np.uint32)
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_region_fit_icgn_loop_without_a_host_hop(speckle_small, resident):
+    """The whole RegionFit -> re-ICGN loop (examples/test_3d_reconstruction_sift_icgn2_regfit.cpp:214-260) with the queue
+    resident in HBM: reliable / unreliable selection (oc_hip_split_reliable), RegionFit over the reliable set, ICGN over the
+    unreliable one, merge of the recovered POIs (oc_hip_merge_recovered) -- two rounds, no record ever crosses PCIe.  Must
+    equal, bit for bit, the same loop with the selections done on the host in NumPy (`resident` False: the C-ABI's
+    OC_HIP_HOST form of the two calls against NumPy as well)."""
+    import torch
+    import opencorr_amd as eng
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    P = oracle.P2
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 30, 26, 30)
+    fftcc = eng.FFTCC2D(16, 16)
+    fftcc.set_images(ref, tar)
+    start = eng.make_pois2d(xs, ys)
+    fftcc.compute(start)
+    rng = np.random.default_rng(9)
+    spoiled = rng.random(len(start)) < 0.2
+    start[spoiled, P["u"]] += 9.0          # guesses far outside the convergence radius
+    start[::37, P["v"]] = np.nan            # and a few NaN guesses: rejected with -5 / guard, in neither set
+    icgn = eng.ICGN2D1(16, 16, 0.001, 10)
+    icgn.share_images(fftcc)
+    icgn.prepare()
+    low, high, crit = 0.7, 0.9, 0.001
+    rf = eng.RegionFit(40.0, 6)
+
+    # ---- the reference loop, selections on the host
+    want = icgn.compute(start.copy())
+    rel_w, unr_w, idx_w = _host_split(want, low, high, crit, P)
+    assert len(unr_w) >= 0.5 * spoiled.sum() and len(rel_w) > 0.6 * len(want)
+    history = []
+    for _ in range(2):
+        rf.set_neighbor(rel_w)
+        rf.prepare()
+        rf.compute(unr_w)
+        icgn.compute(unr_w)
+        ok = (unr_w[:, P["zncc"]] >= high) & (unr_w[:, P["convergence"]] <= crit)
+        want[idx_w[ok]] = unr_w[ok]
+        rel_w = np.ascontiguousarray(np.concatenate([rel_w, unr_w[ok]]))
+        unr_w, idx_w = np.ascontiguousarray(unr_w[~ok]), idx_w[~ok]
+        history.append((int(ok.sum()), len(unr_w)))
+    assert history[0][0] > 0.8 * spoiled.sum()   # the first round repairs most of the spoiled POIs
+
+    # ---- the same loop through the engine's own selections
+    dev = torch.device("cuda", 0)
+    q = torch.from_numpy(start).to(dev) if resident else start.copy()
+    icgn.compute(q)
+    rel, n_rel, unr, idx, n_unr = icgn.split_reliable(q, low, high, crit)
+    got_history = []
+    for _ in range(2):
+        rf.set_neighbor(rel[:n_rel])
+        rf.prepare()
+        rf.compute(unr[:n_unr])
+        icgn.compute(unr[:n_unr])
+        n_rec, n_rem = icgn.merge_recovered(q, unr, idx, n_unr, high, crit, rel, n_rel)
+        n_rel, n_unr = n_rel + n_rec, n_rem
+        got_history.append((n_rec, n_rem))
+    if resident:
+        torch.cuda.synchronize()
+        q, rel, unr, idx = (t.cpu().numpy() for t in (q, rel, unr, idx))
+    assert got_history == history
+    assert np.array_equal(_bits(q), _bits(want))
+    assert np.array_equal(_bits(rel[:n_rel]), _bits(rel_w))
+    assert np.array_equal(_bits(unr[:n_unr]), _bits(unr_w)) and np.array_equal(np.asarray(idx[:n_unr], dtype=np.uint32), idx_w)
+
+
+def test_split_reliable_edge_cases():
+    """Empty queues, queues where one set is empty, 3D records, a queue longer than one scan block row (> 256 * 1024 POIs)."""
+    import torch
+    import opencorr_amd as eng
+    import oracle
+    P3 = oracle.P3
+    g = eng.ICGN3D1(8, 8, 8, 0.001, 10)
+    rng = np.random.default_rng(4)
+    n = 300000
+    q = np.zeros((n, 31), np.float32)
+    q[:, 0] = np.arange(n)
+    q[:, P3["zncc"]] = rng.uniform(0.5, 1.0, n)
+    q[:, P3["convergence"]] = rng.uniform(0, 0.002, n)
+    q[::101, P3["zncc"]] = np.nan
+    rel_w, unr_w, idx_w = _host_split(q, 0.7, 0.9, 0.001, P3)
+    for queue in (q, torch.from_numpy(q).to("cuda:0")):
+        rel, n_rel, unr, idx, n_unr = g.split_reliable(queue, 0.7, 0.9, 0.001)
+        if not isinstance(rel, np.ndarray):
+            rel, unr, idx = rel.cpu().numpy(), unr.cpu().numpy(), idx.cpu().numpy()
+        assert n_rel == len(rel_w) and n_unr == len(unr_w)
+        assert np.array_equal(_bits(rel[:n_rel]), _bits(rel_w)) and np.array_equal(_bits(unr[:n_unr]), _bits(unr_w))
+        assert np.array_equal(np.asarray(idx[:n_unr], dtype=np.uint32), idx_w)
+    # nothing unreliable / nothing reliable / empty
+    rel, n_rel, unr, idx, n_unr = g.split_reliable(q[:1000], -1.0, 0.0, 1.0)
+    assert n_unr == 0 and n_rel == int((~np.isnan(q[:1000, P3["zncc"]])).sum())
+    rel, n_rel, unr, idx, n_unr = g.split_reliable(q[:1000], 2.0, 3.0, 1.0)
+    assert n_rel == 0 and n_unr == int((~np.isnan(q[:1000, P3["zncc"]])).sum())
+    assert g.split_reliable(q[:0], 0.7, 0.9, 0.001)[1::3] == (0, 0)
+    assert g.merge_recovered(q, unr, idx, 0, 0.9, 0.001, rel, 0) == (0, 0)
