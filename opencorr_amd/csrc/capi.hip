@@ -173,6 +173,7 @@ struct oc_hip_engine {
     std::mutex feed_mu;
     std::condition_variable feed_cv;  // the copy-out thread sleeps here until the next chunk has been handed over
     int host_chunk = 65536;  // POIs per chunk ("host_chunk" tuning key; 0 = the whole queue at once)
+    std::atomic<unsigned> single_calls{0};  // compute(POI*) calls on this engine (one hint on stderr when a caller loops over them)
     // device group (oc_hip_set_devices): this engine leads, replicas[i] is a full engine of the same kind on
     // group_devices[i + 1]; every setter, set_images, prepare and compute fans out
     std::vector<oc_hip_engine*> replicas;
@@ -1890,13 +1891,28 @@ int oc_hip_compute_chain(oc_hip_engine* const* engines, int n_engines, void* poi
     return OC_HIP_OK;
 }
 
+// compute(POI*) is a batch of ONE: a kernel launch and two PCIe copies per POI, ~1000 times slower per POI than the batch
+// path.  Right for callers that genuinely have one POI at a time; a caller that loops over a queue with it gets one hint on
+// stderr (per process) at its 4096th call on an engine.  OC_HIP_QUIET=1 silences it.
+static void hint_single_poi_loop(oc_hip_engine* e) {
+    if (e->single_calls.fetch_add(1, std::memory_order_relaxed) + 1 != 4096) return;
+    static std::atomic<bool> said{false};
+    const char* q = getenv("OC_HIP_QUIET");
+    if ((q && *q && *q != '0') || said.exchange(true)) return;
+    fprintf(stderr, "opencorr_hip: compute(POI*) was called 4096 times on one engine -- every call is a GPU launch plus two PCIe copies. "
+                    "Hand the POIs over as one queue (compute(std::vector<POI>&), or computeBestOf() for trial positions per POI) for "
+                    "~1000x the throughput.  OC_HIP_QUIET=1 silences this hint.\n");
+}
+
 int oc_hip_compute_one(oc_hip_engine* e, void* poi) {
     OC_TRY(check_engine(e));
+    hint_single_poi_loop(e);
     return compute_impl(e, poi, nullptr, 1, e->poi_bytes(), OC_HIP_HOST);
 }
 
 int oc_hip_compute_one_with_offset(oc_hip_engine* e, void* poi, const float* center_offset) {
     OC_TRY(check_engine(e));
+    hint_single_poi_loop(e);
     if (!center_offset) return fail(OC_HIP_ERR_INVALID, "null center offset");
     return compute_impl(e, poi, center_offset, 1, e->poi_bytes(), OC_HIP_HOST);
 }

@@ -110,11 +110,11 @@ __global__ __launch_bounds__(256) void colmajor_to_rowmajor_kernel(const float* 
 // The same gradients as a streaming kernel: a thread owns FOUR consecutive pixels of a row (16-byte accesses) and walks
 // down kGradRows rows with the centre values of rows r-2 .. r+2 in a rotating register window, so every pixel is fetched
 // once for the y gradient (the scalar kernel above re-read it four times through L1) and the x gradient of the four
-// pixels comes from two unaligned 16-byte loads (c-2 .. c+1, c+2 .. c+5).  Same expression per pixel, same bits.
+// pixels needs, beside the window's centre values, one aligned pair to the left and one to the right.  Same expression
+// per pixel, same bits.
 // Needs width % 4 == 0 and 16-byte aligned rows; everything else takes the scalar kernel.  The 3D twin (prepare3d.hip)
 // reaches 3.3 TB/s this way; here: 201 MB (4096^2: 4 B in, 8 B out per pixel) in 78.8 us -> see DESIGN.md section 4.
 constexpr int kGradRows = 16;
-typedef float float4u2d __attribute__((ext_vector_type(4), aligned(4)));
 __global__ __launch_bounds__(256) void grad2d4_kernel(const float* __restrict__ img, int height, int width,
                                                       float* __restrict__ gx, float* __restrict__ gy) {
     const float first_factor = 1.f / 12.f;
@@ -136,21 +136,17 @@ __global__ __launch_bounds__(256) void grad2d4_kernel(const float* __restrict__ 
         result += b2 * first_factor;
         return result;
     };
+#pragma unroll 4
     for (int r = r0; r < r1; r++) {
         const float4 p2 = row4(r + 2);
         const size_t g = (size_t)r * width + c;
-        // x: f[c-2 .. c+5] of this row
-        float f[8];
-        if (c >= 4 && c + 8 <= width) {
-            const float4u2d lo = *reinterpret_cast<const float4u2d*>(img + g - 2), hi = *reinterpret_cast<const float4u2d*>(img + g + 2);
-            f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
-        } else {
-#pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const int cc = c - 2 + t;
-                f[t] = (cc >= 0 && cc < width) ? img[(size_t)r * width + cc] : 0.f;
-            }
-        }
+        // x: f[k] = img[r][c - 2 + k], k = 0 .. 7: the four centre values are in the window already; the two values to the
+        // left and the two to the right are 8-byte aligned pairs (c is a multiple of 4).  Where a pair would leave the row
+        // (first / last thread of a row) it is not needed: the pixels that would use it lie in the two-pixel zero border.
+        // (loaded unconditionally from a clamped address -- no branch, no wait in the middle of the row's loads)
+        const float2 lo = *reinterpret_cast<const float2*>(img + g - (c >= 4 ? 2 : 0));
+        const float2 hi = *reinterpret_cast<const float2*>(img + g + (c + 8 <= width ? 4 : 0));
+        const float f[8] = {lo.x, lo.y, c0.x, c0.y, c0.z, c0.w, hi.x, hi.y};
         float vx[4], vy[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
