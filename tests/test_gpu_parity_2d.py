@@ -111,6 +111,40 @@ def test_fftcc2d_fused_kernel_matches_rocfft_pipeline(eng, speckle_small, r):
     assert (fused[:-3, 16] > 0.5).mean() > 0.9
 
 
+@pytest.mark.parametrize("rx,ry", [(8, 16), (16, 8), (10, 24), (32, 12), (20, 16), (24, 32), (16, 20), (12, 8)])
+def test_fftcc2d_fused_rectangular_windows(eng, speckle_small, rx, ry):
+    """rx != ry with both window sides out of {16, 20, 24, 32, 40, 48, 64}: the register-FFT kernel (fftcc2d_fusedr.hip) instead
+    of the five-kernel rocFFT pipeline.  The reference transforms the window's linear buffer re-cut into 2 * rx lines of
+    2 * ry elements there (fftwf_plan_dft_r2c_2d(width, height) over data filled [row * width + col], src/oc_fftcc.cpp:40-42,
+    204-221) and decodes the peak with the window's width; the oracle restates exactly that, the pipeline and the fused
+    kernel must both reproduce it: identical integers, ZNCC to float rounding, guarded POIs untouched."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    xs, ys = synth.poi_grid_2d(h, w, 27, 23, max(rx, ry) + 8)
+    xs = np.concatenate([xs, [3, w - 2, 150]]).astype(np.float32)
+    ys = np.concatenate([ys, [100, 100, 2]]).astype(np.float32)
+    base = eng.make_pois2d(xs, ys)
+    base[::7, 2] = 1.0
+    base[::5, 8] = -2.0
+    f = eng.FFTCC2D(rx, ry)
+    f.set_images(ref, tar)
+    fused = f.compute(base.copy())
+    f.set_tuning("fftcc2d_fused", 0)
+    piped = f.compute(base.copy())
+    want = base.copy()
+    oracle.fftcc2d(ref, tar, rx, ry, want)
+    for col in (2, 8, 14, 15):
+        assert np.array_equal(fused[:, col], piped[:, col]), col
+        assert np.array_equal(fused[:, col], want[:, col]), col
+    assert np.abs(fused[:, 16] - piped[:, 16]).max() <= 3e-6
+    assert np.abs(fused[:, 16] - want[:, 16]).max() <= 3e-5
+    other = [c for c in range(25) if c not in (2, 8, 14, 15, 16)]
+    assert np.array_equal(_bits(fused[:, other]), _bits(base[:, other]))
+    assert np.array_equal(_bits(fused[-3:]), _bits(base[-3:]))
+
+
 def test_fftcc2d_setsubset_replans(eng, speckle_small):
     """FFTCC2D::setSubset between computes (examples/test_3d_dic_epipolar_sift.cpp:188-190): the engine drops its FFT
     plans / picks another kernel for the new window -- fused 32 -> rocFFT pipeline (rx != ry) -> fused 40 -> fused 32
