@@ -1257,7 +1257,9 @@ static int switch_stream(oc_hip_engine* e, hipStream_t next, bool must_succeed) 
     }
     (void)must_succeed;
     e->stream = next;
-    e->tail_marked = false;
+    // the event still marks the end of everything this engine has enqueued anywhere: if the caller moves on to a third
+    // stream before the engine has put work on this one, that stream has to wait for it as well
+    e->tail_marked = have_event;
     return OC_HIP_OK;
 }
 
