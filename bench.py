@@ -14,7 +14,7 @@ timed region and reported separately.
 Workload (BASELINE.json configs[1], SURVEY.md 8d "B"): 4096 x 4096 synthetic speckle
 pair, r = 16 (33 x 33 subset, 32 x 32 FFTCC window), 500 x 500 = 250 000 POIs,
 conv 1e-3, stop 10.  N > 1 is weak scaling: 250 000 POIs per GPU cut from one
-N*250 000-POI queue over a pair replicated on every GPU.  The image grows with N so that
+N*250 000-POI queue over a pair replicated on every GPU (rendered on rank 0, broadcast to the others).  The image grows with N so that
 the POI pitch -- i.e. how much neighbouring subsets overlap, which sets the cache behaviour
 of the kernel -- stays what it is at N = 1: 4096 x 8192 with 1000 x 500 POIs at N = 2,
 8192 x 8192 with 1000 x 1000 at N = 4; N = 8 is BASELINE config "D" as written (8192 x 8192,
@@ -234,7 +234,18 @@ def main():
         nx = int(np.floor(np.sqrt(n_total)))
         ny = -(-n_total // nx)
     t0 = time.time()
-    ref, tar = synth.speckle_pair_2d(height, width, seed=20260925, device=dev)
+    # ONE image pair for all ranks: rank 0 renders it, the others receive it (the GPU renderer adds its speckles with float
+    # atomics, so two renderings of the same seed differ in the last bits of a few pixels -- and with them ~40 of 250 000
+    # POIs; ranks working on private renderings could not be cross-checked bit for bit, and would not be "replicas")
+    if not dist_on or rank == 0:
+        ref, tar = synth.speckle_pair_2d(height, width, seed=20260925, device=dev)
+    else:
+        ref = torch.empty((height, width), dtype=torch.float32, device=dev)
+        tar = torch.empty((height, width), dtype=torch.float32, device=dev)
+    if dist_on:
+        dist.broadcast(ref, src=0)
+        dist.broadcast(tar, src=0)
+        torch.cuda.synchronize()
     xs, ys = synth.poi_grid_2d(height, width, nx, ny, RX + 8)
     xs, ys = xs[:n_total], ys[:n_total]
     n_total = len(xs)
