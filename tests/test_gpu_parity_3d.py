@@ -276,3 +276,26 @@ def test_icgn3d1_global_tap_fallback(big_volumes):
     pois = pois.astype(np.float32)
     want = _icgn3d_case(big_volumes, 16, pois, stop=6.0)
     assert np.isfinite(want[:, P["u"]]).all()
+
+
+def test_compute_chain_3d_matches_separate_calls(volumes):
+    """oc_hip_compute_chain with POI3D records (FFTCC3D -> ICGN3D1, the call pair of examples/test_dvc_fftcc_icgn1.cpp:87-106):
+    host queue and device queue, the bits of the two separate calls."""
+    import torch
+    import opencorr_amd
+    from opencorr_amd import synth
+    ref, tar = volumes
+    xs, ys, zs = synth.poi_grid_3d(*SHAPE, 4, 3, 3, 26)
+    base = opencorr_amd.make_pois3d(xs, ys, zs)
+    f = opencorr_amd.FFTCC3D(8, 8, 8)
+    f.set_images(ref, tar)
+    g = opencorr_amd.ICGN3D1(8, 8, 8, 0.001, 20)
+    g.share_images(f)
+    g.prepare()
+    want = g.compute(f.compute(base.copy()))
+    assert np.array_equal(_bits(opencorr_amd.compute_chain([f, g], base.copy())), _bits(want))
+    q = torch.from_numpy(base).to("cuda:0")
+    opencorr_amd.compute_chain([f, g], q)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(q.cpu().numpy()), _bits(want))
+    assert (want[:, 18] > 0.9).mean() > 0.8
