@@ -430,16 +430,31 @@ def multi_gpu_check(args, dist, torch, dev, rank, world, local_rank, one_device,
     a stale image, a mis-cut block or a gather that landed records in the wrong slot cannot pass.  Ranks must sit on
     distinct devices (PCI bus ids gathered over the process group)."""
     import opencorr_amd
-    assert dist.get_world_size() == world == args.gpus
+    # A failed check is reported in the line (multi_gpu_check.ok = false, the offending items named in .problems) and on
+    # stderr -- a scaling run keeps its numbers and shows what was wrong with them.  OC_BENCH_STRICT=1 (the tests) turns
+    # every failure into an immediate exception instead.
+    strict = os.environ.get("OC_BENCH_STRICT") == "1"
+    problems = []
+
+    def expect(cond, what):
+        if cond:
+            return True
+        if strict:
+            raise AssertionError(what)
+        problems.append(what)
+        print("bench.py multi_gpu_check: " + what, file=sys.stderr, flush=True)
+        return False
+
+    expect(dist.get_world_size() == world == args.gpus, "world size %d != --gpus %d" % (dist.get_world_size(), args.gpus))
     props = torch.cuda.get_device_properties(dev)
     ident = "%s/%s" % (getattr(props, "pci_bus_id", "?"), getattr(props, "uuid", local_rank))
     idents = [None] * world
     dist.all_gather_object(idents, (rank, local_rank, ident))
     distinct = len({i[2] for i in idents}) == world
     if not one_device:
-        assert distinct, "ranks share a device: %r" % (idents,)
+        expect(distinct, "ranks share a device: %r" % (idents,))
     own_ok = bool(np.array_equal(full_np[lo:hi].view(np.uint32), local_np.view(np.uint32)))
-    assert own_ok, "rank %d: its block of the gathered queue differs from what it computed" % rank
+    expect(own_ok, "rank %d: its block of the gathered queue differs from what it computed" % rank)
     checked, ok = 0, True
     if rank == 0:
         per = -(-n_total // world)
@@ -454,13 +469,14 @@ def multi_gpu_check(args, dist, torch, dev, rank, world, local_rank, one_device,
             icgn.compute(q)
             torch.cuda.synchronize()
             same = bool(np.array_equal(q.cpu().numpy().view(np.uint32), full_np[idx].view(np.uint32)))
-            assert same, "records gathered from rank %d differ from rank 0's own solution of the same POIs" % r
+            expect(same, "records gathered from rank %d differ from rank 0's own solution of the same POIs" % r)
             ok = ok and same
             checked += len(idx)
     flag = torch.tensor([1 if (ok and own_ok) else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    assert int(flag.item()) == 1
-    return {"world_size": dist.get_world_size(), "backend": backend, "devices": [i[2] for i in idents],
+    all_ok = int(flag.item()) == 1 and not problems
+    expect(int(flag.item()) == 1 or bool(problems), "another rank reports a failed check")
+    return {"ok": all_ok, "problems": problems, "world_size": dist.get_world_size(), "backend": backend, "devices": [i[2] for i in idents],
             "devices_distinct": distinct, "gathered_equals_local_bits": own_ok,
             "resolved_sample_of_other_ranks": checked, "resolved_sample_bit_identical": ok,
             "ms_per_step_gather_not_overlapped": serial_ms}

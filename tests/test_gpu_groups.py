@@ -262,7 +262,7 @@ def test_bench_nccl_backend_at_world_size_one():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, OC_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, OC_BENCH_FORCE_DIST="1", OC_BENCH_STRICT="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
            "--size", "1024", "--pois", "64", "--no-cpu-baseline"]
@@ -273,6 +273,7 @@ def test_bench_nccl_backend_at_world_size_one():
     assert rec["n_gpus"] == 1 and rec["config"]["collective"].startswith("RCCL")
     assert rec["config"]["all_gather_alone_ms"] is not None and rec["config"]["all_gather_alone_ms"] > 0
     assert rec["multi_gpu_check"]["backend"] == "nccl" and rec["multi_gpu_check"]["gathered_equals_local_bits"]
+    assert rec["multi_gpu_check"]["ok"] and rec["multi_gpu_check"]["problems"] == []
     assert rec["config"]["converged_pois"] >= 0.99 * rec["config"]["total_pois"]
 
 
