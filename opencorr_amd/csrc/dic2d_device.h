@@ -264,8 +264,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 __device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
+// cache-policy bits of the table gathers (experiments: tools/ab_icgn2d.sh -DOC_LUT_AUX=<bits>; gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef OC_LUT_AUX
+#define OC_LUT_AUX 0
+#endif
 __device__ __forceinline__ float4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, OC_LUT_AUX));
 }
 
 // The bicubic coefficient table is stored PLANAR: plane k (the power of dy, k = 0..3) holds for every pixel the
