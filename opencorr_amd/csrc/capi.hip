@@ -142,7 +142,8 @@ struct oc_hip_engine {
     std::shared_ptr<ImagePair> img;
     DevBuf gx, gy, gz, coef;  // coef: 2D LUT (16 floats / px) or 3D coefficient volume
     DevBuf coef_gx, coef_gy;  // NR2D1: LUTs of the target gradients
-    DevBuf tmp;               // scratch for layout conversion / 3D prefilter passes
+    DevBuf tmp;               // scratch for layout conversion / the warped subvolumes of ICGN3D1
+    DevBuf prefilter_tmp;     // second volume of the 3D B-spline prefilter (x pass -> here -> y pass -> coef -> z pass)
     bool ref_ready = false, tar_ready = false;
     DevBuf poi_stage, off_stage;
     DevBuf cursors;  // small device scratch (batch maxima)
@@ -1084,7 +1085,7 @@ static int rehome(oc_hip_engine* e, int device) {
     e->fft.work_fwd.release();
     e->fft.work_inv.release();
     for (DevBuf* b : {&e->gx, &e->gy, &e->gz, &e->coef, &e->coef_gx, &e->coef_gy, &e->tmp, &e->poi_stage, &e->off_stage, &e->cursors,
-                      &e->perm, &e->tiles, &e->perm_slots, &e->split_scratch, &e->split_tmp, &e->st_box, &e->st_counts, &e->st_start, &e->st_cursor, &e->st_slots,
+                      &e->perm, &e->tiles, &e->perm_slots, &e->split_scratch, &e->split_tmp, &e->prefilter_tmp, &e->st_box, &e->st_counts, &e->st_start, &e->st_cursor, &e->st_slots,
                       &e->st_order, &e->st_recs, &e->st_fallback, &e->win, &e->freq, &e->norms, &e->flags, &e->group_mirror,
                       &e->group_off_mirror})
         b->release();
@@ -1361,12 +1362,12 @@ int oc_hip_prepare_tar(oc_hip_engine* e) {
         }
     } else {
         OC_TRY(e->coef.reserve(im.count() * sizeof(float)));
-        // the y pass needs a second volume; it is dead once prepare returns, so it lives in a local buffer
-        DevBuf pass;
-        OC_TRY(pass.reserve(im.count() * sizeof(float)));
+        // the y pass needs a second volume.  It stays with the engine (grow-only, like every other buffer): allocating and
+        // freeing 537 MB around every prepare() of a 512^3 volume cost ~1 ms of hipMalloc / hipFree plus a stream drain --
+        // as much as the three filter passes themselves -- and a DVC run prepares once per volume pair of its sequence
+        OC_TRY(e->prefilter_tmp.reserve(im.count() * sizeof(float)));
         OC_HIP_TRY(ochip::launch_bspline3d_prefilter(im.tar_ptr(), im.dz, im.dy, im.dx, e->coef.as<float>(),
-                                                     pass.as<float>(), e->stream));
-        OC_HIP_TRY(hipStreamSynchronize(e->stream));  // before `pass` is freed
+                                                     e->prefilter_tmp.as<float>(), e->stream));
     }
     e->tar_ready = true;
     OC_TRY(mark_tail(e));
