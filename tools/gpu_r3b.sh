@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-3 session B: full GPU suite (chain, snapshot sharing), the reference's example timing, bench
+# round-3 check session: full GPU suite, bench line, the timing table of the reference's unmodified example main
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r3b
 mkdir -p $OUT
