@@ -156,7 +156,7 @@ struct oc_hip_engine {
     ochip::StrainGrid st_grid{};
     DevBuf st_box, st_counts, st_start, st_cursor, st_slots, st_order, st_recs, st_fallback;
     float lm_lambda = 100.f, lm_alpha = 0.1f, lm_beta = 10.f;  // DampingParameter defaults, src/oc_iclm.h:33-38
-    int icgn2d_tile_px = 64;   // 0 = visit the queue in its own order
+    int icgn2d_tile_px = 128;  // 0 = visit the queue in its own order (64 until round 3; 128 suits the lockstep sweeps: 3.29 vs 3.34 ms)
     // FFTCC working set
     FftPlans fft;
     DevBuf win, freq, norms, flags;

@@ -36,6 +36,20 @@
 #ifndef OC_ABLATE2D
 #define OC_ABLATE2D 0
 #endif
+// Lockstep sweeps (round 3).  The eight waves of a cooperative workgroup solve eight neighbouring POIs of a queue row; their
+// subsets overlap in 25 of 33 columns, so in a given pass they fetch largely the SAME table lines -- if they get there at
+// about the same time, the second to eighth wave find them in the CU's L1 instead of going to the L2 (which the kernel
+// keeps 62 % busy).  Left alone the waves drift apart within an iteration; a barrier every OC_SWEEP_BARRIER groups of passes
+// of the interpolation sweep re-aligns them.  Pure scheduling: no data crosses it, results are bit-identical.  Measured on
+// config B (tools/ab_icgn2d.sh, profiles/r3h_*): K = 0: 3.43 ms, 1: 3.32, 2: 3.29, 3: 3.30, 4: 3.31, 8: 3.35; a barrier before
+// the numerator pass as well: +1 %; with two instead of three workgroups per CU (variant 4) the barriers cost 6 %.
+// ICGN2D2 on config C (r = 20, groups of 3 passes, two workgroups per CU): K = 0: 3.61 ms, 1: 3.61, 2: 3.54, 3: 3.51.
+// All live waves of a workgroup execute the same barrier sequence (one subset size per launch in the table variants; waves
+// that have finished their POI have terminated and are not waited for).
+// OC_SWEEP_BARRIER: -1 = the defaults (2 for the 6-DoF, 3 for the 12-DoF kernels), 0 = off, K > 0 = every K groups.
+#ifndef OC_SWEEP_BARRIER
+#define OC_SWEEP_BARRIER -1
+#endif
 
 namespace ochip {
 
@@ -98,6 +112,12 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     // ICGN2D1 in 8-wave workgroups: the eight 6 x 6 Hessians are inverted by ONE wave (coop_inverse6_x8); two more
     // barriers, which every wave passes exactly once -- also the ones that abandon their POI early (leave())
     constexpr bool COOP = MODE == 4 && DOF == 6 && LM == 0 && WPB == 8;
+    // lockstep sweeps (see OC_SWEEP_BARRIER above): the 8-wave table variants -- one subset size per launch, so every live
+    // wave of a workgroup runs the same number of pass groups
+    // (the 6-DoF kernel with only two workgroups per CU, variant 4, loses 6 % with them: it keeps them off by default)
+    constexpr int SWEEP_SYNC = (MODE == 4 && LM == 0 && WPB == 8)
+                                   ? (OC_SWEEP_BARRIER < 0 ? (DOF == 6 ? (OCC >= 6 ? 2 : 0) : 3) : OC_SWEEP_BARRIER)
+                                   : 0;
     // passes whose global loads are issued together in the load-then-use loops outside the interpolation sweep
     // (reference subset, Hessian sweep, numerator pass): one dependent round trip per batch instead of one per pass
     constexpr int kSetupBatch = 6;
@@ -538,6 +558,9 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             int t0 = 0;
 #pragma nounroll
             for (int q = 0; q < full_groups; q++, t0 += G) {
+                if constexpr (SWEEP_SYNC > 0) {
+                    if (q % SWEEP_SYNC == 0) __builtin_amdgcn_s_barrier();
+                }
 #if OC_ABLATE2D & 4
                 LutFetch(&f)[G] = f_stale;
 #else

@@ -29,6 +29,8 @@ else:
 xs, ys = synth.poi_grid_2d(side, side, ns, ns, r + 8)
 f = oc.FFTCC2D(r, r); f.set_images(ref, tar)
 g = eng(r, r, 0.001, 10.0); g.share_images(f); g.prepare()
+if os.environ.get("ICGN2D_VARIANT"):
+    g.set_tuning("icgn2d_variant", int(os.environ["ICGN2D_VARIANT"]))
 pristine = torch.from_numpy(oc.make_pois2d(xs, ys)).to(dev)
 f.compute(pristine); torch.cuda.synchronize()
 q = pristine.clone()

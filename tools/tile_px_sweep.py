@@ -15,7 +15,7 @@ g = oc.ICGN2D1(r, r, 0.001, 10.0); g.set_stream(stream); g.share_images(f); g.pr
 guess = torch.from_numpy(oc.make_pois2d(xs, ys)).to(dev); f.compute(guess); q = guess.clone()
 out = {}
 for rd in range(3):
-    for t in (32, 48, 64, 96, 128, 192):
+    for t in (48, 64, 80, 96, 128, 192, 256):
         g.set_tuning("icgn2d_tile_px", t)
         tot = 0.0
         for _ in range(10):

@@ -8,6 +8,9 @@
 //   3 coop+dma  : as 1 with global_load_lds_dwordx4 into LDS, then ds_read_b128 x4
 //   4 planar    : the table as four planes [k][H][W] of float4; lane s loads 16 B from each plane (lane stride
 //                 16 B: a wave's load covers two subset rows of ~530 contiguous bytes)          [round-2 kernel]
+//   5 planar, quad-aligned rows (round 3): every subset row takes 36 lane slots (9 quads, 3 idle lanes) so that the four
+//                 lanes of a quad read ONE 64-byte-aligned piece -- 19 passes instead of 18.  With XOFF = 1..3 added to the
+//                 subset origin the same variant (and variant 4) shows what an arbitrary origin costs.
 // Build: hipcc --offload-arch=gfx950 -O3 gather_ubench.hip -o gather_ubench
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -25,24 +28,33 @@ __device__ __forceinline__ unsigned entry_of(int s, int x0, int y0) {
 }
 
 template <int VARIANT, int WPB>
-__global__ __launch_bounds__(64 * WPB) void k(const char* __restrict__ lut, float* __restrict__ out, int npoi, int grid_side) {
+__global__ __launch_bounds__(64 * WPB) void k(const char* __restrict__ lut, float* __restrict__ out, int npoi, int grid_side, int xoff) {
     __shared__ float4 stage[WPB][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = (npoi / WPB + 7) / 8;
     const int grp = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     const int poi = grp * WPB + wave;
     if (poi >= npoi) return;
-    const int x0 = 8 + (poi % grid_side) * 8, y0 = 8 + (poi / grid_side) * 8;
+    const int x0 = 8 + (poi % grid_side) * 8 + xoff, y0 = 8 + (poi / grid_side) * 8;
     float acc = 0.f;
     const int swz = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
     for (int it = 0; it < ITERS; it++) {
-        for (int t = 0; t < NT; t++) {
-            const unsigned e = entry_of(t * 64 + lane, x0, y0 + it);
+        constexpr int NTV = VARIANT == 5 ? (SUB * 36 + 63) / 64 : NT;
+        for (int t = 0; t < NTV; t++) {
+            unsigned e;
+            if (VARIANT == 5) {
+                // slot q = (row, position): the row's first pixel sits at position (x0 & 3), so quads are 64-byte aligned
+                const int q = t * 64 + lane, r = min(q / 36, SUB - 1), p = q - (q / 36) * 36;
+                const int c = min(max(p - (x0 & 3), 0), SUB - 1);
+                e = ((unsigned)(y0 + it + r) * W + (unsigned)(x0 + c)) << 6;
+            } else {
+                e = entry_of(t * 64 + lane, x0, y0 + it);
+            }
             float4 c0, c1, c2, c3;
             if (VARIANT == 0) {
                 const float4* p = reinterpret_cast<const float4*>(lut + e);
                 c0 = p[0]; c1 = p[1]; c2 = p[2]; c3 = p[3];
-            } else if (VARIANT == 4) {
+            } else if (VARIANT == 4 || VARIANT == 5) {
                 constexpr size_t plane = (size_t)W * H * 16;
                 const char* p = lut + (e >> 2);
                 c0 = *reinterpret_cast<const float4*>(p);
@@ -95,17 +107,17 @@ __global__ __launch_bounds__(64 * WPB) void k(const char* __restrict__ lut, floa
 }
 
 template <int VARIANT>
-double run(const char* lut, float* out, int npoi, int side, std::vector<float>& host) {
+double run(const char* lut, float* out, int npoi, int side, std::vector<float>& host, int xoff = 0) {
     constexpr int WPB = 4;
     const int groups = npoi / WPB;
     const int grid = ((groups + 7) / 8) * 8;
     hipEvent_t a, b;
     CHECK(hipEventCreate(&a));
     CHECK(hipEventCreate(&b));
-    hipLaunchKernelGGL((k<VARIANT, WPB>), dim3(grid), dim3(64 * WPB), 0, 0, lut, out, npoi, side);
+    hipLaunchKernelGGL((k<VARIANT, WPB>), dim3(grid), dim3(64 * WPB), 0, 0, lut, out, npoi, side, xoff);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(a));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<VARIANT, WPB>), dim3(grid), dim3(64 * WPB), 0, 0, lut, out, npoi, side);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<VARIANT, WPB>), dim3(grid), dim3(64 * WPB), 0, 0, lut, out, npoi, side, xoff);
     CHECK(hipEventRecord(b));
     CHECK(hipDeviceSynchronize());
     float ms = 0;
@@ -140,5 +152,10 @@ int main() {
     printf("variant 3 coop+dma : %.3f ms  %.2f TB/s  mismatches %zu\n", ms, bytes / ms / 1e9, bad);
     ms = run<4>(lut, out, npoi, side, h);
     printf("variant 4 planar   : %.3f ms  %.2f TB/s (sums differ by design: other bytes)\n", ms, bytes / ms / 1e9);
+    for (int xoff = 0; xoff < 4; xoff++) {
+        const double m4 = run<4>(lut, out, npoi, side, h, xoff), m5 = run<5>(lut, out, npoi, side, h, xoff);
+        printf("origin + %d: planar %.3f ms (%.2f TB/s)   planar, quad-aligned rows (19 passes) %.3f ms (%.2f TB/s of the same samples)\n", xoff, m4,
+               bytes / m4 / 1e9, m5, bytes / m5 / 1e9);
+    }
     return 0;
 }
