@@ -79,7 +79,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # 157.3 Tflop/s counts an FMA as two operations; FMA contraction is excluded by the parity contract)
 VALU_PEAK_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 L2_PEAK_GBS = 34500.0       # aggregate L2 bandwidth, MI355X_MICROARCH.md ("4 MiB per XCD ... ~34.5 TB/s")
-GATHER_UBENCH_GBS = 20350.0  # compute-free gather of the kernel's own access pattern, profiles/r02a_gather_ubench.txt
+# compute-free gather of the kernel's own access pattern in 8-wave workgroups that re-align every two passes (what the
+# kernel does since round 3): profiles/r3j_gather_ubench_lockstep.txt; free-running waves reach 20 350 GB/s (r02a)
+GATHER_UBENCH_GBS = 29780.0
+GATHER_UBENCH_FREE_GBS = 20350.0
+# what the CUs' vector L1 ports can deliver at 64 bytes per clock and CU (every byte of the gather passes through them)
+L1_PORT_PEAK_GBS = 256 * 64 * 2.4
 # HBM bytes per ICGN2D1 launch of THIS workload from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in their
 # own runs, corrected as the guide prescribes); written by tools/pmc_traffic.py, see tools/gpu_round.sh
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "icgn2d1_traffic_configB.json")
@@ -160,9 +165,14 @@ def roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof):
                         "of the algorithmic bytes, so bytes / time exceeds the HBM peak ({:.1f}x) and says nothing"
                         .format(alg_rate / HBM_PEAK_GBS)),
         "gather_ubench": {"value": GATHER_UBENCH_GBS, "unit": "GB/s", "frac": alg_rate / GATHER_UBENCH_GBS,
-                          "source": "profiles/r02a_gather_ubench.txt",
-                          "note": "the same gather pattern with no arithmetic at all (tools/ubench/gather_ubench.hip, "
-                                  "planar table): the kernel's gather rate as a fraction of that ceiling"},
+                          "source": "profiles/r3j_gather_ubench_lockstep.txt",
+                          "free_running_value": GATHER_UBENCH_FREE_GBS,
+                          "note": "the same gather pattern with no arithmetic at all (tools/ubench/gather_ubench.hip, planar table, "
+                                  "8-wave workgroups re-aligned every two passes like the kernel's): the kernel's gather rate as a "
+                                  "fraction of that ceiling; free-running waves (the round-2 ceiling) reach free_running_value"},
+        "l1_port": {"peak": L1_PORT_PEAK_GBS, "unit": "GB/s", "frac": alg_rate / L1_PORT_PEAK_GBS,
+                    "note": "algorithmic bytes over 64 B per clock and CU of vector-L1 bandwidth (256 CUs, 2.4 GHz): since the lockstep "
+                            "sweeps the L2s see 0.68 x the algorithmic bytes (traffic_l2) -- the rest are L1 hits"},
         "valu": {"achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / VALU_PEAK_TFLOPS,
                  "algorithmic_flops_per_launch": alg_flops,
                  "note": "the reference's own fp32 operations over the chip's rate for separately rounded operations"},

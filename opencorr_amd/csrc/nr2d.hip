@@ -38,6 +38,15 @@ constexpr int kNrWaves = 4;  // POIs (waves) per workgroup
 #define OC_NR_BATCH 1
 #endif
 constexpr int kNrBatch = OC_NR_BATCH;
+// Lockstep passes (round 3, as OC_SWEEP_BARRIER in icgn2d.hip): a workgroup barrier every OC_NR_LOCKSTEP passes would keep the
+// four waves of a workgroup -- neighbouring POIs, largely the same lines of the three tables -- close in time.  It does not
+// pay here: with two 4-wave workgroups per CU (2 waves per SIMD) a waiting wave leaves its SIMD idle.  Config B, NR2D1
+// launches (tools/ab_icgn2d.sh with AB_SRC=nr2d, profiles/r3j_nr2d1_ab_lockstep.txt): off 9.04 ms, every pass 9.55,
+// every 2 passes 9.53, every 4 passes 9.32; bit-identical.  Off.
+#ifndef OC_NR_LOCKSTEP
+#define OC_NR_LOCKSTEP 0
+#endif
+constexpr int kNrLockstep = OC_NR_LOCKSTEP;
 
 __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, float* __restrict__ pois, Nr2dLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
             };
             // the gathers of kNrBatch passes (12 x 16 bytes per lane and pass) are in flight before the first is used
             auto fetch = [&](int t, bool valid) {
+                if (kNrLockstep > 0 && t % kNrLockstep == 0) __builtin_amdgcn_s_barrier();
                 NrFetch q;
                 const float xl = (float)(w.c - rx), yl = (float)(w.r - ry);
                 // Deformation2D1::warp, src/oc_deformation.cpp:94-105

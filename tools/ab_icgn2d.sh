@@ -9,7 +9,8 @@ mkdir -p $OUT
 cd $ROOT
 LIB=opencorr_amd/lib
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize"
-OBJS=$(ls $LIB/*.o | grep -v icgn2d)
+SRC=${AB_SRC:-icgn2d}   # the source file the variants rebuild (icgn2d | nr2d)
+OBJS=$(ls $LIB/*.o | grep -v "/$SRC\.o")
 cat > /tmp/time2d_ab.py <<'PY'
 import sys, time, json, os, numpy as np, torch
 sys.path.insert(0, ".")
@@ -17,7 +18,7 @@ import opencorr_amd as oc
 from opencorr_amd import synth
 dev = torch.device("cuda", 0)
 side, r, ns = int(os.environ.get('SIDE', 4096)), int(os.environ.get('RAD', 16)), int(os.environ.get('NS', 500))
-eng = {1: oc.ICGN2D1, 2: oc.ICGN2D2}[int(os.environ.get('ORDER', 1))]
+eng = {1: oc.ICGN2D1, 2: oc.ICGN2D2, 3: oc.NR2D1}[int(os.environ.get('ORDER', 1))]  # ORDER=3 with AB_SRC=nr2d: NR2D1
 # the GPU renderer of the synthetic pair adds its speckles with float atomics: the images differ in a few pixels from process
 # to process (and with them ~40 of 250 000 POIs in the last bits).  Variants are compared on ONE pair, rendered by the first.
 pair = "/tmp/ab_pair_%s.pt" % os.environ.get("AB_PAIR_TAG", "x")
@@ -60,8 +61,8 @@ for rep in 1 2; do
 for v in "${VS[@]}"; do
   name=${v%%:*}; defs=${v#*:}
   if [ ! -f /tmp/libab2_$name.so ]; then
-    hipcc --offload-arch=gfx950 -c opencorr_amd/csrc/icgn2d.hip -o /tmp/icgn2d_$name.o $FLAGS $defs || exit 1
-    hipcc --offload-arch=gfx950 -shared -o /tmp/libab2_$name.so $OBJS /tmp/icgn2d_$name.o -L/opt/rocm/lib -lrocfft -ldl -lpthread || exit 1
+    hipcc --offload-arch=gfx950 -c opencorr_amd/csrc/$SRC.hip -o /tmp/${SRC}_$name.o $FLAGS $defs || exit 1
+    hipcc --offload-arch=gfx950 -shared -o /tmp/libab2_$name.so $OBJS /tmp/${SRC}_$name.o -L/opt/rocm/lib -lrocfft -ldl -lpthread || exit 1
   fi
   [ -z "$first" ] && first=/tmp/res2_$name.npy
   echo -n "$name [$defs]: " | tee -a $OUT/ab.txt

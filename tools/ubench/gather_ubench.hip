@@ -27,7 +27,7 @@ __device__ __forceinline__ unsigned entry_of(int s, int x0, int y0) {
     return ((unsigned)(y0 + r) * W + (unsigned)(x0 + c)) << 6;  // byte offset
 }
 
-template <int VARIANT, int WPB>
+template <int VARIANT, int WPB, int LOCK = 0>
 __global__ __launch_bounds__(64 * WPB) void k(const char* __restrict__ lut, float* __restrict__ out, int npoi, int grid_side, int xoff) {
     __shared__ float4 stage[WPB][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -41,6 +41,9 @@ __global__ __launch_bounds__(64 * WPB) void k(const char* __restrict__ lut, floa
     for (int it = 0; it < ITERS; it++) {
         constexpr int NTV = VARIANT == 5 ? (SUB * 36 + 63) / 64 : NT;
         for (int t = 0; t < NTV; t++) {
+            // LOCK > 0 (round 3): the workgroup's waves re-align every LOCK passes, so that neighbouring POIs ask for the
+            // same table lines at about the same time (what OC_SWEEP_BARRIER does in icgn2d.hip)
+            if (LOCK > 0 && t % LOCK == 0) __builtin_amdgcn_s_barrier();
             unsigned e;
             if (VARIANT == 5) {
                 // slot q = (row, position): the row's first pixel sits at position (x0 & 3), so quads are 64-byte aligned
@@ -106,18 +109,17 @@ __global__ __launch_bounds__(64 * WPB) void k(const char* __restrict__ lut, floa
     out[(size_t)poi * 64 + lane] = acc;
 }
 
-template <int VARIANT>
+template <int VARIANT, int WPB = 4, int LOCK = 0>
 double run(const char* lut, float* out, int npoi, int side, std::vector<float>& host, int xoff = 0) {
-    constexpr int WPB = 4;
     const int groups = npoi / WPB;
     const int grid = ((groups + 7) / 8) * 8;
     hipEvent_t a, b;
     CHECK(hipEventCreate(&a));
     CHECK(hipEventCreate(&b));
-    hipLaunchKernelGGL((k<VARIANT, WPB>), dim3(grid), dim3(64 * WPB), 0, 0, lut, out, npoi, side, xoff);
+    hipLaunchKernelGGL((k<VARIANT, WPB, LOCK>), dim3(grid), dim3(64 * WPB), 0, 0, lut, out, npoi, side, xoff);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(a));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<VARIANT, WPB>), dim3(grid), dim3(64 * WPB), 0, 0, lut, out, npoi, side, xoff);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<VARIANT, WPB, LOCK>), dim3(grid), dim3(64 * WPB), 0, 0, lut, out, npoi, side, xoff);
     CHECK(hipEventRecord(b));
     CHECK(hipDeviceSynchronize());
     float ms = 0;
@@ -156,6 +158,17 @@ int main() {
         const double m4 = run<4>(lut, out, npoi, side, h, xoff), m5 = run<5>(lut, out, npoi, side, h, xoff);
         printf("origin + %d: planar %.3f ms (%.2f TB/s)   planar, quad-aligned rows (19 passes) %.3f ms (%.2f TB/s of the same samples)\n", xoff, m4,
                bytes / m4 / 1e9, m5, bytes / m5 / 1e9);
+    }
+    // round 3: 8-wave workgroups (the shape of the ICGN2D1 kernel), free-running against lockstep
+    {
+        const double a0 = run<4, 8, 0>(lut, out, npoi, side, h), a2 = run<4, 8, 2>(lut, out, npoi, side, h), a4 = run<4, 8, 4>(lut, out, npoi, side, h),
+                     a1 = run<4, 8, 1>(lut, out, npoi, side, h);
+        printf("planar, 8 waves per workgroup: free %.3f ms (%.2f TB/s)  barrier every pass %.3f  every 2 passes %.3f (%.2f TB/s)  every 4 passes %.3f\n", a0,
+               bytes / a0 / 1e9, a1, a2, bytes / a2 / 1e9, a4);
+        const double b0 = run<5, 8, 0>(lut, out, npoi, side, h, 1), b2 = run<5, 8, 2>(lut, out, npoi, side, h, 1), b4 = run<5, 8, 4>(lut, out, npoi, side, h, 1);
+        printf("quad-aligned rows, origin + 1, 8 waves: free %.3f ms  every 2 passes %.3f (%.2f TB/s)  every 4 passes %.3f\n", b0, b2, bytes / b2 / 1e9, b4);
+        const double c0 = run<4, 8, 0>(lut, out, npoi, side, h, 1), c2 = run<4, 8, 2>(lut, out, npoi, side, h, 1);
+        printf("planar, origin + 1, 8 waves: free %.3f ms  every 2 passes %.3f (%.2f TB/s)\n", c0, c2, bytes / c2 / 1e9);
     }
     return 0;
 }
