@@ -1436,12 +1436,16 @@ int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t coun
     if (nchunk > 1) {
         if (!e->copy_stream) OC_HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
         if (!e->copy_in_stream) OC_HIP_TRY(hipStreamCreateWithFlags(&e->copy_in_stream, hipStreamNonBlocking));
+        // (two loops: a failed creation must not leave the lists at different lengths for the next call)
         while (e->chunk_done.size() < nchunk) {
-            hipEvent_t ev = nullptr, ev2 = nullptr;
+            hipEvent_t ev = nullptr;
             OC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             e->chunk_done.push_back(ev);
-            OC_HIP_TRY(hipEventCreateWithFlags(&ev2, hipEventDisableTiming));
-            e->chunk_in.push_back(ev2);
+        }
+        while (e->chunk_in.size() < nchunk) {
+            hipEvent_t ev = nullptr;
+            OC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e->chunk_in.push_back(ev);
         }
     }
     char* stage = e->poi_stage.as<char>();
@@ -1485,7 +1489,7 @@ int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t coun
             {
                 std::unique_lock<std::mutex> hand(e->feed_mu);
                 e->feed_cv.wait(hand, [&] { return e->chunks_fed > c; });
-                if (e->chunks_fed == (size_t)-1) return;  // the feeder failed
+                if (e->chunks_fed == (size_t)-1) break;  // the feeder failed: drain what was issued and stop
             }
             out_err = hipStreamWaitEvent(e->copy_stream, e->chunk_done[c], 0);
             if (out_err == hipSuccess)
