@@ -131,6 +131,9 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dPa
             tn += v[k].y * v[k].y;
         }
         block_sum2(rn, tn, red, lane, wave);
+        // needed only at the very end: without this the compiler keeps the 32 partial sums it has just read from LDS
+        // alive (in scratch) across the whole transform and adds them up there
+        asm volatile("" : "+v"(rn), "+v"(tn));
     }
 
     const int zz = a & 15, half = a >> 4;

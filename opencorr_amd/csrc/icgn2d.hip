@@ -50,6 +50,11 @@
 #ifndef OC_SWEEP_BARRIER
 #define OC_SWEEP_BARRIER -1
 #endif
+// OC_SWEEP_PRIO (experiment): 1 = a wave issues the address arithmetic and the gathers of a pass group at raised priority
+// (s_setprio) and evaluates the polynomials at normal priority, 2 = the other way round
+#ifndef OC_SWEEP_PRIO
+#define OC_SWEEP_PRIO 0
+#endif
 
 namespace ochip {
 
@@ -567,9 +572,22 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 LutFetch f[G];
 #endif
                 bool valid[G];
+#if OC_SWEEP_PRIO == 1
+                __builtin_amdgcn_s_setprio(2);
+#elif OC_SWEEP_PRIO == 2
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 issue(f, valid, t0, std::false_type{});
+#if OC_SWEEP_PRIO == 1
+                __builtin_amdgcn_s_setprio(0);
+#elif OC_SWEEP_PRIO == 2
+                __builtin_amdgcn_s_setprio(2);
+#endif
                 consume(f, valid, t0, std::false_type{});
             }
+#if OC_SWEEP_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma nounroll
             for (; t0 < NT; t0 += G) {
 #if OC_ABLATE2D & 4
