@@ -29,7 +29,23 @@ struct Nr2dLaunch {
     unsigned long long count;  // POIs
 };
 
-constexpr int kNrWaves = 4;  // POIs (waves) per workgroup
+#ifndef OC_NR_WAVES
+#define OC_NR_WAVES 4
+#endif
+constexpr int kNrWaves = OC_NR_WAVES;  // POIs (waves) per workgroup
+// Per-sample LDS arrays of a wave: 4 = zero-mean reference, warped target, its two gradients; 3 = the reference value is
+// re-read from the image in the numerator pass and re-centred with the same subtraction (same bits), which lets three
+// instead of two workgroups share a CU at r = 16.  More resident waves do NOT help this kernel (config B, NR2D1 launches,
+// profiles/r3k_nr2d1_ab_arrays_waves.txt): 4 arrays, 2 x 4 waves per CU 9.01 ms; 3 arrays, 3 x 4 waves 9.60; 3 arrays, 2 x 6
+// waves 11.4; 4 x 2 waves 9.13; 2 x 3 waves 10.05 -- the three tables (3.2 GB) already overrun the caches with eight POIs in
+// flight per CU.  Default 4.
+#ifndef OC_NR_ARRAYS
+#define OC_NR_ARRAYS 4
+#endif
+constexpr int kNrArrays = OC_NR_ARRAYS;
+#ifndef OC_NR_MINBLOCKS
+#define OC_NR_MINBLOCKS (OC_NR_ARRAYS == 3 ? 3 : 2)
+#endif
 
 // passes whose 12 gathers per lane (192 bytes) are issued together.  Measured on config B (FFTCC2D + NR2D1): 9.7 ms with 1,
 // 2 or 3 passes per batch at 109 / 174 / 228 VGPRs -- the engine moves three table entries per sample and iteration and
@@ -48,7 +64,7 @@ constexpr int kNrBatch = OC_NR_BATCH;
 #endif
 constexpr int kNrLockstep = OC_NR_LOCKSTEP;
 
-__global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, float* __restrict__ pois, Nr2dLaunch L) {
+__global__ __launch_bounds__(64 * kNrWaves, OC_NR_MINBLOCKS) void nr2d1_kernel(Nr2dParams P, float* __restrict__ pois, Nr2dLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NT = L.nt;
     const int lane = threadIdx.x & (kWave - 1);
@@ -59,8 +75,9 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
     if (slot >= L.count) return;
     // the k-th wave of the launch solves POI perm[k] (the locality schedule of icgn2d.hip) or simply POI k
     const unsigned long long idx = P.perm ? (unsigned long long)__builtin_amdgcn_readfirstlane((int)P.perm[slot]) : slot;
-    float* __restrict__ l_rs = lds + (size_t)wave * 4 * NT * kWave + lane;
-    float* __restrict__ l_ts = l_rs + NT * kWave;
+    // (with three arrays the reference values pass through the target array while their mean and norm are formed)
+    float* __restrict__ l_rs = lds + (size_t)wave * kNrArrays * NT * kWave + lane;
+    float* __restrict__ l_ts = kNrArrays == 4 ? l_rs + NT * kWave : l_rs;
     float* __restrict__ l_gx = l_ts + NT * kWave;
     float* __restrict__ l_gy = l_gx + NT * kWave;
 
@@ -102,10 +119,9 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
     auto soff = [&](const SampleWalk& w) { return __umul24((unsigned)w.r, w4) + ((unsigned)w.c << 2); };
 
     // ---- reference subset, zero-mean + norm (src/oc_nr.cpp:176-179, src/oc_subset.cpp:39-53)
-    float ref_norm;
+    float ref_norm, ref_mean;
+    const unsigned roff = (unsigned)__builtin_amdgcn_readfirstlane(((int)(py - ry) * width + (int)(px - rx)) * 4);
     {
-        const int x0 = (int)(px - rx), y0 = (int)(py - ry);
-        const unsigned roff = (unsigned)__builtin_amdgcn_readfirstlane((y0 * width + x0) * 4);
         float acc = 0.f;
         SampleWalk w(lane, r0, c0, W, q64, r64);
 #pragma unroll 3
@@ -121,6 +137,7 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
             l_rs[NF * kWave] = v;
         }
         const float mean = wave_allreduce_sum(acc) / fN;
+        ref_mean = mean;
         acc = 0.f;
 #pragma unroll 3
         for (int t = 0; t < NF; t++) {
@@ -241,7 +258,10 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
             auto sample = [&](int t, bool valid) {
                 const float g_x = l_gx[t * kWave], g_y = l_gy[t * kWave];
                 const float tz = l_ts[t * kWave] - tmean;  // same bits as in the norm pass
-                const float e = l_rs[t * kWave] * factor - tz;
+                float rsv;
+                if constexpr (kNrArrays == 4) rsv = l_rs[t * kWave];
+                else rsv = (valid ? buf_f32(r_ref, soff(w), roff) : 0.f) - ref_mean;  // the subtraction of the set-up pass
+                const float e = rsv * factor - tz;
                 const f2 xy = mk2((float)(w.c - rx), (float)(w.r - ry));
                 const f2 A = g_x * xy, B = g_y * xy;
                 const f2 mA = nA + A * e, mB = nB + B * e;
@@ -310,14 +330,14 @@ __global__ __launch_bounds__(64 * kNrWaves, 2) void nr2d1_kernel(Nr2dParams P, f
 
 constexpr int kNrLdsBudget = 160 * 1024;
 
-int nr2d1_max_samples() { return kNrLdsBudget / (4 * kNrWaves * (int)sizeof(float) * kWave) * kWave; }
+int nr2d1_max_samples() { return kNrLdsBudget / (kNrArrays * kNrWaves * (int)sizeof(float) * kWave) * kWave; }
 
 hipError_t launch_nr2d1(const Nr2dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
     if (count == 0) return hipSuccess;
     if ((unsigned long long)p.height * p.width * 64ull > (1ull << 32)) return hipErrorInvalidValue;
     const int N = (2 * p.rx + 1) * (2 * p.ry + 1);
     const int nt = (N + 63) / 64;
-    const size_t lds = (size_t)4 * nt * kWave * sizeof(float) * kNrWaves;
+    const size_t lds = (size_t)kNrArrays * nt * kWave * sizeof(float) * kNrWaves;
     if (lds > (size_t)kNrLdsBudget) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> attr_devices{0};
     int dev = 0;
