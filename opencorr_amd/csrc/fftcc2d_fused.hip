@@ -29,7 +29,14 @@ using namespace fftdev;
 constexpr int FN = 32;               // window side (2 * radius)
 constexpr int FP = FN + 1;           // LDS row pitch in complex elements
 constexpr int FWAVE_LDS = FN * FP;   // float2 elements per wave
-constexpr int kFusedWaves = 4;       // POIs (waves) per workgroup
+// OC_FFTCC2D_X2 = 1 (the default since round 3) launches the two-POIs-per-wave kernel further down instead of this one
+#ifndef OC_FFTCC2D_X2
+#define OC_FFTCC2D_X2 1
+#endif
+#ifndef OC_FFTCC2D_WAVES
+#define OC_FFTCC2D_WAVES 4
+#endif
+constexpr int kFusedWaves = OC_FFTCC2D_WAVES;  // POIs (waves) per workgroup
 
 // One length-32 transform along a line of the LDS tile.  The lane reads elements n and n+16
 // (n = 0..15) at `line + n*step`, forms its half of the first radix-2 stage (h = 0: sums ->
@@ -177,16 +184,210 @@ __global__ __launch_bounds__(64 * kFusedWaves) void fftcc2d_fused32_kernel(Fftcc
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Second mapping (round 3): TWO POIs per wave, one lane per LINE.  Lane (q, l) of half-wave q gathers column l of its POI's
+// two windows -- row k of the window is one coalesced 128-byte read of the half-wave -- so z = ref + i*tar arrives in the
+// registers already in column ownership and the first axis transform needs no LDS at all; every later pass is a whole
+// 32-point FFT in a lane's registers (fft32, shared with the 3D kernel) with ONE transposition through the LDS tile
+// between passes.  Per POI: 3 x 32 x 32 element writes and as many reads, against 5 x 32 x 32 writes and 9 x 32 x 32
+// reads of the (line, half) mapping above, whose two lanes per line both read the whole line; the radix-2 stage is done
+// once per line instead of once per half.  The price: 64 data registers per lane and two tiles per wave.
+// Means and norms are column sums followed by a half-wave butterfly (the first mapping: 16 strided samples per lane,
+// wave butterfly): the float ZNCC moves in its last bits, the integer peak does not.
+// Config B, 250 000 POIs, FFTCC2D launches (tools/ab_icgn2d.sh with TIME_FFTCC=1, profiles/r3l_fftcc2d_ab_two_pois_per_wave.txt):
+// (line, half) mapping 0.70 - 0.72 ms (16 / 19 / 32 resident waves per CU alike); this mapping with c2 tiles (9 waves per CU)
+// 0.60 ms; with the tile split into a real and an imaginary round (OC_FFTCC2D_X2_SPLIT: half the LDS per POI, 16 waves per
+// CU, 120 VGPRs) 0.54 ms.  1 140 VALU (458 of them packed) and 110 LDS wave-instructions per POI against 1 412 / 140.
+#ifndef OC_FFTCC2D_X2_WAVES
+#define OC_FFTCC2D_X2_WAVES 1
+#endif
+#ifndef OC_FFTCC2D_X2_SPLIT
+#define OC_FFTCC2D_X2_SPLIT 1
+#endif
+#ifndef OC_FFTCC2D_X2_OCC
+#define OC_FFTCC2D_X2_OCC (OC_FFTCC2D_X2_SPLIT ? 4 : 2)   // waves per SIMD the register allocation must allow
+#endif
+constexpr int kX2Waves = OC_FFTCC2D_X2_WAVES;  // waves per workgroup, two POIs each
+
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+__global__ __launch_bounds__(64 * kX2Waves, OC_FFTCC2D_X2_OCC) void fftcc2d_fused32x2_kernel(Fftcc2dParams P, float* __restrict__ pois, int stride_f,
+                                                                         unsigned long long count, int xcd_chunk) {
+    __shared__ c2 lds[kX2Waves * 2 * FWAVE_LDS / (OC_FFTCC2D_X2_SPLIT ? 2 : 1)];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 5, l = lane & 31;
+    unsigned long long grp = blockIdx.x;
+    if (xcd_chunk > 0) grp = (unsigned long long)(blockIdx.x & 7u) * xcd_chunk + (blockIdx.x >> 3);
+    const unsigned long long idx = (grp * kX2Waves + wave) * 2 + q;
+    if (idx >= count) return;
+    c2* tile = lds + (wave * 2 + q) * (FWAVE_LDS / (OC_FFTCC2D_X2_SPLIT ? 2 : 1));
+    float* poi = pois + idx * (unsigned long long)stride_f;
+    const float px = poi[poi2d::X], py = poi[poi2d::Y];
+    const float gu = poi[poi2d::U], gv = poi[poi2d::V];
+    const int rx = FN / 2, ry = FN / 2, width = P.width, height = P.height;
+    constexpr int M = FN * FN;
+    // bounds guard: the reference returns silently and leaves the POI untouched (src/oc_fftcc.cpp:190-196)
+    if ((int)px < rx || (int)px >= width - rx || (int)py < ry || (int)py >= height - ry || (int)(px + gu) < rx ||
+        (int)(px + gu) >= width - rx || (int)(py + gv) < ry || (int)(py + gv) >= height - ry)
+        return;
+
+    // ---- window fill (src/oc_fftcc.cpp:198-231): lane l reads column l, row k = 0 .. 31
+    c2 v[FN];
+    float rn, tn;
+    {
+        const __amdgpu_buffer_rsrc_t r_ref = make_rsrc(P.ref), r_tar = make_rsrc(P.tar);
+        const float rxp = px + l - rx, txp = rxp + gu;
+#pragma unroll
+        for (int k = 0; k < FN; k++) {
+            const float ryp = py + k - ry, typ = ryp + gv;
+            const float a = buf_f32(r_ref, (__umul24((unsigned)(int)ryp, (unsigned)width) + (unsigned)(int)rxp) << 2, 0);
+            const float b = buf_f32(r_tar, (__umul24((unsigned)(int)typ, (unsigned)width) + (unsigned)(int)txp) << 2, 0);
+            v[k] = mkc(a, b);
+        }
+        float rsum = 0.f, tsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < FN; k++) {
+            rsum += v[k].x;
+            tsum += v[k].y;
+        }
+        const c2 mean = mkc(half_wave_sum(rsum) / M, half_wave_sum(tsum) / M);
+        rn = 0.f;
+        tn = 0.f;
+#pragma unroll
+        for (int k = 0; k < FN; k++) {
+            v[k] = v[k] - mean;
+            rn += v[k].x * v[k].x;
+            tn += v[k].y * v[k].y;
+        }
+        rn = half_wave_sum(rn);
+        tn = half_wave_sum(tn);
+        asm volatile("" : "+v"(rn), "+v"(tn));  // formed here, used at the very end
+    }
+    // ---- forward along the rows' index (the lane's column), straight from the registers: v[bitrev5(kr)] = Z1(kr, c = l)
+    fft32<false>(v);
+    // Transpositions through the tile happen IN PLACE in the register array: once element W(k) has been written its
+    // register is free to receive element k of the new line (all indices are compile-time constants, so "v[bitrev5(k)]" and
+    // "v[k]" are just register names).
+#if OC_FFTCC2D_X2_SPLIT
+    // the tile holds ONE float per element: real parts travel first, imaginary parts second -- half the LDS per POI,
+    // i.e. twice the waves per CU, for twice the (4-byte) LDS instructions
+    float* __restrict__ ft = reinterpret_cast<float*>(tile);
+#define OC_X2_TRANSPOSE(WRITE_IDX, READ_IDX)                                                   \
+    _Pragma("unroll") for (int k = 0; k < FN; k++) ft[WRITE_IDX] = v[bitrev5(k)].x;            \
+    __builtin_amdgcn_wave_barrier();                                                           \
+    _Pragma("unroll") for (int k = 0; k < FN; k++) v[k].x = ft[READ_IDX];                      \
+    __builtin_amdgcn_wave_barrier();                                                           \
+    _Pragma("unroll") for (int k = 0; k < FN; k++) ft[WRITE_IDX] = v[bitrev5(k)].y;            \
+    __builtin_amdgcn_wave_barrier();                                                           \
+    _Pragma("unroll") for (int k = 0; k < FN; k++) v[k].y = ft[READ_IDX];                      \
+    __builtin_amdgcn_wave_barrier();
+#else
+#define OC_X2_TRANSPOSE(WRITE_IDX, READ_IDX)                                                   \
+    _Pragma("unroll") for (int k = 0; k < FN; k++) tile[WRITE_IDX] = v[bitrev5(k)];            \
+    __builtin_amdgcn_wave_barrier();                                                           \
+    _Pragma("unroll") for (int k = 0; k < FN; k++) v[k] = tile[READ_IDX];                      \
+    __builtin_amdgcn_wave_barrier();
+#endif
+    // ---- transpose; forward along the columns' index: lane l owns row kr = l
+    OC_X2_TRANSPOSE(k * FP + l, l * FP + k)
+    fft32<false>(v);  // v[bitrev5(kc)] = Z(kr = l, kc)
+    // ---- spectra of the two real windows and their product conj(R) * T (src/oc_fftcc.cpp:236-241); Z(-k) is row
+    // (-l) read backwards.  The product replaces Z in its register; the inverse transform takes them in natural order.
+    {
+        const int mrow = ((FN - l) & (FN - 1)) * FP;
+        auto product = [](c2 z, c2 zm) {
+            const float rr = 0.5f * (z.x + zm.x), ri = 0.5f * (z.y - zm.y);
+            const float tr = 0.5f * (z.y + zm.y), ti = -0.5f * (z.x - zm.x);
+            return mkc((rr * tr) + (ri * ti), (rr * ti) - (ri * tr));
+        };
+#if OC_FFTCC2D_X2_SPLIT
+        float zmx[FN];
+#pragma unroll
+        for (int k = 0; k < FN; k++) ft[l * FP + k] = v[bitrev5(k)].x;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < FN; k++) zmx[k] = ft[mrow + ((FN - k) & (FN - 1))];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < FN; k++) ft[l * FP + k] = v[bitrev5(k)].y;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < FN; k++) v[bitrev5(k)] = product(v[bitrev5(k)], mkc(zmx[k], ft[mrow + ((FN - k) & (FN - 1))]));
+        __builtin_amdgcn_wave_barrier();
+#else
+#pragma unroll
+        for (int k = 0; k < FN; k++) tile[l * FP + k] = v[bitrev5(k)];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < FN; k++) v[bitrev5(k)] = product(v[bitrev5(k)], tile[mrow + ((FN - k) & (FN - 1))]);
+        __builtin_amdgcn_wave_barrier();
+#endif
+    }
+    // ---- inverse along kc (row kr = l), transpose, inverse along kr (column c = l); unnormalised like FFTW's c2r
+    c2 u[FN];
+#pragma unroll
+    for (int k = 0; k < FN; k++) u[k] = v[bitrev5(k)];  // natural-order input: a renaming of registers
+    fft32<true>(u);
+#pragma unroll
+    for (int k = 0; k < FN; k++) v[k] = u[k];
+    OC_X2_TRANSPOSE(l * FP + k, k * FP + l)
+#undef OC_X2_TRANSPOSE
+#pragma unroll
+    for (int k = 0; k < FN; k++) u[k] = v[k];
+    fft32<true>(u);  // u[bitrev5(r)] = correlation surface (row r, column l)
+
+    // ---- arg-max with "strict >, scanning from index 0" (src/oc_fftcc.cpp:246-255): the lane's 32 values sit at linear
+    // indices r * 32 + l, ascending in r; then the half-wave's 32 columns, the lower index winning a tie
+    float best = -2.f;
+    int bidx = 0;
+#pragma unroll
+    for (int r = 0; r < FN; r++) {
+        const float val = u[bitrev5(r)].x;
+        if (val > best) { best = val; bidx = r * FN + l; }
+    }
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const float ov = __shfl_xor(best, off, kWave);
+        const int oi = __shfl_xor(bidx, off, kWave);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (l == 0) {
+        int du = bidx % FN, dv = bidx / FN;
+        if (du > rx) du -= FN;
+        if (dv > ry) dv -= FN;
+        poi[poi2d::U] = (float)du + gu;
+        poi[poi2d::V] = (float)dv + gv;
+        poi[poi2d::U0] = gu;
+        poi[poi2d::V0] = gv;
+        poi[poi2d::ZNCC] = best / (sqrtf(rn * tn) * M);
+    }
+}
+
 bool fftcc2d_fused_supported(int rx, int ry) { return rx == FN / 2 && ry == FN / 2; }
 
 hipError_t launch_fftcc2d_fused(const Fftcc2dParams& p, float* pois, int stride_f, size_t count, bool xcd,
                                 hipStream_t stream) {
     if (count == 0) return hipSuccess;
     if (!fftcc2d_fused_supported(p.rx, p.ry)) return hipErrorInvalidValue;
+    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
+#if OC_FFTCC2D_X2
+    {
+        const size_t groups = (count + 2 * kX2Waves - 1) / (2 * kX2Waves);
+        const int chunk = xcd ? (int)((groups + 7) / 8) : 0;
+        const size_t grid = xcd ? (size_t)chunk * 8 : groups;
+        hipLaunchKernelGGL(fftcc2d_fused32x2_kernel, dim3((unsigned)grid), dim3(64 * kX2Waves), 0, stream, p, pois, stride_f,
+                           (unsigned long long)count, chunk);
+        return hipGetLastError();
+    }
+#endif
     const size_t groups = (count + kFusedWaves - 1) / kFusedWaves;
     const int chunk = xcd ? (int)((groups + 7) / 8) : 0;
     const size_t grid = xcd ? (size_t)chunk * 8 : groups;
-    (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(fftcc2d_fused32_kernel, dim3((unsigned)grid), dim3(64 * kFusedWaves), 0, stream, p, pois, stride_f,
                        (unsigned long long)count, chunk);
     return hipGetLastError();
