@@ -300,9 +300,13 @@ __global__ __launch_bounds__(64 * kX2Waves, OC_FFTCC2D_X2_OCC) void fftcc2d_fuse
     // (-l) read backwards.  The product replaces Z in its register; the inverse transform takes them in natural order.
     {
         const int mrow = ((FN - l) & (FN - 1)) * FP;
+        // 2R = z + conj(zm), 2T = (z - conj(zm)) / i; the product is formed WITHOUT the two factors of one half: scaling by
+        // a power of two commutes with every rounding of the inverse transform, so the peak comes out exactly four times too
+        // large and the final division takes the 0.25 (same ZNCC bits as with the factors applied here).  Scalar on purpose: the
+        // packed form needs 3.5 v_mov per element to build its operand pairs and costs the same cycles.
         auto product = [](c2 z, c2 zm) {
-            const float rr = 0.5f * (z.x + zm.x), ri = 0.5f * (z.y - zm.y);
-            const float tr = 0.5f * (z.y + zm.y), ti = -0.5f * (z.x - zm.x);
+            const float rr = z.x + zm.x, ri = z.y - zm.y;
+            const float tr = z.y + zm.y, ti = zm.x - z.x;
             return mkc((rr * tr) + (ri * ti), (rr * ti) - (ri * tr));
         };
 #if OC_FFTCC2D_X2_SPLIT
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(64 * kX2Waves, OC_FFTCC2D_X2_OCC) void fftcc2d_fuse
         poi[poi2d::V] = (float)dv + gv;
         poi[poi2d::U0] = gu;
         poi[poi2d::V0] = gv;
-        poi[poi2d::ZNCC] = best / (sqrtf(rn * tn) * M);
+        poi[poi2d::ZNCC] = (0.25f * best) / (sqrtf(rn * tn) * M);
     }
 }
 
