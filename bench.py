@@ -36,7 +36,7 @@ Besides the contract fields the JSON line carries
                   timed region) as a top-level scalar next to `value` (which the bench contract defines on HBM-resident
                   inputs); details in `pcie_inclusive`,
   roofline_secondary -- the same kind of statement for the dominant kernels of the other BASELINE configs
-                  (fftcc2d_fused32 on B, icgn2d_kernel<12> on C, fftcc3d_fused32 and icgn3d1_kernel on E), each with the
+                  (fftcc2d_fused32x2 on B, icgn2d_kernel<12> on C, fftcc3d_fused32 and icgn3d1_kernel on E), each with the
                   SURVEY 8(d) byte formula, hipEvent-timed on the engines' stream in this run,
   multi_gpu_check -- N > 1 only: world size and device distinctness asserted, rank 0 re-solves a strided sample of every
                   other rank's block and compares it bit for bit with the gathered records, and the step is timed once more
@@ -419,10 +419,10 @@ def main():
             out["pcie_inclusive"] = host_queue_rate(fftcc, icgn, pristine, converged)
             out["value_pcie_inclusive"] = out["pcie_inclusive"]["value"]
             fftcc_block = secondary_block(
-                "fftcc2d_fused32_kernel (FFTCC2D, 32x32 window)", "B: 4096^2, r=16, 250 000 POIs",
+                "fftcc2d_fused32x2_kernel (FFTCC2D, 32x32 window)", "B: 4096^2, r=16, 250 000 POIs",
                 (2 * (2 * RX) * (2 * RY) * 4 + 20) * float(hi - lo), fftcc_ms / max(fftcc_launches, 1), fftcc_launches,
                 "hbm", HBM_PEAK_GBS, "SURVEY 8(d): 2*M2*4 B in + 20 B out = 8 212 B per POI; the kernel itself is VALU-bound "
-                "(about 2 k wave-instructions per POI, DESIGN.md 4.2)")
+                "(about 1.1 k wave-instructions per POI, two POIs per wave, DESIGN.md 4.2)")
             del queues, gather_bufs
             out["roofline_secondary"] = [fftcc_block] + secondary_rooflines(dev, local_rank)
             out["cpu_baseline"] = cpu_baseline(ref, tar, xs, ys, args.cpu_sample)

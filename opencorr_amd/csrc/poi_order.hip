@@ -94,9 +94,10 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(const float* __restri
     if (live) perm[base + (unsigned)pos] = i;
 }
 
-// counts[] holds the END of every tile after the scatter; order the indices inside each tile ascending.  One workgroup per
-// tile: the tile's slots are ranked against each other in LDS (every lane reads the same word per step: a broadcast), which
-// costs ~2 us for config B's 1024 tiles of 256 POIs where a rank loop over global memory took 27 us.
+// counts[] holds the END of every tile after the scatter; order the indices inside each tile ascending.  A workgroup takes
+// 256 slots of one tile and ranks them against the whole tile held in LDS (every lane reads the same word per step: a
+// broadcast): ~2 us for config B's 1024 tiles of 256 POIs where a rank loop over global memory took 27 us.  blockIdx.y
+// spreads the chunks of crowded tiles (a 3 px grid puts 2 000 POIs into a 128 px tile) over several workgroups.
 constexpr int kRankCap = 4096;  // a more crowded tile keeps the scatter's order
 
 __global__ __launch_bounds__(256) void tile_rank_kernel(int ntiles, const unsigned* __restrict__ ends, const unsigned* __restrict__ slots,
@@ -105,15 +106,15 @@ __global__ __launch_bounds__(256) void tile_rank_kernel(int ntiles, const unsign
     const unsigned tid = threadIdx.x;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const unsigned s = t ? ends[t - 1] : 0u, e = ends[t], n = e - s;
-        if (n == 0) continue;
+        if (blockIdx.y * 256u >= n) continue;  // (wave-uniform: whole workgroups skip)
         if (n > (unsigned)kRankCap) {
-            for (unsigned k = tid; k < n; k += 256) perm[s + k] = slots[s + k];
+            for (unsigned k = blockIdx.y * 256u + tid; k < n; k += gridDim.y * 256u) perm[s + k] = slots[s + k];
             continue;
         }
         __syncthreads();  // the previous tile's ranks have been formed
         for (unsigned k = tid; k < n; k += 256) seg[k] = slots[s + k];
         __syncthreads();
-        for (unsigned k = tid; k < n; k += 256) {
+        for (unsigned k = blockIdx.y * 256u + tid; k < n; k += gridDim.y * 256u) {
             const unsigned i = seg[k];
             unsigned r = 0;
             for (unsigned q = 0; q < n; q++) r += seg[q] < i ? 1u : 0u;
@@ -145,7 +146,11 @@ hipError_t launch_poi2d_tile_order(const float* pois, int stride_f, size_t count
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, tiles, ntiles);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, height, width,
                        tile_px, ntx, tiles, slots);
-    hipLaunchKernelGGL(tile_rank_kernel, dim3((unsigned)(ntiles < 65536 ? ntiles : 65536)), dim3(256), 0, stream, ntiles, tiles, slots, perm);
+    // chunks of 256 slots per tile: sized for four times the mean tile population, at most the cap's 16
+    const size_t mean4 = (4 * count / (size_t)ntiles + 255) / 256;
+    const unsigned chunks = (unsigned)(mean4 < 1 ? 1 : (mean4 > (size_t)(kRankCap / 256) ? (size_t)(kRankCap / 256) : mean4));
+    hipLaunchKernelGGL(tile_rank_kernel, dim3((unsigned)(ntiles < 65535 ? ntiles : 65535), chunks), dim3(256), 0, stream, ntiles, tiles,
+                       slots, perm);
     return hipGetLastError();
 }
 
