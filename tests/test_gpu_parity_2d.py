@@ -111,6 +111,50 @@ def test_fftcc2d_fused_kernel_matches_rocfft_pipeline(eng, speckle_small, r):
     assert (fused[:-3, 16] > 0.5).mean() > 0.9
 
 
+@pytest.mark.parametrize("count", [1, 2, 101, 128, 777])
+def test_fftcc2d_two_pois_per_wave_edge_cases(eng, speckle_small, count):
+    """The 32 x 32 kernel serves two POIs per wave (fftcc2d_fused32x2_kernel): odd queue lengths (a lone half-wave at the
+    end), guard trippers in the first or the second half of a wave next to a live partner, fractional POI coordinates and
+    fractional initial guesses (the window indices are truncations of float sums, src/oc_fftcc.cpp:192-216) -- integers as
+    the oracle and the rocFFT pipeline, ZNCC within 1e-5, tripped POIs untouched."""
+    import oracle
+    ref, tar = speckle_small
+    h, w = ref.shape
+    rng = np.random.default_rng(count)
+    xs = rng.uniform(30, w - 30, count).astype(np.float32)
+    ys = rng.uniform(30, h - 30, count).astype(np.float32)
+    xs[::3] = np.floor(xs[::3])          # a third on integer positions, the rest fractional
+    ys[::3] = np.floor(ys[::3])
+    base = eng.make_pois2d(xs, ys)
+    P = oracle.P2
+    base[:, P["u"]] = rng.uniform(-3, 3, count).astype(np.float32)
+    base[:, P["v"]] = rng.uniform(-3, 3, count).astype(np.float32)
+    base[::4, P["u"]] = 0.0
+    trip = [i for i in (0, 5, 50, 51, count - 1) if 0 <= i < count and count > 2]
+    for n, i in enumerate(trip):   # out at the left / right / top / by the displaced target window
+        if n % 4 == 0: base[i, P["x"]] = 3.0
+        elif n % 4 == 1: base[i, P["x"]] = w - 2.0
+        elif n % 4 == 2: base[i, P["y"]] = 2.0
+        else: base[i, P["u"]] = 4000.0
+    f = eng.FFTCC2D(16, 16)
+    f.set_images(ref, tar)
+    fused = f.compute(base.copy())
+    f.set_tuning("fftcc2d_fused", 0)
+    piped = f.compute(base.copy())
+    want = base.copy()
+    oracle.fftcc2d(ref, tar, 16, 16, want)
+    for col in (P["u"], P["v"], P["u0"], P["v0"]):
+        assert np.array_equal(fused[:, col], want[:, col]), col
+        assert np.array_equal(fused[:, col], piped[:, col]), col
+    assert np.abs(fused[:, P["zncc"]] - want[:, P["zncc"]]).max() <= 1e-5
+    assert np.abs(fused[:, P["zncc"]] - piped[:, P["zncc"]]).max() <= 2e-6
+    other = [c for c in range(25) if c not in (P["u"], P["v"], P["u0"], P["v0"], P["zncc"])]
+    assert np.array_equal(_bits(fused[:, other]), _bits(base[:, other]))
+    if trip:
+        assert np.array_equal(_bits(fused[trip]), _bits(base[trip]))
+        assert np.array_equal(_bits(want[trip]), _bits(base[trip]))
+
+
 @pytest.mark.parametrize("rx,ry", [(8, 16), (16, 8), (10, 24), (32, 12), (20, 16), (24, 32), (16, 20), (12, 8)])
 def test_fftcc2d_fused_rectangular_windows(eng, speckle_small, rx, ry):
     """rx != ry with both window sides out of {16, 20, 24, 32, 40, 48, 64}: the register-FFT kernel (fftcc2d_fusedr.hip) instead
