@@ -75,7 +75,9 @@ namespace ochip {
 // G    = samples whose LUT gathers are issued back to back.
 // PIPE = (retired) software-pipelined sweep: the gathers of the next group in flight while this group's polynomials are
 //        evaluated lost in round 1 and again in round 2 (+3.5 % at G = 2 / 4 waves per SIMD, +4 % at G = 1 / 6 waves:
-//        profiles/r03f_icgn2d1_variant_ab_pipelined.json); the parameter stays 0.
+//        profiles/r03f_icgn2d1_variant_ab_pipelined.json), and a third time in round 3 with the lockstep sweeps (G = 1, next
+//        pass's gathers in flight, loop unrolled by two: 3.28 - 3.29 against 3.25 - 3.26 ms, profiles/r3n_icgn2d1_ab_pipelined_lockstep.txt);
+//        the parameter stays 0.
 // OCC  = minimum waves per SIMD the register allocation must allow.
 // Wave-uniform small matrices are kept one COLUMN per lane (lane j < n holds column j):
 // the inverse Hessian, and for 2D2 also the 6x6 warp matrix.
