@@ -249,7 +249,8 @@ int oc_hip_group_queue(const oc_hip_engine* engine, int member, const void** dev
  *   "icgn2d_variant"  index into the ICGN2D kernel-variant table (gather depth, LDS footprint, per-workgroup
  *                     coordinate table, waves per workgroup); -1 (the default) lets the engine choose by subset size
  *   "icgn2d_xcd"      1: workgroups of one XCD serve a contiguous range of the POI queue
- *   "icgn2d_tile_px"  side of the square image tiles the ICGN2D queue is visited by (L2 locality; 0 = queue order)
+ *   "icgn2d_tile_px"  side of the square image tiles the ICGN2D queue is visited by (L1 / L2 locality; default 128;
+ *                     0 = queue order)
  *   "fftcc2d_fused"   1: single-kernel FFTCC2D (LDS / register FFT) for square windows of side 16, 18, 20, 24, 30,
  *                     32, 36, 40, 48, 50, 60, 64 (radius 8, 9, 10, 12, 15, 16, 18, 20, 24, 25, 30, 32) and for rectangular
  *                     windows (radius_x != radius_y) with both sides out of 16, 20, 24, 32, 40, 48, 64; 0: rocFFT pipeline
