@@ -2,15 +2,15 @@
 // (N = 16, 18, 20, 24, 30, 36, 40, 48, 50, 60, 64; N = 32 has its own kernel in fftcc2d_fused.hip); rectangular windows
 // (rx != ry) are instantiated in fftcc2d_fusedr.hip from the same template (fftcc2d_fusedn_impl.h).
 //
-// Same plan as the 32 x 32 kernel: one wavefront per POI keeps the whole FFTCC2D::compute(POI2D*)
-// (src/oc_fftcc.cpp:177-275) on chip -- gather with the arithmetic of fftcc2d_gather_kernel (bit-identical means and
-// norms), z = ref + i*tar, ONE complex N x N FFT, R(k) = (Z(k) + conj Z(-k))/2, T(k) = (Z(k) - conj Z(-k))/(2i),
+// Same plan as the 32 x 32 kernel (fftcc2d_fused32x2_kernel): the whole FFTCC2D::compute(POI2D*) (src/oc_fftcc.cpp:177-275)
+// on chip -- z = ref + i*tar, ONE complex NR x NC FFT, R(k) = (Z(k) + conj Z(-k))/2, T(k) = (Z(k) - conj Z(-k))/(2i),
 // C = conj(R) T, inverse FFT (unnormalised like FFTW's c2r), arg-max with the first-max rule.
-// Here a lane owns a whole line: lane l < N transforms row l (then column l) with an N-point mixed-radix FFT held in
-// registers (fft_device.h: factors 2, 3, 4, 5, twiddles from a generated table); the N x (N+1) complex tile in LDS
-// (odd pitch: rows and columns both conflict-free) carries the data between the row and the column pass.
-// The rocFFT pipeline this replaces spends more time on these windows than the ICGN refinement that follows it
-// (config C, r = 20: 4.9 ms of FFTCC against 4.2 ms of ICGN2D2 for 99 856 POIs).
+// A lane owns a whole column, then a whole line: lane l gathers column l of the transform's array into its registers and
+// transforms it there with an N-point mixed-radix FFT (fft_device.h: factors 2, 3, 4, 5, twiddles from a generated
+// table); an NR x (NC + 1) tile of floats in LDS (odd pitch: lines and columns both conflict-free; real parts travel
+// first, imaginary parts second) carries the data between the passes.  Windows whose longer side fits 32 lanes share a
+// wave in pairs.  The rocFFT pipeline this replaces spends more time on these windows than the ICGN refinement that
+// follows it (config C, r = 20: 4.9 ms of FFTCC against 4.2 ms of ICGN2D2 for 99 856 POIs).
 #include "fftcc2d_fusedn_impl.h"
 
 namespace ochip {
