@@ -253,7 +253,8 @@ int oc_hip_group_queue(const oc_hip_engine* engine, int member, const void** dev
  *                     0 = queue order)
  *   "fftcc2d_fused"   1: single-kernel FFTCC2D (LDS / register FFT) for square windows of side 16, 18, 20, 24, 30,
  *                     32, 36, 40, 48, 50, 60, 64 (radius 8, 9, 10, 12, 15, 16, 18, 20, 24, 25, 30, 32) and for rectangular
- *                     windows (radius_x != radius_y) with both sides out of 16, 20, 24, 32, 40, 48, 64; 0: rocFFT pipeline
+ *                     windows (radius_x != radius_y) with both sides out of 16, 20, 24, 32, 40, 48, 64; 0: rocFFT pipeline;
+ *                     2: as 1, but 32 x 32 windows run the generic NR x NC kernel instead of their own (an A/B switch)
  *   "fftcc3d_fused"   1: single-kernel FFTCC3D (register/LDS FFT) for 32 x 32 x 32 windows; 0: rocFFT pipeline
  *   "host_chunk"      POIs per chunk of the host-queue pipeline (copies of one chunk overlap the kernels of its
  *                     neighbours); 0 = whole queue at once; default 65536

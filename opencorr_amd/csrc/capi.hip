@@ -372,7 +372,8 @@ int ensure_fft(oc_hip_engine* e, size_t chunk) {
 int run_fftcc2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     if (!e->img || e->img->ndim != 2) return fail(OC_HIP_ERR_INVALID, "FFTCC2D: set_images2d has not been called");
     const ImagePair& im = *e->img;
-    const bool fused32 = ochip::fftcc2d_fused_supported(e->rx, e->ry);
+    // ("fftcc2d_fused" = 2: the generic NR x NC kernel also for 32 x 32 windows -- an A/B switch)
+    const bool fused32 = e->fftcc2d_fused != 2 && ochip::fftcc2d_fused_supported(e->rx, e->ry);
     if (e->fftcc2d_fused && (fused32 || ochip::fftcc2d_fusedn_supported(e->rx, e->ry))) {
         ochip::Fftcc2dParams P = {im.ref_ptr(), im.tar_ptr(), im.dy, im.dx, e->rx, e->ry};
         ProfScope prof(e);
@@ -1291,7 +1292,7 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
         if (value < 0 || (value > 0 && value < 16)) return fail(OC_HIP_ERR_INVALID, "icgn2d_tile_px must be 0 (off) or >= 16");
         e->icgn2d_tile_px = value;
     } else if (k == "fftcc2d_fused") {
-        e->fftcc2d_fused = value != 0;
+        e->fftcc2d_fused = value == 2 ? 2 : (value != 0);
     } else if (k == "fftcc3d_fused") {
         e->fftcc3d_fused = value != 0;
     } else if (k == "host_chunk") {

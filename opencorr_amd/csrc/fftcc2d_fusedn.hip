@@ -22,7 +22,7 @@ hipError_t launch_fftcc2d_fusedr(const Fftcc2dParams& p, float* pois, int stride
 
 bool fftcc2d_fusedn_supported(int rx, int ry) {
     if (rx != ry) return fftcc2d_fusedr_supported(rx, ry);
-    return rx == 8 || rx == 9 || rx == 10 || rx == 12 || rx == 15 || rx == 18 || rx == 20 || rx == 24 || rx == 25 || rx == 30 || rx == 32;
+    return rx == 8 || rx == 9 || rx == 10 || rx == 12 || rx == 15 || rx == 16 || rx == 18 || rx == 20 || rx == 24 || rx == 25 || rx == 30 || rx == 32;
 }
 
 hipError_t launch_fftcc2d_fusedn(const Fftcc2dParams& p, float* pois, int stride_f, size_t count, bool xcd,
@@ -32,6 +32,7 @@ hipError_t launch_fftcc2d_fusedn(const Fftcc2dParams& p, float* pois, int stride
     if (p.rx != p.ry) return launch_fftcc2d_fusedr(p, pois, stride_f, count, xcd, stream);
     switch (2 * p.rx) {
         case 16: return launch_n<16, 16>(p, pois, stride_f, count, xcd, stream);
+        case 32: return launch_n<32, 32>(p, pois, stride_f, count, xcd, stream);
         case 18: return launch_n<18, 18>(p, pois, stride_f, count, xcd, stream);
         case 50: return launch_n<50, 50>(p, pois, stride_f, count, xcd, stream);
         case 60: return launch_n<60, 60>(p, pois, stride_f, count, xcd, stream);
