@@ -128,7 +128,10 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     // passes whose global loads are issued together in the load-then-use loops outside the interpolation sweep
     // (reference subset, Hessian sweep, numerator pass): one dependent round trip per batch instead of one per pass
     constexpr int kSetupBatch = 6;
-    constexpr int kHessBatch = 6;  // (6 DoF; the 78 running sums of the 12-DoF Hessian leave no room: passes_prefetched)
+    // (6 DoF; the 78 running sums of the 12-DoF Hessian leave no room: passes_prefetched.  Round 3 split that sweep in two -- 45 + 33
+    // sums, each reduced right away, 2 - 6 passes of loads in flight -- and measured 3.49 - 3.50 ms against 3.49 on config C
+    // (profiles/r3q_icgn2d2_ab_two_hessian_sweeps.txt): the sweep is not waiting for its loads; not kept)
+    constexpr int kHessBatch = 6;
     constexpr int kNumBatch = DOF == 6 ? 6 : 4;
     __shared__ float coop_area[COOP ? WPB * 64 : 1];
     const int NTA = L.nt;  // passes the LDS arrays are sized for (>= the passes of any POI)
