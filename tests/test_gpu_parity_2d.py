@@ -111,6 +111,46 @@ def test_fftcc2d_fused_kernel_matches_rocfft_pipeline(eng, speckle_small, r):
     assert (fused[:-3, 16] > 0.5).mean() > 0.9
 
 
+def test_fftcc2d_every_fused_shape(eng, speckle_small):
+    """All 54 window shapes with a single-kernel FFTCC2D (12 square sides, 42 rectangular pairs; one template instance each,
+    fftcc2d_fusedn_impl.h) on an odd-length queue with fractional positions, integer initial guesses and three guard
+    trippers: integers as the oracle and the rocFFT pipeline, ZNCC within 3e-5, tripped POIs untouched."""
+    import oracle
+    ref, tar = speckle_small
+    h, w = ref.shape
+    P = oracle.P2
+    sides = [16, 20, 24, 32, 40, 48, 64]
+    shapes = [(r, r) for r in (8, 9, 10, 12, 15, 16, 18, 20, 24, 25, 30, 32)] + [(a // 2, b // 2) for a in sides for b in sides if a != b]
+    assert len(shapes) == 54
+    for rx, ry in shapes:
+        rng = np.random.default_rng(rx * 100 + ry)
+        n = 75
+        m = max(rx, ry) + 6
+        xs = rng.uniform(m, w - m, n).astype(np.float32)
+        ys = rng.uniform(m, h - m, n).astype(np.float32)
+        xs[::2] = np.floor(xs[::2])
+        ys[::2] = np.floor(ys[::2])
+        base = eng.make_pois2d(xs, ys)
+        base[:, P["u"]] = rng.integers(-3, 4, n).astype(np.float32)
+        base[:, P["v"]] = rng.integers(-3, 4, n).astype(np.float32)
+        trip = [7, 40, n - 1]
+        base[7, P["x"]] = 2.0
+        base[40, P["y"]] = h - 1.0
+        base[n - 1, P["u"]] = 5000.0
+        f = eng.FFTCC2D(rx, ry)
+        f.set_images(ref, tar)
+        fused = f.compute(base.copy())
+        f.set_tuning("fftcc2d_fused", 0)
+        piped = f.compute(base.copy())
+        want = base.copy()
+        oracle.fftcc2d(ref, tar, rx, ry, want)
+        for c in ("u", "v", "u0", "v0"):
+            assert np.array_equal(fused[:, P[c]], want[:, P[c]]), (rx, ry, c)
+            assert np.array_equal(fused[:, P[c]], piped[:, P[c]]), (rx, ry, c)
+        assert np.abs(fused[:, P["zncc"]] - want[:, P["zncc"]]).max() <= 3e-5, (rx, ry)
+        assert np.array_equal(_bits(fused[trip]), _bits(base[trip])), (rx, ry)
+
+
 @pytest.mark.parametrize("count", [1, 2, 101, 128, 777])
 def test_fftcc2d_two_pois_per_wave_edge_cases(eng, speckle_small, count):
     """The 32 x 32 kernel serves two POIs per wave (fftcc2d_fused32x2_kernel): odd queue lengths (a lone half-wave at the
