@@ -2,17 +2,20 @@
 //
 // FFTCC2D::compute(POI2D*) (src/oc_fftcc.cpp:177-275) needs, per POI, two 2-D real FFTs, a
 // spectrum product and one inverse FFT of a 4 KB window.  The rocFFT pipeline of fftcc2d.hip
-// moves ~50 KB per POI through HBM between five kernels; here one wavefront keeps the whole
-// POI on chip:
-//   gather (coalesced rows, same arithmetic as fftcc2d_gather_kernel: bit-identical means
-//   and norms)  ->  z = ref + i*tar  ->  ONE complex 32x32 FFT in LDS/registers  ->
+// moves ~50 KB per POI through HBM between five kernels; here the whole POI stays on chip:
+//   gather  ->  z = ref + i*tar  ->  ONE complex 32x32 FFT in LDS/registers  ->
 //   R(k) = (Z(k) + conj Z(-k))/2, T(k) = (Z(k) - conj Z(-k))/(2i), C = conj(R) T  ->
 //   inverse complex FFT (unnormalised, like FFTW's c2r)  ->  arg-max with the first-max
 //   rule, wrap, ZNCC.
-// A length-32 transform is one decimation-in-frequency radix-2 step (done while reading the
-// row/column from LDS, each of the two lanes that share a row taking the even or the odd
-// outputs) followed by a 16-point FFT held in registers.  LDS: 32 rows x 33 complex (pitch
-// 33 keeps both the row and the column accesses conflict-free), 8448 B per wave.
+// Two kernels live here:
+//   * fftcc2d_fused32x2_kernel (round 3, what the engine launches): two POIs per wave, one lane per window line -- see
+//     the comment above it;
+//   * fftcc2d_fused32_kernel (rounds 1 - 2, kept as the A/B partner behind -DOC_FFTCC2D_X2=0): one wave per POI; a
+//     length-32 transform is one decimation-in-frequency radix-2 step (done while reading the row / column from LDS, each
+//     of the two lanes that share a row taking the even or the odd outputs) followed by a 16-point FFT held in
+//     registers; gather with the sample -> lane ownership of fftcc2d_gather_kernel (means and norms bit-identical to the
+//     rocFFT pipeline's); LDS: 32 rows x 33 complex (pitch 33 keeps both the row and the column accesses conflict-free),
+//     8448 B per wave.
 // Integer outputs (u, v) are what the reference computes; the float ZNCC differs from
 // FFTW's in the last bits like any other FFT implementation (tested to 1e-5 against the
 // oracle's double-precision DFT).
