@@ -28,6 +28,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
+# lanes of the GPU's 3D reduction order (icgn3d.hip: threads of the workgroup that owns a POI)
+LANES3D = 512
+
+
 def timed(fn, sync, reps=3):
     fn()
     sync()
@@ -38,6 +42,26 @@ def timed(fn, sync, reps=3):
         sync()
         best = min(best, time.perf_counter() - t0)
     return best
+
+
+def vs_reference_order(gpu, seq, cols_disp, col_zncc, col_iter):
+    """north_star's literal statement, GPU against the oracle in the REFERENCE's own loop order (OC_ORDER_SEQ, bit-identical
+    to the reference's compiled sources: tests/test_oracle_vs_ref.py) on the same FFTCC output: "u/v/w and ZNCC within 1e-4,
+    iteration counts and convergence flags bit-identical".  The GPU sums a subset in lane order (OC_ORDER_LANES), a
+    re-association of the reference's sequential sums; this is what that re-association costs.
+    Returns the number of POIs whose failure flag (zncc < 0) differs, the fraction of commonly converged POIs with equal
+    iteration counts, and -- over the POIs with equal iteration counts -- max |d displacement| and max |d ZNCC|."""
+    fa, fb = gpu[:, col_zncc] < 0, seq[:, col_zncc] < 0
+    both = ~fa & ~fb
+    same_it = both & (gpu[:, col_iter] == seq[:, col_iter])
+    dd = np.abs(gpu[same_it][:, cols_disp].astype(np.float64) - seq[same_it][:, cols_disp].astype(np.float64))
+    dz = np.abs(gpu[same_it, col_zncc].astype(np.float64) - seq[same_it, col_zncc].astype(np.float64))
+    # failed POIs keep their codes: -3 / -4 / -5 must be the SAME code on both sides
+    codes_same = bool(np.array_equal(gpu[fa & fb, col_zncc], seq[fa & fb, col_zncc]))
+    return dict(seq_flag_mismatches=int((fa != fb).sum()) + (0 if codes_same else 1),
+                seq_iteration_agreement=float(same_it.sum() / max(1, both.sum())),
+                seq_max_abs_d_disp=float(dd.max()) if dd.size else 0.0,
+                seq_max_abs_d_zncc=float(dz.max()) if dz.size else 0.0, seq_sample=int(len(gpu)))
 
 
 def run_2d(name, side, r, nside, engine, oracle_sample, so=None):
@@ -96,20 +120,25 @@ def run_2d(name, side, r, nside, engine, oracle_sample, so=None):
     fftcc_zncc = float(np.abs(fo[:, 16] - sample[:, 16]).max())
     untouched = np.delete(np.arange(25), [2, 8, 14, 15, 16])
     fftcc_same = fftcc_same and bool(np.array_equal(fo[:, untouched].view(np.uint32), sample[:, untouched].view(np.uint32)))
+    seq = sample.copy()  # the same FFTCC output, refined in the reference's own loop order
     if engine == 3:
-        oracle.nr2d1(oracle.PreparedNR2D(ref_h, tar_h), r, r, 0.001, 10.0, sample,
-                     order=oracle.ORDER_LANES, lanes=64)
+        prep = oracle.PreparedNR2D(ref_h, tar_h)
+        oracle.nr2d1(prep, r, r, 0.001, 10.0, sample, order=oracle.ORDER_LANES, lanes=64)
+        oracle.nr2d1(prep, r, r, 0.001, 10.0, seq, order=oracle.ORDER_SEQ)
     else:
         prep = oracle.Prepared2D(ref_h, tar_h)
-        (oracle.icgn2d1 if engine == 1 else oracle.icgn2d2)(prep, r, r, 0.001, 10.0, sample, order=oracle.ORDER_LANES, lanes=64)
-        del prep
+        solve = oracle.icgn2d1 if engine == 1 else oracle.icgn2d2
+        solve(prep, r, r, 0.001, 10.0, sample, order=oracle.ORDER_LANES, lanes=64)
+        solve(prep, r, r, 0.001, 10.0, seq, order=oracle.ORDER_SEQ)
+    del prep
     bit_exact = bool(np.array_equal(sample.view(np.uint32), after[::step_s].view(np.uint32)))
+    vs_seq = vs_reference_order(after[::step_s], seq, [2, 8], 16, 17)
     return dict(config=name, engine="FFTCC2D+" + {1: "ICGN2D1", 2: "ICGN2D2", 3: "NR2D1"}[engine], image="%dx%d" % (side, side), radius=r, pois=n,
                 seconds=secs, pois_per_s=float(conv.sum() / secs), converged=int(conv.sum()),
                 mean_iterations=float(after[conv, 17].astype(np.float64).mean()), prepare_s=prepare_s,
                 median_abs_err_u=float(np.median(du)), max_abs_err_u=float(du.max()), max_abs_err_v=float(dv.max()),
                 oracle_sample=len(sample), oracle_bit_exact=bit_exact, split_queue_same_bits=same_split,
-                fftcc_oracle_same_integers=fftcc_same, fftcc_oracle_max_zncc_diff=fftcc_zncc)
+                fftcc_oracle_same_integers=fftcc_same, fftcc_oracle_max_zncc_diff=fftcc_zncc, **vs_seq)
 
 
 def run_strain(name, side, r, nside, radius, nmin):
@@ -200,15 +229,19 @@ def run_3d(name, dim, r, nside, oracle_sample):
     fftcc_zncc = float(np.abs(fo[:, P["zncc"]] - sample[:, P["zncc"]]).max())
     prep = oracle.Prepared3D(ref_h, tar_h)
     t0 = time.perf_counter()
-    oracle.icgn3d1(prep, r, r, r, 0.001, 20.0, sample, order=oracle.ORDER_LANES, lanes=512)
+    seq = sample.copy()
+    oracle.icgn3d1(prep, r, r, r, 0.001, 20.0, sample, order=oracle.ORDER_LANES, lanes=LANES3D)
     oracle_s = time.perf_counter() - t0
+    oracle.icgn3d1(prep, r, r, r, 0.001, 20.0, seq, order=oracle.ORDER_SEQ)
     bit_exact = bool(np.array_equal(sample.view(np.uint32), after[::step_s].view(np.uint32)))
+    vs_seq = vs_reference_order(after[::step_s], seq, [P["u"], P["v"], P["w"]], P["zncc"], P["iteration"])
     return dict(config=name, engine="FFTCC3D+ICGN3D1", volume="%d^3" % dim, radius=r, pois=n, fftcc_seconds=t_f,
                 icgn_seconds=t_g, pois_per_s=float(conv.sum() / (t_f + t_g)), converged=int(conv.sum()),
                 mean_iterations=float(after[conv, P["iteration"]].astype(np.float64).mean()), prepare_s=prepare_s, generate_s=gen_s,
                 median_abs_err=float(np.median(err)), max_abs_err=float(err.max()), oracle_sample=len(sample),
                 oracle_seconds=oracle_s, oracle_pois_per_s=len(sample) / oracle_s, oracle_cores=oracle.max_threads(),
-                oracle_bit_exact=bit_exact, fftcc_oracle_same_integers=fftcc_same, fftcc_oracle_max_zncc_diff=fftcc_zncc)
+                oracle_bit_exact=bit_exact, fftcc_oracle_same_integers=fftcc_same, fftcc_oracle_max_zncc_diff=fftcc_zncc,
+                **vs_seq)
 
 
 def main():

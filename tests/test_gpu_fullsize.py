@@ -10,7 +10,12 @@ Size-independent properties + a strided oracle sample, the checks of tests/fulls
   * split queue == whole queue bit for bit (what multi-GPU sharding relies on: a POI's result does not depend on
     which block of the queue it travels in),
   * the analytic displacement field the synthetic pair was rendered with is recovered,
-  * (almost) every POI converges.
+  * (almost) every POI converges,
+  * **north_star's literal statement, GPU against the REFERENCE's loop order**: the oracle refines the same FFTCC output a
+    second time in OC_ORDER_SEQ (bit-identical to the reference's own compiled sources, tests/test_oracle_vs_ref.py), and
+    on that sample the GPU shows the same failure flags and codes, >= 99.5 % equal iteration counts, and on POIs with
+    equal counts |d u, v(, w)| <= 1e-4 and |d ZNCC| <= 1e-5 (`_check_vs_reference_order`; the numbers travel into
+    profiles/*configs*.json through tests/fullsize/run_configs.py).
 """
 import importlib.util
 import os
@@ -29,7 +34,14 @@ def _configs():
     return mod
 
 
+def _check_vs_reference_order(rec):
+    assert rec["seq_flag_mismatches"] == 0, rec
+    assert rec["seq_iteration_agreement"] >= 0.995, rec
+    assert rec["seq_max_abs_d_disp"] <= 1e-4 and rec["seq_max_abs_d_zncc"] <= 1e-5, rec
+
+
 def _check(rec, min_converged, max_err):
+    _check_vs_reference_order(rec)
     assert rec["oracle_bit_exact"], rec
     assert rec["fftcc_oracle_same_integers"] and rec["fftcc_oracle_max_zncc_diff"] <= 5e-5, rec
     assert rec["split_queue_same_bits"], rec
@@ -71,6 +83,7 @@ def test_config_e_full_size():
     POIs, FFTCC3D -> ICGN3D1 (stop 20); >= 96 strided POIs against the oracle, 3D-affine field recovered."""
     rec = _configs().run_3d("E", 512, 16, 37, 96)
     assert rec["pois"] == 50653 and rec["oracle_sample"] >= 96
+    _check_vs_reference_order(rec)
     assert rec["oracle_bit_exact"], rec
     assert rec["fftcc_oracle_same_integers"] and rec["fftcc_oracle_max_zncc_diff"] <= 1e-4, rec
     assert rec["converged"] >= 0.999 * rec["pois"], rec
