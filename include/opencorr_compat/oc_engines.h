@@ -500,7 +500,7 @@ inline size_t mergeRecovered(Engine& engine, std::vector<Poi>& poi_queue, std::v
     if (n == 0) return 0;
     pois_reliable.resize(r0 + n, pois_unreliable[0]);
     size_t nrec = 0, nrem = 0;
-    hipdetail::check(oc_hip_merge_recovered(engine.handle(), poi_queue.data(), sizeof(Poi), sizeof(Poi) == OC_HIP_POI2D_BYTES ? 2 : 3,
+    hipdetail::check(oc_hip_merge_recovered(engine.handle(), poi_queue.data(), poi_queue.size(), sizeof(Poi), sizeof(Poi) == OC_HIP_POI2D_BYTES ? 2 : 3,
                                             pois_unreliable.data(), pois_unreliable_idx.data(), n, zncc_threshold_high, conv_criterion,
                                             pois_reliable.data(), r0, &nrec, &nrem, OC_HIP_HOST));
     pois_reliable.resize(r0 + nrec, pois_unreliable[0]);

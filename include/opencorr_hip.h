@@ -178,8 +178,11 @@ int oc_hip_split_reliable(oc_hip_engine* engine, const void* pois, size_t count,
  * zncc_threshold_high && result.convergence <= conv_criterion is written back to pois[unreliable_index[j]] and appended to
  * `reliable` (from record `reliable_offset` on); the others are moved to the front of `unreliable` / `unreliable_index`
  * in their old order.  (The example erases inside its loop and thereby skips the POI after every success for one round;
- * here every POI is looked at in every round.) */
-int oc_hip_merge_recovered(oc_hip_engine* engine, void* pois, size_t stride_bytes, int ndim, void* unreliable,
+ * here every POI is looked at in every round.)  `count` = records in `pois`: an unreliable_index entry >= count is never
+ * written through -- the call fails with OC_HIP_ERR_INVALID (HOST: before anything is touched; DEVICE: the offending
+ * records are not written back, `unreliable` / `unreliable_index` are left as they were).  On both paths only the
+ * record's own bytes are written: with stride_bytes > the record size the caller's bytes between records are kept. */
+int oc_hip_merge_recovered(oc_hip_engine* engine, void* pois, size_t count, size_t stride_bytes, int ndim, void* unreliable,
                            unsigned* unreliable_index, size_t n_unreliable, float zncc_threshold_high, float conv_criterion,
                            void* reliable, size_t reliable_offset, size_t* n_recovered, size_t* n_remaining, int memory);
 /* FFTCC3D(int rx, int ry, int rz, int thread_number)  src/oc_fftcc.cpp:300-313 */

@@ -126,7 +126,7 @@ def lib():
     L.oc_hip_select_best.argtypes = [vp, vp, sz, sz, vp, sz, vp, sz, i]
     psz = ctypes.POINTER(sz)
     L.oc_hip_split_reliable.argtypes = [vp, vp, sz, sz, i, f, f, f, vp, sz, vp, vp, psz, psz, i]
-    L.oc_hip_merge_recovered.argtypes = [vp, vp, sz, i, vp, vp, sz, f, f, vp, sz, psz, psz, i]
+    L.oc_hip_merge_recovered.argtypes = [vp, vp, sz, sz, i, vp, vp, sz, f, f, vp, sz, psz, psz, i]
     L.oc_hip_strain_create.argtypes = [f, i, i, pp]
     L.oc_hip_strain_set.argtypes = [vp, f, i, f, i]
     L.oc_hip_strain_prepare.argtypes = [vp, vp, sz, sz, i, i]

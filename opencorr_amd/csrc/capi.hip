@@ -24,7 +24,29 @@
 #include <thread>
 #include <vector>
 
-#include <rccl/rccl.h>  // types and enumerators only: the library itself is loaded with dlopen on first use (struct Rccl)
+// RCCL: types and enumerators only -- the library itself is loaded with dlopen on first use (struct Rccl), and a
+// single-GPU host needs neither the library nor its development headers: without <rccl/rccl.h> the few declarations the
+// binding uses are restated here (the stable NCCL 2.x C API: opaque communicator handle, ncclResult_t with ncclSuccess = 0,
+// ncclUint8 = 1 in ncclDataType_t) and the version check against the loaded library is what guards them.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#define OC_HIP_RCCL_HEADER 1
+#else
+#define OC_HIP_RCCL_HEADER 0
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart();
+ncclResult_t ncclGroupEnd();
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+const char* ncclGetErrorString(ncclResult_t result);
+ncclResult_t ncclGetVersion(int* version);
+}
+#define NCCL_MAJOR 2
+#endif
 
 #include "oc_kernels.h"
 
@@ -282,6 +304,27 @@ int mark_tail(oc_hip_engine* e) {
     e->tail_marked = true;
     return OC_HIP_OK;
 }
+
+// Scope guard of the entry points that enqueue work: whatever way the function leaves -- also an error exit after some
+// kernels or copies were already enqueued on a CALLER-owned stream -- the engine's tail event covers that work, so a later
+// set_stream / destroy / set_devices drains it through the event instead of relying on hipFree's implicit device
+// synchronisation.  Quiet: a failure to record never replaces the error message the function itself reports, and the
+// success paths' own mark_tail (finish_device_call) simply records the same point twice.
+struct TailGuard {
+    oc_hip_engine* e;
+    explicit TailGuard(oc_hip_engine* engine) : e(engine) {}
+    TailGuard(const TailGuard&) = delete;
+    TailGuard& operator=(const TailGuard&) = delete;
+    ~TailGuard() {
+        if (!e || e->stream == e->own_stream) return;
+        if (!e->switch_ev && hipEventCreateWithFlags(&e->switch_ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        if (hipEventRecord(e->switch_ev, e->stream) == hipSuccess) e->tail_marked = true;
+        else (void)hipGetLastError();
+    }
+};
 
 // Host-side wait for everything this engine has enqueued, without ever touching a caller's (possibly destroyed) stream.
 void drain_engine(oc_hip_engine* e) {
@@ -786,6 +829,7 @@ static int plane_prepare(oc_hip_engine* e, int kind, const void* pois, size_t co
     OC_ACTIVATE(e);
     if (e->kind != kind) return fail(OC_HIP_ERR_INVALID, "prepare: wrong engine kind for this entry point");
     std::lock_guard<std::mutex> lock(e->mu);
+    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
     e->st_count = 0;
     if (count == 0) return OC_HIP_OK;
     OC_TRY(order_after_default_stream(e));
@@ -835,6 +879,7 @@ int oc_hip_region_fit_compute(oc_hip_engine* e, void* pois, size_t count, size_t
     OC_ACTIVATE(e);
     if (count == 0) return OC_HIP_OK;
     std::lock_guard<std::mutex> lock(e->mu);
+    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
     if (e->kind != OC_HIP_REGION_FIT) return fail(OC_HIP_ERR_INVALID, "not a RegionFit engine");
     if (e->st_count == 0)
         return fail(OC_HIP_ERR_INVALID, "RegionFit: setNeighbor + prepare has not been called (or the radius changed since)");
@@ -863,6 +908,7 @@ int oc_hip_strain_compute(oc_hip_engine* e, void* pois, size_t count, size_t str
     OC_ACTIVATE(e);
     if (count == 0) return OC_HIP_OK;
     std::lock_guard<std::mutex> lock(e->mu);
+    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
     if (e->kind != OC_HIP_STRAIN) return fail(OC_HIP_ERR_INVALID, "not a Strain engine");
     if (e->st_count == 0) return fail(OC_HIP_ERR_INVALID, "Strain: prepare(poi_queue) has not been called (or the radius changed since)");
     if (e->st_count != count || e->st_ndim != ndim)
@@ -967,6 +1013,7 @@ int oc_hip_set_images2d(oc_hip_engine* e, const float* ref, const float* tar, in
     if (height < 5 || width < 5) return fail(OC_HIP_ERR_INVALID, "image too small: %d x %d", width, height);
     if (layout != OC_HIP_ROW_MAJOR && layout != OC_HIP_COL_MAJOR) return fail(OC_HIP_ERR_INVALID, "bad layout %d", layout);
     std::lock_guard<std::mutex> lock(e->mu);
+    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
     OC_TRY(order_after_default_stream(e));
     auto img = std::make_shared<ImagePair>();
     img->ndim = 2;
@@ -1004,6 +1051,7 @@ int oc_hip_set_images3d(oc_hip_engine* e, const float* ref, const float* tar, in
     if (dim_x < 15 || dim_y < 15 || dim_z < 15)
         return fail(OC_HIP_ERR_INVALID, "volume too small: %d x %d x %d", dim_x, dim_y, dim_z);
     std::lock_guard<std::mutex> lock(e->mu);
+    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
     OC_TRY(order_after_default_stream(e));
     auto img = std::make_shared<ImagePair>();
     img->ndim = 3;
@@ -1314,6 +1362,7 @@ int oc_hip_prepare_ref(oc_hip_engine* e) {
     if (!e->is_icgn()) return OC_HIP_OK;  // FFTCC::prepare() is empty in the reference
     if (!e->img) return fail(OC_HIP_ERR_INVALID, "prepare: set_images has not been called");
     std::lock_guard<std::mutex> lock(e->mu);
+    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
     OC_TRY(order_after_default_stream(e));  // images used in place may have been written on the default stream
     const ImagePair& im = *e->img;
     const size_t bytes = im.count() * sizeof(float);
@@ -1345,6 +1394,7 @@ int oc_hip_prepare_tar(oc_hip_engine* e) {
     if (!e->is_icgn()) return OC_HIP_OK;
     if (!e->img) return fail(OC_HIP_ERR_INVALID, "prepare: set_images has not been called");
     std::lock_guard<std::mutex> lock(e->mu);
+    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
     OC_TRY(order_after_default_stream(e));
     const ImagePair& im = *e->img;
     if (im.ndim == 2) {
@@ -1807,6 +1857,7 @@ static int compute_impl(oc_hip_engine* e, void* pois, const float* offsets, size
     if (offsets && e->kind != OC_HIP_ICGN2D1 && e->kind != OC_HIP_ICGN2D2)
         return fail(OC_HIP_ERR_INVALID, "center offsets are an ICGN2D1/ICGN2D2 feature (src/oc_icgn.h:75-76,130-131)");
     std::lock_guard<std::mutex> lock(e->mu);
+    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
     // a queue of a few POIs is not worth waking the other devices for; "group_force_rccl" sends a lone engine's DEVICE
     // queue down the group path as well (a group of one, whose all-gather is a one-rank ncclAllGather)
     const bool lone_rccl = e->replicas.empty() && e->group_allgather && e->group_force_rccl && memory == OC_HIP_DEVICE;
@@ -1934,6 +1985,7 @@ int oc_hip_select_best(oc_hip_engine* e, const void* candidates, size_t n_candid
         (stride_bytes & 3))
         return fail(OC_HIP_ERR_INVALID, "select_best: POI2D records need a stride >= %d bytes, multiple of 4", OC_HIP_POI2D_BYTES);
     std::lock_guard<std::mutex> lock(e->mu);
+    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
     OC_TRY(order_after_default_stream(e));
     const float* d_cand = static_cast<const float*>(candidates);
     const unsigned* d_seg = segment_starts;
@@ -1980,14 +2032,25 @@ static int split_params(int ndim, size_t stride_bytes, float low, float high, fl
     return OC_HIP_OK;
 }
 
-static int read_split_totals(oc_hip_engine* e, size_t count, size_t totals[2]) {
-    unsigned host[2] = {0, 0};
-    const unsigned* d = e->split_scratch.as<unsigned>() + ochip::poi_split_scratch_words(count) - 2;
+// totals[0], totals[1]: records of class 0 / 1; totals[2]: a main-queue index was out of range (merge_recovered)
+static int read_split_totals(oc_hip_engine* e, size_t count, size_t totals[3]) {
+    unsigned host[3] = {0, 0, 0};
+    const unsigned* d = e->split_scratch.as<unsigned>() + ochip::poi_split_scratch_words(count) - 3;
     OC_HIP_TRY(hipMemcpyAsync(host, d, sizeof(host), hipMemcpyDeviceToHost, e->stream));
     OC_HIP_TRY(hipStreamSynchronize(e->stream));
     totals[0] = host[0];
     totals[1] = host[1];
+    totals[2] = host[2];
     return OC_HIP_OK;
+}
+
+// device records (stride_bytes apart) -> the caller's host queue: only the record's own bytes travel, so whatever the
+// caller keeps between records (stride_bytes > record size) stays as it was -- like on the DEVICE path, whose scatter
+// writes rec_floats per record
+static hipError_t copy_records_to_host(void* dst, const void* src, size_t n, size_t stride_bytes, size_t rec_bytes, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (stride_bytes == rec_bytes) return hipMemcpyAsync(dst, src, n * stride_bytes, hipMemcpyDeviceToHost, stream);
+    return hipMemcpy2DAsync(dst, stride_bytes, src, stride_bytes, rec_bytes, n, hipMemcpyDeviceToHost, stream);
 }
 
 int oc_hip_split_reliable(oc_hip_engine* e, const void* pois, size_t count, size_t stride_bytes, int ndim, float zncc_threshold_low,
@@ -2001,13 +2064,15 @@ int oc_hip_split_reliable(oc_hip_engine* e, const void* pois, size_t count, size
     ochip::PoiSplitParams P;
     OC_TRY(split_params(ndim, stride_bytes, zncc_threshold_low, zncc_threshold_high, conv_criterion, 0, &P));
     std::lock_guard<std::mutex> lock(e->mu);
+    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
     OC_TRY(order_after_default_stream(e));
     OC_TRY(e->split_scratch.reserve(ochip::poi_split_scratch_words(count) * sizeof(unsigned)));
     const int stride_f = (int)(stride_bytes / 4);
-    size_t totals[2];
+    const size_t rec_bytes = (size_t)P.rec_floats * 4;
+    size_t totals[3];
     if (memory == OC_HIP_DEVICE) {
         OC_HIP_TRY(ochip::launch_poi_split(static_cast<const float*>(pois), stride_f, count, P, nullptr, static_cast<float*>(reliable),
-                                           reliable_offset, nullptr, static_cast<float*>(unreliable), unreliable_index, nullptr,
+                                           reliable_offset, nullptr, static_cast<float*>(unreliable), unreliable_index, nullptr, 0,
                                            e->split_scratch.as<unsigned>(), e->stream));
         OC_TRY(read_split_totals(e, count, totals));
     } else {
@@ -2019,12 +2084,12 @@ int oc_hip_split_reliable(oc_hip_engine* e, const void* pois, size_t count, size
         float* d_unr = reinterpret_cast<float*>(base + 2 * qb);
         unsigned* d_idx = reinterpret_cast<unsigned*>(base + 3 * qb);
         OC_HIP_TRY(hipMemcpyAsync(d_in, pois, qb, hipMemcpyHostToDevice, e->stream));
-        OC_HIP_TRY(ochip::launch_poi_split(d_in, stride_f, count, P, nullptr, d_rel, 0, nullptr, d_unr, d_idx, nullptr,
+        OC_HIP_TRY(ochip::launch_poi_split(d_in, stride_f, count, P, nullptr, d_rel, 0, nullptr, d_unr, d_idx, nullptr, 0,
                                            e->split_scratch.as<unsigned>(), e->stream));
         OC_TRY(read_split_totals(e, count, totals));
-        if (totals[0]) OC_HIP_TRY(hipMemcpyAsync(static_cast<char*>(reliable) + reliable_offset * stride_bytes, d_rel, totals[0] * stride_bytes, hipMemcpyDeviceToHost, e->stream));
+        OC_HIP_TRY(copy_records_to_host(static_cast<char*>(reliable) + reliable_offset * stride_bytes, d_rel, totals[0], stride_bytes, rec_bytes, e->stream));
         if (totals[1]) {
-            OC_HIP_TRY(hipMemcpyAsync(unreliable, d_unr, totals[1] * stride_bytes, hipMemcpyDeviceToHost, e->stream));
+            OC_HIP_TRY(copy_records_to_host(unreliable, d_unr, totals[1], stride_bytes, rec_bytes, e->stream));
             OC_HIP_TRY(hipMemcpyAsync(unreliable_index, d_idx, totals[1] * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
         }
         OC_HIP_TRY(hipStreamSynchronize(e->stream));
@@ -2034,9 +2099,9 @@ int oc_hip_split_reliable(oc_hip_engine* e, const void* pois, size_t count, size
     return OC_HIP_OK;
 }
 
-int oc_hip_merge_recovered(oc_hip_engine* e, void* pois, size_t stride_bytes, int ndim, void* unreliable, unsigned* unreliable_index,
-                           size_t n_unreliable, float zncc_threshold_high, float conv_criterion, void* reliable, size_t reliable_offset,
-                           size_t* n_recovered, size_t* n_remaining, int memory) {
+int oc_hip_merge_recovered(oc_hip_engine* e, void* pois, size_t count, size_t stride_bytes, int ndim, void* unreliable,
+                           unsigned* unreliable_index, size_t n_unreliable, float zncc_threshold_high, float conv_criterion, void* reliable,
+                           size_t reliable_offset, size_t* n_recovered, size_t* n_remaining, int memory) {
     OC_ACTIVATE(e);
     if (!n_recovered || !n_remaining) return fail(OC_HIP_ERR_INVALID, "merge_recovered: null count pointer");
     *n_recovered = 0;
@@ -2046,11 +2111,13 @@ int oc_hip_merge_recovered(oc_hip_engine* e, void* pois, size_t stride_bytes, in
     ochip::PoiSplitParams P;
     OC_TRY(split_params(ndim, stride_bytes, 0.f, zncc_threshold_high, conv_criterion, 1, &P));
     std::lock_guard<std::mutex> lock(e->mu);
+    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
     OC_TRY(order_after_default_stream(e));
     OC_TRY(e->split_scratch.reserve(ochip::poi_split_scratch_words(n_unreliable) * sizeof(unsigned)));
     const int stride_f = (int)(stride_bytes / 4);
     const size_t qb = n_unreliable * stride_bytes, ib = n_unreliable * sizeof(unsigned);
-    size_t totals[2];
+    const size_t rec_bytes = (size_t)P.rec_floats * 4;
+    size_t totals[3];
     if (memory == OC_HIP_DEVICE) {
         // the POIs that stay unreliable are compacted into a scratch copy first (an in-place compaction would overwrite
         // records other threads still have to read), then moved back to the front of the caller's arrays
@@ -2059,8 +2126,10 @@ int oc_hip_merge_recovered(oc_hip_engine* e, void* pois, size_t stride_bytes, in
         unsigned* t_idx = reinterpret_cast<unsigned*>(e->split_tmp.as<char>() + qb);
         OC_HIP_TRY(ochip::launch_poi_split(static_cast<const float*>(unreliable), stride_f, n_unreliable, P, unreliable_index,
                                            static_cast<float*>(reliable), reliable_offset, nullptr, t_rec, t_idx, static_cast<float*>(pois),
-                                           e->split_scratch.as<unsigned>(), e->stream));
+                                           count, e->split_scratch.as<unsigned>(), e->stream));
         OC_TRY(read_split_totals(e, n_unreliable, totals));
+        // an index outside the main queue: the kernel wrote nothing through it; the caller's lists are left as they were
+        if (totals[2]) return fail(OC_HIP_ERR_INVALID, "merge_recovered: an unreliable_index entry is >= the main queue's %zu records", count);
         if (totals[1]) {
             OC_HIP_TRY(hipMemcpyAsync(unreliable, t_rec, totals[1] * stride_bytes, hipMemcpyDeviceToDevice, e->stream));
             OC_HIP_TRY(hipMemcpyAsync(unreliable_index, t_idx, totals[1] * sizeof(unsigned), hipMemcpyDeviceToDevice, e->stream));
@@ -2081,21 +2150,25 @@ int oc_hip_merge_recovered(oc_hip_engine* e, void* pois, size_t stride_bytes, in
     unsigned* d_idx_rem = d_idx_rec + n_unreliable;
     OC_HIP_TRY(hipMemcpyAsync(d_in, unreliable, qb, hipMemcpyHostToDevice, e->stream));
     OC_HIP_TRY(hipMemcpyAsync(d_idx_in, unreliable_index, ib, hipMemcpyHostToDevice, e->stream));
-    OC_HIP_TRY(ochip::launch_poi_split(d_in, stride_f, n_unreliable, P, d_idx_in, d_rec, 0, d_idx_rec, d_rem, d_idx_rem, nullptr,
+    // every index is checked BEFORE anything of the caller's is touched (the host knows the list; the device path has the
+    // kernel's own bound)
+    for (size_t j = 0; j < n_unreliable; j++)
+        if (unreliable_index[j] >= count)
+            return fail(OC_HIP_ERR_INVALID, "merge_recovered: unreliable_index[%zu] = %u is >= the main queue's %zu records", j, unreliable_index[j], count);
+    OC_HIP_TRY(ochip::launch_poi_split(d_in, stride_f, n_unreliable, P, d_idx_in, d_rec, 0, d_idx_rec, d_rem, d_idx_rem, nullptr, 0,
                                        e->split_scratch.as<unsigned>(), e->stream));
     OC_TRY(read_split_totals(e, n_unreliable, totals));
     std::vector<unsigned> rec_idx(totals[0]);
     char* rel_dst = static_cast<char*>(reliable) + reliable_offset * stride_bytes;
     if (totals[0]) {
-        OC_HIP_TRY(hipMemcpyAsync(rel_dst, d_rec, totals[0] * stride_bytes, hipMemcpyDeviceToHost, e->stream));
+        OC_HIP_TRY(copy_records_to_host(rel_dst, d_rec, totals[0], stride_bytes, rec_bytes, e->stream));
         OC_HIP_TRY(hipMemcpyAsync(rec_idx.data(), d_idx_rec, totals[0] * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     }
     if (totals[1]) {
-        OC_HIP_TRY(hipMemcpyAsync(unreliable, d_rem, totals[1] * stride_bytes, hipMemcpyDeviceToHost, e->stream));
+        OC_HIP_TRY(copy_records_to_host(unreliable, d_rem, totals[1], stride_bytes, rec_bytes, e->stream));
         OC_HIP_TRY(hipMemcpyAsync(unreliable_index, d_idx_rem, totals[1] * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     }
     OC_HIP_TRY(hipStreamSynchronize(e->stream));
-    const size_t rec_bytes = (size_t)P.rec_floats * 4;
     for (size_t j = 0; j < totals[0]; j++)
         std::memcpy(static_cast<char*>(pois) + (size_t)rec_idx[j] * stride_bytes, rel_dst + j * stride_bytes, rec_bytes);
     *n_recovered = totals[0];

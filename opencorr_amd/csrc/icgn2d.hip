@@ -125,6 +125,21 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     constexpr int SWEEP_SYNC = (MODE == 4 && LM == 0 && WPB == 8)
                                    ? (OC_SWEEP_BARRIER < 0 ? (DOF == 6 ? (OCC >= 6 ? 2 : 0) : 3) : OC_SWEEP_BARRIER)
                                    : 0;
+    // What keeps the sweep barriers deadlock-free although the waves of a workgroup run different iteration counts and may
+    // leave at any point (guard, out-of-range sample, convergence) -- three invariants of THIS kernel shape:
+    //   (a) one POI per wave and no POI loop: a wave that is done with its POI TERMINATES, and the hardware drops terminated
+    //       waves from the workgroup's barrier count;
+    //   (b) every wave passes the data-carrying barriers (the table fill, COOP's two) strictly BEFORE its first sweep
+    //       barrier, the early leavers through leave() -- so a sweep barrier can only ever pair with sweep barriers;
+    //   (c) nothing after the iteration loop waits on a barrier.
+    // A persistent POI loop, a barrier behind the loop, or a table whose pass count differs between the waves of a workgroup
+    // would break one of them (hang, or sweep barriers pairing with COOP's).  kOnePoiPerWave / kBarrierFreeEpilogue state
+    // (a) and (c) where such a change would have to flip them; tests/test_gpu_parity_2d.py::
+    // test_icgn2d_lockstep_barriers_with_mixed_wave_lifetimes runs workgroups that mix every kind of early leaver with 1-
+    // and stop-iteration POIs.
+    constexpr bool kOnePoiPerWave = true, kBarrierFreeEpilogue = true;
+    static_assert(SWEEP_SYNC == 0 || (kOnePoiPerWave && kBarrierFreeEpilogue && TAB && LM == 0),
+                  "lockstep sweep barriers need one POI per wave, one pass count per workgroup and a barrier-free epilogue");
     // passes whose global loads are issued together in the load-then-use loops outside the interpolation sweep
     // (reference subset, Hessian sweep, numerator pass): one dependent round trip per batch instead of one per pass
     constexpr int kSetupBatch = 6;

@@ -185,9 +185,12 @@ struct PoiSplitParams {
     int zncc_at, conv_at;
     float zncc_low, zncc_high, conv;
 };
-size_t poi_split_scratch_words(size_t count);  // unsigned words of device scratch: per-block counts + the two totals (last two words)
+// unsigned words of device scratch: per-block counts, then the two totals and the bad-index flag (the last three words)
+size_t poi_split_scratch_words(size_t count);
+// main_queue / main_count: class-0 records are also written back to main_queue[index_in[i]] -- never past main_count
+// records (the flag word is raised instead)
 hipError_t launch_poi_split(const float* pois, int stride_floats, size_t count, const PoiSplitParams& p, const unsigned* index_in,
                             float* out0, size_t out0_offset, unsigned* index_out0, float* out1, unsigned* index_out,
-                            float* main_queue, unsigned* scratch, hipStream_t stream);
+                            float* main_queue, size_t main_count, unsigned* scratch, hipStream_t stream);
 
 }  // namespace ochip

@@ -84,13 +84,15 @@ __global__ __launch_bounds__(1024) void poi_split_scan_kernel(unsigned* __restri
 
 // Copies record i to its place: class 0 -> out0[off0 + rank] (and, when a main queue is given, back into
 // main[index_in[i]]; index_out0[rank], if wanted, receives that main-queue index), class 1 -> out1[rank] with
-// index_out[rank] = the POI's index in the MAIN queue.
+// index_out[rank] = the POI's index in the MAIN queue.  A main-queue index >= main_count is never written through:
+// the record still goes to out0, *bad_index is raised and the host reports OC_HIP_ERR_INVALID.
 __global__ __launch_bounds__(kSplitBlock) void poi_split_scatter_kernel(const float* __restrict__ pois, int stride_f, unsigned count,
                                                                          PoiSplitParams P, const unsigned* __restrict__ block_offsets,
                                                                          const unsigned* __restrict__ index_in, float* __restrict__ out0,
                                                                          unsigned off0, unsigned* __restrict__ index_out0,
                                                                          float* __restrict__ out1, unsigned* __restrict__ index_out,
-                                                                         float* __restrict__ main_queue) {
+                                                                         float* __restrict__ main_queue, unsigned main_count,
+                                                                         unsigned* __restrict__ bad_index) {
     __shared__ unsigned wave_base[2][kSplitBlock / 64];
     const unsigned i = blockIdx.x * kSplitBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -111,7 +113,12 @@ __global__ __launch_bounds__(kSplitBlock) void poi_split_scatter_kernel(const fl
     if (c == 0) {
         const unsigned r = b0 + (unsigned)__popcll(m0 & below);
         float* dst = out0 + (size_t)(off0 + r) * stride_f;
-        float* back = main_queue ? main_queue + (size_t)index_in[i] * stride_f : nullptr;
+        float* back = nullptr;
+        if (main_queue) {
+            const unsigned at = index_in[i];
+            if (at < main_count) back = main_queue + (size_t)at * stride_f;
+            else *bad_index = 1u;  // (a plain store of the same value from any number of threads)
+        }
         for (int k = 0; k < P.rec_floats; k++) {
             const float v = rec[k];
             dst[k] = v;
@@ -128,19 +135,23 @@ __global__ __launch_bounds__(kSplitBlock) void poi_split_scatter_kernel(const fl
 
 }  // namespace
 
-size_t poi_split_scratch_words(size_t count) { return 2 * ((count + kSplitBlock - 1) / kSplitBlock) + 2; }
+// per-block counts (2 per block) | totals[2] | bad-index flag
+size_t poi_split_scratch_words(size_t count) { return 2 * ((count + kSplitBlock - 1) / kSplitBlock) + 3; }
 
 hipError_t launch_poi_split(const float* pois, int stride_f, size_t count, const PoiSplitParams& P, const unsigned* index_in,
                             float* out0, size_t off0, unsigned* index_out0, float* out1, unsigned* index_out, float* main_queue,
-                            unsigned* scratch, hipStream_t stream) {
+                            size_t main_count, unsigned* scratch, hipStream_t stream) {
     if (count == 0 || count > 0x7fffffffull || off0 > 0x7fffffffull) return count == 0 ? hipSuccess : hipErrorInvalidValue;
+    if (main_count > 0xffffffffull) main_count = 0xffffffffull;  // indices are 32-bit
     const unsigned nblocks = (unsigned)((count + kSplitBlock - 1) / kSplitBlock);
     unsigned* totals = scratch + 2 * (size_t)nblocks;
+    hipError_t merr = hipMemsetAsync(totals + 2, 0, sizeof(unsigned), stream);
+    if (merr != hipSuccess) return merr;
     (void)hipGetLastError();
     hipLaunchKernelGGL(poi_split_count_kernel, dim3(nblocks), dim3(kSplitBlock), 0, stream, pois, stride_f, (unsigned)count, P, scratch);
     hipLaunchKernelGGL(poi_split_scan_kernel, dim3(1), dim3(1024), 0, stream, scratch, nblocks, totals);
     hipLaunchKernelGGL(poi_split_scatter_kernel, dim3(nblocks), dim3(kSplitBlock), 0, stream, pois, stride_f, (unsigned)count, P, scratch,
-                       index_in, out0, (unsigned)off0, index_out0, out1, index_out, main_queue);
+                       index_in, out0, (unsigned)off0, index_out0, out1, index_out, main_queue, (unsigned)main_count, totals + 2);
     return hipGetLastError();
 }
 

@@ -242,59 +242,104 @@ class _Engine:
         return pois
 
     # -- the two selections of the RegionFit -> re-ICGN loop, on the device --------------------------------------
+    def _record_floats(self):
+        return capi.POI2D_FLOATS if self._ndim == 2 else capi.POI3D_FLOATS
+
+    def _queue_buf(self, x, name, want_mem=None, rows=None, stride_bytes=None):
+        """(pointer, memory kind, row stride in bytes) of a POI queue argument, checked the way compute() checks its
+        queue: float32, C-contiguous rows of at least one record (the record type is the ENGINE's: a 2D queue padded to
+        32 floats per row is still a POI2D queue), CUDA tensor or NumPy array, and -- when other queues of the call are
+        already known -- the same memory kind and row stride."""
+        floats = self._record_floats()
+        if _is_torch(x):
+            p, mem, _ = _buf(x)  # float32, contiguous, on the GPU -- or ValueError
+            ndim, width, stride, n = x.dim(), x.shape[1] if x.dim() == 2 else 0, (x.stride(0) * 4 if x.dim() == 2 else 0), x.shape[0]
+        else:
+            if not isinstance(x, np.ndarray) or x.dtype != np.float32 or not x.flags.c_contiguous:
+                raise ValueError("%s must be a C-contiguous float32 NumPy array or a contiguous float32 CUDA tensor" % name)
+            p, mem = ctypes.c_void_p(x.ctypes.data), capi.HOST
+            ndim, width, stride, n = x.ndim, x.shape[1] if x.ndim == 2 else 0, (x.strides[0] if x.ndim == 2 else 0), x.shape[0]
+        if ndim != 2 or width < floats:
+            raise ValueError("%s must have shape (n, >= %d): POI%dD records" % (name, floats, self._ndim))
+        if want_mem is not None and mem != want_mem:
+            raise ValueError("%s must live in the same memory space as the POI queue" % name)
+        if stride_bytes is not None and stride != stride_bytes:
+            raise ValueError("%s must have the POI queue's row stride (%d bytes, got %d)" % (name, stride_bytes, stride))
+        if rows is not None and n < rows:
+            raise ValueError("%s needs room for %d records (has %d)" % (name, rows, n))
+        return p, mem, stride
+
+    @staticmethod
+    def _index_buf(index, name, want_mem, rows):
+        """pointer of a queue-index list: one 32-bit integer per record, same memory kind as the queues"""
+        if _is_torch(index):
+            import torch
+            if index.dtype not in (torch.int32, torch.uint32) or not index.is_contiguous() or index.dim() != 1 or not index.is_cuda:
+                raise ValueError("%s must be a contiguous 1-d int32 CUDA tensor" % name)
+            mem, n, p = capi.DEVICE, index.shape[0], ctypes.c_void_p(index.data_ptr())
+        else:
+            if not isinstance(index, np.ndarray) or index.dtype not in (np.uint32, np.int32) or index.ndim != 1 or not index.flags.c_contiguous:
+                raise ValueError("%s must be a contiguous 1-d uint32 / int32 NumPy array" % name)
+            mem, n, p = capi.HOST, index.shape[0], ctypes.c_void_p(index.ctypes.data)
+        if mem != want_mem:
+            raise ValueError("%s must live in the same memory space as the POI queue" % name)
+        if n < rows:
+            raise ValueError("%s needs room for %d entries (has %d)" % (name, rows, n))
+        return p
+
     def split_reliable(self, pois, zncc_threshold_low, zncc_threshold_high, conv_criterion, reliable=None, reliable_offset=0):
         """``oc_hip_split_reliable``: order-preserving partition of a finished queue (examples/
         test_3d_reconstruction_sift_icgn2_regfit.cpp:216-229).  Returns ``(reliable, n_reliable, unreliable, index,
         n_unreliable)``: ``reliable[reliable_offset : reliable_offset + n_reliable]`` and ``unreliable[:n_unreliable]`` hold
         the records, ``index[:n_unreliable]`` the queue positions of the unreliable ones.  CUDA tensors stay on the device
-        (the buffers are allocated with ``len(pois)`` records unless ``reliable`` is passed in)."""
+        (the buffers are allocated with ``len(pois)`` records unless ``reliable`` is passed in).  The record type is the
+        engine's (POI2D for 2D engines, POI3D for 3D ones), whatever the row width."""
         self._adopt_stream_of(pois)
-        n, floats = pois.shape
-        ndim = 2 if floats == capi.POI2D_FLOATS else 3
+        reliable_offset = int(reliable_offset)
+        if reliable_offset < 0:
+            raise ValueError("reliable_offset must not be negative")
+        p, mem, stride = self._queue_buf(pois, "pois")
+        n, width = pois.shape
         if _is_torch(pois):
             import torch
-            p, mem, _ = _buf(pois)
             if reliable is None:
-                reliable = torch.empty((reliable_offset + n, floats), dtype=torch.float32, device=pois.device)
-            unreliable = torch.empty((n, floats), dtype=torch.float32, device=pois.device)
+                reliable = torch.empty((reliable_offset + n, width), dtype=torch.float32, device=pois.device)
+            unreliable = torch.empty((n, width), dtype=torch.float32, device=pois.device)
             index = torch.empty((n,), dtype=torch.int32, device=pois.device)
-            rp, up, ip = (ctypes.c_void_p(t.data_ptr()) for t in (reliable, unreliable, index))
-            stride = pois.stride(0) * 4
+            if not _is_torch(reliable) or reliable.device != pois.device:
+                raise ValueError("reliable must be a CUDA tensor on the POI queue's device")
         else:
-            p, mem = ctypes.c_void_p(pois.ctypes.data), capi.HOST
             if reliable is None:
-                reliable = np.zeros((reliable_offset + n, floats), dtype=np.float32)
-            unreliable = np.zeros((n, floats), dtype=np.float32)
+                reliable = np.zeros((reliable_offset + n, width), dtype=np.float32)
+            unreliable = np.zeros((n, width), dtype=np.float32)
             index = np.zeros((n,), dtype=np.uint32)
-            rp, up, ip = (ctypes.c_void_p(a.ctypes.data) for a in (reliable, unreliable, index))
-            stride = pois.strides[0]
-        if reliable.shape[0] < reliable_offset + n:
-            raise ValueError("the reliable buffer needs room for reliable_offset + len(pois) records")
+        rp, _, _ = self._queue_buf(reliable, "reliable", mem, reliable_offset + n, stride)
+        up, _, _ = self._queue_buf(unreliable, "unreliable", mem, n, stride)
+        ip = self._index_buf(index, "index", mem, n)
         n_rel, n_unr = ctypes.c_size_t(), ctypes.c_size_t()
-        capi.check(capi.lib().oc_hip_split_reliable(self._h, p, n, stride, ndim, zncc_threshold_low, zncc_threshold_high, conv_criterion,
+        capi.check(capi.lib().oc_hip_split_reliable(self._h, p, n, stride, self._ndim, zncc_threshold_low, zncc_threshold_high, conv_criterion,
                                                     rp, reliable_offset, up, ip, ctypes.byref(n_rel), ctypes.byref(n_unr), mem))
         return reliable, n_rel.value, unreliable, index, n_unr.value
 
     def merge_recovered(self, pois, unreliable, index, n_unreliable, zncc_threshold_high, conv_criterion, reliable, reliable_offset):
         """``oc_hip_merge_recovered``: after RegionFit + ICGN over ``unreliable[:n_unreliable]`` -- the POIs that now pass go
         back into ``pois`` (at their ``index``) and to ``reliable[reliable_offset:]``, the rest move to the front of
-        ``unreliable`` / ``index``.  Returns ``(n_recovered, n_remaining)``."""
+        ``unreliable`` / ``index``.  Returns ``(n_recovered, n_remaining)``.  All four buffers must share one memory kind
+        (all NumPy or all CUDA tensors on one device), dtype and row stride; an ``index`` entry outside ``pois`` is refused
+        (``OC_HIP_ERR_INVALID``) instead of written through."""
         self._adopt_stream_of(pois)
-        floats = pois.shape[1]
-        ndim = 2 if floats == capi.POI2D_FLOATS else 3
-        if _is_torch(pois):
-            mem = capi.DEVICE
-            pp_, up, ip, rp = (ctypes.c_void_p(t.data_ptr()) for t in (pois, unreliable, index, reliable))
-            stride = pois.stride(0) * 4
-        else:
-            mem = capi.HOST
-            pp_, up, ip, rp = (ctypes.c_void_p(a.ctypes.data) for a in (pois, unreliable, index, reliable))
-            stride = pois.strides[0]
-        if reliable.shape[0] < reliable_offset + n_unreliable:
-            raise ValueError("the reliable buffer needs room for reliable_offset + n_unreliable records")
+        n_unreliable, reliable_offset = int(n_unreliable), int(reliable_offset)
+        if n_unreliable < 0 or reliable_offset < 0:
+            raise ValueError("n_unreliable and reliable_offset must not be negative")
+        pp_, mem, stride = self._queue_buf(pois, "pois")
+        up, _, _ = self._queue_buf(unreliable, "unreliable", mem, n_unreliable, stride)
+        rp, _, _ = self._queue_buf(reliable, "reliable", mem, reliable_offset + n_unreliable, stride)
+        ip = self._index_buf(index, "index", mem, n_unreliable)
+        if mem == capi.DEVICE and not (pois.device == unreliable.device == reliable.device == index.device):
+            raise ValueError("pois, unreliable, index and reliable must live on one device")
         n_rec, n_rem = ctypes.c_size_t(), ctypes.c_size_t()
-        capi.check(capi.lib().oc_hip_merge_recovered(self._h, pp_, stride, ndim, up, ip, n_unreliable, zncc_threshold_high, conv_criterion,
-                                                     rp, reliable_offset, ctypes.byref(n_rec), ctypes.byref(n_rem), mem))
+        capi.check(capi.lib().oc_hip_merge_recovered(self._h, pp_, pois.shape[0], stride, self._ndim, up, ip, n_unreliable, zncc_threshold_high,
+                                                     conv_criterion, rp, reliable_offset, ctypes.byref(n_rec), ctypes.byref(n_rem), mem))
         return n_rec.value, n_rem.value
 
     def compute_one(self, poi):

@@ -320,6 +320,53 @@ def test_icgn2d_coordinate_table_variants(eng, speckle_small, variant, dof):
     assert np.array_equal(_bits(icgn.compute(sa.copy())), _bits(want))
 
 
+@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("dof", [6, 12])
+def test_icgn2d_lockstep_barriers_with_mixed_wave_lifetimes(eng, speckle_small, variant, dof):
+    """The lockstep sweep barriers (icgn2d.hip, SWEEP_SYNC) sit inside the per-iteration sweep of 8-wave workgroups whose
+    waves live for different numbers of iterations.  EVERY workgroup of this queue (8 consecutive POIs, queue order: the
+    queue is below the tile-schedule threshold) holds: a guard reject (zncc < 0 on entry), a POI whose first sweep leaves
+    the image (abort with -3 after ONE sweep), a NaN guess, a POI that converges in its first iteration (it starts from
+    its own converged parameters), a far-off guess that runs to the stop limit (-4), and normal 2-4 iteration POIs.  Must
+    terminate and equal the oracle bit for bit, three times in a row (the barriers carry no data, but a wrong pairing
+    would hang or desynchronise the COOP inverse)."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    r = 16
+    P = oracle.P2
+    xs, ys = synth.poi_grid_2d(h, w, 32, 30, 26)     # 960 POIs = 120 workgroups of 8
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, r, r, pois)
+    prep = oracle.Prepared2D(ref, tar)
+    fn = oracle.icgn2d1 if dof == 6 else oracle.icgn2d2
+    solved = pois.copy()
+    fn(prep, r, r, 0.001, 10, solved, order=oracle.ORDER_LANES, lanes=64)
+    q = pois.copy()
+    slot = np.arange(len(q)) % 8
+    q[slot == 0, P["zncc"]] = -2.0                                   # guard: leaves before any sweep
+    q[slot == 1, P["u"]] = w - 30.0                                   # in range for the guard (|u| < width), outside for the LUT
+    q[slot == 2, P["v"]] = np.nan                                     # guard
+    one = slot == 3                                                   # starts converged: exactly one iteration
+    q[one, 2:14] = solved[one, 2:14]
+    q[slot == 4, P["u"]] += 6.5                                       # far-off guess: wanders to the stop limit or aborts
+    q[slot == 4, P["v"]] -= 5.5
+    want = q.copy()
+    fn(prep, r, r, 0.001, 10, want, order=oracle.ORDER_LANES, lanes=64)
+    it = want[:, P["iteration"]]
+    assert (want[slot == 1, P["zncc"]] == -3.0).all() and (want[slot == 0, P["zncc"]] == -2.0).all()
+    # (ICGN2D2 promotes a first-order guess, src/oc_icgn.cpp:765-770: its second-order terms start at zero -> two iterations)
+    assert (it[one & (want[:, P["zncc"]] > 0)] <= (1 if dof == 6 else 3)).mean() > 0.9
+    assert ((want[slot == 4, P["zncc"]] == -4.0) | (it[slot == 4] >= 6)).mean() > 0.5    # long-lived waves in (almost) every workgroup
+    icgn = (eng.ICGN2D1 if dof == 6 else eng.ICGN2D2)(r, r, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    icgn.set_tuning("icgn2d_variant", variant)
+    for _ in range(3):
+        assert np.array_equal(_bits(icgn.compute(q.copy())), _bits(want))
+
+
 def test_icgn2d_tile_schedule_changes_no_bits(eng, speckle_small):
     """The locality schedule (poi_order.hip) only reorders the independent per-POI solves: a queue long
     enough to engage it gives the same bits as queue order, and the same bits as the oracle."""

@@ -314,3 +314,83 @@ def test_split_reliable_edge_cases():
     assert n_rel == 0 and n_unr == int((~np.isnan(q[:1000, P3["zncc"]])).sum())
     assert g.split_reliable(q[:0], 0.7, 0.9, 0.001)[1::3] == (0, 0)
     assert g.merge_recovered(q, unr, idx, 0, 0.9, 0.001, rel, 0) == (0, 0)
+
+
+def test_split_merge_padded_rows_bad_indices_and_buffer_checks():
+    """Round-3 advisor findings on the two selection calls:
+    * the record type is the ENGINE's, not guessed from the row width: a POI2D queue padded to 32 floats per row is split
+      on result.zncc = float 16 / convergence = float 18 (a POI3D reading would look at floats 18 / 20),
+    * HOST queues with stride > record size: the bytes between records in `reliable` / `unreliable` / the main queue are
+      the caller's and stay untouched (the DEVICE path never touched them),
+    * an `unreliable_index` entry outside the main queue is refused -- nothing is written through it, on either path,
+    * CPU torch tensors, wrong dtypes, mismatched strides or memory kinds raise ValueError instead of reaching a kernel."""
+    import torch
+    import opencorr_amd as eng
+    import oracle
+    P = oracle.P2
+    g = eng.ICGN2D1(8, 8, 0.001, 10)
+    rng = np.random.default_rng(12)
+    n, width = 5000, 32
+    q = np.full((n, width), 7.5, np.float32)       # floats 25..31: the caller's own payload
+    q[:, :25] = 0
+    q[:, 0] = np.arange(n)
+    q[:, P["zncc"]] = rng.uniform(0.5, 1.0, n)
+    q[:, P["convergence"]] = rng.uniform(0, 0.002, n)
+    q[:, 20] = 5.0                                  # POI3D's convergence slot: must play no role
+    q[::53, P["zncc"]] = np.nan
+    rel_w, unr_w, idx_w = _host_split(q[:, :25], 0.7, 0.9, 0.001, P)
+    for resident in (False, True):
+        queue = torch.from_numpy(q).to("cuda:0") if resident else q.copy()
+        if resident:
+            rel0 = torch.full((n + 3, width), -9.0, dtype=torch.float32, device="cuda:0")
+        else:
+            rel0 = np.full((n + 3, width), -9.0, np.float32)
+        rel, n_rel, unr, idx, n_unr = g.split_reliable(queue, 0.7, 0.9, 0.001, reliable=rel0, reliable_offset=3)
+        relh, unrh, idxh = (t.cpu().numpy() if resident else t for t in (rel, unr, idx))
+        assert n_rel == len(rel_w) and n_unr == len(unr_w)
+        assert np.array_equal(_bits(relh[3:3 + n_rel, :25]), _bits(rel_w)) and np.array_equal(_bits(unrh[:n_unr, :25]), _bits(unr_w))
+        assert np.array_equal(np.asarray(idxh[:n_unr], dtype=np.uint32), idx_w)
+        assert (relh[:3] == -9.0).all() and (relh[3:3 + n_rel, 25:] == -9.0).all()   # padding and the records before the offset
+        # merge: make every second unreliable POI pass, mark their payload; the main queue's padding must survive
+        unr_m = unrh.copy()
+        unr_m[:n_unr:2, P["zncc"]] = 0.95
+        unr_m[:n_unr:2, P["convergence"]] = 0.0005
+        unr_m[:, 25:] = 3.25
+        unr_in = torch.from_numpy(unr_m).to("cuda:0") if resident else unr_m.copy()
+        main_before = queue.cpu().numpy().copy() if resident else queue.copy()
+        n_rec, n_rem = g.merge_recovered(queue, unr_in, idx, n_unr, 0.9, 0.001, rel, 3 + n_rel)
+        main = queue.cpu().numpy() if resident else queue
+        relh = rel.cpu().numpy() if resident else rel
+        ok = np.zeros(n_unr, bool)
+        ok[::2] = True
+        assert (n_rec, n_rem) == (int(ok.sum()), int((~ok).sum()))
+        assert np.array_equal(_bits(main[idx_w[ok], :25]), _bits(unr_m[:n_unr][ok][:, :25]))
+        assert np.array_equal(_bits(main[:, 25:]), _bits(main_before[:, 25:]))       # only the record's own bytes are written back
+        assert np.array_equal(_bits(relh[3 + n_rel:3 + n_rel + n_rec, :25]), _bits(unr_m[:n_unr][ok][:, :25]))
+        assert (relh[3 + n_rel:3 + n_rel + n_rec, 25:] == -9.0).all()
+        # an index past the main queue is refused and writes nothing
+        bad_idx = idxh.copy()
+        bad_idx[0] = n + 10
+        bad = torch.from_numpy(bad_idx.astype(np.int32)).to("cuda:0") if resident else bad_idx.astype(np.uint32)
+        snap = queue.cpu().numpy().copy() if resident else queue.copy()
+        unr_again = torch.from_numpy(unr_m).to("cuda:0") if resident else unr_m.copy()
+        with pytest.raises(RuntimeError, match="unreliable_index"):
+            g.merge_recovered(queue[:n], unr_again, bad, n_unr, 0.9, 0.001, rel, 0)
+        after = queue.cpu().numpy() if resident else queue
+        assert np.array_equal(_bits(after[idx_w[0]]), _bits(snap[idx_w[0]]))
+    # argument checks: no kernel may see these
+    dq = torch.from_numpy(q).to("cuda:0")
+    with pytest.raises(ValueError):
+        g.split_reliable(torch.from_numpy(q), 0.7, 0.9, 0.001)                      # CPU torch tensor
+    with pytest.raises(ValueError):
+        g.split_reliable(q.astype(np.float64), 0.7, 0.9, 0.001)
+    with pytest.raises(ValueError):
+        g.split_reliable(q[:, :20].copy(), 0.7, 0.9, 0.001)                         # shorter than a POI2D record
+    with pytest.raises(ValueError):
+        g.split_reliable(dq, 0.7, 0.9, 0.001, reliable=np.zeros((n, width), np.float32))   # mixed memory kinds
+    with pytest.raises(ValueError):
+        g.merge_recovered(dq, torch.from_numpy(unr_m), idx, 1, 0.9, 0.001, rel, 0)   # CPU tensor among device queues
+    with pytest.raises(ValueError):
+        g.merge_recovered(q, unr_m, idx_w.astype(np.int64), 1, 0.9, 0.001, rel_w, 0)
+    with pytest.raises(ValueError):
+        g.merge_recovered(q, unr_m[:, :25].copy(), idx_w, 1, 0.9, 0.001, np.zeros((n, width), np.float32), 0)  # stride mismatch
