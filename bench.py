@@ -16,9 +16,11 @@ pair, r = 16 (33 x 33 subset, 32 x 32 FFTCC window), 500 x 500 = 250 000 POIs,
 conv 1e-3, stop 10.  N > 1 is weak scaling: 250 000 POIs per GPU cut from one
 N*250 000-POI queue over a pair replicated on every GPU (rendered on rank 0, broadcast to the others).  The image grows with N so that
 the POI pitch -- i.e. how much neighbouring subsets overlap, which sets the cache behaviour
-of the kernel -- stays what it is at N = 1: 4096 x 8192 with 1000 x 500 POIs at N = 2,
-8192 x 8192 with 1000 x 1000 at N = 4; N = 8 is BASELINE config "D" as written (8192 x 8192,
-1414 x 1414 POIs; a denser grid, 8192^2 being the largest image the 32-bit LUT offsets address).
+of the kernel -- stays what it is at N = 1 for EVERY N: a x b tiles of 4096 x 4096 px with 500 x 500 POIs each, a = the largest
+divisor of N up to sqrt(N), b = N / a (`weak_layout`): 4096 x 8192 with 1000 x 500 POIs at N = 2, 8192 x 8192 with 1000 x 1000 at
+N = 4, 8192 x 16384 with 2000 x 1000 at N = 8 (2^27 px: inside the 2^28 px the per-plane 32-bit LUT offsets address,
+check_image2d_limits in capi.hip; N <= 16).  BASELINE config "D" as written (8192 x 8192, 1414 x 1414 POIs: a denser grid) is
+`--scaling strong`.
 
 For N > 1 the all-gather of step k overlaps the correlation of step k+1 (double-buffered
 queues, `async_op=True`): a production pipeline streams image pairs, and xGMI moving one
@@ -105,14 +107,25 @@ def parse():
     ap.add_argument("--settle", type=int, default=0,
                     help="extra untimed steps BEFORE the W warm-up steps (experiments only: the default run warms up with exactly "
                          "W steps, as the bench contract says; a non-zero value is reported in the JSON line)")
-    ap.add_argument("--size", type=int, default=0, help="override image side (debug)")
-    ap.add_argument("--pois", type=int, default=0, help="override POIs per GPU side (debug)")
+    ap.add_argument("--size", type=int, default=0, help="override the side of one GPU's image tile (debug; default 4096)")
+    ap.add_argument("--pois", type=int, default=0, help="override POIs per GPU side (debug; default 500)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the side measurements (CPU baseline, host-queue rate): profiler runs")
     ap.add_argument("--cpu-sample", type=int, default=125000)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="strong: BASELINE config D (8192^2, 1414 x 1414 POIs) cut into N blocks, whatever N is")
     return ap.parse_args()
+
+
+def weak_layout(world, tile=4096, per_side=POIS_PER_GPU_SIDE):
+    """Weak scaling that keeps the POI pitch (and with it the per-POI cache behaviour) of N = 1 at every N: the image is
+    a x b tiles of `tile` x `tile` pixels, each carrying per_side x per_side POIs; a = the largest divisor of N that is
+    <= sqrt(N).  Returns (height, width, nx, ny)."""
+    if world < 1 or world > 16:
+        raise SystemExit("bench.py: weak scaling is defined for 1 <= N <= 16 (2^28-pixel image limit), got %d" % world)
+    a = max(d for d in range(1, int(world ** 0.5) + 1) if world % d == 0)
+    b = world // a
+    return a * tile, b * tile, b * per_side, a * per_side
 
 
 def algorithmic_bytes_icgn2d1(pois_np, rx, ry):
@@ -225,24 +238,12 @@ def main():
     strong = args.scaling == "strong"
     if strong:
         n_total = 1414 * 1414
-    # image (height, width) and POI grid (nx, ny) per world size: constant POI pitch up to N = 4
+    # image (height, width) and POI grid (nx, ny) per world size: constant POI pitch at every N (weak_layout)
     if strong:
         height = width = 8192
         nx = ny = 1414
-    elif args.size:
-        height = width = args.size
-        nx = int(np.floor(np.sqrt(n_total)))
-        ny = -(-n_total // nx)
-    elif world == 1:
-        height, width, nx, ny = 4096, 4096, per_side, per_side
-    elif world == 2:
-        height, width, nx, ny = 4096, 8192, 2 * per_side, per_side
-    elif world == 4:
-        height, width, nx, ny = 8192, 8192, 2 * per_side, 2 * per_side
     else:
-        height = width = 8192
-        nx = int(np.floor(np.sqrt(n_total)))
-        ny = -(-n_total // nx)
+        height, width, nx, ny = weak_layout(world, args.size or 4096, per_side)
     t0 = time.time()
     # ONE image pair for all ranks: rank 0 renders it, the others receive it (the GPU renderer adds its speckles with float
     # atomics, so two renderings of the same seed differ in the last bits of a few pixels -- and with them ~40 of 250 000

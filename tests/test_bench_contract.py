@@ -4,6 +4,7 @@ import ast
 import os
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -99,3 +100,21 @@ def test_the_default_run_has_no_hidden_warmup():
     finally:
         sys.argv = argv
     assert a.settle == 0 and a.gpus == 1
+
+
+def test_weak_layout_keeps_the_poi_pitch_at_every_n():
+    """Weak scaling: the image is a x b tiles of 4096^2 px with 500 x 500 POIs each, so the POI pitch (how much
+    neighbouring subsets overlap, i.e. the kernel's cache behaviour per POI) is N = 1's at every N -- also at N = 8, which
+    round 3 ran on a denser grid -- and the image stays inside the 2^28-pixel limit of the 32-bit LUT plane offsets."""
+    import bench
+    base = bench.weak_layout(1)
+    assert base == (4096, 4096, 500, 500)
+    for n in range(1, 17):
+        h, w, nx, ny = bench.weak_layout(n)
+        assert nx * ny == n * 250000 and h * w == n * 4096 * 4096 <= 2 ** 28
+        assert (w / nx, h / ny) == (4096 / 500, 4096 / 500)
+        assert h <= w < 2 ** 22
+    assert bench.weak_layout(8) == (8192, 16384, 2000, 1000)
+    assert bench.weak_layout(2, 512, 40) == (512, 1024, 80, 40)
+    with pytest.raises(SystemExit):
+        bench.weak_layout(17)

@@ -277,6 +277,97 @@ def test_bench_nccl_backend_at_world_size_one():
     assert rec["config"]["converged_pois"] >= 0.99 * rec["config"]["total_pois"]
 
 
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_bench_control_flow_at_n2_and_n8_on_one_device(nranks):
+    """The WHOLE N > 1 control flow of bench.py with N = 2 and N = 8 ranks on the one GPU of this box (OC_BENCH_ONE_DEVICE=1:
+    every rank on device 0, gloo instead of RCCL -- the RCCL backend itself runs in the test above): the pitch-preserving
+    weak layout (a x b image tiles), the block cuts of an N-rank queue, the broadcast image pair, double-buffered queues
+    with overlapped all-gathers, barriers, max-over-ranks, and -- strict mode -- multi_gpu_check for N ranks: every rank's
+    block of the gathered queue equals what it computed and rank 0 re-solves a sample of every other rank's block bit for
+    bit.  No scaling number comes out of this (N processes share one GPU); it shows the N = 8 path EXECUTES."""
+    import json
+    import socket
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, OC_BENCH_ONE_DEVICE="1", OC_BENCH_STRICT="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    tile, per_side = 512, 40
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nranks), "--steps", "2", "--warmup", "1",
+           "--size", str(tile), "--pois", str(per_side), "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    chk = rec["multi_gpu_check"]
+    assert rec["n_gpus"] == nranks and rec["scaling"] == "weak" and chk["world_size"] == nranks and chk["backend"] == "gloo"
+    assert chk["ok"] and chk["problems"] == [] and chk["gathered_equals_local_bits"] and chk["resolved_sample_bit_identical"]
+    assert chk["resolved_sample_of_other_ranks"] >= (nranks - 1) * 500
+    assert not chk["devices_distinct"]                       # one GPU: said so, not hidden
+    assert rec["config"]["total_pois"] == nranks * per_side * per_side
+    a = {2: 1, 8: 2}[nranks]
+    assert "%dx%d speckle pair" % (nranks // a * tile, a * tile) in rec["config"]["workload"]   # width x height
+    assert rec["config"]["converged_pois"] >= 0.99 * rec["config"]["total_pois"]
+    assert chk["ms_per_step_gather_not_overlapped"] > 0
+
+
+def test_group_of_eight_on_config_d_queue():
+    """oc_hip_set_devices with EIGHT members over BASELINE config D's whole queue (8192^2 pair, 1414 x 1414 = 1 999 396 POIs,
+    the 8-GPU configuration), device 0 named eight times: eight engines with their own tables (8 x 4.3 GB), eight streams,
+    eight blocks of ceil(n / 8) records pulled and pushed with peer copies, the all-gather into every member's mirror
+    (emulated by peer copies: a communicator cannot hold a device twice) -- bit-identical to the single engine, for the
+    FFTCC2D -> ICGN2D1 sequence on a DEVICE queue.  The shard cuts and the padded last block of an 8-way split of this
+    queue are thereby executed under the driver's eyes; what stays unexecuted without a node is only RCCL over distinct
+    devices."""
+    import torch
+    import opencorr_amd
+    from opencorr_amd import synth
+    dev = torch.device("cuda", 0)
+    side, r, nside = 8192, 16, 1414
+    ref, tar = synth.speckle_pair_2d(side, side, seed=20260925, device=dev)
+    xs, ys = synth.poi_grid_2d(side, side, nside, nside, r + 8)
+    n = len(xs)
+    assert n == 1999396 and n % 8 != 0
+    pristine = torch.from_numpy(opencorr_amd.make_pois2d(xs, ys)).to(dev)
+    f1 = opencorr_amd.FFTCC2D(r, r)
+    f1.set_images(ref, tar)
+    g1 = opencorr_amd.ICGN2D1(r, r, 0.001, 10)
+    g1.share_images(f1)
+    g1.prepare()
+    want = pristine.clone()
+    f1.compute(want)
+    g1.compute(want)
+    torch.cuda.synchronize()
+    want = want.cpu().numpy()
+    g1.close()
+    f1.close()
+    f8 = opencorr_amd.FFTCC2D(r, r)
+    f8.set_devices([0] * 8)
+    f8.set_images(ref, tar)
+    g8 = opencorr_amd.ICGN2D1(r, r, 0.001, 10)
+    g8.set_devices([0] * 8)
+    g8.set_images(ref, tar)
+    g8.prepare()
+    g8.set_tuning("group_allgather", 1)
+    assert g8.devices() == [0] * 8
+    q = pristine.clone()
+    f8.compute(q)
+    g8.compute(q)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(q.cpu().numpy()), _bits(want))
+    floats = want.shape[1]
+    per = -(-n // 8)
+    for member in (0, 3, 7):
+        ptr, block = g8.group_queue(member)
+        assert block == per * floats * 4
+        mirror = _download(ptr, 8 * block).reshape(8 * per, floats)[:n]
+        assert np.array_equal(_bits(mirror), _bits(want)), member
+    g8.close()
+    f8.close()
+
+
 def test_host_pipeline_chunks_change_no_bits():
     """Host queues travel in chunks (H2D / kernels / D2H of neighbouring chunks overlap): same bits as one piece and as
     the device-resident queue."""
