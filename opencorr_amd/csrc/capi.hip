@@ -187,7 +187,8 @@ struct oc_hip_engine {
     bool self_adaptive = false;  // DIC::setSelfAdaptive
     int icgn2d_xcd = 1;
     int fftcc2d_fused = 1;    // single-kernel FFTCC2D when the window is 32 x 32
-    int fftcc3d_fused = 1;    // single-kernel FFTCC3D when the window is 32 x 32 x 32
+    int fftcc3d_fused = 1;    // single-kernel FFTCC3D for cubic windows of side 8 ... 64 (three kernels by size)
+    int fftcc3d_planes_blocks = 0;  // persistent workgroups (= scratch volumes) of the plane-wise kernel; 0 = 256
     // host-queue pipeline (compute_host): the queue travels in chunks, copies of one chunk overlap the kernels of
     // its neighbours; one event per chunk orders the copy-out stream behind the kernels
     hipStream_t copy_stream = nullptr, copy_in_stream = nullptr;
@@ -605,14 +606,28 @@ size_t fftcc3d_chunk_limit() {
 int run_fftcc3d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     if (!e->img || e->img->ndim != 3) return fail(OC_HIP_ERR_INVALID, "FFTCC3D: set_images3d has not been called");
     const ImagePair& im = *e->img;
-    if (e->fftcc3d_fused && ochip::fftcc3d_fused_supported(e->rx, e->ry, e->rz)) {
+    const bool fused32 = ochip::fftcc3d_fused_supported(e->rx, e->ry, e->rz);
+    if (e->fftcc3d_fused && ochip::fftcc3d_planes_supported(e->rx, e->ry, e->rz)) {
+        // cubes too large for the chip: persistent workgroups, each with a private complex N^3 scratch volume (fftcc3d_planes.hip)
+        ochip::Fftcc3dParams P = {im.ref_ptr(), im.tar_ptr(), im.dz, im.dy, im.dx, e->rx, e->ry, e->rz};
+        int blocks = e->fftcc3d_planes_blocks > 0 ? e->fftcc3d_planes_blocks : 256;
+        blocks = (blocks + 7) / 8 * 8;
+        if ((size_t)blocks > (count + 7) / 8 * 8) blocks = (int)((count + 7) / 8 * 8);
+        OC_TRY(e->win.reserve(ochip::fftcc3d_planes_scratch_bytes(e->rx, blocks)));
+        ProfScope prof(e);
+        hipError_t err = ochip::launch_fftcc3d_planes(P, d_pois, stride_f, count, e->win.p, blocks, e->stream);
+        if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "plane-wise FFTCC3D kernel launch failed: %s", hipGetErrorString(err));
+        return OC_HIP_OK;
+    }
+    if (e->fftcc3d_fused && (fused32 || ochip::fftcc3d_fusedn_supported(e->rx, e->ry, e->rz))) {
         ochip::Fftcc3dParams P = {im.ref_ptr(), im.tar_ptr(), im.dz, im.dy, im.dx, e->rx, e->ry, e->rz};
         ProfScope prof(e);
         const size_t kMaxGrid = 1u << 30;
         for (size_t first = 0; first < count; first += kMaxGrid) {
             const size_t n = (count - first) < kMaxGrid ? (count - first) : kMaxGrid;
-            hipError_t err = ochip::launch_fftcc3d_fused(P, d_pois + first * (size_t)stride_f, stride_f, n, e->icgn2d_xcd != 0,
-                                                         e->stream);
+            float* q = d_pois + first * (size_t)stride_f;
+            hipError_t err = fused32 ? ochip::launch_fftcc3d_fused(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream)
+                                     : ochip::launch_fftcc3d_fusedn(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream);
             if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "fused FFTCC3D kernel launch failed: %s", hipGetErrorString(err));
         }
         return OC_HIP_OK;
@@ -1114,6 +1129,7 @@ static int clone_engine(const oc_hip_engine* e, int device, oc_hip_engine** out)
     r->icgn2d_xcd = e->icgn2d_xcd;
     r->fftcc2d_fused = e->fftcc2d_fused;
     r->fftcc3d_fused = e->fftcc3d_fused;
+    r->fftcc3d_planes_blocks = e->fftcc3d_planes_blocks;
     r->host_chunk = e->host_chunk;
     r->group_allgather = e->group_allgather;
     r->group_force_rccl = e->group_force_rccl;
@@ -1343,6 +1359,9 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
         e->fftcc2d_fused = value == 2 ? 2 : (value != 0);
     } else if (k == "fftcc3d_fused") {
         e->fftcc3d_fused = value != 0;
+    } else if (k == "fftcc3d_planes_blocks") {
+        if (value < 0 || value > 4096) return fail(OC_HIP_ERR_INVALID, "fftcc3d_planes_blocks must be 0 (default) ... 4096");
+        e->fftcc3d_planes_blocks = value;
     } else if (k == "host_chunk") {
         if (value < 0 || (value > 0 && value < 16384)) return fail(OC_HIP_ERR_INVALID, "host_chunk must be 0 (off) or >= 16384 POIs");
         e->host_chunk = value;

@@ -10,6 +10,10 @@
 
 #include <type_traits>
 
+// The mixed-radix transforms are plain arithmetic on register arrays: they also compile for the HOST, where
+// tests/cpp/fft_host_check.hip runs every supported size against a double-precision DFT (no GPU needed).
+#define OC_FFT_FN __host__ __device__ __forceinline__
+
 namespace ochip {
 namespace fftdev {
 
@@ -21,7 +25,7 @@ __device__ constexpr float kSin32[16] = {0.000000000e+00f, 1.950903220e-01f, 3.8
 // complex numbers as 2-wide vectors (re, im): additions and the twiddle products then run on the packed-fp32
 // pipe (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), one instruction per complex operation
 typedef float c2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ c2 mkc(float re, float im) {
+OC_FFT_FN c2 mkc(float re, float im) {
     c2 r = {re, im};
     return r;
 }
@@ -29,7 +33,7 @@ __device__ __forceinline__ c2 mkc(float re, float im) {
 // d * exp(-/+ i*angle) with (c, s) = (cos, sin) of the angle; INV selects the + sign:
 // forward (d.x c + d.y s, d.y c - d.x s), inverse (d.x c - d.y s, d.y c + d.x s)
 template <bool INV>
-__device__ __forceinline__ c2 cmul_tw(c2 d, float c, float s) {
+OC_FFT_FN c2 cmul_tw(c2 d, float c, float s) {
 #pragma clang fp contract(fast)
     return d * c + d.yx * (INV ? mkc(-s, s) : mkc(s, -s));
 }
@@ -82,12 +86,19 @@ __device__ __forceinline__ void fft32(c2 (&v)[32]) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Mixed-radix transforms for window sides other than 32 (fftcc2d_fusedn.hip): N = product of 2, 3, 4, 5.
+// Mixed-radix transforms for window sides other than 32 (fftcc2d_fusedn.hip): N = product of 2, 3, 4, 5 and -- round 4 --
+// of any odd primes up to 31 (7, 11, 13 for the sides 14, 22, 26, 28, 42, 44, 52, 56; 17 ... 31 for 34, 38, 46, 58, 62).
 // One decimation-in-frequency step per factor R (N = R * M): the R elements n2 + M*j are transformed, twiddled by
 // W_N^(n2*s) and left in place; the R blocks of M elements are then transformed recursively.  Everything is unrolled
 // at compile time on register arrays; X[k] ends in v[fft_pos(N, k)].
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int fft_radix(int n) { return n % 4 == 0 ? 4 : n % 2 == 0 ? 2 : n % 3 == 0 ? 3 : n % 5 == 0 ? 5 : n; }
+constexpr int fft_smallest_odd_factor(int n) {
+    for (int p = 3; p * p <= n; p += 2)
+        if (n % p == 0) return p;
+    return n;
+}
+constexpr int fft_radix(int n) { return n % 4 == 0 ? 4 : n % 2 == 0 ? 2 : fft_smallest_odd_factor(n); }
+constexpr int kFftMaxPrime = 31;
 constexpr int fft_pos(int n, int idx) {
     int pos = 0;
     while (n > 1) {
@@ -103,16 +114,80 @@ constexpr int fft_pos(int n, int idx) {
 // `#pragma unroll`, the loop index is a constant EXPRESSION inside the body, so fft_pos() and the twiddle indices are
 // evaluated by the front end (a run-time fft_pos() would turn the register arrays into scratch memory).
 template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
+OC_FFT_FN void static_for(F&& f) {
     if constexpr (B < E) {
         f(std::integral_constant<int, B>{});
         static_for<B + 1, E>(f);
     }
 }
 
-// cos / sin of 2*pi*k / N for the supported top-level sizes (generated: tools/gen_twiddles.py)
+// cos / sin of 2*pi*k / N.  The sizes of rounds 1-3 keep their generated tables below (tools/gen_twiddles.py: the bits
+// those kernels were validated with); every other size takes the primary template, whose table the front end computes:
+// double-precision Taylor series on an argument reduced to [0, pi/4] by the octant symmetries (error < 1e-16, then ONE
+// rounding to float -- the same values the generated tables hold).
+namespace twdetail {
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double sin_small(double x) {  // |x| <= pi/4
+    const double x2 = x * x;
+    double term = x, sum = x;
+    for (int n = 1; n <= 12; n++) {
+        term = -term * x2 / ((2.0 * n) * (2.0 * n + 1.0));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double cos_small(double x) {
+    const double x2 = x * x;
+    double term = 1.0, sum = 1.0;
+    for (int n = 1; n <= 12; n++) {
+        term = -term * x2 / ((2.0 * n - 1.0) * (2.0 * n));
+        sum += term;
+    }
+    return sum;
+}
+// (cos, sin) of 2*pi*k/n with exact symmetries: k is reduced in integers, so cos(pi/2) etc. come out as exact zeros
+// only where the generated tables have their 6e-17 -- irrelevant after rounding of the products, but the sign
+// structure (which outputs are exact mirror images) is what keeps X(N-k) = conj X(k) tight for real inputs
+constexpr double cos2pi(int k, int n) {
+    k %= n;
+    if (k < 0) k += n;
+    if (2 * k > n) k = n - k;          // cos is even about pi
+    if (4 * k > n) return -cos2pi(n - 2 * k, 2 * n) ;  // cos(x) = -cos(pi - x): pi - 2 pi k / n = 2 pi (n - 2k) / (2n)
+    if (8 * k > n) return sin_small(2.0 * kPi * (n - 4 * k) / (4.0 * n));  // cos(x) = sin(pi/2 - x)
+    return cos_small(2.0 * kPi * k / n);
+}
+constexpr double sin2pi(int k, int n) {
+    k %= n;
+    if (k < 0) k += n;
+    if (2 * k > n) return -sin2pi(n - k, n);
+    if (4 * k > n) return sin2pi(n - 2 * k, 2 * n);    // sin(x) = sin(pi - x)
+    if (8 * k > n) return cos_small(2.0 * kPi * (n - 4 * k) / (4.0 * n));  // sin(x) = cos(pi/2 - x)
+    return sin_small(2.0 * kPi * k / n);
+}
 template <int N>
-struct Twiddle;
+struct Table {
+    float v[N];
+    constexpr float operator[](int i) const { return v[i]; }
+};
+template <int N>
+constexpr Table<N> make_cos() {
+    Table<N> t{};
+    for (int k = 0; k < N; k++) t.v[k] = (float)cos2pi(k, N);
+    return t;
+}
+template <int N>
+constexpr Table<N> make_sin() {
+    Table<N> t{};
+    for (int k = 0; k < N; k++) t.v[k] = (float)sin2pi(k, N);
+    return t;
+}
+}  // namespace twdetail
+
+template <int N>
+struct Twiddle {
+    static constexpr twdetail::Table<N> c = twdetail::make_cos<N>();
+    static constexpr twdetail::Table<N> s = twdetail::make_sin<N>();
+};
 
 template <>
 struct Twiddle<20> {
@@ -189,19 +264,19 @@ struct Twiddle<64> {
 
 // multiplication by -i (forward) / +i (inverse)
 template <bool INV>
-__device__ __forceinline__ c2 rot90(c2 d) {
+OC_FFT_FN c2 rot90(c2 d) {
     return INV ? mkc(-d.y, d.x) : mkc(d.y, -d.x);
 }
 
 template <bool INV>
-__device__ __forceinline__ void dft2(c2& a, c2& b) {
+OC_FFT_FN void dft2(c2& a, c2& b) {
     const c2 t = a + b;
     b = a - b;
     a = t;
 }
 
 template <bool INV>
-__device__ __forceinline__ void dft3(c2& a0, c2& a1, c2& a2) {
+OC_FFT_FN void dft3(c2& a0, c2& a1, c2& a2) {
 #pragma clang fp contract(fast)
     const c2 t = a1 + a2, d = rot90<INV>((a1 - a2) * 8.6602540378e-01f);  // sin(2 pi / 3), times -/+ i
     const c2 m = a0 - t * 0.5f;
@@ -211,7 +286,7 @@ __device__ __forceinline__ void dft3(c2& a0, c2& a1, c2& a2) {
 }
 
 template <bool INV>
-__device__ __forceinline__ void dft4(c2& a0, c2& a1, c2& a2, c2& a3) {
+OC_FFT_FN void dft4(c2& a0, c2& a1, c2& a2, c2& a3) {
     const c2 s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = rot90<INV>(a1 - a3);
     a0 = s02 + s13;
     a1 = d02 + d13;
@@ -220,7 +295,7 @@ __device__ __forceinline__ void dft4(c2& a0, c2& a1, c2& a2, c2& a3) {
 }
 
 template <bool INV>
-__device__ __forceinline__ void dft5(c2& a0, c2& a1, c2& a2, c2& a3, c2& a4) {
+OC_FFT_FN void dft5(c2& a0, c2& a1, c2& a2, c2& a3, c2& a4) {
 #pragma clang fp contract(fast)
     constexpr float c1 = 3.0901699437e-01f, c2_ = -8.0901699437e-01f, s1 = 9.5105651630e-01f, s2 = 5.8778525229e-01f;
     const c2 p14 = a1 + a4, m14 = a1 - a4, p23 = a2 + a3, m23 = a2 - a3;
@@ -233,15 +308,51 @@ __device__ __forceinline__ void dft5(c2& a0, c2& a1, c2& a2, c2& a3, c2& a4) {
     a3 = r2 - i2;
 }
 
+// P-point DFT for an odd prime P on the elements v[OFF + j * M], j < P, in place (the symmetric form: with
+// p_j = a_j + a_(P-j), m_j = a_j - a_(P-j), j = 1 .. H = (P-1)/2:
+//   X_0 = a_0 + sum p_j,   X_k, X_(P-k) = (a_0 + sum_j p_j cos(2 pi j k / P))  -/+  i (sum_j m_j sin(2 pi j k / P))
+// -- 2 H^2 multiply-adds instead of the (P-1)^2 complex products of the plain sum).  The inputs are dead once p, m are
+// formed, so the outputs land in their registers.
+template <bool INV, int P, int OFF, int M, int LEN>
+OC_FFT_FN void dft_prime(c2 (&v)[LEN]) {
+#pragma clang fp contract(fast)
+    constexpr int H = (P - 1) / 2;
+    c2 ps[H], ms[H];
+    static_for<0, H>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const c2 a = v[OFF + (j + 1) * M], b = v[OFF + (P - 1 - j) * M];
+        ps[j] = a + b;
+        ms[j] = a - b;
+    });
+    const c2 a0 = v[OFF];
+    c2 total = a0;
+    static_for<0, H>([&](auto jc) { total = total + ps[decltype(jc)::value]; });
+    static_for<1, H + 1>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        c2 re = a0, im = mkc(0.f, 0.f);
+        static_for<0, H>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int idx = ((j + 1) * k) % P;
+            constexpr float cc = Twiddle<P>::c[idx], ss = Twiddle<P>::s[idx];
+            re = re + ps[j] * cc;
+            im = im + ms[j] * ss;
+        });
+        const c2 ri = rot90<INV>(im);  // forward: -i * im
+        v[OFF + k * M] = re + ri;
+        v[OFF + (P - k) * M] = re - ri;
+    });
+    v[OFF] = total;
+}
+
 template <bool INV, int TOP, int M, int OFF, int LEN, int S, int R>
-__device__ __forceinline__ void fft_mixed_blocks(c2 (&v)[LEN]);
+OC_FFT_FN void fft_mixed_blocks(c2 (&v)[LEN]);
 
 // N-point transform on v[OFF .. OFF+N); TOP is the size whose twiddle table is used (TOP % N == 0)
 template <bool INV, int TOP, int N, int OFF, int LEN>
-__device__ __forceinline__ void fft_mixed_at(c2 (&v)[LEN]) {
+OC_FFT_FN void fft_mixed_at(c2 (&v)[LEN]) {
     if constexpr (N > 1) {
         constexpr int R = fft_radix(N), M = N / R;
-        static_assert(R <= 5, "window side must factor into 2, 3, 4, 5");
+        static_assert(R <= kFftMaxPrime, "window side must factor into primes <= 31");
         static_for<0, M>([&](auto n2c) {
             constexpr int n2 = decltype(n2c)::value;
             if constexpr (R == 2) dft2<INV>(v[OFF + n2], v[OFF + n2 + M]);
@@ -249,6 +360,7 @@ __device__ __forceinline__ void fft_mixed_at(c2 (&v)[LEN]) {
             if constexpr (R == 4) dft4<INV>(v[OFF + n2], v[OFF + n2 + M], v[OFF + n2 + 2 * M], v[OFF + n2 + 3 * M]);
             if constexpr (R == 5)
                 dft5<INV>(v[OFF + n2], v[OFF + n2 + M], v[OFF + n2 + 2 * M], v[OFF + n2 + 3 * M], v[OFF + n2 + 4 * M]);
+            if constexpr (R > 5) dft_prime<INV, R, OFF + n2, M, LEN>(v);
             if constexpr (n2 != 0) {
                 static_for<1, R>([&](auto sc) {
                     constexpr int s = decltype(sc)::value;
@@ -264,7 +376,7 @@ __device__ __forceinline__ void fft_mixed_at(c2 (&v)[LEN]) {
 
 // the R sub-transforms of M elements each (compile-time recursion: the block offset is a template argument)
 template <bool INV, int TOP, int M, int OFF, int LEN, int S, int R>
-__device__ __forceinline__ void fft_mixed_blocks(c2 (&v)[LEN]) {
+OC_FFT_FN void fft_mixed_blocks(c2 (&v)[LEN]) {
     if constexpr (S < R) {
         fft_mixed_at<INV, TOP, M, OFF + S * M, LEN>(v);
         fft_mixed_blocks<INV, TOP, M, OFF, LEN, S + 1, R>(v);
@@ -272,7 +384,7 @@ __device__ __forceinline__ void fft_mixed_blocks(c2 (&v)[LEN]) {
 }
 
 template <bool INV, int N>
-__device__ __forceinline__ void fft_mixed(c2 (&v)[N]) {
+OC_FFT_FN void fft_mixed(c2 (&v)[N]) {
     fft_mixed_at<INV, N, N, 0, N>(v);
 }
 

@@ -177,6 +177,20 @@ bool fftcc3d_fused_supported(int rx, int ry, int rz);
 hipError_t launch_fftcc3d_fused(const Fftcc3dParams& p, float* pois, int stride_floats, size_t count, bool xcd,
                                 hipStream_t stream);
 
+// ---- fftcc3d_fusedn.hip ----------------------------------------------------
+// the same for cubic windows of side 8 ... 26 (radius 4 ... 13): the complex volume stays in LDS between the axis passes
+bool fftcc3d_fusedn_supported(int rx, int ry, int rz);
+hipError_t launch_fftcc3d_fusedn(const Fftcc3dParams& p, float* pois, int stride_floats, size_t count, bool xcd,
+                                 hipStream_t stream);
+
+// ---- fftcc3d_planes.hip / fftcc3d_planesb.hip -------------------------------
+// the same for cubic windows of side 28 ... 64 (except 32): one persistent 512-thread workgroup per scratch slot, the complex
+// volume passes through a private N^3 scratch volume between the in-LDS plane transforms and the z pass
+bool fftcc3d_planes_supported(int rx, int ry, int rz);
+size_t fftcc3d_planes_scratch_bytes(int radius, int blocks);
+hipError_t launch_fftcc3d_planes(const Fftcc3dParams& p, float* pois, int stride_floats, size_t count, void* scratch, int blocks,
+                                 hipStream_t stream);
+
 // ---- poi_split.hip ----------------------------------------------------------
 // order-preserving partition of a POI queue by result quality (oc_hip_split_reliable / oc_hip_merge_recovered)
 struct PoiSplitParams {

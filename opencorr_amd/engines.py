@@ -253,14 +253,15 @@ class _Engine:
         floats = self._record_floats()
         if _is_torch(x):
             p, mem, _ = _buf(x)  # float32, contiguous, on the GPU -- or ValueError
-            ndim, width, stride, n = x.dim(), x.shape[1] if x.dim() == 2 else 0, (x.stride(0) * 4 if x.dim() == 2 else 0), x.shape[0]
+            ndim, width, n = x.dim(), x.shape[1] if x.dim() == 2 else 0, x.shape[0]
         else:
             if not isinstance(x, np.ndarray) or x.dtype != np.float32 or not x.flags.c_contiguous:
                 raise ValueError("%s must be a C-contiguous float32 NumPy array or a contiguous float32 CUDA tensor" % name)
             p, mem = ctypes.c_void_p(x.ctypes.data), capi.HOST
-            ndim, width, stride, n = x.ndim, x.shape[1] if x.ndim == 2 else 0, (x.strides[0] if x.ndim == 2 else 0), x.shape[0]
+            ndim, width, n = x.ndim, x.shape[1] if x.ndim == 2 else 0, x.shape[0]
         if ndim != 2 or width < floats:
             raise ValueError("%s must have shape (n, >= %d): POI%dD records" % (name, floats, self._ndim))
+        stride = width * 4  # contiguous rows (checked above); an EMPTY array reports a stride of 0, its width does not
         if want_mem is not None and mem != want_mem:
             raise ValueError("%s must live in the same memory space as the POI queue" % name)
         if stride_bytes is not None and stride != stride_bytes:

@@ -76,7 +76,7 @@ def test_fftcc2d_matches_oracle(eng, speckle_small, rx, ry):
     assert np.array_equal(_bits(got[:, untouched]), _bits(want[:, untouched]))
 
 
-@pytest.mark.parametrize("r", [16, 8, 9, 10, 12, 15, 18, 20, 24, 25, 30, 32])
+@pytest.mark.parametrize("r", [16, 8, 9, 10, 12, 15, 18, 20, 24, 25, 30, 32, 7, 11, 13, 14, 21, 23, 27, 31])
 def test_fftcc2d_fused_kernel_matches_rocfft_pipeline(eng, speckle_small, r):
     """Square windows of side 16, 18, 20, 24, 30, 32, 36, 40, 48, 50, 60, 64 run a single-kernel FFT (fftcc2d_fused.hip for 32, the mixed-radix
     fftcc2d_fusedn.hip otherwise) by default; the rocFFT pipeline and the oracle must agree: identical integer
@@ -112,16 +112,18 @@ def test_fftcc2d_fused_kernel_matches_rocfft_pipeline(eng, speckle_small, r):
 
 
 def test_fftcc2d_every_fused_shape(eng, speckle_small):
-    """All 54 window shapes with a single-kernel FFTCC2D (12 square sides, 42 rectangular pairs; one template instance each,
-    fftcc2d_fusedn_impl.h) on an odd-length queue with fractional positions, integer initial guesses and three guard
-    trippers: integers as the oracle and the rocFFT pipeline, ZNCC within 3e-5, tripped POIs untouched."""
+    """All 71 window shapes with a single-kernel FFTCC2D -- EVERY square radius from 4 to 32 (29 sides from 8 to 64: the
+    5-smooth ones, and since round 4 the sides with a prime factor of 7 ... 31: 14, 22, 26, 28, 34, 38, 42, 44, 46, 52, 56,
+    58, 62) and 42 rectangular pairs; one template instance each, fftcc2d_fusedn_impl.h -- on an odd-length queue with
+    fractional positions, integer initial guesses and three guard trippers: integers as the oracle and the rocFFT
+    pipeline, ZNCC within 3e-5, tripped POIs untouched."""
     import oracle
     ref, tar = speckle_small
     h, w = ref.shape
     P = oracle.P2
     sides = [16, 20, 24, 32, 40, 48, 64]
-    shapes = [(r, r) for r in (8, 9, 10, 12, 15, 16, 18, 20, 24, 25, 30, 32)] + [(a // 2, b // 2) for a in sides for b in sides if a != b]
-    assert len(shapes) == 54
+    shapes = [(r, r) for r in range(4, 33)] + [(a // 2, b // 2) for a in sides for b in sides if a != b]
+    assert len(shapes) == 71
     for rx, ry in shapes:
         rng = np.random.default_rng(rx * 100 + ry)
         n = 75

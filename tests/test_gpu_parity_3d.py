@@ -144,6 +144,89 @@ def test_fftcc3d_fused_kernel_matches_oracle_and_rocfft_pipeline(volumes):
     assert (fused[:inner, P["zncc"]] > 0.5).mean() > 0.9
 
 
+@pytest.fixture(scope="module")
+def big_volumes():
+    """104 x 100 x 96 voxels: room for the 64^3 windows of radius 32 around a few POIs."""
+    from opencorr_amd import synth
+    return synth.speckle_pair_3d(96, 100, 104, seed=23)
+
+
+# every cubic radius with a single-kernel FFTCC3D: 4 ... 13 keep the complex volume in LDS (fftcc3d_fusedn.hip), 16 in
+# registers (fftcc3d_fused.hip), 14, 15, 17 ... 32 pass it through a private scratch volume between in-LDS plane transforms
+# (fftcc3d_planes.hip) -- among them r = 30, the 60^3 windows of the reference's own DVC example
+@pytest.mark.parametrize("r", list(range(4, 33)))
+def test_fftcc3d_every_fused_cube(big_volumes, r):
+    """Same integer peak as the oracle (inner POIs) and as the rocFFT pipeline (all POIs, clamped border windows
+    included); ZNCC within north_star's 1e-4 of the oracle (the reference's sequential float sums of means and norms,
+    src/oc_fftcc.cpp:340-376, carry up to ~8e-5 at these voxel counts) and within 2e-5 of the pipeline; everything else in
+    the records untouched.  Odd queue lengths, integer initial guesses."""
+    import opencorr_amd
+    import oracle
+    ref, tar = big_volumes
+    dz, dy, dx = ref.shape
+    P = oracle.P3
+    rng = np.random.default_rng(100 + r)
+    n = 11
+    m = r + 4
+    xs = rng.uniform(m, dx - m, n).astype(np.float32)
+    ys = rng.uniform(m, dy - m, n).astype(np.float32)
+    zs = rng.uniform(m, dz - m, n).astype(np.float32)
+    xs[::2], ys[::2], zs[::2] = np.floor(xs[::2]), np.floor(ys[::2]), np.floor(zs[::2])
+    pois = oracle.make_pois3d(xs, ys, zs)
+    pois[::3, P["u"]] = rng.integers(-2, 3, len(pois[::3]))  # integer initial guesses displace the target window
+    pois[1::3, P["w"]] = rng.integers(-2, 3, len(pois[1::3]))
+    inner = len(pois)
+    border = oracle.make_pois3d([3.0, 40.0, dx - 2.0], [40.0, 2.0, 40.0], [40.0, 40.0, dz - 3.0])
+    pois = np.concatenate([pois, border]).astype(np.float32)
+    want = pois.copy()
+    oracle.fftcc3d(ref, tar, r, r, r, want)
+    f = opencorr_amd.FFTCC3D(r, r, r)
+    f.set_images(ref, tar)
+    fused = f.compute(pois.copy())
+    again = f.compute(pois.copy())     # persistent workgroups reuse their scratch volumes: same bits the second time
+    assert np.array_equal(_bits(fused), _bits(again))
+    f.set_tuning("fftcc3d_fused", 0)
+    base = f.compute(pois.copy())
+    for key in ("u", "v", "w", "u0", "v0", "w0"):
+        assert np.array_equal(fused[:inner, P[key]], want[:inner, P[key]]), key
+        assert np.array_equal(fused[:, P[key]], base[:, P[key]]), key
+    assert np.abs(fused[:inner, P["zncc"]] - want[:inner, P["zncc"]]).max() <= 1e-4
+    assert np.abs(fused[:, P["zncc"]] - base[:, P["zncc"]]).max() <= 2e-5
+    untouched = [c for c in range(31) if c not in (P["u"], P["v"], P["w"], P["u0"], P["v0"], P["w0"], P["zncc"])]
+    assert np.array_equal(_bits(fused[:, untouched]), _bits(pois[:, untouched]))
+    assert (fused[:inner, P["zncc"]] > 0.5).mean() > 0.8
+
+
+def test_fftcc3d_planes_kernel_long_queue_and_block_counts(big_volumes):
+    """The plane-wise kernel is persistent: a queue longer than its workgroup count (every workgroup walks several POIs of
+    its XCD's eighth) and three workgroup counts -- 8, 64, 256 scratch volumes -- give the same bits as the rocFFT pipeline's
+    integers POI by POI, and as each other."""
+    import opencorr_amd
+    import oracle
+    ref, tar = big_volumes
+    dz, dy, dx = ref.shape
+    P = oracle.P3
+    r = 15
+    rng = np.random.default_rng(5)
+    n = 333
+    xs = np.floor(rng.uniform(r + 3, dx - r - 3, n)).astype(np.float32)
+    ys = np.floor(rng.uniform(r + 3, dy - r - 3, n)).astype(np.float32)
+    zs = np.floor(rng.uniform(r + 3, dz - r - 3, n)).astype(np.float32)
+    pois = oracle.make_pois3d(xs, ys, zs)
+    f = opencorr_amd.FFTCC3D(r, r, r)
+    f.set_images(ref, tar)
+    runs = []
+    for blocks in (8, 64, 0):
+        f.set_tuning("fftcc3d_planes_blocks", blocks)
+        runs.append(f.compute(pois.copy()))
+    assert np.array_equal(_bits(runs[0]), _bits(runs[1])) and np.array_equal(_bits(runs[0]), _bits(runs[2]))
+    f.set_tuning("fftcc3d_fused", 0)
+    base = f.compute(pois.copy())
+    for key in ("u", "v", "w", "u0", "v0", "w0"):
+        assert np.array_equal(runs[0][:, P[key]], base[:, P[key]]), key
+    assert np.abs(runs[0][:, P["zncc"]] - base[:, P["zncc"]]).max() <= 2e-5
+
+
 @pytest.mark.parametrize("r", [(8, 8, 8), (5, 7, 6)])
 def test_icgn3d1_bit_exact_vs_oracle(volumes, r):
     import opencorr_amd
