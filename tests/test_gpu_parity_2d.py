@@ -104,7 +104,7 @@ def test_fftcc2d_fused_kernel_matches_rocfft_pipeline(eng, speckle_small, r):
     assert np.abs(fused[:, 16] - piped[:, 16]).max() <= 2e-6
     # the oracle restates the reference's sequential float sums of means and norms (src/oc_fftcc.cpp:198-231); over
     # 1600+ samples they differ from the GPU's tree sums by ~1e-5 (the rocFFT pipeline deviates by the same amount)
-    assert np.abs(fused[:, 16] - want[:, 16]).max() <= (1e-5 if r <= 16 else 3e-5)
+    assert np.abs(fused[:, 16] - want[:, 16]).max() <= (1.5e-5 if r <= 16 else 3e-5)
     other = [c for c in range(25) if c not in (2, 8, 14, 15, 16)]
     assert np.array_equal(_bits(fused[:, other]), _bits(base[:, other]))
     assert np.array_equal(_bits(fused[-3:]), _bits(base[-3:]))
