@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libopencorr_hip.so")
-SOURCES = ["capi.hip", "prepare2d.hip", "icgn2d.hip", "nr2d.hip", "poi_order.hip", "poi_split.hip", "strain.hip", "fftcc2d.hip", "fftcc2d_fused.hip", "fftcc2d_fusedn.hip", "fftcc2d_fusedp.hip", "fftcc2d_fusedr.hip", "prepare3d.hip", "icgn3d.hip", "fftcc3d.hip", "fftcc3d_fused.hip", "fftcc3d_fusedn.hip", "fftcc3d_planes.hip", "fftcc3d_planesb.hip"]
-HEADERS = ["oc_device.h", "oc_kernels.h", "dic2d_device.h", "fft_device.h", "fftcc2d_fusedn_impl.h", "fftcc3d_planes_impl.h", os.path.join("..", "..", "include", "opencorr_hip.h")]
+SOURCES = ["capi.hip", "prepare2d.hip", "icgn2d.hip", "nr2d.hip", "poi_order.hip", "poi_split.hip", "strain.hip", "fftcc2d.hip", "fftcc2d_fused.hip", "fftcc2d_fusedn.hip", "fftcc2d_fusedp.hip", "fftcc2d_fusedr.hip", "prepare3d.hip", "icgn3d.hip", "icgn3d_rows.hip", "fftcc3d.hip", "fftcc3d_fused.hip", "fftcc3d_fusedn.hip", "fftcc3d_planes.hip", "fftcc3d_planesb.hip"]
+HEADERS = ["oc_device.h", "oc_kernels.h", "dic2d_device.h", "fft_device.h", "fftcc2d_fusedn_impl.h", "fftcc3d_planes_impl.h", "icgn3d_device.h", os.path.join("..", "..", "include", "opencorr_hip.h")]
 ARCH = "gfx950"
 # -fno-slp-vectorize: the SLP vectoriser pairs independent scalar fp32 operations into v_pk_mul_f32 / v_pk_add_f32.  On gfx950 a
 # packed op occupies a SIMD for 4.3 cycles against 2.4 for the plain one (profiles/r02b_valu_ubench.json) -- a 10 % gain that the

@@ -189,6 +189,8 @@ struct oc_hip_engine {
     int fftcc2d_fused = 1;    // single-kernel FFTCC2D when the window is 32 x 32
     int fftcc3d_fused = 1;    // single-kernel FFTCC3D for cubic windows of side 8 ... 64 (three kernels by size)
     int fftcc3d_planes_blocks = 0;  // persistent workgroups (= scratch volumes) of the plane-wise kernel; 0 = 256
+    int icgn3d_mapping = 1;   // ICGN3D1: 1 = one half-wave per subvolume row (icgn3d_rows.hip; oracle order OC_ORDER_ROWS),
+                              // 0 = sample s owned by thread s mod 512 (icgn3d.hip; OC_ORDER_LANES) -- the A/B partner
     // host-queue pipeline (compute_host): the queue travels in chunks, copies of one chunk overlap the kernels of
     // its neighbours; one event per chunk orders the copy-out stream behind the kernels
     hipStream_t copy_stream = nullptr, copy_in_stream = nullptr;
@@ -674,13 +676,17 @@ int run_icgn3d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
         return fail(OC_HIP_ERR_INVALID, "ICGN3D1: prepare() has not been called since the last set_images");
     const ImagePair& im = *e->img;
     int blocks = 0;
-    const size_t scratch = ochip::icgn3d1_scratch_floats(e->rx, e->ry, e->rz, &blocks);
+    size_t scratch = ochip::icgn3d1_scratch_floats(e->rx, e->ry, e->rz, &blocks);
+    // the row mapping (icgn3d_rows.hip, the default) keeps whole steps per thread: its slots are a little larger
+    const size_t rows_scratch = ochip::icgn3d1_rows_slot_floats(e->rx, e->ry, e->rz) * (size_t)blocks;
+    if (e->icgn3d_mapping != 0 && rows_scratch > scratch) scratch = rows_scratch;
     if (scratch) OC_TRY(e->tmp.reserve(scratch * sizeof(float)));
     ochip::Icgn3dParams P = {im.ref_ptr(), e->gx.as<float>(), e->gy.as<float>(), e->gz.as<float>(), e->coef.as<float>(),
                              im.dz, im.dy, im.dx, e->rx, e->ry, e->rz, e->conv, e->stop,
-                             scratch ? e->tmp.as<float>() : nullptr, 1};
+                             scratch ? e->tmp.as<float>() : nullptr, 1, 1};
     ProfScope prof(e);
-    hipError_t err = ochip::launch_icgn3d1(P, d_pois, stride_f, count, e->stream);
+    hipError_t err = e->icgn3d_mapping != 0 ? ochip::launch_icgn3d1_rows(P, d_pois, stride_f, count, e->stream)
+                                            : ochip::launch_icgn3d1(P, d_pois, stride_f, count, e->stream);
     if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "ICGN3D1 kernel launch failed: %s", hipGetErrorString(err));
     return OC_HIP_OK;
 }
@@ -1130,6 +1136,7 @@ static int clone_engine(const oc_hip_engine* e, int device, oc_hip_engine** out)
     r->fftcc2d_fused = e->fftcc2d_fused;
     r->fftcc3d_fused = e->fftcc3d_fused;
     r->fftcc3d_planes_blocks = e->fftcc3d_planes_blocks;
+    r->icgn3d_mapping = e->icgn3d_mapping;
     r->host_chunk = e->host_chunk;
     r->group_allgather = e->group_allgather;
     r->group_force_rccl = e->group_force_rccl;
@@ -1359,6 +1366,8 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
         e->fftcc2d_fused = value == 2 ? 2 : (value != 0);
     } else if (k == "fftcc3d_fused") {
         e->fftcc3d_fused = value != 0;
+    } else if (k == "icgn3d_mapping") {
+        e->icgn3d_mapping = value != 0;
     } else if (k == "fftcc3d_planes_blocks") {
         if (value < 0 || value > 4096) return fail(OC_HIP_ERR_INVALID, "fftcc3d_planes_blocks must be 0 (default) ... 4096");
         e->fftcc3d_planes_blocks = value;

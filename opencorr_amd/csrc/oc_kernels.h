@@ -122,12 +122,17 @@ struct Icgn3dParams {
     int rx, ry, rz;
     float conv, stop;
     float* scratch;  // per-workgroup slots for the warped subvolume
-    int samples_per_pass;  // samples per thread between two coefficient-box stagings (set by launch_icgn3d1)
+    int samples_per_pass;  // samples (row mapping: steps of 16 rows) per thread between two coefficient-box stagings (set by the launchers)
+    int tail_steps_per_pass;  // row mapping: steps of 512 tail samples per tail pass (set by launch_icgn3d1_rows)
 };
 // floats of global scratch the kernel needs for this radius (0 when the subvolume fits LDS);
 // *blocks receives the number of persistent workgroups in scratch mode (0 in LDS mode)
 size_t icgn3d1_scratch_floats(int rx, int ry, int rz, int* blocks);
 hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);
+// icgn3d_rows.hip: the same solver with one half-wave per subvolume row (the default; oracle order OC_ORDER_ROWS); its scratch
+// slots are a little larger (whole steps): icgn3d1_rows_slot_floats floats per workgroup, 512 workgroups
+size_t icgn3d1_rows_slot_floats(int rx, int ry, int rz);
+hipError_t launch_icgn3d1_rows(const Icgn3dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);
 
 // ---- fftcc2d.hip -----------------------------------------------------------
 struct Fftcc2dParams {

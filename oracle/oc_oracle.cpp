@@ -38,7 +38,7 @@ namespace {
 template <int K>
 struct AccSeq {
     float a[K];
-    explicit AccSeq(int /*lanes*/) { for (int k = 0; k < K; k++) a[k] = 0.f; }
+    explicit AccSeq(int /*lanes*/, int /*row_length*/ = 0) { for (int k = 0; k < K; k++) a[k] = 0.f; }
     inline void add(int /*s*/, int k, float v) { a[k] += v; }
     inline void finish() {}
     inline float get(int k) const { return a[k]; }
@@ -48,9 +48,53 @@ template <int K>
 struct AccLanes {
     int P;
     std::vector<float> part;  // [K][P]
-    explicit AccLanes(int lanes) : P(lanes), part((size_t)K * lanes, 0.f) {}
+    explicit AccLanes(int lanes, int /*row_length*/ = 0) : P(lanes), part((size_t)K * lanes, 0.f) {}
     inline void add(int s, int k, float v) { part[(size_t)k * P + (s & (P - 1))] += v; }
     inline void finish() {
+        std::vector<float> tmp(P);
+        for (int k = 0; k < K; k++) {
+            float* p = &part[(size_t)k * P];
+            for (int off = 1; off < P; off <<= 1) {
+                for (int l = 0; l < P; l++) tmp[l] = p[l] + p[l ^ off];
+                for (int l = 0; l < P; l++) p[l] = tmp[l];
+            }
+        }
+    }
+    inline float get(int k) const { return part[(size_t)k * P]; }
+};
+
+// OC_ORDER_ROWS (oc_oracle.h): the association of the ICGN3D1 kernel that gives every subvolume row to one half-wave
+// (opencorr_amd/csrc/icgn3d_rows.hip).  Samples arrive in row-major order s = r * SX + k; a body sample goes straight to
+// its thread's running sum (a thread's body samples arrive in increasing (r, k)); tail samples are parked and added
+// in finish(), in increasing q, AFTER the body -- one running sum per thread, body first.
+template <int K>
+struct AccRows {
+    int P, SX, BW, RT;
+    std::vector<float> part;                // [K][P]
+    std::vector<float> tail;                // [K][number of tail samples], q-indexed
+    long ntail;
+    explicit AccRows(int lanes, int row_length) : P(lanes), SX(row_length > 0 ? row_length : 1), part((size_t)K * lanes, 0.f), ntail(0) {
+        const int fc = SX / 32, rc = SX % 32;
+        const int nch = fc >= 2 ? 2 : fc + (rc >= 28 ? 1 : 0);
+        BW = SX < 32 * nch ? SX : 32 * nch;
+        RT = SX - BW;
+    }
+    inline void add(int s, int k, float v) {
+        const int r = s / SX, col = s - r * SX;
+        if (col < BW) {
+            part[(size_t)k * P + (size_t)((r % (P / 32)) * 32 + (col & 31))] += v;
+        } else {
+            const long q = (long)r * RT + (col - BW);
+            if (q >= ntail) {
+                ntail = q + 1;
+                if (tail.size() < (size_t)K * (size_t)ntail) tail.resize((size_t)K * (size_t)(ntail + 4096), 0.f);
+            }
+            tail[(size_t)q * K + k] = v;
+        }
+    }
+    inline void finish() {
+        for (long q = 0; q < ntail; q++)
+            for (int k = 0; k < K; k++) part[(size_t)k * P + (size_t)(q % P)] += tail[(size_t)q * K + k];
         std::vector<float> tmp(P);
         for (int k = 0; k < K; k++) {
             float* p = &part[(size_t)k * P];
@@ -929,7 +973,7 @@ static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, 
     float ref_norm;
     {
         const float sx = px - rx, sy = py - ry, sz = pz - rz;
-        Acc<1> a(lanes);
+        Acc<1> a(lanes, SX);
         int s = 0;
         for (int i = 0; i < SZ; i++)
             for (int j = 0; j < SY; j++)
@@ -940,7 +984,7 @@ static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, 
                 }
         a.finish();
         float mean = a.get(0) / (float)N;
-        Acc<1> b(lanes);
+        Acc<1> b(lanes, SX);
         for (s = 0; s < N; s++) {
             rs[s] = rs[s] - mean;
             b.add(s, 0, rs[s] * rs[s]);
@@ -952,7 +996,7 @@ static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, 
     // SD image + Hessian, src/oc_icgn.cpp:1299-1337
     float hess[144];
     {
-        Acc<78> a(lanes);
+        Acc<78> a(lanes, SX);
         const int cx = (int)px, cy = (int)py, cz = (int)pz;
         int s = 0;
         for (int i = 0; i < SZ; i++)
@@ -997,7 +1041,7 @@ static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, 
     do {
         iter++;
         bool out_of_range = false;
-        Acc<1> am(lanes);
+        Acc<1> am(lanes, SX);
         int s = 0;
         for (int i = 0; i < SZ; i++)
             for (int j = 0; j < SY; j++)
@@ -1015,7 +1059,7 @@ static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, 
         if (out_of_range) { res[3] = -3.f; return; }
         am.finish();
         float tmean = am.get(0) / (float)N;
-        Acc<1> an(lanes);
+        Acc<1> an(lanes, SX);
         for (s = 0; s < N; s++) {
             ts[s] = ts[s] - tmean;
             an.add(s, 0, ts[s] * ts[s]);
@@ -1023,7 +1067,7 @@ static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, 
         an.finish();
         float tar_norm = std::sqrt(an.get(0));
         float factor = ref_norm / tar_norm;
-        Acc<13> ae(lanes);
+        Acc<13> ae(lanes, SX);
         s = 0;
         for (int i = 0; i < SZ; i++)
             for (int j = 0; j < SY; j++)
@@ -1743,6 +1787,8 @@ void oc_oracle_icgn3d1(const float* ref, const float* gx, const float* gy, const
         for (long i = 0; i < n; i++) {
             if (order == OC_ORDER_SEQ)
                 icgn3d1_poi<AccSeq>(im, rx, ry, rz, conv, stop, pois + i * OC_POI3D_FLOATS, lanes, scratch);
+            else if (order == OC_ORDER_ROWS)
+                icgn3d1_poi<AccRows>(im, rx, ry, rz, conv, stop, pois + i * OC_POI3D_FLOATS, lanes, scratch);
             else
                 icgn3d1_poi<AccLanes>(im, rx, ry, rz, conv, stop, pois + i * OC_POI3D_FLOATS, lanes, scratch);
         }

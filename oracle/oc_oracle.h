@@ -47,7 +47,19 @@
  *                     partial sums (sample s belongs to lane s % lanes, each
  *                     lane adds its samples in increasing s) combined by an
  *                     xor-butterfly with ascending offsets 1,2,4,...,lanes/2.
- *                     The HIP kernels are bit-exact against this mode.
+ *                     The 2D HIP kernels (lanes = 64) and the ICGN3D1 kernel of
+ *                     icgn3d.hip (lanes = 512) are bit-exact against this mode.
+ *   OC_ORDER_ROWS   : ICGN3D1 only -- the association of the default 3D kernel
+ *                     (icgn3d_rows.hip, one half-wave per subvolume row), `lanes`
+ *                     = 512 threads: with SX = 2rx+1 samples per row and NCH =
+ *                     (SX/32 >= 2 ? 2 : SX/32 + (SX%32 >= 28)) chunks of 32 columns,
+ *                     sample (row r = i*SY + j, column k) with k < BW = min(SX, 32 NCH)
+ *                     belongs to thread (r % 16)*32 + k % 32 ("body"), the other
+ *                     columns to thread q % 512, q = r*(SX-BW) + (k-BW) ("tail");
+ *                     a thread adds its body samples in increasing (r, k), then its
+ *                     tail samples in increasing q, all into ONE running sum; the
+ *                     512 partials are combined by the same xor-butterfly.  With no
+ *                     body (SX < 28) this IS OC_ORDER_LANES with lanes = 512.
  * Everything else (interpolation polynomial, warp algebra, LU inverse, guards,
  * flags) is identical in both modes.  No FMA contraction anywhere
  * (-ffp-contract=off on both the oracle and the HIP side).
@@ -61,6 +73,7 @@ extern "C" {
 
 #define OC_ORDER_SEQ 0
 #define OC_ORDER_LANES 1
+#define OC_ORDER_ROWS 2
 
 #define OC_POI2D_FLOATS 25
 #define OC_POI3D_FLOATS 31

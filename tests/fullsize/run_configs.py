@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
-# lanes of the GPU's 3D reduction order (icgn3d.hip: threads of the workgroup that owns a POI)
+# threads of the workgroup that owns a POI in the 3D kernels (the reduction order itself is oracle.GPU_ORDER_3D)
 LANES3D = 512
 
 
@@ -230,7 +230,7 @@ def run_3d(name, dim, r, nside, oracle_sample):
     prep = oracle.Prepared3D(ref_h, tar_h)
     t0 = time.perf_counter()
     seq = sample.copy()
-    oracle.icgn3d1(prep, r, r, r, 0.001, 20.0, sample, order=oracle.ORDER_LANES, lanes=LANES3D)
+    oracle.icgn3d1(prep, r, r, r, 0.001, 20.0, sample, order=oracle.GPU_ORDER_3D, lanes=LANES3D)
     oracle_s = time.perf_counter() - t0
     oracle.icgn3d1(prep, r, r, r, 0.001, 20.0, seq, order=oracle.ORDER_SEQ)
     bit_exact = bool(np.array_equal(sample.view(np.uint32), after[::step_s].view(np.uint32)))

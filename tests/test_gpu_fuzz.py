@@ -151,7 +151,7 @@ def test_fuzz_icgn3d1(seed):
     g.prepare()
     got = g.compute(pois.copy())
     want = pois.copy()
-    oracle.icgn3d1(oracle.Prepared3D(ref, tar), rx, ry, rz, conv, stop, want, order=oracle.ORDER_LANES, lanes=512)
+    oracle.icgn3d1(oracle.Prepared3D(ref, tar), rx, ry, rz, conv, stop, want, order=oracle.GPU_ORDER_3D, lanes=oracle.GPU_LANES_3D)
     same = (_bits(got) == _bits(want)).all(axis=1)
     assert same.all(), (seed, rx, ry, rz, np.flatnonzero(~same)[:5], got[~same][:2], want[~same][:2])
     assert (got[:, P["zncc"]] > 0.5).sum() > 20

@@ -85,7 +85,7 @@ def test_icgn3d1_lanes_vs_seq_on_config_e_shaped_field(r):
     oracle.fftcc3d(ref, tar, r, r, r, pois)
     prep = oracle.Prepared3D(ref, tar)
     a, b = pois.copy(), pois.copy()
-    oracle.icgn3d1(prep, r, r, r, 0.001, 20, a, order=oracle.ORDER_LANES, lanes=lanes3d)
+    oracle.icgn3d1(prep, r, r, r, 0.001, 20, a, order=oracle.GPU_ORDER_3D, lanes=lanes3d)
     oracle.icgn3d1(prep, r, r, r, 0.001, 20, b, order=oracle.ORDER_SEQ)
     rec = vs(a, b, [P3["u"], P3["v"], P3["w"]], P3["zncc"], P3["iteration"])
     assert rec["seq_sample"] == 64 and (a[:, P3["zncc"]] > 0.9).all()
