@@ -189,8 +189,9 @@ struct oc_hip_engine {
     int fftcc2d_fused = 1;    // single-kernel FFTCC2D when the window is 32 x 32
     int fftcc3d_fused = 1;    // single-kernel FFTCC3D for cubic windows of side 8 ... 64 (three kernels by size)
     int fftcc3d_planes_blocks = 0;  // persistent workgroups (= scratch volumes) of the plane-wise kernel; 0 = 256
-    int icgn3d_mapping = 1;   // ICGN3D1: 1 = one half-wave per subvolume row (icgn3d_rows.hip; oracle order OC_ORDER_ROWS),
-                              // 0 = sample s owned by thread s mod 512 (icgn3d.hip; OC_ORDER_LANES) -- the A/B partner
+    int icgn3d_mapping = 0;   // ICGN3D1: 0 = sample s owned by thread s mod 512 (icgn3d.hip; oracle order OC_ORDER_LANES) -- the default:
+                              // 1 = one half-wave per subvolume row (icgn3d_rows.hip; OC_ORDER_ROWS), built and measured in round 4:
+                              // bit-exact against its own order, 12 - 25 % SLOWER -- kept as the A/B partner
     // host-queue pipeline (compute_host): the queue travels in chunks, copies of one chunk overlap the kernels of
     // its neighbours; one event per chunk orders the copy-out stream behind the kernels
     hipStream_t copy_stream = nullptr, copy_in_stream = nullptr;

@@ -372,8 +372,45 @@ __device__ __forceinline__ float lut_poly(const LutFetch& f) {
     v = v + (f.c3.w * dy3) * dx3;
     return v;
 }
+// The same 16 terms with the 24 products formed as 14 packed multiplies on the register pairs the 16-byte loads deliver
+// ((x, y) and (z, w) of each float4): (c.x, c.y) * dy^k, then * (1, dx); (c.z, c.w) * dy^k, then * (dx^2, dx^3) -- every
+// product is the reference's ((c * dy^k) * dx^l, the factor 1.f is exact), the 15 additions stay the left-to-right chain:
+// identical bits, 10 VALU instructions fewer per sample.  Round 2 found v_pk_mul_f32 at 4.3 cycles against 2.4 for a plain
+// multiply in an ideal dual-issue stream; in the kernels themselves a VALU instruction costs ~4.4 cycles whatever its kind
+// (tools/ubench/coissue_ubench.hip), which is where a packed pair WITHOUT operand moves pays.  OC_POLY_PACKED selects it.
+#ifndef OC_POLY_PACKED
+#define OC_POLY_PACKED 1
+#endif
+__device__ __forceinline__ float lut_poly_pk(const LutFetch& f) {
+    const float dx = f.dx, dy = f.dy;
+    const float dx2 = dx * dx, dy2 = dy * dy;
+    const float dx3 = dx2 * dx, dy3 = dy2 * dy;
+    const f2 m01 = mk2(1.f, dx), m23 = mk2(dx2, dx3);
+    const f2 a01 = mk2(f.c0.x, f.c0.y) * m01, a23 = mk2(f.c0.z, f.c0.w) * m23;
+    const f2 b01 = (mk2(f.c1.x, f.c1.y) * dy) * m01, b23 = (mk2(f.c1.z, f.c1.w) * dy) * m23;
+    const f2 c01 = (mk2(f.c2.x, f.c2.y) * dy2) * m01, c23 = (mk2(f.c2.z, f.c2.w) * dy2) * m23;
+    const f2 d01 = (mk2(f.c3.x, f.c3.y) * dy3) * m01, d23 = (mk2(f.c3.z, f.c3.w) * dy3) * m23;
+    float v = a01.x;
+    v = v + a01.y;
+    v = v + a23.x;
+    v = v + a23.y;
+    v = v + b01.x;
+    v = v + b01.y;
+    v = v + b23.x;
+    v = v + b23.y;
+    v = v + c01.x;
+    v = v + c01.y;
+    v = v + c23.x;
+    v = v + c23.y;
+    v = v + d01.x;
+    v = v + d01.y;
+    v = v + d23.x;
+    v = v + d23.y;
+    return v;
+}
+__device__ __forceinline__ float lut_value(const LutFetch& f) { return OC_POLY_PACKED ? lut_poly_pk(f) : lut_poly(f); }
 __device__ __forceinline__ float lut_eval(const LutFetch& f) {
-    const float v = lut_poly(f);
+    const float v = lut_value(f);
     return f.dy < 0.f ? -1.f : v;
 }
 

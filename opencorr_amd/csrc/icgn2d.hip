@@ -563,9 +563,9 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
 #pragma unroll
                 for (int g = 0; g < G; g++) {
 #if OC_ABLATE2D & 8
-                    const float v = iter > 1 ? f[g].c0.x + f[g].c1.y * f[g].dx + f[g].c2.z * f[g].dy + f[g].c3.w : lut_poly(f[g]);
+                    const float v = iter > 1 ? f[g].c0.x + f[g].c1.y * f[g].dx + f[g].c2.z * f[g].dy + f[g].c3.w : lut_value(f[g]);
 #else
-                    const float v = LM ? lut_eval(f[g]) : lut_poly(f[g]);
+                    const float v = LM ? lut_eval(f[g]) : lut_value(f[g]);
 #endif
                     if constexpr (CHECKED) {
                         negative = negative || (valid[g] && v < 0.f);

@@ -197,6 +197,25 @@ __device__ __forceinline__ T basis3(T t) { return (1.f / 6.f) * (t * t * t); }
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned 16-byte load
 
+// ((b0 * r0 + b1 * r1) + b2 * r2) + b3 * r3 -- the weighted sum of four taps as the reference writes it
+// (src/oc_cubic_bspline.cpp:390-401): four separately rounded products, three additions left to right.  OC_TAPS_PACKED
+// forms the products as two packed multiplies (v_pk_mul_f32 on the pairs (r0, r1), (r2, r3): a ds_read2_b32 / a 16-byte
+// load delivers exactly those register pairs); the same IEEE products, so the same bits, 2 instead of 4 multiply
+// instructions -- 42 of the 84 per sample.  In the kernels a VALU instruction costs ~4.4 cycles whatever its kind
+// (tools/ubench/coissue_ubench.hip), so the packed form is the cheaper one there (round 2's 4.3-against-2.4-cycle finding
+// holds for ideal dual-issue streams only).
+#ifndef OC_TAPS_PACKED
+#define OC_TAPS_PACKED 1
+#endif
+__device__ __forceinline__ float taps4(float b0, float b1, float b2, float b3, float r0, float r1, float r2, float r3) {
+#if OC_TAPS_PACKED
+    const f2 p01 = mk2(r0, r1) * mk2(b0, b1), p23 = mk2(r2, r3) * mk2(b2, b3);
+    return ((p01.x + p01.y) + p23.x) + p23.y;
+#else
+    return ((b0 * r0 + b1 * r1) + b2 * r2) + b3 * r3;
+#endif
+}
+
 // TricubicBspline::compute, src/oc_cubic_bspline.cpp:353-405
 __device__ __forceinline__ float bspline3d_eval(const float* __restrict__ coef, int dz, int dy, int dx, float x,
                                                 float y, float z) {
@@ -215,11 +234,11 @@ __device__ __forceinline__ float bspline3d_eval(const float* __restrict__ coef, 
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const float4u row = *reinterpret_cast<const float4u*>(base + ((size_t)i * dy + j) * dx);
-            sum_x[j] = ((bx0 * row.x + bx1 * row.y) + bx2 * row.z) + bx3 * row.w;
+            sum_x[j] = taps4(bx0, bx1, bx2, bx3, row.x, row.y, row.z, row.w);
         }
-        sum_y[i] = ((by[0] * sum_x[0] + by[1] * sum_x[1]) + by[2] * sum_x[2]) + by[3] * sum_x[3];
+        sum_y[i] = taps4(by[0], by[1], by[2], by[3], sum_x[0], sum_x[1], sum_x[2], sum_x[3]);
     }
-    const float v = ((bz[0] * sum_y[0] + bz[1] * sum_y[1]) + bz[2] * sum_y[2]) + bz[3] * sum_y[3];
+    const float v = taps4(bz[0], bz[1], bz[2], bz[3], sum_y[0], sum_y[1], sum_y[2], sum_y[3]);
     return out ? -1.f : v;
 }
 
@@ -255,11 +274,11 @@ __device__ __forceinline__ float bspline3d_eval_lds(const float* __restrict__ wi
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             lds_cfp row = pl + j * nx;
-            sum_x[j] = ((bx0 * row[0] + bx1 * row[1]) + bx2 * row[2]) + bx3 * row[3];
+            sum_x[j] = taps4(bx0, bx1, bx2, bx3, row[0], row[1], row[2], row[3]);
         }
-        sum_y[i] = ((by[0] * sum_x[0] + by[1] * sum_x[1]) + by[2] * sum_x[2]) + by[3] * sum_x[3];
+        sum_y[i] = taps4(by[0], by[1], by[2], by[3], sum_x[0], sum_x[1], sum_x[2], sum_x[3]);
     }
-    const float v = ((bz[0] * sum_y[0] + bz[1] * sum_y[1]) + bz[2] * sum_y[2]) + bz[3] * sum_y[3];
+    const float v = taps4(bz[0], bz[1], bz[2], bz[3], sum_y[0], sum_y[1], sum_y[2], sum_y[3]);
     return out ? -1.f : v;
 }
 

@@ -19,7 +19,7 @@ ORDER_LANES = 1
 ORDER_ROWS = 2   # ICGN3D1 only: the association of the default 3D kernel (one half-wave per subvolume row), lanes = 512
 # what the HIP kernels are bit-exact against (tests pass these to icgn2d* / icgn3d1)
 GPU_ORDER_2D, GPU_LANES_2D = ORDER_LANES, 64
-GPU_ORDER_3D, GPU_LANES_3D = ORDER_ROWS, 512      # icgn3d_rows.hip, the default mapping; icgn3d.hip ("icgn3d_mapping" = 0): ORDER_LANES, 512
+GPU_ORDER_3D, GPU_LANES_3D = ORDER_LANES, 512     # icgn3d.hip, the default mapping; icgn3d_rows.hip ("icgn3d_mapping" = 1): ORDER_ROWS, 512
 POI2D_FLOATS = 25
 POI3D_FLOATS = 31
 

@@ -1,0 +1,58 @@
+#!/bin/bash
+# Every roofline fraction of the bench line from ONE script (round 4; tools/gpu_traffic.sh generalised): for configs B (bench.py),
+# C and E -- a rocprofv3 kernel trace (--kernel-trace --stats) and, in SEPARATE runs (one counter set each, --pmc never combined
+# with a trace), the PMC passes FETCH_SIZE / WRITE_SIZE / TCC_REQ+HIT+MISS, reduced per dominant kernel to
+#     profiles/<tag>_traffic_config{B,C,E}.json      (HBM bytes = FETCH_SIZE x 2 + WRITE_SIZE; L2-side bytes = TCC_REQ x calibrated size)
+#     profiles/<tag>_config{B,C,E}_kernel_stats.csv
+# which bench.py reads for roofline.traffic and roofline_secondary[*].traffic.  `spread` runs config B's HBM passes a second time
+# and records both values: the run-to-run spread of the counter (2.29 vs 2.60 GB were seen in round 3).
+#   bash tools/gpu_profiles.sh <tag> [configs="B C E"]        (on the GPU box; results under gpurun_out/<tag>/)
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r4p}
+CONFIGS=${2:-"B C E"}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+REPS=3
+cd /tmp
+if [ ! -x $ROOT/tools/ubench/l2_req_calib ]; then
+  hipcc --offload-arch=gfx950 -O3 $ROOT/tools/ubench/l2_req_calib.hip -o $ROOT/tools/ubench/l2_req_calib
+fi
+# calibration of the L2 request size and of the FETCH_SIZE correction on a read-once stream of 1 GiB
+timeout 300 rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --kernel-include-regex "stream_read" --output-format csv \
+    -d $OUT/pmc_calib -o calib -- $ROOT/tools/ubench/l2_req_calib > $OUT/pmc_calib.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "stream_read" --output-format csv \
+    -d $OUT/pmc_calib_fetch -o calibf -- $ROOT/tools/ubench/l2_req_calib > $OUT/pmc_calib_fetch.log 2>&1
+for cfg in $CONFIGS; do
+  case $cfg in
+    B) CMD="python $ROOT/bench.py --steps $REPS --warmup 2 --no-cpu-baseline"; KERNELS="icgn2d_kernel fftcc2d_fused32x2_kernel";;
+    C) CMD="python $ROOT/tools/run_config_kernels.py C --reps $REPS"; KERNELS="icgn2d_kernel fftcc2d_fusedn_kernel";;
+    E) CMD="python $ROOT/tools/run_config_kernels.py E --reps $REPS"; KERNELS="icgn3d1 fftcc3d_fused32_kernel";;
+    E30) CMD="python $ROOT/tools/run_config_kernels.py E30 --reps $REPS"; KERNELS="icgn3d1 fftcc3d_planes_kernel";;
+  esac
+  D=$OUT/cfg$cfg
+  mkdir -p $D
+  REGEX=$(echo $KERNELS | tr ' ' '|')
+  echo "== config $cfg: kernel trace"
+  timeout 900 rocprofv3 --kernel-trace --stats -d $D/trace -o trace -- $CMD > $D/trace.log 2>&1
+  python $ROOT/tools/rocpd_summary.py $(ls $D/trace/*.db | head -1) $OUT/${TAG}_config${cfg}_kernel_stats.csv 2>&1 | head -6
+  for c in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"; do
+    name=${c%%:*}; ctr=${c#*:}
+    timeout 900 rocprofv3 --pmc $ctr --kernel-include-regex "$REGEX" --output-format csv -d $D/pmc_$name -o $name -- $CMD > $D/pmc_$name.log 2>&1
+    echo "config $cfg pmc $name rc=$?"
+  done
+  ln -sfn $OUT/pmc_calib $D/pmc_calib; ln -sfn $OUT/pmc_calib_fetch $D/pmc_calib_fetch
+  python $ROOT/tools/pmc_traffic.py $D "$REGEX" $OUT/${TAG}_traffic_config${cfg}.json --launches $REPS --kernels $KERNELS \
+      --stats $OUT/${TAG}_config${cfg}_kernel_stats.csv --command "$(echo $CMD | sed "s#$ROOT/##g")" | cut -c1-400
+  if [ "$cfg" = "B" ]; then
+    # the HBM passes once more: run-to-run spread of FETCH_SIZE / WRITE_SIZE on the same command
+    mkdir -p $D/again
+    for c in "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+      name=${c%%:*}; ctr=${c#*:}
+      timeout 900 rocprofv3 --pmc $ctr --kernel-include-regex "$REGEX" --output-format csv -d $D/again/pmc_$name -o $name -- $CMD > $D/again/pmc_$name.log 2>&1
+    done
+    python $ROOT/tools/pmc_traffic.py $D/again "$REGEX" $OUT/${TAG}_traffic_configB_second_run.json --launches $REPS --kernels $KERNELS \
+        --command "$(echo $CMD | sed "s#$ROOT/##g") (second collection: spread of the HBM counters)" | cut -c1-300
+  fi
+  rm -rf $D/trace
+done

@@ -40,15 +40,43 @@ def main():
     ap.add_argument("--launches", type=int, default=5)
     ap.add_argument("--note", default="")
     ap.add_argument("--command", default="", help="the profiled command, recorded in the output")
+    ap.add_argument("--kernels", nargs="*", default=[], help="several kernels of one profiled command: one record each under "
+                    "`per_kernel` (the top-level fields describe the FIRST one, what bench.py's main block reads)")
+    ap.add_argument("--stats", default="", help="kernel-stats csv of the same command (tools/rocpd_summary.py): its average and "
+                    "median durations are copied into the per-kernel records")
     a = ap.parse_args()
-    rx = re.compile(a.kernel)
+    if a.kernels:
+        recs = {}
+        for k in a.kernels:
+            recs[k] = one_kernel(a, re.compile(k))
+        rec = dict(recs[a.kernels[0]])
+        rec["kernel_regex"] = a.kernels[0]
+        rec["per_kernel"] = recs
+        if a.stats and os.path.exists(a.stats):
+            for row in csv.DictReader(open(a.stats)):
+                for k in a.kernels:
+                    if re.search(k, row["kernel"]) and "avg_us" not in recs[k]:
+                        recs[k].update({"kernel_name": row["kernel"][:120], "calls": int(row["calls"]), "avg_us": float(row["avg_us"]),
+                                        "median_us": float(row["median_us"]), "vgpr": int(row["vgpr"]), "lds_bytes": int(row["lds_bytes"]),
+                                        "scratch_bytes": int(row["scratch_bytes"])})
+        with open(a.out, "w") as f:
+            json.dump(rec, f, indent=1)
+        print(json.dumps({k: {kk: v.get(kk) for kk in ("hbm_bytes_per_launch", "l2_bytes_per_launch", "avg_us")} for k, v in recs.items()}))
+        return
+    rec = one_kernel(a, re.compile(a.kernel))
+    with open(a.out, "w") as f:
+        json.dump(rec, f, indent=1)
+    print(json.dumps(rec))
+
+
+def one_kernel(a, rx):
     fetch = per_dispatch(glob.glob(os.path.join(a.root, "pmc_fetch", "*_counter_collection.csv"))[0], "FETCH_SIZE", rx)
     write = per_dispatch(glob.glob(os.path.join(a.root, "pmc_write", "*_counter_collection.csv"))[0], "WRITE_SIZE", rx)
     fetch, write = fetch[-a.launches:], write[-a.launches:]
     f_kb = sum(fetch) / len(fetch)
     w_kb = sum(write) / len(write)
     rec = {
-        "kernel_regex": a.kernel,
+        "kernel_regex": rx.pattern,
         "launches_averaged": len(fetch),
         "FETCH_SIZE_kb_per_launch_raw": f_kb,
         "WRITE_SIZE_kb_per_launch_raw": w_kb,
@@ -81,9 +109,7 @@ def main():
                 cf = per_dispatch(calf[0], "FETCH_SIZE", crx)
                 rec["fetch_size_kb_of_the_1GiB_stream"] = sum(cf[1:]) / max(len(cf[1:]), 1)
                 rec["fetch_correction_measured"] = cbytes / 1024.0 / rec["fetch_size_kb_of_the_1GiB_stream"]
-    with open(a.out, "w") as f:
-        json.dump(rec, f, indent=1)
-    print(json.dumps(rec))
+    return rec
 
 
 if __name__ == "__main__":

@@ -30,7 +30,8 @@ using namespace ochip;
 
 constexpr int W = 4096, H = 4096, RX = 16, SUB = 33, N = SUB * SUB, NT = (N + 63) / 64, NF = N / 64, ITERS = 3, G = 2, WPB = 8;
 
-// MODE 0 = A (both), 1 = B (gathers only), 2 = C (VALU only)
+// MODE 0 = A (both), 1 = B (gathers only), 2 = C (VALU only); 3 / 4 = A / C with the polynomial's products as packed pairs
+// (lut_poly_pk: same bits, 10 instructions fewer per sample)
 template <int MODE, int LOCK>
 __global__ __launch_bounds__(64 * WPB, 6) void sweep(const float* __restrict__ lut, float* __restrict__ out, int npoi, int grid_side) {
     __shared__ f2 tab_xy[NT * 64];
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(64 * WPB, 6) void sweep(const float* __restrict__ l
                 const float wy = (Wm[3] * xl + Wm[4] * yl) + Wm[5];
                 const float ax = px + wx, ay = py + wy;
                 bool outside;
-                if (MODE == 2) {
+                if (MODE == 2 || MODE == 4) {
                     const unsigned off = lut_locate<false>(f[g], H, W, ax, ay, outside);
                     if (it == 0) r_lut.load(keep[g], off);
                     keep[g].dx = f[g].dx;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(64 * WPB, 6) void sweep(const float* __restrict__ l
                 if (MODE == 1)  // every fetched float is used (or the loads would be narrowed): 15 adds instead of 43 operations
                     v = (((f[g].c0.x + f[g].c0.y) + (f[g].c0.z + f[g].c0.w)) + ((f[g].c1.x + f[g].c1.y) + (f[g].c1.z + f[g].c1.w))) +
                         (((f[g].c2.x + f[g].c2.y) + (f[g].c2.z + f[g].c2.w)) + ((f[g].c3.x + f[g].c3.y) + (f[g].c3.z + f[g].c3.w)));
+                else if (MODE >= 3) v = lut_poly_pk(f[g]);
                 else v = lut_poly(f[g]);
                 negative = negative || v < 0.f;
                 acc = acc + v;
@@ -134,8 +136,10 @@ int main() {
     const double samples = (double)npoi * ITERS * (NF / G) * G * 64, bytes = samples * 64;
     const double a2 = run<0, 2>(lut, out, npoi, side), b2 = run<1, 2>(lut, out, npoi, side), c2 = run<2, 2>(lut, out, npoi, side);
     const double a0 = run<0, 0>(lut, out, npoi, side), b0 = run<1, 0>(lut, out, npoi, side), c0 = run<2, 0>(lut, out, npoi, side);
+    const double p2 = run<3, 2>(lut, out, npoi, side), q2 = run<4, 2>(lut, out, npoi, side);
     printf("{\"iters\": %d, \"passes\": %d, \"samples\": %.0f, \"bytes\": %.0f,\n", ITERS, (NF / G) * G, samples, bytes);
     printf(" \"lockstep2\": {\"both_ms\": %.4f, \"gather_only_ms\": %.4f, \"valu_only_ms\": %.4f, \"both_TBps\": %.2f},\n", a2, b2, c2, bytes / a2 / 1e9);
+    printf(" \"lockstep2_packed_products\": {\"both_ms\": %.4f, \"valu_only_ms\": %.4f},\n", p2, q2);
     printf(" \"free_running\": {\"both_ms\": %.4f, \"gather_only_ms\": %.4f, \"valu_only_ms\": %.4f, \"both_TBps\": %.2f}}\n", a0, b0, c0, bytes / a0 / 1e9);
     return 0;
 }
