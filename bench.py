@@ -91,6 +91,11 @@ L1_PORT_PEAK_GBS = 256 * 64 * 2.4
 # own runs, corrected as the guide prescribes); written by tools/pmc_traffic.py, see tools/gpu_round.sh
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "icgn2d1_traffic_configB.json")
 TRAFFIC_JSON_OLD = os.path.join(ROOT, "profiles", "icgn2d1_hbm_traffic_configB.json")  # rounds 1-2: HBM side only
+# round 4: ONE script (tools/gpu_profiles.sh) collects kernel stats + PMC traffic of the dominant kernels of configs B, C and E;
+# its records fill roofline.traffic and roofline_secondary[*].traffic (tools/pmc_traffic.py --kernels: `per_kernel`)
+TRAFFIC_BY_CONFIG = {c: os.path.join(ROOT, "profiles", "traffic_config%s.json" % c) for c in "BCE"}
+# sweep of icgn2d_kernel<6> as a micro-benchmark: its gather pattern AND its VALU mix, nothing else (tools/ubench/coissue_ubench.hip)
+COISSUE_JSON = os.path.join(ROOT, "profiles", "coissue_ubench.json")
 # ds_read2_b32 serves 128 B per clock and CU (MI355X_MICROARCH.md, LDS table): 256 CUs x 128 B x 2.4 GHz
 LDS_READ2_PEAK_GBS = 256 * 128 * 2.4
 CLOCK_GHZ = 2.4
@@ -151,7 +156,14 @@ def algorithmic_flops_icgn2d1(pois_np, rx, ry):
     return float(ran.sum() * 50 * n2 + it[ran].sum() * 75 * n2)
 
 
-def roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof):
+def sample_slots_icgn2d1(pois_np, rx, ry):
+    """Sample slots the interpolation sweeps of a launch occupy: iterations x ceil(N2 / 64) passes x 64 lanes, summed over the POIs."""
+    n2 = (2 * rx + 1) * (2 * ry + 1)
+    it = pois_np[:, 17].astype(np.float64)
+    return float(it[it > 0].sum() * ((n2 + 63) // 64) * 64)
+
+
+def roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof, sample_slots=None):
     """The `roofline` object of the JSON line (a function so that the CPU tests can exercise it)."""
     secs = icgn_avg_ms * 1e-3
     alg_rate = alg_bytes / secs / 1e9 if secs > 0 else 0.0      # GB/s
@@ -189,6 +201,8 @@ def roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof):
         "valu": {"achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / VALU_PEAK_TFLOPS,
                  "algorithmic_flops_per_launch": alg_flops,
                  "note": "the reference's own fp32 operations over the chip's rate for separately rounded operations"},
+        "combined": (combined_ceiling(icgn_avg_ms, sample_slots, (prof or {}).get("valu_wave_instr_per_launch"))
+                     if sample_slots else None),
         "hbm_traffic_profiled": prof,
     }
 
@@ -402,7 +416,7 @@ def main():
                                if dist_on else "none"),
                 "all_gather_alone_ms": gather_alone_ms,
             },
-            "roofline": roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof),
+            "roofline": roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof, sample_slots_icgn2d1(local_np, RX, RY)),
             "stage_ms": {
                 "fftcc_pipeline_avg": fftcc_ms / max(fftcc_launches, 1),
                 "icgn_kernel_avg": icgn_avg_ms,
@@ -423,7 +437,8 @@ def main():
                 "fftcc2d_fused32x2_kernel (FFTCC2D, 32x32 window)", "B: 4096^2, r=16, 250 000 POIs",
                 (2 * (2 * RX) * (2 * RY) * 4 + 20) * float(hi - lo), fftcc_ms / max(fftcc_launches, 1), fftcc_launches,
                 "hbm", HBM_PEAK_GBS, "SURVEY 8(d): 2*M2*4 B in + 20 B out = 8 212 B per POI; the kernel itself is VALU-bound "
-                "(about 1.1 k wave-instructions per POI, two POIs per wave, DESIGN.md 4.2)")
+                "(about 1.1 k wave-instructions per POI, two POIs per wave, DESIGN.md 4.2)",
+                traffic=kernel_traffic("B", "fftcc2d_fused32x2_kernel"))
             del queues, gather_bufs
             out["roofline_secondary"] = [fftcc_block] + secondary_rooflines(dev, local_rank)
             out["cpu_baseline"] = cpu_baseline(ref, tar, xs, ys, args.cpu_sample)
@@ -493,15 +508,65 @@ def multi_gpu_check(args, dist, torch, dev, rank, world, local_rank, one_device,
             "ms_per_step_gather_not_overlapped": serial_ms}
 
 
-def secondary_block(kernel, config, alg_bytes, avg_ms, launches, bound, peak_gbs, note, extra=None):
+def kernel_traffic(config, kernel_regex):
+    """HBM / L2-side bytes per launch of one kernel from the committed PMC record of its config (tools/gpu_profiles.sh), or None."""
+    path = TRAFFIC_BY_CONFIG.get(config)
+    if not path or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f)
+    k = (rec.get("per_kernel") or {}).get(kernel_regex)
+    if not k:
+        return None
+    return {"hbm_bytes_per_launch": k.get("hbm_bytes_per_launch"), "l2_bytes_per_launch": k.get("l2_bytes_per_launch"),
+            "l2_hit_rate": k.get("l2_hit_rate"), "rocprof_avg_ms": (k["avg_us"] * 1e-3 if k.get("avg_us") else None),
+            "rocprof_median_ms": (k["median_us"] * 1e-3 if k.get("median_us") else None), "scratch_bytes": k.get("scratch_bytes"),
+            "vgpr": k.get("vgpr"), "source": os.path.relpath(path, ROOT) + (" (%s)" % rec["collected"] if rec.get("collected") else "")}
+
+
+def secondary_block(kernel, config, alg_bytes, avg_ms, launches, bound, peak_gbs, note, extra=None, traffic=None):
     secs = avg_ms * 1e-3
     rate = alg_bytes / secs / 1e9 if secs > 0 else 0.0
     blk = {"kernel": kernel, "config": config, "bound": bound, "achieved": rate, "peak": peak_gbs, "unit": "GB/s",
-           "frac": rate / peak_gbs, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
-           "launches_timed": launches, "hbm_frac_of_algorithmic_bytes": rate / HBM_PEAK_GBS, "note": note}
+           "frac": rate / peak_gbs, "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
+           "traffic_l2": (traffic or {}).get("l2_bytes_per_launch"), "traffic_source": (traffic or {}).get("source"),
+           "rocprof_avg_ms": (traffic or {}).get("rocprof_avg_ms"), "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+           "launches_timed": launches, "hbm_frac_of_algorithmic_bytes": rate / HBM_PEAK_GBS,
+           "hbm_frac_by_counters": ((traffic or {}).get("hbm_bytes_per_launch") or 0.0) / secs / 1e9 / HBM_PEAK_GBS if secs > 0 else None,
+           "note": note}
     if extra:
         blk.update(extra)
     return blk
+
+
+def combined_ceiling(icgn_avg_ms, sample_slots, valu_instr_per_launch):
+    """ONE ceiling for the metric kernel.  tools/ubench/coissue_ubench.hip runs the kernel's interpolation sweep --
+    its exact gather pattern in lockstep 8-wave workgroups AND its per-sample VALU mix (the kernel's own device functions) -- and
+    nothing else, in three builds: both, gathers only, VALU only.  Measured: `both` = `gathers only` (the VALU work hides under
+    the gather), and the VALU-only build sustains ~4.4 cycles per VALU wave-instruction and SIMD at the kernel's occupancy.
+    Scaled to this run: gather side = both_ms x (this run's sample slots / the benchmark's), VALU side = the kernel's VALU
+    wave-instructions (PMC, committed) x that cycle cost; the larger one is the ceiling no schedule of THIS instruction stream
+    can beat, frac = ceiling / measured."""
+    if not os.path.exists(COISSUE_JSON):
+        return None
+    with open(COISSUE_JSON) as f:
+        u = json.load(f)
+    lock = u["lockstep2"]
+    per_slot_ms = lock["both_ms"] / (u["samples"] / 64.0)          # ms per wave-pass (64 sample slots)
+    gather_ms = per_slot_ms * sample_slots / 64.0
+    valu_instr_ubench = u.get("valu_wave_instr_valu_only")          # VALU wave-instructions of the VALU-only build (ISA count x passes)
+    cyc = lock["valu_only_ms"] * 1e-3 * CLOCK_GHZ * 1e9 * 1024 / valu_instr_ubench if valu_instr_ubench else None
+    valu_ms = valu_instr_per_launch * cyc / (1024 * CLOCK_GHZ * 1e9) * 1e3 if (cyc and valu_instr_per_launch) else None
+    ceiling = max(gather_ms, valu_ms or 0.0)
+    return {"ceiling_ms": ceiling, "frac": ceiling / icgn_avg_ms if icgn_avg_ms > 0 else None,
+            "gather_side_ms": gather_ms, "valu_side_ms": valu_ms, "valu_cycles_per_instr_measured": cyc,
+            "kernel_valu_wave_instr_per_launch": valu_instr_per_launch,
+            "sweep_ubench": {"both_ms": lock["both_ms"], "gather_only_ms": lock["gather_only_ms"], "valu_only_ms": lock["valu_only_ms"],
+                             "sample_slots": u["samples"]},
+            "source": os.path.relpath(COISSUE_JSON, ROOT),
+            "note": "both = gathers only: the sweep's VALU work hides completely under its gathers (perfect overlap INSIDE the sweep); "
+                    "over the whole kernel the VALU side is the larger one -- the kernel issues VALU instructions at the rate this "
+                    "instruction mix sustains on the hardware, i.e. what is left is instruction count, not overlap"}
 
 
 def _timed_launches(torch, eng, fn, reps):
@@ -547,7 +612,8 @@ def secondary_rooflines(dev, device, reps=3):
     alg = float(ran.sum() * (3 * n2 * 4 + 200) + it[ran].sum() * n2 * 64 + (~ran).sum() * 200)
     out.append(secondary_block("icgn2d_kernel<12,...> (ICGN2D2)", "C: 4096^2, r=20 (41x41), %d POIs" % len(xs), alg, avg, n, "l2",
                                L2_PEAK_GBS, "SURVEY 8(d): 3*N2*4 + k*N2*64 + 200 B per POI, N2 = 1681; same L1/L2 table gather as ICGN2D1",
-                               {"mean_iterations": float(it[ran].mean()), "converged": int((res[:, 16] >= 0).sum())}))
+                               {"mean_iterations": float(it[ran].mean()), "converged": int((res[:, 16] >= 0).sum())},
+                               traffic=kernel_traffic("C", "icgn2d_kernel")))
     del f, g, ref, tar, guess, q
     # ---- E: 512^3, r = 16, FFTCC3D + ICGN3D1, 37^3 POIs
     r = 16
@@ -567,7 +633,7 @@ def secondary_rooflines(dev, device, reps=3):
     out.append(secondary_block("fftcc3d_fused32_kernel (FFTCC3D, 32^3 window)", "E: 512^3, r=16, %d POIs" % len(xs),
                                (2 * m3 * 4 + 28) * float(len(xs)), avg_f, n_f, "hbm", HBM_PEAK_GBS,
                                "SURVEY 8(d): 2*M3*4 B in + 28 B out = 262 172 B per POI; the kernel is VALU + LDS-exchange bound "
-                               "(six 32-point FFT passes per thread, DESIGN.md 4.2b)"))
+                               "(six 32-point FFT passes per thread, DESIGN.md 4.2b)", traffic=kernel_traffic("E", "fftcc3d_fused32_kernel")))
     q = guess.clone()
     avg, n = _timed_launches(torch, g, lambda: (q.copy_(guess), g.compute(q)), reps)
     res = q.cpu().numpy()
@@ -579,7 +645,8 @@ def secondary_rooflines(dev, device, reps=3):
                                LDS_READ2_PEAK_GBS, "SURVEY 8(d): 4*N3*4 + k*N3*256 + 248 B per POI; the 256 B per sample and iteration are "
                                "the 64 tricubic taps, served from the LDS-staged coefficient box: judged against the LDS read rate "
                                "(ds_read2_b32: 128 B per clock and CU)",
-                               {"mean_iterations": float(it[ran].mean()), "converged": int((res[:, 18] >= 0).sum())}))
+                               {"mean_iterations": float(it[ran].mean()), "converged": int((res[:, 18] >= 0).sum())},
+                               traffic=kernel_traffic("E", "icgn3d1")))
     return out
 
 
@@ -614,14 +681,23 @@ def pmc_profile(world):
     tools/gpu_round.sh); a constant read from profiles/, not something measured in this run."""
     if world != 1:
         return None
-    path = TRAFFIC_JSON if os.path.exists(TRAFFIC_JSON) else TRAFFIC_JSON_OLD
-    if not os.path.exists(path):
+    path = next((p for p in (TRAFFIC_BY_CONFIG["B"], TRAFFIC_JSON, TRAFFIC_JSON_OLD) if os.path.exists(p)), None)
+    if path is None:
         return None
     with open(path) as f:
         rec = json.load(f)
+    # run-to-run spread of the HBM counters: the same passes collected a second time by the same script
+    second = os.path.join(os.path.dirname(path), "traffic_configB_second_run.json")
+    spread = None
+    if os.path.exists(second):
+        with open(second) as f:
+            spread = float(json.load(f)["hbm_bytes_per_launch"])
     return {"hbm_bytes_per_launch": float(rec["hbm_bytes_per_launch"]),
+            "hbm_bytes_per_launch_second_collection": spread,
             "l2_bytes_per_launch": (float(rec["l2_bytes_per_launch"]) if rec.get("l2_bytes_per_launch") else None),
             "l2_request_bytes_calibrated": rec.get("l2_request_bytes"), "l2_hit_rate": rec.get("l2_hit_rate"),
+            "valu_wave_instr_per_launch": rec.get("SQ_INSTS_VALU_per_launch"),
+            "rocprof_avg_ms": (rec["avg_us"] * 1e-3 if rec.get("avg_us") else None),
             "source": os.path.relpath(path, ROOT) + (" (%s)" % rec["collected"] if rec.get("collected") else ""),
             "note": "PMC counters over `python bench.py --no-cpu-baseline`, one counter set per rocprofv3 run (tools/gpu_traffic.sh): "
                     "HBM = FETCH_SIZE x 2 + WRITE_SIZE; L2 side = TCC_REQ_sum x a request size calibrated on a gather of known byte "

@@ -23,10 +23,9 @@ ARCH = "gfx950"
 # v_mov_b32 forming the register pairs turn into a loss (ICGN2D sweep: 48 moves per 3 samples, 17 % more issue cycles).
 # Code that wants packed arithmetic says so with float2 vector types.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
-# per-file additions.  icgn3d*.hip: the tricubic tap sums form their products as packed pairs (taps4, icgn3d_device.h); LLVM's
-# VectorCombine then also rewrites the scalar ADDITIONS on the pair halves into packed instructions with one useful lane each and
-# ~60 operand moves per sample -- switched off for these two files (tap block: 190 -> 153 VALU instructions per sample).
-EXTRA_FLAGS = {"icgn3d.hip": ["-mllvm", "-disable-vector-combine"], "icgn3d_rows.hip": ["-mllvm", "-disable-vector-combine"]}
+# per-file additions (none at present; round 4 built icgn3d*.hip with `-mllvm -disable-vector-combine` for the packed tap
+# products of OC_TAPS_PACKED=1 -- measured slower, see icgn3d_device.h)
+EXTRA_FLAGS = {}
 
 
 def hipcc():

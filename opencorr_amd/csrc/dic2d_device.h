@@ -375,11 +375,13 @@ __device__ __forceinline__ float lut_poly(const LutFetch& f) {
 // The same 16 terms with the 24 products formed as 14 packed multiplies on the register pairs the 16-byte loads deliver
 // ((x, y) and (z, w) of each float4): (c.x, c.y) * dy^k, then * (1, dx); (c.z, c.w) * dy^k, then * (dx^2, dx^3) -- every
 // product is the reference's ((c * dy^k) * dx^l, the factor 1.f is exact), the 15 additions stay the left-to-right chain:
-// identical bits, 10 VALU instructions fewer per sample.  Round 2 found v_pk_mul_f32 at 4.3 cycles against 2.4 for a plain
-// multiply in an ideal dual-issue stream; in the kernels themselves a VALU instruction costs ~4.4 cycles whatever its kind
-// (tools/ubench/coissue_ubench.hip), which is where a packed pair WITHOUT operand moves pays.  OC_POLY_PACKED selects it.
+// identical bits, 10 VALU instructions fewer per sample (134 -> 115 per two samples in the sweep, no operand moves).
+// MEASURED in round 4 and NOT faster (profiles/r4d_ab_packed_products.txt): ICGN2D1 on config B 3.27 - 3.28 against 3.24 ms,
+// ICGN2D2 on config C 3.53 against 3.52 - 3.53, the sweep's VALU side alone 1.12 against 1.04 ms -- a v_pk_mul_f32 holds the
+// SIMD twice as long as a v_mul_f32 (round 2: 4.3 against 2.4 cycles), so two products per instruction buy nothing: VALU
+// time follows issue cycles, not instruction counts.  Kept behind OC_POLY_PACKED (default 0) as the A/B partner.
 #ifndef OC_POLY_PACKED
-#define OC_POLY_PACKED 1
+#define OC_POLY_PACKED 0
 #endif
 __device__ __forceinline__ float lut_poly_pk(const LutFetch& f) {
     const float dx = f.dx, dy = f.dy;

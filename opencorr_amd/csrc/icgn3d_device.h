@@ -201,11 +201,13 @@ typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // 4-byt
 // (src/oc_cubic_bspline.cpp:390-401): four separately rounded products, three additions left to right.  OC_TAPS_PACKED
 // forms the products as two packed multiplies (v_pk_mul_f32 on the pairs (r0, r1), (r2, r3): a ds_read2_b32 / a 16-byte
 // load delivers exactly those register pairs); the same IEEE products, so the same bits, 2 instead of 4 multiply
-// instructions -- 42 of the 84 per sample.  In the kernels a VALU instruction costs ~4.4 cycles whatever its kind
-// (tools/ubench/coissue_ubench.hip), so the packed form is the cheaper one there (round 2's 4.3-against-2.4-cycle finding
-// holds for ideal dual-issue streams only).
+// instructions: with `-mllvm -disable-vector-combine` (or LLVM also packs the additions, one useful lane each, with ~60
+// operand moves) the tap block shrinks from 190 to 153 VALU instructions per sample.  MEASURED in round 4 and SLOWER
+// (profiles/r4d_ab_packed_products.txt, 256^3 / 8 000 POIs, bit-identical): 12.25 - 12.30 ms against 11.81 -- a packed
+// multiply occupies the SIMD about twice as long as a plain one, so VALU time follows issue cycles, not instruction counts
+// (round 2's finding, confirmed on the 3D kernel).  Default 0; the macro stays for the A/B.
 #ifndef OC_TAPS_PACKED
-#define OC_TAPS_PACKED 1
+#define OC_TAPS_PACKED 0
 #endif
 __device__ __forceinline__ float taps4(float b0, float b1, float b2, float b3, float r0, float r1, float r2, float r3) {
 #if OC_TAPS_PACKED

@@ -36,7 +36,8 @@ for cfg in $CONFIGS; do
   echo "== config $cfg: kernel trace"
   timeout 900 rocprofv3 --kernel-trace --stats -d $D/trace -o trace -- $CMD > $D/trace.log 2>&1
   python $ROOT/tools/rocpd_summary.py $(ls $D/trace/*.db | head -1) $OUT/${TAG}_config${cfg}_kernel_stats.csv 2>&1 | head -6
-  for c in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"; do
+  for c in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" \
+           "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU2 SQ_LDS_BANK_CONFLICT"; do
     name=${c%%:*}; ctr=${c#*:}
     timeout 900 rocprofv3 --pmc $ctr --kernel-include-regex "$REGEX" --output-format csv -d $D/pmc_$name -o $name -- $CMD > $D/pmc_$name.log 2>&1
     echo "config $cfg pmc $name rc=$?"

@@ -109,6 +109,14 @@ def one_kernel(a, rx):
                 cf = per_dispatch(calf[0], "FETCH_SIZE", crx)
                 rec["fetch_size_kb_of_the_1GiB_stream"] = sum(cf[1:]) / max(len(cf[1:]), 1)
                 rec["fetch_correction_measured"] = cbytes / 1024.0 / rec["fetch_size_kb_of_the_1GiB_stream"]
+    sq = glob.glob(os.path.join(a.root, "pmc_sq", "*_counter_collection.csv"))
+    if sq:
+        avg = lambda v: sum(v[-a.launches:]) / max(len(v[-a.launches:]), 1)
+        for name in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
+                     "SQ_ACTIVE_INST_VALU2", "SQ_LDS_BANK_CONFLICT"):
+            v = per_dispatch(sq[0], name, rx)
+            if v:
+                rec[name + "_per_launch"] = avg(v)
     return rec
 
 
