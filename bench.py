@@ -565,8 +565,11 @@ def combined_ceiling(icgn_avg_ms, sample_slots, valu_instr_per_launch):
                              "sample_slots": u["samples"]},
             "source": os.path.relpath(COISSUE_JSON, ROOT),
             "note": "both = gathers only: the sweep's VALU work hides completely under its gathers (perfect overlap INSIDE the sweep); "
-                    "over the whole kernel the VALU side is the larger one -- the kernel issues VALU instructions at the rate this "
-                    "instruction mix sustains on the hardware, i.e. what is left is instruction count, not overlap"}
+                    "over the whole kernel the VALU side is the larger one: the kernel's VALU wave-instructions x the cycles per "
+                    "instruction its own sweep mix sustains when run alone (an extrapolation from the sweep to the set-up, numerator and "
+                    "reduction phases, whose mixes hold more packed / DPP / readlane instructions, i.e. cost at least as much) -- what is "
+                    "left is VALU issue cycles, not overlap; packed products (fewer instructions, same issue cycles) were measured and "
+                    "do not help (profiles/r4d_ab_packed_products.txt)"}
 
 
 def _timed_launches(torch, eng, fn, reps):
