@@ -13,7 +13,7 @@ CONFIGS=${2:-"B C E"}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-REPS=3
+REPS=${OC_PROFILE_REPS:-10}   # launches averaged per kernel (the first ones -- warm-up -- are dropped)
 cd /tmp
 if [ ! -x $ROOT/tools/ubench/l2_req_calib ]; then
   hipcc --offload-arch=gfx950 -O3 $ROOT/tools/ubench/l2_req_calib.hip -o $ROOT/tools/ubench/l2_req_calib
@@ -25,10 +25,10 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "stream_read" --ou
     -d $OUT/pmc_calib_fetch -o calibf -- $ROOT/tools/ubench/l2_req_calib > $OUT/pmc_calib_fetch.log 2>&1
 for cfg in $CONFIGS; do
   case $cfg in
-    B) CMD="python $ROOT/bench.py --steps $REPS --warmup 2 --no-cpu-baseline"; KERNELS="icgn2d_kernel fftcc2d_fused32x2_kernel";;
-    C) CMD="python $ROOT/tools/run_config_kernels.py C --reps $REPS"; KERNELS="icgn2d_kernel fftcc2d_fusedn_kernel";;
-    E) CMD="python $ROOT/tools/run_config_kernels.py E --reps $REPS"; KERNELS="icgn3d1 fftcc3d_fused32_kernel";;
-    E30) CMD="python $ROOT/tools/run_config_kernels.py E30 --reps $REPS"; KERNELS="icgn3d1 fftcc3d_planes_kernel";;
+    B) CMD="python $ROOT/bench.py --steps $REPS --warmup 5 --no-cpu-baseline"; KERNELS="icgn2d_kernel fftcc2d_fused32x2_kernel";;
+    C) CMD="python $ROOT/tools/run_config_kernels.py C --reps $REPS --warm 3"; KERNELS="icgn2d_kernel fftcc2d_fusedn_kernel";;
+    E) CMD="python $ROOT/tools/run_config_kernels.py E --reps $REPS --warm 2"; KERNELS="icgn3d1 fftcc3d_fused32_kernel";;
+    E30) CMD="python $ROOT/tools/run_config_kernels.py E30 --reps $REPS --warm 2"; KERNELS="icgn3d1 fftcc3d_planes_kernel";;
   esac
   D=$OUT/cfg$cfg
   mkdir -p $D

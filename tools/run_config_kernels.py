@@ -5,17 +5,19 @@ tools/gpu_profiles.sh collects the kernel trace and the PMC traffic of configs C
     python tools/run_config_kernels.py C|E|E30 [--reps 3]
 """
 import argparse
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import opencorr_amd as oc
 from opencorr_amd import synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("config")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--warm", type=int, default=1, help="untimed passes before the `reps` the profile averages")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
@@ -37,7 +39,7 @@ g.set_stream(stream)
 g.share_images(f)
 g.prepare()
 q = pristine.clone()
-for _ in range(a.reps + 1):   # the first pass is the warm-up (tools/pmc_traffic.py averages the last `reps` launches)
+for _ in range(a.reps + a.warm):   # warm-up passes first (tools/pmc_traffic.py averages the last `reps` launches)
     q.copy_(pristine)
     f.compute(q)
     g.compute(q)
