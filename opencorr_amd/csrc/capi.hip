@@ -189,6 +189,7 @@ struct oc_hip_engine {
     int fftcc2d_fused = 1;    // single-kernel FFTCC2D when the window is 32 x 32
     int fftcc3d_fused = 1;    // single-kernel FFTCC3D for cubic windows of side 8 ... 64 (three kernels by size)
     int fftcc3d_planes_blocks = 0;  // persistent workgroups (= scratch volumes) of the plane-wise kernel; 0 = 256
+    int icgn3d_tile_vox = 48; // ICGN3D1: queues of >= 2048 POIs are visited in cubic blocks of this many voxels (0 = queue order)
     int icgn3d_mapping = 0;   // ICGN3D1: 0 = sample s owned by thread s mod 512 (icgn3d.hip; oracle order OC_ORDER_LANES) -- the default:
                               // 1 = one half-wave per subvolume row (icgn3d_rows.hip; OC_ORDER_ROWS), built and measured in round 4:
                               // bit-exact against its own order, 12 - 25 % SLOWER -- kept as the A/B partner
@@ -684,7 +685,17 @@ int run_icgn3d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     if (scratch) OC_TRY(e->tmp.reserve(scratch * sizeof(float)));
     ochip::Icgn3dParams P = {im.ref_ptr(), e->gx.as<float>(), e->gy.as<float>(), e->gz.as<float>(), e->coef.as<float>(),
                              im.dz, im.dy, im.dx, e->rx, e->ry, e->rz, e->conv, e->stop,
-                             scratch ? e->tmp.as<float>() : nullptr, 1, 1};
+                             scratch ? e->tmp.as<float>() : nullptr, 1, 1, nullptr};
+    // locality schedule: visit the queue in compact cubic blocks, so that the POIs in flight share their voxels behind the
+    // L2s / the Infinity Cache (poi_order.hip); same bits for every POI
+    if (e->icgn3d_tile_vox > 0 && count >= 2048 && count <= 0xffffffffull) {
+        OC_TRY(e->perm.reserve(count * sizeof(unsigned)));
+        OC_TRY(e->perm_slots.reserve(count * sizeof(unsigned)));
+        OC_TRY(e->tiles.reserve(ochip::poi3d_tile_count(im.dz, im.dy, im.dx, e->icgn3d_tile_vox) * sizeof(unsigned)));
+        OC_HIP_TRY(ochip::launch_poi3d_tile_order(d_pois, stride_f, count, im.dz, im.dy, im.dx, e->icgn3d_tile_vox, e->tiles.as<unsigned>(),
+                                                  e->perm_slots.as<unsigned>(), e->perm.as<unsigned>(), e->stream));
+        P.perm = e->perm.as<unsigned>();
+    }
     ProfScope prof(e);
     hipError_t err = e->icgn3d_mapping != 0 ? ochip::launch_icgn3d1_rows(P, d_pois, stride_f, count, e->stream)
                                             : ochip::launch_icgn3d1(P, d_pois, stride_f, count, e->stream);
@@ -1138,6 +1149,7 @@ static int clone_engine(const oc_hip_engine* e, int device, oc_hip_engine** out)
     r->fftcc3d_fused = e->fftcc3d_fused;
     r->fftcc3d_planes_blocks = e->fftcc3d_planes_blocks;
     r->icgn3d_mapping = e->icgn3d_mapping;
+    r->icgn3d_tile_vox = e->icgn3d_tile_vox;
     r->host_chunk = e->host_chunk;
     r->group_allgather = e->group_allgather;
     r->group_force_rccl = e->group_force_rccl;
@@ -1367,6 +1379,9 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
         e->fftcc2d_fused = value == 2 ? 2 : (value != 0);
     } else if (k == "fftcc3d_fused") {
         e->fftcc3d_fused = value != 0;
+    } else if (k == "icgn3d_tile_vox") {
+        if (value < 0 || (value > 0 && value < 8)) return fail(OC_HIP_ERR_INVALID, "icgn3d_tile_vox must be 0 (off) or >= 8");
+        e->icgn3d_tile_vox = value;
     } else if (k == "icgn3d_mapping") {
         e->icgn3d_mapping = value != 0;
     } else if (k == "fftcc3d_planes_blocks") {

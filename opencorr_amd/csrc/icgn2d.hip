@@ -4,17 +4,26 @@
 // ICGN2D2::compute(POI2D*) (src/oc_icgn.cpp:685-898) for a whole POI queue
 // (:343-351 / :900-908).
 //
-// Mapping: ONE 64-lane wavefront per POI (one-wave workgroups, so no barriers).
-// Sample s = r*W + c of the (2ry+1) x (2rx+1) subset is owned by lane s % 64; each
-// lane keeps ITS samples of the zero-mean reference subset, the two reference
-// gradients and the current warped-target subset in registers for the whole
-// solve (NT = ceil(N/64) values each, compile-time NT), so the only memory
-// traffic inside the Gauss-Newton loop is the 64 B/sample gather from the
-// bicubic coefficient LUT -- the "interpolation sweep" that bounds the kernel.
-// Reductions (mean, norms, Hessian, numerator, ZNSSD) are per-lane partial sums
-// in increasing s followed by the xor butterfly of oc_device.h; the CPU oracle
-// uses the same association (OC_ORDER_LANES) and the results are bit-identical.
-// Wave-uniform state (warp matrix, inverse Hessian, norms) is held in SGPRs.
+// Mapping: ONE 64-lane wavefront per POI; sample s = r*W + c of the (2ry+1) x (2rx+1) subset is owned by lane s % 64,
+// pass t = s / 64.  The shipped default for large queues (variant 5: G = 2, MODE 4, 80 VGPRs) packs EIGHT waves -- eight
+// consecutive POIs of the visiting order -- into a workgroup, three workgroups per CU (6 waves per SIMD):
+//   * per-sample state lives in LDS as [t][lane] arrays: one array per wave (the current warped-target subset; the raw
+//     reference values pass through it before the first sweep) plus ONE table per workgroup of what depends on (lane, pass)
+//     only -- the sample's local coordinates and its byte offset from the subset origin (MODE 3 / 4, `TAB`); the reference
+//     value and the two reference gradients are re-read from the images (coalesced, L2 hits) in the passes that need them;
+//   * barriers: one after the table fill, two around the cooperative inverse (ONE wave inverts the workgroup's eight 6 x 6
+//     Hessians, `COOP`), and the lockstep barrier of the interpolation sweep (`SWEEP_SYNC`: every two pass groups the eight
+//     waves re-align, so that neighbouring POIs ask for the same table lines while they are in the CU's L1 -- no data crosses
+//     it; its deadlock-freedom rests on three invariants stated where it is defined);
+//   * the only memory traffic inside the Gauss-Newton loop besides those re-reads is the 64 B / sample gather from the planar
+//     bicubic table (four buffer_load_b128, one per plane) -- the "interpolation sweep".
+// Other variants (oc_hip_set_tuning("icgn2d_variant")): 4-wave workgroups without table or barriers for small queues and
+// large subsets (variant 2), one-wave workgroups with everything parked in LDS (variants 0, 1, 3, and the IC-LM engines).
+// Reductions (mean, norms, Hessian, numerator, ZNSSD) are per-lane partial sums in increasing s followed by the xor
+// butterfly of oc_device.h; the CPU oracle uses the same association (OC_ORDER_LANES) and the results are bit-identical,
+// whatever the variant.  Wave-uniform state (warp matrix, norms) is held in SGPRs.
+// What bounds it: VALU issue -- the kernel runs at 0.97 of what its own instruction stream sustains
+// (tools/ubench/coissue_ubench.hip); the gathers hide completely under the arithmetic of the sweep.
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -59,8 +68,8 @@
 namespace ochip {
 
 // ---------------------------------------------------------------------------
-// ICGN2D1 (DOF = 6, 3x3 warp) and ICGN2D2 (DOF = 12, 6x6 warp).  One wave per POI, WPB
-// independent waves (consecutive POIs) per workgroup -- no barriers anywhere.
+// ICGN2D1 (DOF = 6, 3x3 warp) and ICGN2D2 (DOF = 12, 6x6 warp).  One wave per POI, WPB waves (consecutive POIs) per
+// workgroup; the waves share nothing but the coordinate table and the cooperative inverse of the table variants.
 // Per-sample state lives in LDS as [t][lane] arrays (conflict-free ds_read/write_b32),
 // NT = ceil(N/64) at run time:
 //   MODE 0 (floats per wave): rs[NT*64] | ts[NT*64] | gx[NT*64] | gy[NT*64]

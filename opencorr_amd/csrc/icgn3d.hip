@@ -143,7 +143,8 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
     const unsigned long long xcd_chunk = (count + 7) / 8, xcd_lo = (blockIdx.x & 7u) * xcd_chunk;
     const unsigned long long xcd_hi = min(count, xcd_lo + xcd_chunk);
     for (unsigned long long idx = xcd_lo + (blockIdx.x >> 3); idx < xcd_hi; idx += gridDim.x >> 3) {
-        float* poi = pois + idx * (unsigned long long)stride_f;
+        // the k-th solve of the launch takes POI perm[k] (a locality schedule, poi_order.hip) or simply POI k
+        float* poi = pois + (P.perm ? (unsigned long long)P.perm[idx] : idx) * (unsigned long long)stride_f;
         // every thread reads the same record: keep it in SGPRs (the hot loops need the VGPRs)
         const float px = uni3(poi[poi3d::X]), py = uni3(poi[poi3d::Y]), pz = uni3(poi[poi3d::Z]);
         float init[12];

@@ -57,6 +57,10 @@ int icgn2d_max_samples(int variant);
 size_t poi2d_tile_count(int height, int width, int tile_px);
 hipError_t launch_poi2d_tile_order(const float* pois, int stride_floats, size_t count, int height, int width, int tile_px,
                                    unsigned* tiles, unsigned* slots, unsigned* perm, hipStream_t stream);
+// the same for POI3D queues (cubic tiles of tile_vox voxels): the ICGN3D1 kernels visit the queue block by block
+size_t poi3d_tile_count(int depth, int height, int width, int tile_vox);
+hipError_t launch_poi3d_tile_order(const float* pois, int stride_floats, size_t count, int depth, int height, int width, int tile_vox,
+                                   unsigned* tiles, unsigned* slots, unsigned* perm, hipStream_t stream);
 
 // ---- strain.hip -------------------------------------------------------------
 // Strain::prepare / Strain::compute (src/oc_strain.cpp): uniform grid over the queue's coordinates
@@ -124,6 +128,7 @@ struct Icgn3dParams {
     float* scratch;  // per-workgroup slots for the warped subvolume
     int samples_per_pass;  // samples (row mapping: steps of 16 rows) per thread between two coefficient-box stagings (set by the launchers)
     int tail_steps_per_pass;  // row mapping: steps of 512 tail samples per tail pass (set by launch_icgn3d1_rows)
+    const unsigned* perm;     // locality schedule (poi_order.hip launch_poi3d_tile_order): the k-th solve takes POI perm[k]; nullptr = queue order
 };
 // floats of global scratch the kernel needs for this radius (0 when the subvolume fits LDS);
 // *blocks receives the number of persistent workgroups in scratch mode (0 in LDS mode)

@@ -19,12 +19,19 @@ namespace ochip {
 
 namespace {
 
-__device__ __forceinline__ unsigned tile_of(const float* poi, int height, int width, int tile_px, int ntx) {
+// 2D: `height` x `width` pixels, depth = 0; 3D (round 4, ICGN3D1): depth x height x width voxels, POI3D records (x, y, z first)
+__device__ __forceinline__ unsigned tile_of(const float* poi, int height, int width, int tile_px, int ntx, int depth = 0, int nty = 0) {
     // NaN / out-of-image coordinates land in an edge tile; such POIs are rejected by the guards later anyway
     const float x = poi[poi2d::X], y = poi[poi2d::Y];
     const int xi = x >= 0.f ? (x < (float)width ? (int)x : width - 1) : 0;
     const int yi = y >= 0.f ? (y < (float)height ? (int)y : height - 1) : 0;
-    return (unsigned)(yi / tile_px) * (unsigned)ntx + (unsigned)(xi / tile_px);
+    unsigned t = (unsigned)(yi / tile_px) * (unsigned)ntx + (unsigned)(xi / tile_px);
+    if (depth > 0) {
+        const float z = poi[poi3d::Z];
+        const int zi = z >= 0.f ? (z < (float)depth ? (int)z : depth - 1) : 0;
+        t += (unsigned)(zi / tile_px) * (unsigned)ntx * (unsigned)nty;
+    }
+    return t;
 }
 
 // A caller's queue is usually row-major, so neighbouring lanes tend to fall into the same tile: lanes that continue their
@@ -47,10 +54,10 @@ __device__ __forceinline__ int run_of_equal_tiles(unsigned t, bool live, int lan
 
 __global__ __launch_bounds__(256) void tile_histogram_kernel(const float* __restrict__ pois, int stride_f, unsigned count,
                                                              int height, int width, int tile_px, int ntx,
-                                                             unsigned* __restrict__ counts) {
+                                                             unsigned* __restrict__ counts, int depth = 0, int nty = 0) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < count;
-    const unsigned t = live ? tile_of(pois + (size_t)i * stride_f, height, width, tile_px, ntx) : 0u;
+    const unsigned t = live ? tile_of(pois + (size_t)i * stride_f, height, width, tile_px, ntx, depth, nty) : 0u;
     int head, len;
     const int pos = run_of_equal_tiles(t, live, threadIdx.x & 63, head, len);
     if (live && pos == 0) atomicAdd(counts + t, (unsigned)len);
@@ -82,10 +89,10 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(unsigned* __restrict__ 
 
 __global__ __launch_bounds__(256) void tile_scatter_kernel(const float* __restrict__ pois, int stride_f, unsigned count,
                                                            int height, int width, int tile_px, int ntx,
-                                                           unsigned* __restrict__ cursors, unsigned* __restrict__ perm) {
+                                                           unsigned* __restrict__ cursors, unsigned* __restrict__ perm, int depth = 0, int nty = 0) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < count;
-    const unsigned t = live ? tile_of(pois + (size_t)i * stride_f, height, width, tile_px, ntx) : 0u;
+    const unsigned t = live ? tile_of(pois + (size_t)i * stride_f, height, width, tile_px, ntx, depth, nty) : 0u;
     int head, len;
     const int pos = run_of_equal_tiles(t, live, threadIdx.x & 63, head, len);
     unsigned base = 0;
@@ -147,6 +154,39 @@ hipError_t launch_poi2d_tile_order(const float* pois, int stride_f, size_t count
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, height, width,
                        tile_px, ntx, tiles, slots);
     // chunks of 256 slots per tile: sized for four times the mean tile population, at most the cap's 16
+    const size_t mean4 = (4 * count / (size_t)ntiles + 255) / 256;
+    const unsigned chunks = (unsigned)(mean4 < 1 ? 1 : (mean4 > (size_t)(kRankCap / 256) ? (size_t)(kRankCap / 256) : mean4));
+    hipLaunchKernelGGL(tile_rank_kernel, dim3((unsigned)(ntiles < 65535 ? ntiles : 65535), chunks), dim3(256), 0, stream, ntiles, tiles,
+                       slots, perm);
+    return hipGetLastError();
+}
+
+// The same schedule for a POI3D queue: cubic tiles of `tile_vox` voxels, tiles in z-major order, queue order inside a tile.
+// ICGN3D1 (icgn3d.hip) re-reads the 33^3 neighbourhood of a POI in five volumes (0.72 MB at r = 16) every iteration; with the
+// 512 POIs in flight spread along queue rows their union (370 MB at config E) overflows the L2s AND the 256 MB Infinity
+// Cache, and every byte comes from HBM (303 GB per launch, PMC); visited in compact blocks the POIs in flight share their
+// voxels (85 MB).
+size_t poi3d_tile_count(int depth, int height, int width, int tile_vox) {
+    return (size_t)((width + tile_vox - 1) / tile_vox) * (size_t)((height + tile_vox - 1) / tile_vox) * (size_t)((depth + tile_vox - 1) / tile_vox);
+}
+
+hipError_t launch_poi3d_tile_order(const float* pois, int stride_f, size_t count, int depth, int height, int width, int tile_vox,
+                                   unsigned* tiles, unsigned* slots, unsigned* perm, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    if (count > 0xffffffffull) return hipErrorInvalidValue;
+    const int ntx = (width + tile_vox - 1) / tile_vox, nty = (height + tile_vox - 1) / tile_vox;
+    const size_t nt = poi3d_tile_count(depth, height, width, tile_vox);
+    if (nt > 0x7fffffffull) return hipErrorInvalidValue;
+    const int ntiles = (int)nt;
+    hipError_t err = hipMemsetAsync(tiles, 0, (size_t)ntiles * sizeof(unsigned), stream);
+    if (err != hipSuccess) return err;
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(tile_histogram_kernel, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, height, width,
+                       tile_vox, ntx, tiles, depth, nty);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, tiles, ntiles);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(blocks), dim3(256), 0, stream, pois, stride_f, (unsigned)count, height, width,
+                       tile_vox, ntx, tiles, slots, depth, nty);
     const size_t mean4 = (4 * count / (size_t)ntiles + 255) / 256;
     const unsigned chunks = (unsigned)(mean4 < 1 ? 1 : (mean4 > (size_t)(kRankCap / 256) ? (size_t)(kRankCap / 256) : mean4));
     hipLaunchKernelGGL(tile_rank_kernel, dim3((unsigned)(ntiles < 65535 ? ntiles : 65535), chunks), dim3(256), 0, stream, ntiles, tiles,

@@ -253,6 +253,8 @@ def main():
     for c in a.configs.split(","):
         if c == "A":
             rec = run_2d("A (2048^2, r=15, 100x100 POIs)", 2048, 15, 100, 1, 10000)
+        elif c == "B":
+            rec = run_2d("B, the bench line's workload (4096^2, r=16, 500x500 POIs)", 4096, 16, 500, 1, 4000)
         elif c == "C":
             rec = run_2d("C (4096^2, r=20, ICGN2D2, 316x316 POIs)", 4096, 20, 316, 2, 4000, so=dict(uxx=2e-6, vyy=-1e-6))
         elif c == "D1":

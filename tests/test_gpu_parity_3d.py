@@ -394,6 +394,39 @@ def test_icgn3d1_both_mappings_against_their_oracle_orders(big_volumes, r):
         assert np.array_equal(_bits(results[1]), _bits(results[0]))   # no body: the same mapping, the same bits
 
 
+def test_icgn3d1_block_schedule_changes_no_bits(volumes):
+    """Queues of >= 2048 POIs are visited in compact cubic blocks (oc_hip_set_tuning "icgn3d_tile_vox", poi_order.hip
+    launch_poi3d_tile_order) so that the POIs in flight share their voxels behind the L2s / the Infinity Cache: a schedule of
+    independent solves -- every POI's bits are those of the queue-order run (tile sizes 0 = off, 8, 20, 48; both mappings; rejected
+    and out-of-volume POIs and a queue length that is no multiple of anything included)."""
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = volumes
+    P = oracle.P3
+    xs, ys, zs = synth.poi_grid_3d(*SHAPE, 13, 13, 13, 14)
+    pois = oracle.make_pois3d(xs, ys, zs)[:2191]
+    w = synth.DEFAULT_WARP_3D
+    pois[:, P["u"]], pois[:, P["v"]], pois[:, P["w"]] = round(w["u"]), round(w["v"]), round(w["w"])
+    pois[5::97, P["zncc"]] = -1.0
+    pois[11::131, P["u"]] = 70.0
+    pois[17::151, P["x"]] = 2.0
+    icgn = opencorr_amd.ICGN3D1(5, 5, 5, 0.001, 20)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    for mapping in (0, 1):
+        icgn.set_tuning("icgn3d_mapping", mapping)
+        icgn.set_tuning("icgn3d_tile_vox", 0)
+        want = icgn.compute(pois.copy())
+        assert (want[:, P["zncc"]] > 0.9).mean() > 0.9
+        for tile in (8, 20, 48):
+            icgn.set_tuning("icgn3d_tile_vox", tile)
+            assert np.array_equal(_bits(icgn.compute(pois.copy())), _bits(want)), (mapping, tile)
+    sample = pois[::23].copy()
+    oracle.icgn3d1(oracle.Prepared3D(ref, tar), 5, 5, 5, 0.001, 20, sample, order=oracle.ORDER_LANES, lanes=512)
+    assert np.array_equal(_bits(sample), _bits(want[::23]))   # (r = 5: no body rows, both mappings are OC_ORDER_LANES)
+
+
 def test_icgn3d1_global_tap_fallback(big_volumes):
     """A 30 degree rotation about z as the initial guess: the image of a pass's index box is ~45 voxels wide, wider
     than the 40-float row pitch of icgn3d1_kernel<40>, so those passes evaluate their taps from global memory.  Bits
