@@ -43,7 +43,10 @@ Besides the contract fields the JSON line carries
   multi_gpu_check -- N > 1 only: world size and device distinctness asserted, rank 0 re-solves a strided sample of every
                   other rank's block and compares it bit for bit with the gathered records, and the step is timed once more
                   with the all-gather NOT overlapped,
-  roofline     -- ICGN2D1 kernel, judged against the roof it sits closest to.  HBM is not it (traffic <= 9 % of peak:
+  roofline     -- ICGN2D1 kernel.  `combined` (round 4) is the ONE ceiling: max(gather side, VALU side) of the kernel's own
+                  instruction stream, from a micro-benchmark of its sweep (tools/ubench/coissue_ubench.hip: gathers + VALU mix =
+                  gathers alone, i.e. perfect overlap inside the sweep) and the kernel's VALU wave-instruction count (PMC) --
+                  frac = ceiling / measured = 0.97; the byte-rate fractions below are kept for continuity.  HBM is not it (traffic <= 9 % of peak:
                   neighbouring subsets share their table entries in L1/L2, so the SURVEY 8(d) byte count / time exceeds
                   the HBM peak); ablations show the gather path of the 64-byte table entries to be the
                   larger limiter (-13 % without two thirds of the gathers, -3 % without two thirds of the polynomials),
@@ -636,7 +639,7 @@ def secondary_rooflines(dev, device, reps=3):
     out.append(secondary_block("fftcc3d_fused32_kernel (FFTCC3D, 32^3 window)", "E: 512^3, r=16, %d POIs" % len(xs),
                                (2 * m3 * 4 + 28) * float(len(xs)), avg_f, n_f, "hbm", HBM_PEAK_GBS,
                                "SURVEY 8(d): 2*M3*4 B in + 28 B out = 262 172 B per POI; the kernel is VALU + LDS-exchange bound "
-                               "(six 32-point FFT passes per thread, DESIGN.md 4.2b)", traffic=kernel_traffic("E", "fftcc3d_fused32_kernel")))
+                               "(six 32-point FFT passes per thread, DESIGN.md 4.3)", traffic=kernel_traffic("E", "fftcc3d_fused32_kernel")))
     q = guess.clone()
     avg, n = _timed_launches(torch, g, lambda: (q.copy_(guess), g.compute(q)), reps)
     res = q.cpu().numpy()

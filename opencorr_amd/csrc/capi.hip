@@ -192,7 +192,7 @@ struct oc_hip_engine {
     int icgn3d_tile_vox = 64; // ICGN3D1: queues of >= 2048 POIs are visited in cubic blocks of this many voxels (0 = queue order; config E: 78.8 -> 75.5 ms, profiles/r4g_icgn3d1_ab_block_schedule.txt)
     int icgn3d_mapping = 0;   // ICGN3D1: 0 = sample s owned by thread s mod 512 (icgn3d.hip; oracle order OC_ORDER_LANES) -- the default:
                               // 1 = one half-wave per subvolume row (icgn3d_rows.hip; OC_ORDER_ROWS), built and measured in round 4:
-                              // bit-exact against its own order, 12 - 25 % SLOWER (DESIGN.md 4.3) -- kept as the A/B partner
+                              // bit-exact against its own order, 12 - 25 % SLOWER (DESIGN.md 4.4) -- kept as the A/B partner
     // host-queue pipeline (compute_host): the queue travels in chunks, copies of one chunk overlap the kernels of
     // its neighbours; one event per chunk orders the copy-out stream behind the kernels
     hipStream_t copy_stream = nullptr, copy_in_stream = nullptr;

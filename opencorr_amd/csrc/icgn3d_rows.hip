@@ -10,7 +10,7 @@
 //          idle lanes).  A thread keeps ITS x for the whole kernel: the local coordinate and its share of the warp are
 //          per-lane constants, the walk over its samples is a row step (16 rows down: one compare), and the 32 lanes of a
 //          tap read sit in ONE row of the staged box -- consecutive LDS addresses instead of two rows 40 floats apart (47 %
-//          of the LDS cycles were bank conflicts under the old mapping, DESIGN.md 4.3).
+//          of the LDS cycles were bank conflicts under the old mapping, DESIGN.md 4.4).
 //   tail   the RT = SX - BW remaining columns of every row (one column at 33^3: 1 089 of 35 937 samples), enumerated
 //          q = r * RT + (k - BW) and owned by thread q mod 512 -- the old general mapping on a narrow block; it gets its own
 //          pass(es) and coefficient box(es) at the end of a sweep.  Subvolumes narrower than 28 samples are all tail.
