@@ -46,7 +46,7 @@ Besides the contract fields the JSON line carries
   roofline     -- ICGN2D1 kernel.  `combined` (round 4) is the ONE ceiling: max(gather side, VALU side) of the kernel's own
                   instruction stream, from a micro-benchmark of its sweep (tools/ubench/coissue_ubench.hip: gathers + VALU mix =
                   gathers alone, i.e. perfect overlap inside the sweep) and the kernel's VALU wave-instruction count (PMC) --
-                  frac = ceiling / measured = 0.97; the byte-rate fractions below are kept for continuity.  HBM is not it (traffic <= 9 % of peak:
+                  frac = ceiling / measured = 0.70 (what is missing is overlap BETWEEN the kernel's phases: DESIGN.md 4.1); the byte-rate fractions below are kept for continuity.  HBM is not it (traffic <= 9 % of peak:
                   neighbouring subsets share their table entries in L1/L2, so the SURVEY 8(d) byte count / time exceeds
                   the HBM peak); ablations show the gather path of the 64-byte table entries to be the
                   larger limiter (-13 % without two thirds of the gathers, -3 % without two thirds of the polynomials),
@@ -546,7 +546,7 @@ def combined_ceiling(icgn_avg_ms, sample_slots, valu_instr_per_launch):
     """ONE ceiling for the metric kernel.  tools/ubench/coissue_ubench.hip runs the kernel's interpolation sweep --
     its exact gather pattern in lockstep 8-wave workgroups AND its per-sample VALU mix (the kernel's own device functions) -- and
     nothing else, in three builds: both, gathers only, VALU only.  Measured: `both` = `gathers only` (the VALU work hides under
-    the gather), and the VALU-only build sustains ~4.4 cycles per VALU wave-instruction and SIMD at the kernel's occupancy.
+    the gather), and the VALU-only build sustains 3.2 cycles per VALU wave-instruction and SIMD at the kernel's occupancy.
     Scaled to this run: gather side = both_ms x (this run's sample slots / the benchmark's), VALU side = the kernel's VALU
     wave-instructions (PMC, committed) x that cycle cost; the larger one is the ceiling no schedule of THIS instruction stream
     can beat, frac = ceiling / measured."""
@@ -570,9 +570,8 @@ def combined_ceiling(icgn_avg_ms, sample_slots, valu_instr_per_launch):
             "note": "both = gathers only: the sweep's VALU work hides completely under its gathers (perfect overlap INSIDE the sweep); "
                     "over the whole kernel the VALU side is the larger one: the kernel's VALU wave-instructions x the cycles per "
                     "instruction its own sweep mix sustains when run alone (an extrapolation from the sweep to the set-up, numerator and "
-                    "reduction phases, whose mixes hold more packed / DPP / readlane instructions, i.e. cost at least as much) -- what is "
-                    "left is VALU issue cycles, not overlap; packed products (fewer instructions, same issue cycles) were measured and "
-                    "do not help (profiles/r4d_ab_packed_products.txt)"}
+                    "reduction phases).  What separates the kernel from this ceiling is the overlap BETWEEN its phases (texture-bound "
+                    "sweeps, latency-bound set-up / solve) with three lockstep workgroups per CU: DESIGN.md 4.1 lists what was tried"}
 
 
 def _timed_launches(torch, eng, fn, reps):

@@ -11,6 +11,21 @@ __device__ __forceinline__ float uni(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
+// A wave-uniform value held in a VECTOR register on purpose.  VALU instructions that read an SGPR operand issue markedly
+// slower on gfx950 than the same instruction on vector operands (tools/ubench/valu_mix_ubench.hip: the interpolation sweep's
+// VALU stream with the six warp coefficients per lane instead of wave-uniform: 186 -> 160 cycles per polynomial and SIMD), so
+// the per-sample loops CAN read their uniform factors from VGPRs (OC_UNIFORM_IN_VGPR in icgn2d.hip; the empty asm hides the
+// uniformity from the compiler).  Inside the kernel it does not pay -- config B 3.31 - 3.42 against 3.24 ms
+// (profiles/r4i_icgn2d1_ab_uniform_in_vgpr.txt): the sweep is not bound by its VALU side -- so the default stays SGPRs.
+__device__ __forceinline__ float in_vgpr(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int in_vgpr(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // ---------------------------------------------------------------------------
 // small dense algebra on wave-uniform values (every lane computes the same
 // thing).  Same operation order as the oracle (oracle/oc_oracle.cpp lu_inverse,

@@ -22,8 +22,10 @@
 // Reductions (mean, norms, Hessian, numerator, ZNSSD) are per-lane partial sums in increasing s followed by the xor
 // butterfly of oc_device.h; the CPU oracle uses the same association (OC_ORDER_LANES) and the results are bit-identical,
 // whatever the variant.  Wave-uniform state (warp matrix, norms) is held in SGPRs.
-// What bounds it: VALU issue -- the kernel runs at 0.97 of what its own instruction stream sustains
-// (tools/ubench/coissue_ubench.hip); the gathers hide completely under the arithmetic of the sweep.
+// What bounds it: no single pipe.  Inside the sweep the arithmetic hides completely under the gathers
+// (tools/ubench/coissue_ubench.hip); over the whole kernel the gathers need 2.07 ms and the VALU instructions 2.25 ms of the 3.23 ms
+// a launch takes on config B (0.70): the sweep and the latency-bound phases around it overlap only through the three workgroups a
+// CU holds.
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -63,6 +65,22 @@
 // (s_setprio) and evaluates the polynomials at normal priority, 2 = the other way round
 #ifndef OC_SWEEP_PRIO
 #define OC_SWEEP_PRIO 0
+#endif
+// OC_UNIFORM_IN_VGPR (bit mask): which wave-uniform factors of the per-sample loops are read from vector registers instead of
+// SGPRs (in_vgpr, dic2d_device.h): 1 = the warp coefficients and the subset centre in the interpolation sweep (6-DoF),
+// 2 = the image size in the sweep's range test and address, 4 = mean / scale factors of the norm and numerator passes
+// passes whose loads are issued together in the reference-subset pass, the Hessian sweep and the numerator pass (6-DoF)
+#ifndef OC_SETUP_BATCH
+#define OC_SETUP_BATCH 6
+#endif
+#ifndef OC_HESS_BATCH
+#define OC_HESS_BATCH 6
+#endif
+#ifndef OC_NUM_BATCH
+#define OC_NUM_BATCH 6
+#endif
+#ifndef OC_UNIFORM_IN_VGPR
+#define OC_UNIFORM_IN_VGPR 0
 #endif
 
 namespace ochip {
@@ -131,8 +149,8 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     // lockstep sweeps (see OC_SWEEP_BARRIER above): the 8-wave table variants -- one subset size per launch, so every live
     // wave of a workgroup runs the same number of pass groups
     // (the 6-DoF kernel with only two workgroups per CU, variant 4, loses 6 % with them: it keeps them off by default)
-    constexpr int SWEEP_SYNC = (MODE == 4 && LM == 0 && WPB == 8)
-                                   ? (OC_SWEEP_BARRIER < 0 ? (DOF == 6 ? (OCC >= 6 ? 2 : 0) : 3) : OC_SWEEP_BARRIER)
+    constexpr int SWEEP_SYNC = (MODE == 4 && LM == 0 && (WPB == 8 || WPB == 4))
+                                   ? (OC_SWEEP_BARRIER < 0 ? (DOF == 6 ? ((OCC >= 6 || WPB == 4) ? 2 : 0) : 3) : OC_SWEEP_BARRIER)
                                    : 0;
     // What keeps the sweep barriers deadlock-free although the waves of a workgroup run different iteration counts and may
     // leave at any point (guard, out-of-range sample, convergence) -- three invariants of THIS kernel shape:
@@ -151,12 +169,12 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                   "lockstep sweep barriers need one POI per wave, one pass count per workgroup and a barrier-free epilogue");
     // passes whose global loads are issued together in the load-then-use loops outside the interpolation sweep
     // (reference subset, Hessian sweep, numerator pass): one dependent round trip per batch instead of one per pass
-    constexpr int kSetupBatch = 6;
+    constexpr int kSetupBatch = OC_SETUP_BATCH;
     // (6 DoF; the 78 running sums of the 12-DoF Hessian leave no room: passes_prefetched.  Round 3 split that sweep in two -- 45 + 33
     // sums, each reduced right away, 2 - 6 passes of loads in flight -- and measured 3.49 - 3.50 ms against 3.49 on config C
     // (profiles/r3q_icgn2d2_ab_two_hessian_sweeps.txt): the sweep is not waiting for its loads; not kept)
-    constexpr int kHessBatch = 6;
-    constexpr int kNumBatch = DOF == 6 ? 6 : 4;
+    constexpr int kHessBatch = OC_HESS_BATCH;
+    constexpr int kNumBatch = DOF == 6 ? OC_NUM_BATCH : 4;
     __shared__ float coop_area[COOP ? WPB * 64 : 1];
     const int NTA = L.nt;  // passes the LDS arrays are sized for (>= the passes of any POI)
     const int lane = threadIdx.x & (kWave - 1);
@@ -511,6 +529,12 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         float acc = 0.f;
         {
             SampleWalk w(lane, r0, c0, W, q64, r64);
+            constexpr bool kWarpV = (OC_UNIFORM_IN_VGPR & 1) != 0 && DOF == 6, kSizeV = (OC_UNIFORM_IN_VGPR & 2) != 0;
+            float Wv[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) Wv[i] = kWarpV ? in_vgpr(Wm[i]) : Wm[i];
+            const float tcxv = kWarpV ? in_vgpr(tcx) : tcx, tcyv = kWarpV ? in_vgpr(tcy) : tcy;
+            const int heightv = kSizeV ? in_vgpr(height) : height, widthv = kSizeV ? in_vgpr(width) : width;
             // warp the next G samples of this lane and issue their LUT gathers.  CHECKED = std::false_type: every
             // lane owns a sample in all G passes (the common case: no validity selects at all).
             // !LM: a sample outside the interpolatable range makes the reference abandon the POI (:251-255: -1.f is
@@ -536,8 +560,8 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     if constexpr (DOF == 6) {
                         // Deformation2D1::warp, src/oc_deformation.cpp:94-105: (W0 x + W1 y) + W2 * 1 (the product
                         // with 1.f is exact and dropped)
-                        wx = (Wm[0] * xl + Wm[1] * yl) + Wm[2];
-                        wy = (Wm[3] * xl + Wm[4] * yl) + Wm[5];
+                        wx = (Wv[0] * xl + Wv[1] * yl) + Wv[2];
+                        wy = (Wv[3] * xl + Wv[4] * yl) + Wv[5];
                     } else {
                         // Deformation2D2::warp, src/oc_deformation.cpp:268-282: rows 3, 4 of W * [x^2 xy y^2 x y 1]
                         const float pv[6] = {xl * xl, xl * yl, yl * yl, xl, yl, 1.f};
@@ -551,18 +575,18 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     }
                     // tar_subset->center = POI + center_offset, then + warped_coor (src/oc_icgn.cpp:425-426,452);
                     // a lane past the end of the subset fetches a harmless in-range point
-                    float ax = tcx + wx, ay = tcy + wy;
+                    float ax = tcxv + wx, ay = tcyv + wy;
                     if constexpr (CHECKED) {
                         ax = valid[g] ? ax : 1.f;
                         ay = valid[g] ? ay : 1.f;
                     }
                     bool out;
                     if constexpr ((OC_ABLATE2D & 6) != 0) {
-                        unsigned off = lut_locate<LM != 0>(f[g], height, width, ax, ay, out);
+                        unsigned off = lut_locate<LM != 0>(f[g], heightv, widthv, ax, ay, out);
                         if (OC_ABLATE2D & 2) off = iter > 1 ? (off & 0x3ff0u) : off;
                         if (!(OC_ABLATE2D & 4) || iter == 1) r_lut.load(f[g], off);
                     } else {
-                        lut_fetch<LM != 0>(f[g], r_lut, height, width, ax, ay, out);
+                        lut_fetch<LM != 0>(f[g], r_lut, heightv, widthv, ax, ay, out);
                     }
                     if constexpr (!LM) negative = negative || out;
                 }
@@ -638,7 +662,8 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
             }
         }
         // zeroMeanNorm of the target subset (src/oc_icgn.cpp:257)
-        const float tmean = wave_allreduce_sum(acc) / fN;
+        float tmean = wave_allreduce_sum(acc) / fN;
+        if constexpr ((OC_UNIFORM_IN_VGPR & 4) != 0) tmean = in_vgpr(tmean);
         acc = 0.f;
 #pragma unroll 6
         for (int t = 0; t < NF; t++) {
@@ -651,7 +676,12 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         }
         const float tar_norm = uni(sqrtf(wave_allreduce_sum(acc)));
         // error image, ZNSSD, numerator (src/oc_icgn.cpp:260-276)
-        const float factor = ref_norm / tar_norm;
+        float factor = ref_norm / tar_norm;
+        float ref_mean_v = ref_mean;
+        if constexpr ((OC_UNIFORM_IN_VGPR & 4) != 0) {
+            factor = in_vgpr(factor);
+            ref_mean_v = in_vgpr(ref_mean_v);
+        }
         float num[DOF];
 #pragma unroll
         for (int i = 0; i < DOF; i++) num[i] = 0.f;
@@ -685,7 +715,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 [[maybe_unused]] const float ref_v = v.ref;
                 const float tz = l_ts[t * kWave] - tmean;  // same bits as in the norm pass
                 // the zero-mean reference value: parked in LDS, or re-formed from the image (same subtraction, same bits)
-                const float rsv = KEEP_RS ? l_rs[t * kWave] : ref_v - ref_mean;
+                const float rsv = KEEP_RS ? l_rs[t * kWave] : ref_v - ref_mean_v;
                 const float e = tz * factor - rsv;
                 const float e2 = e * e;
                 ssd = valid ? ssd + e2 : ssd;
@@ -932,6 +962,8 @@ static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, siz
 //    per CU -- the ICGN2D1 default.  Interleaved A/B timing on config B (tools/variant_ab.py,
 //    profiles/r02w_icgn2d1_variant_ab.json): 2: 3.71 ms, 4: 3.65, 5: 3.64; G = 3 at 6 waves per SIMD spills (4.29 ms),
 //    G = 4 / G = 1 / 5 waves per SIMD lose 1 - 4 %.  The kernel is VALU-issue bound: occupancy barely matters.
+//    6 (round 4): variant 5's table and lockstep sweeps in 4-wave workgroups, four per CU (more independent workgroups per CU,
+//    fewer waves per SIMD): 3.47 against 3.30 ms (profiles/r4i_icgn2d1_variant_ab_4wave_lockstep.json) -- not selected automatically.
 // Round 1's G = 2 and software-pipelined variants never won a sweep and are gone.
 //        id  G mode pipe wpb occ
 #define OC_ICGN2D_VARIANTS(X) \
@@ -940,9 +972,10 @@ static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, siz
     X(2, 3, 1, 0, 4, 4)       \
     X(3, 4, 1, 0, 1, 3)       \
     X(4, 3, 4, 0, 8, 4)       \
-    X(5, 2, 4, 0, 8, 6)
+    X(5, 2, 4, 0, 8, 6)       \
+    X(6, 2, 4, 0, 4, 4)
 
-constexpr int kIcgn2dVariants = 6;
+constexpr int kIcgn2dVariants = 7;
 
 int icgn2d_variant_count() { return kIcgn2dVariants; }
 
