@@ -94,6 +94,9 @@ def lib():
         L.oc_oracle_region_fit3d.restype = None
         L.oc_oracle_pow_lambda.argtypes = [f, f]
         L.oc_oracle_pow_lambda.restype = f
+        L.oc_oracle_inverse.argtypes = [fp, fp, i]
+        L.oc_oracle_inverse.restype = i
+        L.oc_oracle_mat_mul.argtypes = [fp, fp, fp, i]
         L.oc_oracle_icgn2d1_ex.restype = None
         L.oc_oracle_icgn2d2_ex.restype = None
         L.oc_oracle_gradient3d.argtypes = [fp, i, i, i, fp, fp, fp, i]
@@ -237,6 +240,25 @@ def iclm2d2(prep, rx, ry, conv, stop, pois, damping=DEFAULT_DAMPING, order=ORDER
 
 def pow_lambda(lam, q):
     return float(lib().oc_oracle_pow_lambda(float(lam), float(q)))
+
+
+def inverse(a):
+    """Inverse of a small square float32 matrix as the solvers compute it (cofactors for 3 x 3 / 4 x 4, LU with partial
+    pivoting otherwise: what the reference takes from Eigen, src/oc_icgn.cpp:210,290,759,831,1339,1439)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[0] == a.shape[1]
+    out = np.empty_like(a)
+    if lib().oc_oracle_inverse(_fp(a), _fp(out), a.shape[0]) != 0:
+        raise ValueError("unsupported matrix size %d" % a.shape[0])
+    return out
+
+
+def mat_mul(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    c = np.empty_like(a)
+    lib().oc_oracle_mat_mul(_fp(a), _fp(b), _fp(c), a.shape[0])
+    return c
 
 
 def strain2d(pois, subregion_radius, neighbor_number_min, zncc_threshold=0.9, approximation=1, threads=0):

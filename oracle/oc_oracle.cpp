@@ -1621,6 +1621,17 @@ void oc_oracle_region_fit3d(const float* reliable, long n_reliable, int reliable
 
 float oc_oracle_pow_lambda(float lambda, float q) { return pow_lambda(std::log((double)lambda), q); }
 
+// the small dense inverses on their own (tests/test_oracle_dense_algebra.py pins them on LAPACK through numpy: the compiled
+// reference of oracle/_ref links a stand-in Eigen, so an independent library has to say that these ARE inverses)
+int oc_oracle_inverse(const float* a, float* ainv, int n) {
+    if (n == 3) inverse3(a, ainv);
+    else if (n == 4) inverse4(a, ainv);
+    else if (n >= 1 && n <= 12) lu_inverse(a, ainv, n);
+    else return -1;
+    return 0;
+}
+void oc_oracle_mat_mul(const float* a, const float* b, float* c, int n) { mat_mul(a, b, c, n); }
+
 void oc_oracle_nr2d1(const float* ref, const float* tar_lut, const float* tar_lut_gx, const float* tar_lut_gy, int height,
                      int width, int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes,
                      int threads) {

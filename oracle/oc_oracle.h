@@ -122,6 +122,12 @@ void oc_oracle_iclm2d(int dof, const float* ref, const float* gx, const float* g
                       int stride_floats, int order, int lanes, int threads);
 /* the fixed-arithmetic restatement of powf(lambda, q) used for the first damping value (src/oc_iclm.cpp:253) */
 float oc_oracle_pow_lambda(float lambda, float q);
+/* The small dense algebra the solvers take from Eigen, on its own: inverse of an n x n row-major matrix -- n = 3 and 4 by
+ * cofactors (Eigen compute_inverse), n = 1, 2, 5 ... 12 by LU with partial pivoting (PartialPivLU::inverse; the 6 x 6 and
+ * 12 x 12 Hessians of src/oc_icgn.cpp:210,759,1339 and the 6 x 6 warp of :831) -- and the coefficient-wise product.
+ * Returns -1 for an unsupported n. */
+int oc_oracle_inverse(const float* a, float* ainv, int n);
+void oc_oracle_mat_mul(const float* a, const float* b, float* c, int n);
 
 /* Strain::compute(poi_queue) for POI2D (src/oc_strain.cpp:149-247) and POI3D (:372-488), after Strain::prepare
  * (:96-147): subregion_radius, neighbor_number_min as in the constructor (:31-46); zncc_threshold default 0.9
