@@ -927,8 +927,12 @@ template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC, int OFFS, int LM
 static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int nt, bool xcd,
                            hipStream_t stream) {
     constexpr int arrays = MODE == 0 ? 4 : (MODE == 4 ? 1 : 2);
-    const size_t lds = ((size_t)arrays * WPB + (MODE >= 3 ? 3 : 0)) * nt * kWave * sizeof(float);
+    size_t lds = ((size_t)arrays * WPB + (MODE >= 3 ? 3 : 0)) * nt * kWave * sizeof(float);
     if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
+    // experiments only (tools/icgn2d_occupancy_probe.py): OC_ICGN2D_LDS_PAD=<bytes> raises the workgroup's LDS request, i.e.
+    // lowers the number of workgroups a CU holds, with nothing else changed
+    static const size_t lds_pad = std::getenv("OC_ICGN2D_LDS_PAD") ? (size_t)std::atol(std::getenv("OC_ICGN2D_LDS_PAD")) : 0;
+    if (lds_pad && lds_pad <= (size_t)kLdsBudget && lds_pad > lds) lds = lds_pad;
     auto kern = icgn2d_kernel<DOF, G, MODE, PIPE, WPB, OCC, OFFS, LM>;
     // the dynamic-LDS limit is a per-device property of the loaded function: raise it once on every
     // device this process launches on (one engine per device is a supported host layout)
