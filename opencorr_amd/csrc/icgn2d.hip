@@ -79,6 +79,13 @@
 #ifndef OC_NUM_BATCH
 #define OC_NUM_BATCH 6
 #endif
+// gathers in flight and register budget (waves per SIMD) of variant 5 (experiments: tools/ab_build.py)
+#ifndef OC_V5_G
+#define OC_V5_G 2
+#endif
+#ifndef OC_V5_OCC
+#define OC_V5_OCC 6
+#endif
 #ifndef OC_UNIFORM_IN_VGPR
 #define OC_UNIFORM_IN_VGPR 0
 #endif
@@ -976,7 +983,7 @@ static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, siz
     X(2, 3, 1, 0, 4, 4)       \
     X(3, 4, 1, 0, 1, 3)       \
     X(4, 3, 4, 0, 8, 4)       \
-    X(5, 2, 4, 0, 8, 6)       \
+    X(5, OC_V5_G, 4, 0, 8, OC_V5_OCC) \
     X(6, 2, 4, 0, 4, 4)
 
 constexpr int kIcgn2dVariants = 7;
