@@ -7,14 +7,28 @@ rejected records mixed in.  The bar is the usual one: every float of every recor
 (ORDER_LANES), whatever the POI did -- converge, hit the iteration limit (-4), leave the image (-3), turn NaN (-5).
 Seeds are fixed: the cases are the same on every run.
 """
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
+# soak runs: OC_FUZZ_EXTRA=<n> adds n further seeds to every test below (tools/gpu_fuzz_soak.sh; the driver's suite runs the fixed ones)
+_EXTRA = int(os.environ.get("OC_FUZZ_EXTRA", "0"))
+
 
 def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _same(got, want):
+    """Element-wise identity of two float arrays: the same bits, or NaN on both sides.  (An INVALID operation -- inf - inf,
+    0 * inf -- yields the default NaN of the machine it runs on: negative on x86, positive on gfx950.  Which fields of an
+    abandoned POI hold NaN is compared; the sign bit of a NaN that neither the reference nor any caller reads is not.)"""
+    got = np.ascontiguousarray(got, dtype=np.float32)
+    want = np.ascontiguousarray(want, dtype=np.float32)
+    return (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
 
 
 def _queue2d(rng, h, w, rx, ry, n):
@@ -51,7 +65,7 @@ def _guess2d(rng, pois, P, true_u, true_v, spread):
     return pois.astype(np.float32)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 + _EXTRA))
 def test_fuzz_icgn2d1_icgn2d2_nr2d1_iclm(seed):
     import opencorr_amd
     import oracle
@@ -75,22 +89,23 @@ def test_fuzz_icgn2d1_icgn2d2_nr2d1_iclm(seed):
         got = eng.compute(pois.copy())
         want = pois.copy()
         solve(prep, rx, ry, conv, stop, want, order=oracle.ORDER_LANES, lanes=64)
-        same = (_bits(got) == _bits(want)).all(axis=1)
+        same = _same(got, want).all(axis=1)
         assert same.all(), (name, seed, rx, ry, np.flatnonzero(~same)[:5], got[~same][:2], want[~same][:2])
         # the cases are not all trivial: some POIs converge, some do not
         z = got[:, P["zncc"]]
-        assert (z > 0.5).sum() > 40 and (z < 0).sum() >= 3, (name, seed)
+        if seed < 6:   # (the fixed seeds were looked at; a soak seed may draw a case in which hardly anything converges)
+            assert (z > 0.5).sum() > 40 and (z < 0).sum() >= 3, (name, seed)
     nr = opencorr_amd.NR2D1(rx, ry, conv, stop)
     nr.set_images(ref, tar)
     nr.prepare()
     got = nr.compute(pois.copy())
     want = pois.copy()
     oracle.nr2d1(oracle.PreparedNR2D(ref, tar), rx, ry, conv, stop, want, order=oracle.ORDER_LANES, lanes=64)
-    same = (_bits(got) == _bits(want)).all(axis=1)
+    same = _same(got, want).all(axis=1)
     assert same.all(), ("NR2D1", seed, rx, ry, np.flatnonzero(~same)[:5])
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(4 + _EXTRA))
 def test_fuzz_fftcc2d(seed):
     """FFTCC2D with float POI positions and float initial guesses (truncating casts, src/oc_fftcc.cpp:190-216): fused
     sizes and rocFFT-pipeline sizes, rx != ry."""
@@ -116,10 +131,10 @@ def test_fuzz_fftcc2d(seed):
             assert np.array_equal(got[:, P[k]], want[:, P[k]]), (seed, rx, ry, k)
         assert np.abs(got[:, P["zncc"]] - want[:, P["zncc"]]).max() <= 3e-5
         other = [c for c in range(25) if c not in (P["u"], P["v"], P["u0"], P["v0"], P["zncc"])]
-        assert np.array_equal(_bits(got[:, other]), _bits(want[:, other]))
+        assert _same(got[:, other], want[:, other]).all()
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(3 + _EXTRA))
 def test_fuzz_icgn3d1(seed):
     import opencorr_amd
     import oracle
@@ -152,12 +167,13 @@ def test_fuzz_icgn3d1(seed):
     got = g.compute(pois.copy())
     want = pois.copy()
     oracle.icgn3d1(oracle.Prepared3D(ref, tar), rx, ry, rz, conv, stop, want, order=oracle.GPU_ORDER_3D, lanes=oracle.GPU_LANES_3D)
-    same = (_bits(got) == _bits(want)).all(axis=1)
+    same = _same(got, want).all(axis=1)
     assert same.all(), (seed, rx, ry, rz, np.flatnonzero(~same)[:5], got[~same][:2], want[~same][:2])
-    assert (got[:, P["zncc"]] > 0.5).sum() > 20
+    if seed < 3:
+        assert (got[:, P["zncc"]] > 0.5).sum() > 20
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(4 + _EXTRA))
 def test_fuzz_offsets_and_self_adaptive(seed):
     """ICGN2D1 / ICGN2D2 with per-POI centre offsets (src/oc_icgn.cpp:353-557, 910-1136) and with per-POI subset radii
     (setSelfAdaptive, :152-158), separately and together, on float POI positions."""
@@ -181,19 +197,19 @@ def test_fuzz_offsets_and_self_adaptive(seed):
         eng.prepare()
         want = pois.copy()
         solve(prep, rx, ry, 1e-3, 10, want, order=oracle.ORDER_LANES, lanes=64, center_offsets=off)
-        assert np.array_equal(_bits(eng.compute_with_offsets(pois.copy(), off)), _bits(want)), (seed, "offsets")
+        assert _same(eng.compute_with_offsets(pois.copy(), off), want).all(), (seed, "offsets")
         eng.set_self_adaptive(True)
         q = pois.copy()
         q[:, 23:25] = radii
         want = q.copy()
         solve(prep, rx, ry, 1e-3, 10, want, order=oracle.ORDER_LANES, lanes=64, self_adaptive=True)
-        assert np.array_equal(_bits(eng.compute(q.copy())), _bits(want)), (seed, "self-adaptive")
+        assert _same(eng.compute(q.copy()), want).all(), (seed, "self-adaptive")
         want = q.copy()
         solve(prep, rx, ry, 1e-3, 10, want, order=oracle.ORDER_LANES, lanes=64, center_offsets=off, self_adaptive=True)
-        assert np.array_equal(_bits(eng.compute_with_offsets(q.copy(), off)), _bits(want)), (seed, "both")
+        assert _same(eng.compute_with_offsets(q.copy(), off), want).all(), (seed, "both")
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(3 + _EXTRA))
 def test_fuzz_fftcc3d(seed):
     import opencorr_amd
     import oracle
