@@ -21,6 +21,13 @@
 #include "fft_device.h"
 #include "oc_kernels.h"
 
+// OC_FUSED32_WAVE_XY: 1 = the x <-> y exchanges synchronise inside the half-wave that owns a z-plane (a wave-level fence) and
+// keep only the workgroup barrier between the two z-halves; 0 = two workgroup barriers per half (rounds 1 - 3).  Config E:
+// 9.08 against 9.32 ms, bit-identical (profiles/r4s_fftcc3d_fused32_ab_wave_local_xy.txt).
+#ifndef OC_FUSED32_WAVE_XY
+#define OC_FUSED32_WAVE_XY 1
+#endif
+
 namespace ochip {
 
 namespace {
@@ -36,6 +43,14 @@ constexpr int kHalf = 16 * TN * TP;       // complex elements of half a volume i
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned 16-byte load
 
 __device__ __forceinline__ int clampi3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// orders this wave's earlier LDS writes before its later LDS reads (data exchanged between lanes of ONE wave: the LDS executes
+// a wave's instructions in issue order, so all that is needed is that the compiler keeps the order and waits for the writes)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // two block-wide sums at once; every thread returns the same values
 __device__ __forceinline__ void block_sum2(float& x, float& y, float* red, int lane, int wave) {
@@ -139,14 +154,21 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dPa
     const int zz = a & 15, half = a >> 4;
     // ---- forward x, then LX -> LY through LDS [z & 15][y][x], one z-half at a time
     fft32<false>(v);
+    // (a z-plane is written and read by the 32 threads of ONE half-wave: inside the plane a wave-level fence orders its
+    // LDS writes before its reads -- the LDS serves a wave's instructions in order -- and the workgroup barrier is only
+    // needed where the two z-halves hand the 16 plane slots over)
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         if (half == h) {
 #pragma unroll
             for (int k = 0; k < TN; k++) lds[(zz * TN + b) * TP + k] = v[bitrev5(k)];
+#if OC_FUSED32_WAVE_XY
+            wave_lds_fence();
+#else
         }
         __syncthreads();
         if (half == h) {
+#endif
 #pragma unroll
             for (int j = 0; j < TN; j++) v[j] = lds[(zz * TN + j) * TP + b];
         }
@@ -216,9 +238,13 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dPa
         if (half == h) {
 #pragma unroll
             for (int j = 0; j < TN; j++) lds[(zz * TN + j) * TP + b] = u[bitrev5(j)];
+#if OC_FUSED32_WAVE_XY
+            wave_lds_fence();
+#else
         }
         __syncthreads();
         if (half == h) {
+#endif
 #pragma unroll
             for (int k = 0; k < TN; k++) q[k] = lds[(zz * TN + b) * TP + k];
         }
