@@ -52,11 +52,11 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// two block-wide sums at once; every thread returns the same values
+// two block-wide sums at once; every thread returns the same values.  ONE barrier: `red` must not be in use by an earlier
+// call (each call site has its own 2 * kWaves floats)
 __device__ __forceinline__ void block_sum2(float& x, float& y, float* red, int lane, int wave) {
     x = wave_allreduce_sum(x);
     y = wave_allreduce_sum(y);
-    __syncthreads();
     if (lane == 0) {
         red[wave] = x;
         red[kWaves + wave] = y;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dPa
                                                                       unsigned long long count, int xcd_chunk) {
     __shared__ c2 lds[kHalf];
     __shared__ int tab[6][TN];  // voxel index of window coordinate k: ref x, y, z, tar x, y, z
-    __shared__ float red[2 * kWaves];
+    __shared__ float red[2 * kWaves], red2[2 * kWaves];
     __shared__ int redi[kWaves];
     const int tid = threadIdx.x;
     const int a = tid >> 5, b = tid & 31;
@@ -100,9 +100,17 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dPa
         if (axis >= 3) c = c + g;
         tab[axis][k] = clampi3((int)c, 0, D - 1);
     }
-    __syncthreads();
-    // both windows' x indices contiguous (true unless a window is clamped at the border): 16-byte loads
-    const bool contig = __syncthreads_and(tab[0][b] == tab[0][0] + b && tab[3][b] == tab[3][0] + b) != 0;
+    // both windows' x indices contiguous (true unless a window is clamped at the border): 16-byte loads.  Every thread forms
+    // the four table entries the test needs itself, so that the vote's barrier is also the one that publishes `tab`
+    bool mine_contig;
+    {
+        const float p = poi[poi3d::X], g = poi[poi3d::U];
+        const float c0 = p + 0 - R, cb = p + b - R;
+        const int r0 = clampi3((int)c0, 0, P.dx - 1), rb = clampi3((int)cb, 0, P.dx - 1);
+        const int t0 = clampi3((int)(c0 + g), 0, P.dx - 1), tb = clampi3((int)(cb + g), 0, P.dx - 1);
+        mine_contig = rb == r0 + b && tb == t0 + b;
+    }
+    const bool contig = __syncthreads_and(mine_contig) != 0;
 
     // ---- gather: thread (z = a, y = b) reads its x-line of both windows; z = ref + i*tar
     c2 v[TN];
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dPa
             rn += v[k].x * v[k].x;
             tn += v[k].y * v[k].y;
         }
-        block_sum2(rn, tn, red, lane, wave);
+        block_sum2(rn, tn, red2, lane, wave);
         // needed only at the very end: without this the compiler keeps the 32 partial sums it has just read from LDS
         // alive (in scratch) across the whole transform and adds them up there
         asm volatile("" : "+v"(rn), "+v"(tn));
