@@ -26,6 +26,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-
 # per-file additions (none at present; round 4 built icgn3d*.hip with `-mllvm -disable-vector-combine` for the packed tap
 # products of OC_TAPS_PACKED=1 -- measured slower, see icgn3d_device.h)
 EXTRA_FLAGS = {}
+# the solver files that exist in two arithmetic modes (csrc/oc_device.h): compiled a second time with -DOC_FMA=1 into
+# <name>_fma.o (kernels in ochip::fma; oc_hip_set_tuning("arith_fma", 1) launches them)
+FMA_SOURCES = ["icgn2d.hip", "icgn3d.hip"]
 
 
 def hipcc():
@@ -48,12 +51,14 @@ def build(force=False, verbose=True):
     objs = []
     cc = hipcc()
     procs = []
-    for src in SOURCES:
+    units = [(src, src.replace(".hip", ".o"), []) for src in SOURCES]
+    units += [(src, src.replace(".hip", "_fma.o"), ["-DOC_FMA=1"]) for src in FMA_SOURCES]
+    for src, obj, defs in units:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        o = os.path.join(LIBDIR, obj)
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [cc, "--offload-arch=" + ARCH, "-c", s, "-o", o] + FLAGS + EXTRA_FLAGS.get(src, [])
+            cmd = [cc, "--offload-arch=" + ARCH, "-c", s, "-o", o] + FLAGS + EXTRA_FLAGS.get(src, []) + defs
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

@@ -186,6 +186,11 @@ struct oc_hip_engine {
     int icgn2d_variant = -1;  // -1 = automatic (run_icgn2d; MI355X sweeps), else the variant oc_hip_set_tuning chose
     bool self_adaptive = false;  // DIC::setSelfAdaptive
     int icgn2d_xcd = 1;
+    // ICGN2D1 / ICGN2D2 / ICLM2D1 / ICLM2D2 / ICGN3D1: 0 = every multiply and add of the solver rounds on its own (oracle
+    // OC_ORDER_LANES; the reference built for baseline x86-64), 1 = the per-sample multiply-adds are fused (oc_device.h
+    // OC_FMA; oracle OC_ORDER_LANES_FMA) -- the only tuning key that changes result bits (by rounding, inside north_star's
+    // tolerance: DESIGN.md section 3)
+    int arith_fma = 0;
     int fftcc2d_fused = 1;    // single-kernel FFTCC2D when the window is 32 x 32
     int fftcc3d_fused = 1;    // single-kernel FFTCC3D for cubic windows of side 8 ... 64 (three kernels by size)
     int fftcc3d_planes_blocks = 0;  // persistent workgroups (= scratch volumes) of the plane-wise kernel; 0 = 256
@@ -529,7 +534,7 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
                              e->conv,      e->stop,            d_offsets,         nullptr,
                              e->self_adaptive ? 1 : 0,
                              lm ? std::log((double)e->lm_lambda) : 0.0,
-                             e->lm_alpha,  e->lm_beta};
+                             e->lm_alpha,  e->lm_beta,         e->arith_fma};
     const long long N = (2LL * rx + 1) * (2LL * ry + 1);
     // fall back to the LDS-light single-wave variant when the tuned one cannot hold the subset
     int variant = e->icgn2d_variant;
@@ -685,7 +690,9 @@ int run_icgn3d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     if (scratch) OC_TRY(e->tmp.reserve(scratch * sizeof(float)));
     ochip::Icgn3dParams P = {im.ref_ptr(), e->gx.as<float>(), e->gy.as<float>(), e->gz.as<float>(), e->coef.as<float>(),
                              im.dz, im.dy, im.dx, e->rx, e->ry, e->rz, e->conv, e->stop,
-                             scratch ? e->tmp.as<float>() : nullptr, 1, 1, nullptr};
+                             scratch ? e->tmp.as<float>() : nullptr, 1, 1, nullptr, e->arith_fma};
+    if (e->arith_fma && e->icgn3d_mapping != 0)
+        return fail(OC_HIP_ERR_UNSUPPORTED, "ICGN3D1: the row mapping (icgn3d_mapping = 1) has no fused-arithmetic build (arith_fma = 1)");
     // locality schedule: visit the queue in compact cubic blocks, so that the POIs in flight share their voxels behind the
     // L2s / the Infinity Cache (poi_order.hip); same bits for every POI
     if (e->icgn3d_tile_vox > 0 && count >= 2048 && count <= 0xffffffffull) {
@@ -1145,6 +1152,7 @@ static int clone_engine(const oc_hip_engine* e, int device, oc_hip_engine** out)
     r->icgn2d_variant = e->icgn2d_variant;
     r->self_adaptive = e->self_adaptive;
     r->icgn2d_xcd = e->icgn2d_xcd;
+    r->arith_fma = e->arith_fma;
     r->fftcc2d_fused = e->fftcc2d_fused;
     r->fftcc3d_fused = e->fftcc3d_fused;
     r->fftcc3d_planes_blocks = e->fftcc3d_planes_blocks;
@@ -1372,6 +1380,10 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
         e->icgn2d_variant = value;
     } else if (k == "icgn2d_xcd" || k == "xcd") {
         e->icgn2d_xcd = value != 0;
+    } else if (k == "arith_fma") {
+        if (value != 0 && !(e->is_icgn2d() || e->kind == OC_HIP_ICGN3D1))
+            return fail(OC_HIP_ERR_UNSUPPORTED, "arith_fma: only the ICGN2D1 / ICGN2D2 / ICLM2D1 / ICLM2D2 / ICGN3D1 engines have a fused-arithmetic build");
+        e->arith_fma = value != 0;
     } else if (k == "icgn2d_tile_px") {
         if (value < 0 || (value > 0 && value < 16)) return fail(OC_HIP_ERR_INVALID, "icgn2d_tile_px must be 0 (off) or >= 16");
         e->icgn2d_tile_px = value;

@@ -175,13 +175,7 @@ struct SampleWalk {
     }
 };
 
-// Two floats that travel through the packed-fp32 pipe (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per issue
-// slot, each rounded on its own, so results are those of the scalar instructions).
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 mk2(float a, float b) {
-    f2 r = {a, b};
-    return r;
-}
+// (f2 / mk2 / mad: oc_device.h)
 
 // SampleWalk for the engines whose local coordinates are integers (no centre offset): the lane's sample as the
 // float pair (x_local, y_local) -- small integers, so every step is exact -- plus its byte offset from the subset
@@ -369,6 +363,27 @@ __device__ __forceinline__ float lut_poly(const LutFetch& f) {
     const float dx = f.dx, dy = f.dy;
     const float dx2 = dx * dx, dy2 = dy * dy;
     const float dx3 = dx2 * dx, dy3 = dy2 * dy;
+#if OC_FMA
+    // the same 16 terms left to right with every "+ product" fused (oracle bspline2d_eval<true>): 4 + 9 multiplies and
+    // 15 v_fma_f32 instead of 28 multiplies and 15 adds
+    float w = f.c0.x;
+    w = mad(f.c0.y, dx, w);
+    w = mad(f.c0.z, dx2, w);
+    w = mad(f.c0.w, dx3, w);
+    w = mad(f.c1.x, dy, w);
+    w = mad(f.c1.y * dy, dx, w);
+    w = mad(f.c1.z * dy, dx2, w);
+    w = mad(f.c1.w * dy, dx3, w);
+    w = mad(f.c2.x, dy2, w);
+    w = mad(f.c2.y * dy2, dx, w);
+    w = mad(f.c2.z * dy2, dx2, w);
+    w = mad(f.c2.w * dy2, dx3, w);
+    w = mad(f.c3.x, dy3, w);
+    w = mad(f.c3.y * dy3, dx, w);
+    w = mad(f.c3.z * dy3, dx2, w);
+    w = mad(f.c3.w * dy3, dx3, w);
+    return w;
+#endif
     float v = f.c0.x;
     v = v + f.c0.y * dx;
     v = v + f.c0.z * dx2;
@@ -397,6 +412,9 @@ __device__ __forceinline__ float lut_poly(const LutFetch& f) {
 // time follows issue cycles, not instruction counts.  Kept behind OC_POLY_PACKED (default 0) as the A/B partner.
 #ifndef OC_POLY_PACKED
 #define OC_POLY_PACKED 0
+#endif
+#if OC_POLY_PACKED && OC_FMA
+#error "the packed-product polynomial exists in the separately rounded mode only"
 #endif
 __device__ __forceinline__ float lut_poly_pk(const LutFetch& f) {
     const float dx = f.dx, dy = f.dy;

@@ -128,6 +128,10 @@ namespace ochip {
 // Every variant performs the same floating-point operations in the same order, so all
 // of them are bit-identical to the oracle in OC_ORDER_LANES.
 // ---------------------------------------------------------------------------
+// (the kernel and its launchers live in ochip::sep or ochip::fma -- this file is compiled once per arithmetic mode,
+// oc_device.h -- so that the two builds of the same template are different functions)
+namespace OC_ARITH {
+
 struct Icgn2dLaunch {
     int stride_f;              // floats between POI records
     int nt;                    // ceil(N / 64)
@@ -314,12 +318,12 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         for (int t = 0; t < NF; t++) {
             const float d = l_rs[t * kWave] - mean;
             if constexpr (KEEP_RS) l_rs[t * kWave] = d;
-            acc = acc + d * d;
+            acc = mad(d, d, acc);
         }
         if (NF < NT) {
             const float d = l_rs[NF * kWave] - mean;
             if constexpr (KEEP_RS) l_rs[NF * kWave] = d;
-            acc = (NF * kWave + lane) < N ? acc + d * d : acc;
+            acc = (NF * kWave + lane) < N ? mad(d, d, acc) : acc;
         }
         ref_norm = uni(sqrtf(wave_allreduce_sum(acc)));
     }
@@ -357,10 +361,11 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 if constexpr (TAB) xy = tab_at(t) - mk2(offx, offy);
                 else xy = v.xy;
                 const f2 A = g_x * xy, B = g_y * xy;
-                const f2 nAA = hAA + A * A, nBB = hBB + B * B, nAB = hAB + A * B, nAs = hAs + A * B.yx;
-                const f2 nxA = hxA + g_x * A, nyA = hyA + g_y * A, nxB = hxB + g_x * B, nyB = hyB + g_y * B;
-                const float n00 = h00 + g_x * g_x, n33 = h33 + g_y * g_y, n30 = h30 + g_y * g_x;
-                const float n21 = h21 + A.y * A.x, n54 = h54 + B.y * B.x;
+                // (mad: product and add rounded separately, or -- OC_FMA -- one fused multiply-add per running sum)
+                const f2 nAA = mad(A, A, hAA), nBB = mad(B, B, hBB), nAB = mad(A, B, hAB), nAs = mad(A, B.yx, hAs);
+                const f2 nxA = mad(g_x, A, hxA), nyA = mad(g_y, A, hyA), nxB = mad(g_x, B, hxB), nyB = mad(g_y, B, hyB);
+                const float n00 = mad(g_x, g_x, h00), n33 = mad(g_y, g_y, h33), n30 = mad(g_y, g_x, h30);
+                const float n21 = mad(A.y, A.x, h21), n54 = mad(B.y, B.x, h54);
                 if (valid) {
                     hAA = nAA; hBB = nBB; hAB = nAB; hAs = nAs; hxA = nxA; hyA = nyA; hxB = nxB; hyB = nyB;
                     h00 = n00; h33 = n33; h30 = n30; h21 = n21; h54 = n54;
@@ -413,10 +418,10 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     const float sr = (r & 1) ? sdp[r / 2].y : sdp[r / 2].x;
 #pragma unroll
                     for (int q = 0; q < (r + 1) / 2; q++) {
-                        const f2 nv = hp[r][q] + sr * sdp[q];
+                        const f2 nv = mad(sr, sdp[q], hp[r][q]);
                         hp[r][q] = valid ? nv : hp[r][q];
                     }
-                    if ((r & 1) == 0) hd[r] = valid ? hd[r] + sr * sr : hd[r];
+                    if ((r & 1) == 0) hd[r] = valid ? mad(sr, sr, hd[r]) : hd[r];
                 }
             };
             passes_prefetched(NF, NT, (NF * kWave + lane) < N, fetch, sample);
@@ -566,9 +571,9 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     float wx, wy;
                     if constexpr (DOF == 6) {
                         // Deformation2D1::warp, src/oc_deformation.cpp:94-105: (W0 x + W1 y) + W2 * 1 (the product
-                        // with 1.f is exact and dropped)
-                        wx = (Wv[0] * xl + Wv[1] * yl) + Wv[2];
-                        wy = (Wv[3] * xl + Wv[4] * yl) + Wv[5];
+                        // with 1.f is exact and dropped); OC_FMA: the second product joins the first sum
+                        wx = mad(Wv[1], yl, Wv[0] * xl) + Wv[2];
+                        wy = mad(Wv[4], yl, Wv[3] * xl) + Wv[5];
                     } else {
                         // Deformation2D2::warp, src/oc_deformation.cpp:268-282: rows 3, 4 of W * [x^2 xy y^2 x y 1]
                         const float pv[6] = {xl * xl, xl * yl, yl * yl, xl, yl, 1.f};
@@ -576,8 +581,8 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                         wy = row4[0] * pv[0];
 #pragma unroll
                         for (int k = 1; k < 6; k++) {
-                            wx = wx + row3[k] * pv[k];
-                            wy = wy + row4[k] * pv[k];
+                            wx = mad(row3[k], pv[k], wx);
+                            wy = mad(row4[k], pv[k], wy);
                         }
                     }
                     // tar_subset->center = POI + center_offset, then + warped_coor (src/oc_icgn.cpp:425-426,452);
@@ -675,11 +680,11 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
 #pragma unroll 6
         for (int t = 0; t < NF; t++) {
             const float d = l_ts[t * kWave] - tmean;
-            acc = acc + d * d;
+            acc = mad(d, d, acc);
         }
         if (NF < NT) {
             const float d = l_ts[NF * kWave] - tmean;
-            acc = (NF * kWave + lane) < N ? acc + d * d : acc;
+            acc = (NF * kWave + lane) < N ? mad(d, d, acc) : acc;
         }
         const float tar_norm = uni(sqrtf(wave_allreduce_sum(acc)));
         // error image, ZNSSD, numerator (src/oc_icgn.cpp:260-276)
@@ -723,16 +728,15 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                 const float tz = l_ts[t * kWave] - tmean;  // same bits as in the norm pass
                 // the zero-mean reference value: parked in LDS, or re-formed from the image (same subtraction, same bits)
                 const float rsv = KEEP_RS ? l_rs[t * kWave] : ref_v - ref_mean_v;
-                const float e = tz * factor - rsv;
-                const float e2 = e * e;
-                ssd = valid ? ssd + e2 : ssd;
+                const float e = mad(tz, factor, -rsv);
+                ssd = valid ? mad(e, e, ssd) : ssd;
                 if constexpr (DOF == 6) {
                     f2 xy;
                     if constexpr (TAB) xy = tab_at(t) - mk2(offx, offy);
                     else xy = v.xy;
                     const f2 A = g_x * xy, B = g_y * xy;  // (sd1, sd2), (sd4, sd5)
-                    const f2 mA = nA + A * e, mB = nB + B * e;
-                    const float m0 = num[0] + g_x * e, m3 = num[3] + g_y * e;
+                    const f2 mA = mad(A, e, nA), mB = mad(B, e, nB);
+                    const float m0 = mad(g_x, e, num[0]), m3 = mad(g_y, e, num[3]);
                     if (valid) {
                         nA = mA; nB = mB; num[0] = m0; num[3] = m3;
                     }
@@ -746,7 +750,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                     const f2 sdp[6] = {g_x * m01, g_x * m23, g_x * m45, g_y * m01, g_y * m23, g_y * m45};
 #pragma unroll
                     for (int q = 0; q < 6; q++) {
-                        const f2 nv = np12[q] + sdp[q] * e;
+                        const f2 nv = mad(sdp[q], e, np12[q]);
                         np12[q] = valid ? nv : np12[q];
                     }
                 }
@@ -986,28 +990,6 @@ static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, siz
     X(5, OC_V5_G, 4, 0, 8, OC_V5_OCC) \
     X(6, 2, 4, 0, 4, 4)
 
-constexpr int kIcgn2dVariants = 7;
-
-int icgn2d_variant_count() { return kIcgn2dVariants; }
-
-int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int* occ) {
-    switch (variant) {
-#define X(ID, GG, MM, PP, WW, OO) \
-    case ID: *g = GG; *mode = MM; *pipe = PP; *wpb = WW; *occ = OO; return 0;
-        OC_ICGN2D_VARIANTS(X)
-#undef X
-        default: return -1;
-    }
-}
-
-// largest sample count a variant can hold in LDS
-int icgn2d_max_samples(int variant) {
-    int g, mode, pipe, wpb, occ;
-    if (icgn2d_variant_info(variant, &g, &mode, &pipe, &wpb, &occ)) return 0;
-    const int arrays = mode == 0 ? 4 : (mode == 4 ? 1 : 2);
-    return kLdsBudget / ((arrays * wpb + (mode >= 3 ? 3 : 0)) * (int)sizeof(float) * kWave) * kWave;
-}
-
 template <int DOF>
 static hipError_t launch_dof(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
                              hipStream_t stream) {
@@ -1038,8 +1020,6 @@ hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_f, size
 
 // IC-LM: one launch shape each (G = 3, gradients re-read, one wave per workgroup so the LDS limit is the
 // largest; the per-iteration LU keeps more registers live, hence occupancy 3)
-int iclm2d_max_samples() { return kLdsBudget / (2 * (int)sizeof(float) * kWave) * kWave; }
-
 hipError_t launch_iclm2d1(const Icgn2dParams& p, float* pois, int stride_f, size_t count, bool xcd, hipStream_t stream) {
     if (count == 0) return hipSuccess;
     const int nt = ((2 * p.rx + 1) * (2 * p.ry + 1) + 63) / 64;
@@ -1050,6 +1030,53 @@ hipError_t launch_iclm2d2(const Icgn2dParams& p, float* pois, int stride_f, size
     if (count == 0) return hipSuccess;
     const int nt = ((2 * p.rx + 1) * (2 * p.ry + 1) + 63) / 64;
     return launch_t<12, 4, 1, 0, 1, 3, 0, 1>(p, pois, stride_f, count, nt, xcd, stream);
+}
+
+}  // namespace OC_ARITH
+
+#if !OC_FMA
+// ---- the arithmetic-independent part and the dispatch between the two builds (this translation unit only) ----
+using OC_ARITH::kLdsBudget;
+constexpr int kIcgn2dVariants = 7;
+
+int icgn2d_variant_count() { return kIcgn2dVariants; }
+
+int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int* occ) {
+    switch (variant) {
+#define X(ID, GG, MM, PP, WW, OO) \
+    case ID: *g = GG; *mode = MM; *pipe = PP; *wpb = WW; *occ = OO; return 0;
+        OC_ICGN2D_VARIANTS(X)
+#undef X
+        default: return -1;
+    }
+}
+
+// largest sample count a variant can hold in LDS
+int icgn2d_max_samples(int variant) {
+    int g, mode, pipe, wpb, occ;
+    if (icgn2d_variant_info(variant, &g, &mode, &pipe, &wpb, &occ)) return 0;
+    const int arrays = mode == 0 ? 4 : (mode == 4 ? 1 : 2);
+    return kLdsBudget / ((arrays * wpb + (mode >= 3 ? 3 : 0)) * (int)sizeof(float) * kWave) * kWave;
+}
+
+int iclm2d_max_samples() { return kLdsBudget / (2 * (int)sizeof(float) * kWave) * kWave; }
+
+// p.arith_fma selects the build whose per-sample multiply-adds are fused (oc_device.h; icgn2d_fma.o)
+hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
+                          hipStream_t stream) {
+    return p.arith_fma ? fma::launch_icgn2d1(p, pois, stride_f, count, variant, xcd, stream)
+                       : sep::launch_icgn2d1(p, pois, stride_f, count, variant, xcd, stream);
+}
+hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
+                          hipStream_t stream) {
+    return p.arith_fma ? fma::launch_icgn2d2(p, pois, stride_f, count, variant, xcd, stream)
+                       : sep::launch_icgn2d2(p, pois, stride_f, count, variant, xcd, stream);
+}
+hipError_t launch_iclm2d1(const Icgn2dParams& p, float* pois, int stride_f, size_t count, bool xcd, hipStream_t stream) {
+    return p.arith_fma ? fma::launch_iclm2d1(p, pois, stride_f, count, xcd, stream) : sep::launch_iclm2d1(p, pois, stride_f, count, xcd, stream);
+}
+hipError_t launch_iclm2d2(const Icgn2dParams& p, float* pois, int stride_f, size_t count, bool xcd, hipStream_t stream) {
+    return p.arith_fma ? fma::launch_iclm2d2(p, pois, stride_f, count, xcd, stream) : sep::launch_iclm2d2(p, pois, stride_f, count, xcd, stream);
 }
 
 // largest subset radii of a POI queue (self-adaptive mode sizes the LDS arrays from them)
@@ -1074,5 +1101,7 @@ hipError_t launch_poi2d_max_radius(const float* pois, int stride_f, size_t count
                        out2);
     return hipGetLastError();
 }
+
+#endif  // !OC_FMA
 
 }  // namespace ochip

@@ -40,6 +40,8 @@
 #endif
 
 namespace ochip {
+// (kernel and launcher live in ochip::sep or ochip::fma: this file is compiled once per arithmetic mode, oc_device.h)
+namespace OC_ARITH {
 
 // Hessian rows [R0, R1): sums of sd[r]*sd[c], c <= r, over all samples (src/oc_icgn.cpp:1299-1337),
 // block-reduced and filed into the symmetric matrix A (LDS).
@@ -81,8 +83,8 @@ __device__ __forceinline__ void hessian_rows(const Icgn3dParams& P, int tid, int
             for (int r = R0; r < R1; r++) {
                 const float sr = (r & 1) ? sdp[r / 2].y : sdp[r / 2].x;
 #pragma unroll
-                for (int q2 = 0; q2 < (r + 1) / 2; q2++) hp[r][q2] = hp[r][q2] + sr * sdp[q2];
-                if ((r & 1) == 0) hd[r] = hd[r] + sr * sr;
+                for (int q2 = 0; q2 < (r + 1) / 2; q2++) hp[r][q2] = mad(sr, sdp[q2], hp[r][q2]);
+                if ((r & 1) == 0) hd[r] = mad(sr, sr, hd[r]);
             }
         });
     float h[NE];
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
             Walk3 w2(tid, SX, SY, 0, DX, DY);
             sweep_batched<8>(w2, rx, ry, rz, cnt, ref_of, [&](const WalkPoint&, float v, int) {
                 const float d = v - ref_mean;
-                acc[0] += d * d;
+                acc[0] = mad(d, d, acc[0]);
             });
             block_allreduce<1>(acc, red, wave, lane);
             ref_norm = sqrtf(acc[0]);
@@ -249,9 +251,11 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
             float acc[1] = {0.f};
             {
                 // Deformation3D1::warp (src/oc_deformation.cpp:518-530) + subvolume centre, as every sample evaluates it
-                auto warp_x = [&](float xl, float yl, float zl) { return px + (((Wm[0] * xl + Wm[1] * yl) + Wm[2] * zl) + Wm[3] * 1.f); };
-                auto warp_y = [&](float xl, float yl, float zl) { return py + (((Wm[4] * xl + Wm[5] * yl) + Wm[6] * zl) + Wm[7] * 1.f); };
-                auto warp_z = [&](float xl, float yl, float zl) { return pz + (((Wm[8] * xl + Wm[9] * yl) + Wm[10] * zl) + Wm[11] * 1.f); };
+                // (OC_FMA: the second and third products join the running sum; mad is monotone in every argument like the
+                // separately rounded form, so the corner argument of the coefficient boxes below holds in both modes)
+                auto warp_x = [&](float xl, float yl, float zl) { return px + (mad(Wm[2], zl, mad(Wm[1], yl, Wm[0] * xl)) + Wm[3] * 1.f); };
+                auto warp_y = [&](float xl, float yl, float zl) { return py + (mad(Wm[6], zl, mad(Wm[5], yl, Wm[4] * xl)) + Wm[7] * 1.f); };
+                auto warp_z = [&](float xl, float yl, float zl) { return pz + (mad(Wm[10], zl, mad(Wm[9], yl, Wm[8] * xl)) + Wm[11] * 1.f); };
                 // ---- coefficient boxes of all passes of this sweep, one pass per thread (the box of a pass
                 // costs more arithmetic than a sample does, so it is not recomputed by every wave in every pass).
                 // A pass = M * 512 consecutive samples: thread tid owns s = tid + 512 * (M * pass + m), m < M.
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
                 sweep_batched<8>(w, rx, ry, rz, cnt, [&](const WalkPoint&, int sidx) { return ts[sidx]; },
                                  [&](const WalkPoint&, float v, int) {
                                      const float d = v - tmean;
-                                     acc[0] += d * d;
+                                     acc[0] = mad(d, d, acc[0]);
                                  });
             }
             block_allreduce<1>(acc, red, wave, lane);
@@ -419,13 +423,13 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
                         [&](const WalkPoint& q, const S5& v, int) {
                             const float rsv = v.r - ref_mean;
                             const float tz = v.t - tmean;
-                            const float e = factor * tz - rsv;
+                            const float e = mad(factor, tz, -rsv);
                             const float g_x = v.x, g_y = v.y, g_z = v.z;
                             const float fx = q.x, fy = q.y, fz = q.z;
-                            num[12] += e * e;
-                            num[0] += g_x * e; num[1] += (g_x * fx) * e; num[2] += (g_x * fy) * e; num[3] += (g_x * fz) * e;
-                            num[4] += g_y * e; num[5] += (g_y * fx) * e; num[6] += (g_y * fy) * e; num[7] += (g_y * fz) * e;
-                            num[8] += g_z * e; num[9] += (g_z * fx) * e; num[10] += (g_z * fy) * e; num[11] += (g_z * fz) * e;
+                            num[12] = mad(e, e, num[12]);
+                            num[0] = mad(g_x, e, num[0]); num[1] = mad(g_x * fx, e, num[1]); num[2] = mad(g_x * fy, e, num[2]); num[3] = mad(g_x * fz, e, num[3]);
+                            num[4] = mad(g_y, e, num[4]); num[5] = mad(g_y * fx, e, num[5]); num[6] = mad(g_y * fy, e, num[6]); num[7] = mad(g_y * fz, e, num[7]);
+                            num[8] = mad(g_z, e, num[8]); num[9] = mad(g_z * fx, e, num[9]); num[10] = mad(g_z * fy, e, num[10]); num[11] = mad(g_z * fz, e, num[11]);
                         });
                 };
                 if (ref_box) numerator(ref_fast);
@@ -505,6 +509,9 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
     }
 }
 
+}  // namespace OC_ARITH
+
+#if !OC_FMA
 // persistent workgroups (two per CU), each with one scratch slot for the warped subvolume
 size_t icgn3d1_scratch_floats(int rx, int ry, int rz, int* blocks) {
     const size_t n = (size_t)(2 * rx + 1) * (2 * ry + 1) * (2 * rz + 1);
@@ -515,6 +522,13 @@ size_t icgn3d1_scratch_floats(int rx, int ry, int rz, int* blocks) {
     return n * (size_t)*blocks;
 }
 
+// p.arith_fma selects the build whose per-sample multiply-adds are fused (oc_device.h; icgn3d_fma.o)
+hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
+    return p.arith_fma ? fma::launch_icgn3d1(p, pois, stride_f, count, stream) : sep::launch_icgn3d1(p, pois, stride_f, count, stream);
+}
+#endif  // !OC_FMA
+
+namespace OC_ARITH {
 hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
     if (count == 0) return hipSuccess;
     if (!p.scratch) return hipErrorInvalidValue;
@@ -551,5 +565,6 @@ hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_f, size
     }
     return hipGetLastError();
 }
+}  // namespace OC_ARITH
 
 }  // namespace ochip

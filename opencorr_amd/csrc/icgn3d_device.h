@@ -178,20 +178,30 @@ __device__ __forceinline__ void set_warp_3d1(float (&w)[16], const float (&q)[12
     w[12] = 0.f; w[13] = 0.f; w[14] = 0.f; w[15] = 1.f;
 }
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 mk2(float a, float b) {
-    f2 r = {a, b};
-    return r;
-}
-
 // cubic B-spline basis functions, src/oc_cubic_bspline.cpp:35-53; T = float, or a packed pair of arguments (the same
 // IEEE operations, two per issue slot)
+// OC_FMA: every Horner step "product + constant" is one fused multiply-add (oracle basis*_fma)
+template <class T>
+__device__ __forceinline__ T cst(float v);
+template <>
+__device__ __forceinline__ float cst<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ f2 cst<f2>(float v) { return splat2(v); }
+#if OC_FMA
+template <class T>
+__device__ __forceinline__ T basis0(T t) { return (1.f / 6.f) * mad(t, mad(t, -t + 3.f, cst<T>(-3.f)), cst<T>(1.f)); }
+template <class T>
+__device__ __forceinline__ T basis1(T t) { return (1.f / 6.f) * mad(t * t, mad(cst<T>(3.f), t, cst<T>(-6.f)), cst<T>(4.f)); }
+template <class T>
+__device__ __forceinline__ T basis2(T t) { return (1.f / 6.f) * mad(t, mad(t, mad(cst<T>(-3.f), t, cst<T>(3.f)), cst<T>(3.f)), cst<T>(1.f)); }
+#else
 template <class T>
 __device__ __forceinline__ T basis0(T t) { return (1.f / 6.f) * (t * (t * (-t + 3.f) - 3.f) + 1.f); }
 template <class T>
 __device__ __forceinline__ T basis1(T t) { return (1.f / 6.f) * (t * t * (3.f * t - 6.f) + 4.f); }
 template <class T>
 __device__ __forceinline__ T basis2(T t) { return (1.f / 6.f) * (t * (t * (-3.f * t + 3.f) + 3.f) + 1.f); }
+#endif
 template <class T>
 __device__ __forceinline__ T basis3(T t) { return (1.f / 6.f) * (t * t * t); }
 
@@ -209,8 +219,15 @@ typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // 4-byt
 #ifndef OC_TAPS_PACKED
 #define OC_TAPS_PACKED 0
 #endif
+#if OC_TAPS_PACKED && OC_FMA
+#error "the packed tap products exist in the separately rounded mode only"
+#endif
 __device__ __forceinline__ float taps4(float b0, float b1, float b2, float b3, float r0, float r1, float r2, float r3) {
-#if OC_TAPS_PACKED
+#if OC_FMA
+    // one product, three fused multiply-adds (oracle taps4<true>): the 21 four-tap sums of a sample are 21 v_mul_f32 +
+    // 63 v_fma_f32 instead of 84 multiplies + 63 adds
+    return mad(b3, r3, mad(b2, r2, mad(b1, r1, b0 * r0)));
+#elif OC_TAPS_PACKED
     const f2 p01 = mk2(r0, r1) * mk2(b0, b1), p23 = mk2(r2, r3) * mk2(b2, b3);
     return ((p01.x + p01.y) + p23.x) + p23.y;
 #else

@@ -1,20 +1,68 @@
 // oc_device.h -- device-side helpers shared by the gfx950 kernels.
 //
-// Arithmetic contract: IEEE float32, every multiply and add
-// rounded separately (the library is built with -ffp-contract=off), correctly
+// Arithmetic contract: IEEE float32, the compiler contracts
+// nothing (the library is built with -ffp-contract=off), correctly
 // rounded division and sqrt (hipcc default), no fast-math.  Reductions over the
 // samples of a subset use ONE fixed association: sample s is owned by lane
 // (s % P) which adds its samples in increasing s, and the P partials are
 // combined by an xor butterfly with ascending offsets 1, 2, 4, ... P/2.  The CPU
 // oracle implements the same association (OC_ORDER_LANES) so results are
 // bit-identical.
+//
+// Two arithmetic modes exist for the ICGN / IC-LM solvers, selected per translation unit by OC_FMA (icgn2d.hip and
+// icgn3d.hip are compiled twice; oc_hip_set_tuning("arith_fma") picks the build at run time):
+//   OC_FMA = 0 ("sep")  every multiply and every add rounds on its own -- the reference built for baseline x86-64;
+//                       oracle orders OC_ORDER_LANES / OC_ORDER_SEQ;
+//   OC_FMA = 1 ("fma")  every PER-SAMPLE multiply-add is ONE explicit fused multiply-add (`mad` below -> v_fma_f32 /
+//                       v_pk_fma_f32), at exactly the sites oracle/oc_oracle.h lists under "Arithmetic contract" -- the
+//                       contraction a compiler with FMA hardware makes of the reference's source expressions; oracle
+//                       orders OC_ORDER_LANES_FMA / OC_ORDER_SEQ_FMA.  IEEE fusedMultiplyAdd is defined bit for bit, so
+//                       GPU == oracle stays exact; the per-POI dense algebra is NOT fused in either mode.
+// Helpers whose bodies depend on OC_FMA are __device__ __forceinline__ only (no symbol is ever emitted for them, and
+// every translation unit is its own device code object), and the kernels built from them live in ochip::sep / ochip::fma.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
+#ifndef OC_FMA
+#define OC_FMA 0
+#endif
+#if OC_FMA
+#define OC_ARITH fma
+#else
+#define OC_ARITH sep
+#endif
+
 namespace ochip {
 
 constexpr int kWave = 64;
+
+// Two floats that travel through the packed-fp32 pipe (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two IEEE operations
+// per issue slot, each rounded on its own, so results are those of the scalar instructions).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) {
+    f2 r = {a, b};
+    return r;
+}
+__device__ __forceinline__ f2 splat2(float a) { return mk2(a, a); }
+
+// a * b + c under the translation unit's arithmetic mode: two roundings ("sep") or one ("fma")
+__device__ __forceinline__ float mad(float a, float b, float c) {
+#if OC_FMA
+    return __builtin_fmaf(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+__device__ __forceinline__ f2 mad(f2 a, f2 b, f2 c) {
+#if OC_FMA
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+__device__ __forceinline__ f2 mad(float a, f2 b, f2 c) { return mad(splat2(a), b, c); }
+__device__ __forceinline__ f2 mad(f2 a, float b, f2 c) { return mad(a, splat2(b), c); }
 
 // offsets inside a POI2D / POI3D record, in floats (src/oc_poi.h:25-222)
 namespace poi2d {

@@ -26,6 +26,7 @@ struct Icgn2dParams {
     // IC-LM only (launch_iclm2d*): DampingParameter of src/oc_iclm.h:33-38 with ln(lambda) taken on the host
     double lm_log_lambda;
     float lm_alpha, lm_beta;
+    int arith_fma;  // 1: the build whose per-sample multiply-adds are fused (oc_device.h OC_FMA; oracle OC_ORDER_LANES_FMA)
 };
 // writes max over the queue of (int)subset_radius.x / .y to out2[0], out2[1]
 hipError_t launch_poi2d_max_radius(const float* pois, int stride_floats, size_t count, int* out2, hipStream_t stream);
@@ -41,6 +42,21 @@ hipError_t launch_iclm2d2(const Icgn2dParams& p, float* pois, int stride_floats,
 int iclm2d_max_samples();
 hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, int variant, bool xcd,
                           hipStream_t stream);
+// the two builds of icgn2d.hip (oc_device.h: OC_FMA = 0 / 1) behind the four launchers above
+#define OC_DECLARE_ICGN2D_LAUNCHERS                                                                                          \
+    hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, int variant, bool xcd,   \
+                              hipStream_t stream);                                                                          \
+    hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, int variant, bool xcd,   \
+                              hipStream_t stream);                                                                          \
+    hipError_t launch_iclm2d1(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream); \
+    hipError_t launch_iclm2d2(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
+namespace sep {
+OC_DECLARE_ICGN2D_LAUNCHERS
+}
+namespace fma {
+OC_DECLARE_ICGN2D_LAUNCHERS
+}
+#undef OC_DECLARE_ICGN2D_LAUNCHERS
 int icgn2d_variant_count();
 int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int* occ);
 // variants with a per-workgroup coordinate table (mode >= 3) need one subset radius per launch
@@ -129,12 +145,20 @@ struct Icgn3dParams {
     int samples_per_pass;  // samples (row mapping: steps of 16 rows) per thread between two coefficient-box stagings (set by the launchers)
     int tail_steps_per_pass;  // row mapping: steps of 512 tail samples per tail pass (set by launch_icgn3d1_rows)
     const unsigned* perm;     // locality schedule (poi_order.hip launch_poi3d_tile_order): the k-th solve takes POI perm[k]; nullptr = queue order
+    int arith_fma;            // 1: the build whose per-sample multiply-adds are fused (icgn3d.hip only; the row mapping has no such build)
 };
 // floats of global scratch the kernel needs for this radius (0 when the subvolume fits LDS);
 // *blocks receives the number of persistent workgroups in scratch mode (0 in LDS mode)
 size_t icgn3d1_scratch_floats(int rx, int ry, int rz, int* blocks);
 hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);
-// icgn3d_rows.hip: the same solver with one half-wave per subvolume row (the default; oracle order OC_ORDER_ROWS); its scratch
+namespace sep {
+hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);
+}
+namespace fma {
+hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);
+}
+// icgn3d_rows.hip (A/B builds only, OC_BUILD_AB; NOT the default -- the default is icgn3d.hip, oracle order OC_ORDER_LANES): the
+// same solver with one half-wave per subvolume row (oracle order OC_ORDER_ROWS), measured 12 - 25 % slower; its scratch
 // slots are a little larger (whole steps): icgn3d1_rows_slot_floats floats per workgroup, 512 workgroups
 size_t icgn3d1_rows_slot_floats(int rx, int ry, int rz);
 hipError_t launch_icgn3d1_rows(const Icgn3dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);

@@ -16,7 +16,12 @@ _LIB_PATH = os.path.join(_HERE, "liboc_oracle.so")
 
 ORDER_SEQ = 0
 ORDER_LANES = 1
-ORDER_ROWS = 2   # ICGN3D1 only: the association of the default 3D kernel (one half-wave per subvolume row), lanes = 512
+ORDER_ROWS = 2   # ICGN3D1 only: the association of the row-mapping A/B kernel (one half-wave per subvolume row), lanes = 512
+# OR into an order: every per-sample multiply-add is ONE fmaf (oc_oracle.h "Arithmetic contract"); the HIP engines under
+# set_tuning("arith_fma", 1) are bit-exact against ORDER_LANES_FMA
+ARITH_FMA = 0x100
+ORDER_SEQ_FMA = ORDER_SEQ | ARITH_FMA
+ORDER_LANES_FMA = ORDER_LANES | ARITH_FMA
 # what the HIP kernels are bit-exact against (tests pass these to icgn2d* / icgn3d1)
 GPU_ORDER_2D, GPU_LANES_2D = ORDER_LANES, 64
 GPU_ORDER_3D, GPU_LANES_3D = ORDER_LANES, 512     # icgn3d.hip, the default mapping; icgn3d_rows.hip ("icgn3d_mapping" = 1): ORDER_ROWS, 512
@@ -33,14 +38,40 @@ P3 = dict(x=0, y=1, z=2, u=3, ux=4, uy=5, uz=6, v=7, vx=8, vy=9, vz=10, w=11, wx
           exx=22, eyy=23, ezz=24, exy=25, eyz=26, ezx=27, srx=28, sry=29, srz=30)
 
 
+def _host_has_fma():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("flags"):
+                    return " fma " in line + " "
+    except OSError:
+        pass
+    return False
+
+
+_FLAGS_NOTE = os.path.join(_HERE, ".liboc_oracle.flags")   # "-mfma" when the library holds vfmadd / VEX instructions
+
+
 def build(force=False):
-    """Compile the oracle with its Makefile (g++ only, no third-party deps)."""
+    """Compile the oracle with its Makefile (g++ only, no third-party deps).  The library is built with -mfma where the
+    building host has the instruction (the OC_ARITH_FMA orders are ~20 x faster with it, same bits); a library that
+    arrived from such a host on one without it (a box snapshot) is rebuilt in the portable form before it is loaded."""
     src = os.path.join(_HERE, "oc_oracle.cpp")
-    if (not force and os.path.exists(_LIB_PATH)
+    fma = "-mfma" if _host_has_fma() else ""
+    try:
+        with open(_FLAGS_NOTE) as fh:
+            built = fh.read().strip()
+    except OSError:
+        built = None
+    usable = built is None or built == "" or fma == "-mfma"   # unknown / portable builds run anywhere
+    if (not force and usable and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src),
-                                                   os.path.getmtime(os.path.join(_HERE, "oc_oracle.h")))):
+                                                   os.path.getmtime(os.path.join(_HERE, "oc_oracle.h")),
+                                                   os.path.getmtime(os.path.join(_HERE, "Makefile")))):
         return _LIB_PATH
-    subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
+    subprocess.check_call(["make", "-C", _HERE, "-B", "-s", "FMA_FLAG=" + fma, "liboc_oracle.so"])
+    with open(_FLAGS_NOTE, "w") as fh:
+        fh.write(fma + "\n")
     return _LIB_PATH
 
 
@@ -66,8 +97,8 @@ def use_timing_build():
 def lib():
     global _lib
     if _lib is None:
-        if _lib_path == _LIB_PATH and not os.path.exists(_LIB_PATH):
-            build()
+        if _lib_path == _LIB_PATH:
+            build()   # no-op when the library is current and runs on this host
         L = ctypes.CDLL(_lib_path)
         fp = ctypes.POINTER(ctypes.c_float)
         i, f, l = ctypes.c_int, ctypes.c_float, ctypes.c_long
@@ -75,6 +106,11 @@ def lib():
         L.oc_oracle_bspline2d_lut.argtypes = [fp, i, i, fp, i]
         L.oc_oracle_bspline2d_eval.argtypes = [fp, i, i, f, f]
         L.oc_oracle_bspline2d_eval.restype = f
+        L.oc_oracle_bspline2d_eval_fma.argtypes = [fp, i, i, f, f]
+        L.oc_oracle_bspline2d_eval_fma.restype = f
+        L.oc_oracle_bspline3d_eval_fma.argtypes = [fp, i, i, i, f, f, f]
+        L.oc_oracle_bspline3d_eval_fma.restype = f
+        L.oc_oracle_fma_is_hardware.restype = i
         L.oc_oracle_fftcc2d.argtypes = [fp, fp, i, i, i, i, fp, l, i, fp]
         L.oc_oracle_icgn2d1.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i]
         L.oc_oracle_icgn2d2.argtypes = [fp, fp, fp, fp, i, i, i, i, f, f, fp, l, i, i, i]

@@ -33,13 +33,28 @@ namespace {
 // ---------------------------------------------------------------------------
 // reductions
 // ---------------------------------------------------------------------------
+// The arithmetic contract (oc_oracle.h, "OC_ARITH_FMA"): FMA = false rounds every multiply and every add on its own
+// (the reference built for baseline x86-64); FMA = true fuses the PER-SAMPLE multiply-adds -- a*b + c becomes ONE
+// correctly rounded fmaf(a, b, c), exactly the contraction a compiler with -ffp-contract=fast / -mfma makes of the
+// reference's source expressions (association unchanged, one rounding fewer).  IEEE-754 fusedMultiplyAdd is defined
+// bit for bit, so std::fmaf here and v_fma_f32 / v_pk_fma_f32 on gfx950 agree.
+template <bool FMA>
+static inline float mad(float a, float b, float c) {
+    if constexpr (FMA) return __builtin_fmaf(a, b, c);
+    else return a * b + c;
+}
+
 // K simultaneous sums over samples s = 0..N-1.  SEQ: one running float per sum.
 // LANES: P strided partials per sum + ascending xor butterfly (oc_oracle.h).
+// mac<FMA>(s, k, x, y): sum k receives the product x * y of sample s -- as a separately rounded product and an add, or
+// fused into the running sum.
 template <int K>
 struct AccSeq {
     float a[K];
     explicit AccSeq(int /*lanes*/, int /*row_length*/ = 0) { for (int k = 0; k < K; k++) a[k] = 0.f; }
     inline void add(int /*s*/, int k, float v) { a[k] += v; }
+    template <bool FMA>
+    inline void mac(int /*s*/, int k, float x, float y) { a[k] = mad<FMA>(x, y, a[k]); }
     inline void finish() {}
     inline float get(int k) const { return a[k]; }
 };
@@ -50,6 +65,11 @@ struct AccLanes {
     std::vector<float> part;  // [K][P]
     explicit AccLanes(int lanes, int /*row_length*/ = 0) : P(lanes), part((size_t)K * lanes, 0.f) {}
     inline void add(int s, int k, float v) { part[(size_t)k * P + (s & (P - 1))] += v; }
+    template <bool FMA>
+    inline void mac(int s, int k, float x, float y) {
+        float& slot = part[(size_t)k * P + (s & (P - 1))];
+        slot = mad<FMA>(x, y, slot);
+    }
     inline void finish() {
         std::vector<float> tmp(P);
         for (int k = 0; k < K; k++) {
@@ -91,6 +111,12 @@ struct AccRows {
             }
             tail[(size_t)q * K + k] = v;
         }
+    }
+    // (the row mapping is the A/B partner of the default kernel and exists with separately rounded products only)
+    template <bool FMA>
+    inline void mac(int s, int k, float x, float y) {
+        static_assert(!FMA, "OC_ORDER_ROWS has no fused-arithmetic form");
+        add(s, k, x * y);
     }
     inline void finish() {
         for (long q = 0; q < ntail; q++)
@@ -214,6 +240,7 @@ static const float BC[4][4] = {
     {-198.0f / 336.0f, -18.0f / 336.0f, 270.0f / 336.0f, -54.0f / 336.0f},
     {0.0f, 1.0f, 0.0f, 0.0f}};
 
+template <bool FMA = false>
 static inline float bspline2d_eval(const float* lut, int height, int width, float x, float y) {
     // src/oc_cubic_bspline.cpp:137-142
     if (x < 1 || y < 1 || x >= width - 2 || y >= height - 2 || std::isnan(x) || std::isnan(y)) return -1.f;
@@ -223,6 +250,26 @@ static inline float bspline2d_eval(const float* lut, int height, int width, floa
     float dx2 = dx * dx, dy2 = dy * dy;
     float dx3 = dx2 * dx, dy3 = dy2 * dy;
     const float* c = lut + ((size_t)yi * width + xi) * 16;
+    if constexpr (FMA) {
+        // the same 16 terms, left to right, every "+ product" fused: v + (c * dy^k) * dx^l -> fmaf(c * dy^k, dx^l, v)
+        float v = c[0];
+        v = mad<true>(c[1], dx, v);
+        v = mad<true>(c[2], dx2, v);
+        v = mad<true>(c[3], dx3, v);
+        v = mad<true>(c[4], dy, v);
+        v = mad<true>(c[5] * dy, dx, v);
+        v = mad<true>(c[6] * dy, dx2, v);
+        v = mad<true>(c[7] * dy, dx3, v);
+        v = mad<true>(c[8], dy2, v);
+        v = mad<true>(c[9] * dy2, dx, v);
+        v = mad<true>(c[10] * dy2, dx2, v);
+        v = mad<true>(c[11] * dy2, dx3, v);
+        v = mad<true>(c[12], dy3, v);
+        v = mad<true>(c[13] * dy3, dx, v);
+        v = mad<true>(c[14] * dy3, dx2, v);
+        v = mad<true>(c[15] * dy3, dx3, v);
+        return v;
+    }
     // explicit 16-term left-to-right sum of src/oc_cubic_bspline.cpp:159-177
     float v = c[0];
     v = v + c[1] * dx;
@@ -253,7 +300,18 @@ static inline float basis0(float t) { return (1.f / 6.f) * (t * (t * (-t + 3.f) 
 static inline float basis1(float t) { return (1.f / 6.f) * (t * t * (3.f * t - 6.f) + 4.f); }
 static inline float basis2(float t) { return (1.f / 6.f) * (t * (t * (-3.f * t + 3.f) + 3.f) + 1.f); }
 static inline float basis3(float t) { return (1.f / 6.f) * (t * t * t); }
+// the same Horner forms with every "product + constant" fused (src/oc_cubic_bspline.cpp:35-53 under contraction)
+static inline float basis0_fma(float t) { return (1.f / 6.f) * mad<true>(t, mad<true>(t, -t + 3.f, -3.f), 1.f); }
+static inline float basis1_fma(float t) { return (1.f / 6.f) * mad<true>(t * t, mad<true>(3.f, t, -6.f), 4.f); }
+static inline float basis2_fma(float t) { return (1.f / 6.f) * mad<true>(t, mad<true>(t, mad<true>(-3.f, t, 3.f), 3.f), 1.f); }
+// ((b0 * r0 + b1 * r1) + b2 * r2) + b3 * r3, src/oc_cubic_bspline.cpp:390-401; fused: one product, three fmaf
+template <bool FMA>
+static inline float taps4(const float* b, float r0, float r1, float r2, float r3) {
+    if constexpr (FMA) return mad<true>(b[3], r3, mad<true>(b[2], r2, mad<true>(b[1], r1, b[0] * r0)));
+    else return ((b[0] * r0 + b[1] * r1) + b[2] * r2) + b[3] * r3;
+}
 
+template <bool FMA = false>
 static inline float bspline3d_eval(const float* coef, int dz, int dy, int dx, float x, float y, float z) {
     if (x < 1 || y < 1 || z < 1 || x >= dx - 2 || y >= dy - 2 || z >= dz - 2 || std::isnan(x) || std::isnan(y) ||
         std::isnan(z))
@@ -263,16 +321,21 @@ static inline float bspline3d_eval(const float* coef, int dz, int dy, int dx, fl
     float bx[4] = {basis0(fx), basis1(fx), basis2(fx), basis3(fx)};
     float by[4] = {basis0(fy), basis1(fy), basis2(fy), basis3(fy)};
     float bz[4] = {basis0(fz), basis1(fz), basis2(fz), basis3(fz)};
+    if constexpr (FMA) {
+        bx[0] = basis0_fma(fx); bx[1] = basis1_fma(fx); bx[2] = basis2_fma(fx);
+        by[0] = basis0_fma(fy); by[1] = basis1_fma(fy); by[2] = basis2_fma(fy);
+        bz[0] = basis0_fma(fz); bz[1] = basis1_fma(fz); bz[2] = basis2_fma(fz);
+    }
     float sum_y[4];
     for (int i = 0; i < 4; i++) {
         float sum_x[4];
         for (int j = 0; j < 4; j++) {
             const float* row = coef + ((size_t)(zi + i - 1) * dy + (yi + j - 1)) * dx + (xi - 1);
-            sum_x[j] = ((bx[0] * row[0] + bx[1] * row[1]) + bx[2] * row[2]) + bx[3] * row[3];
+            sum_x[j] = taps4<FMA>(bx, row[0], row[1], row[2], row[3]);
         }
-        sum_y[i] = ((by[0] * sum_x[0] + by[1] * sum_x[1]) + by[2] * sum_x[2]) + by[3] * sum_x[3];
+        sum_y[i] = taps4<FMA>(by, sum_x[0], sum_x[1], sum_x[2], sum_x[3]);
     }
-    return ((bz[0] * sum_y[0] + bz[1] * sum_y[1]) + bz[2] * sum_y[2]) + bz[3] * sum_y[3];
+    return taps4<FMA>(bz, sum_y[0], sum_y[1], sum_y[2], sum_y[3]);
 }
 
 // ---------------------------------------------------------------------------
@@ -527,7 +590,7 @@ struct LmDamping {
 // off: centre offset {x, y} of the compute(POI2D*, Point2D&) overloads (src/oc_icgn.cpp:353-547,
 // 910-1126), or nullptr for the plain compute(POI2D*).  self_adaptive: DIC::setSelfAdaptive, the
 // subset radius comes from poi->subset_radius (:152-158).
-template <int DOF, template <int> class Acc>
+template <int DOF, template <int> class Acc, bool FMA = false>
 static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float stop, float* poi, int lanes,
                        std::vector<float>& scratch, const float* off = nullptr, int self_adaptive = 0,
                        const LmDamping* lm = nullptr) {
@@ -576,7 +639,7 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
         Acc<1> b(lanes);
         for (int s = 0; s < N; s++) {
             rs[s] = rs[s] - mean;
-            b.add(s, 0, rs[s] * rs[s]);
+            b.template mac<FMA>(s, 0, rs[s], rs[s]);
         }
         b.finish();
         ref_norm = std::sqrt(b.get(0));
@@ -603,7 +666,7 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
                     sd_row<DOF>(g_x, g_y, xl, yl, sd);
                 int t = 0;
                 for (int i = 0; i < DOF; i++)
-                    for (int j = 0; j <= i; j++) a.add(s, t++, sd[i] * sd[j]);
+                    for (int j = 0; j <= i; j++) a.template mac<FMA>(s, t++, sd[i], sd[j]);
             }
         a.finish();
         int t = 0;
@@ -653,8 +716,9 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
                 float wx, wy;
                 if constexpr (DOF == 6) {
                     // src/oc_deformation.cpp:94-105
-                    wx = (Wm[0] * xl + Wm[1] * yl) + Wm[2] * 1.f;
-                    wy = (Wm[3] * xl + Wm[4] * yl) + Wm[5] * 1.f;
+                    // (fused: the second product joins the first sum; "* 1.f" is exact, so nothing is left to fuse there)
+                    wx = mad<FMA>(Wm[1], yl, Wm[0] * xl) + Wm[2] * 1.f;
+                    wy = mad<FMA>(Wm[4], yl, Wm[3] * xl) + Wm[5] * 1.f;
                 } else {
                     // src/oc_deformation.cpp:268-282: rows 3 and 4 of W * [x^2 xy y^2 x y 1]
                     float pv[6] = {xl * xl, xl * yl, yl * yl, xl, yl, 1.f};
@@ -663,13 +727,13 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
                     wx = r3[0] * pv[0];
                     wy = r4[0] * pv[0];
                     for (int k = 1; k < 6; k++) {
-                        wx = wx + r3[k] * pv[k];
-                        wy = wy + r4[k] * pv[k];
+                        wx = mad<FMA>(r3[k], pv[k], wx);
+                        wy = mad<FMA>(r4[k], pv[k], wy);
                     }
                 }
                 // tar_subset->center = POI (+ center_offset, src/oc_icgn.cpp:425-426), then + warped_coor
                 float cx = off ? px + off[0] : px, cy = off ? py + off[1] : py;
-                float v = bspline2d_eval(im.lut, height, width, cx + wx, cy + wy);
+                float v = bspline2d_eval<FMA>(im.lut, height, width, cx + wx, cy + wy);
                 if (v < 0.f) negative = true;
                 ts[s] = v;
                 am.add(s, 0, v);
@@ -684,7 +748,7 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
         Acc<1> an(lanes);
         for (int s = 0; s < N; s++) {
             ts[s] = ts[s] - tmean;
-            an.add(s, 0, ts[s] * ts[s]);
+            an.template mac<FMA>(s, 0, ts[s], ts[s]);
         }
         an.finish();
         float tar_norm = std::sqrt(an.get(0));
@@ -694,14 +758,14 @@ static void icgn2d_poi(const Images2D& im, int rx, int ry, float conv, float sto
         for (int r = 0; r < H; r++)
             for (int c = 0; c < W; c++) {
                 int s = r * W + c;
-                float e = ts[s] * factor - rs[s];
-                ae.add(s, DOF, e * e);
+                float e = mad<FMA>(ts[s], factor, -rs[s]);
+                ae.template mac<FMA>(s, DOF, e, e);
                 float sd[DOF];
                 if (off)
                     sd_row_f<DOF>(sgx[s], sgy[s], (float)(c - rx) - off[0], (float)(r - ry) - off[1], sd);
                 else
                     sd_row<DOF>(sgx[s], sgy[s], c - rx, r - ry, sd);
-                for (int i = 0; i < DOF; i++) ae.add(s, i, sd[i] * e);
+                for (int i = 0; i < DOF; i++) ae.template mac<FMA>(s, i, sd[i], e);
             }
         ae.finish();
         znssd = ae.get(DOF) / (ref_norm * ref_norm);
@@ -945,7 +1009,7 @@ struct Images3D {
     int dz, dy, dx;
 };
 
-template <template <int> class Acc>
+template <template <int> class Acc, bool FMA = false>
 static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, float stop, float* poi, int lanes,
                         std::vector<float>& scratch) {
     const float px = poi[0], py = poi[1], pz = poi[2];
@@ -987,7 +1051,7 @@ static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, 
         Acc<1> b(lanes, SX);
         for (s = 0; s < N; s++) {
             rs[s] = rs[s] - mean;
-            b.add(s, 0, rs[s] * rs[s]);
+            b.template mac<FMA>(s, 0, rs[s], rs[s]);
         }
         b.finish();
         ref_norm = std::sqrt(b.get(0));
@@ -1010,7 +1074,7 @@ static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, 
                                     g_z, g_z * xl, g_z * yl, g_z * zl};
                     int t = 0;
                     for (int r = 0; r < 12; r++)
-                        for (int c = 0; c <= r; c++) a.add(s, t++, sd[r] * sd[c]);
+                        for (int c = 0; c <= r; c++) a.template mac<FMA>(s, t++, sd[r], sd[c]);
                 }
         a.finish();
         int t = 0;
@@ -1048,10 +1112,11 @@ static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, 
                 for (int k = 0; k < SX; k++, s++) {
                     float xl = (float)(k - rx), yl = (float)(j - ry), zl = (float)(i - rz);
                     // src/oc_deformation.cpp:518-530
-                    float wx = ((Wm[0] * xl + Wm[1] * yl) + Wm[2] * zl) + Wm[3] * 1.f;
-                    float wy = ((Wm[4] * xl + Wm[5] * yl) + Wm[6] * zl) + Wm[7] * 1.f;
-                    float wz = ((Wm[8] * xl + Wm[9] * yl) + Wm[10] * zl) + Wm[11] * 1.f;
-                    float v = bspline3d_eval(im.coef, DZ, DY, DX, px + wx, py + wy, pz + wz);
+                    // (fused: the second and third products join the running sum; "* 1.f" is exact)
+                    float wx = mad<FMA>(Wm[2], zl, mad<FMA>(Wm[1], yl, Wm[0] * xl)) + Wm[3] * 1.f;
+                    float wy = mad<FMA>(Wm[6], zl, mad<FMA>(Wm[5], yl, Wm[4] * xl)) + Wm[7] * 1.f;
+                    float wz = mad<FMA>(Wm[10], zl, mad<FMA>(Wm[9], yl, Wm[8] * xl)) + Wm[11] * 1.f;
+                    float v = bspline3d_eval<FMA>(im.coef, DZ, DY, DX, px + wx, py + wy, pz + wz);
                     if (v < 0.f) out_of_range = true;
                     ts[s] = v;
                     am.add(s, 0, v);
@@ -1062,7 +1127,7 @@ static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, 
         Acc<1> an(lanes, SX);
         for (s = 0; s < N; s++) {
             ts[s] = ts[s] - tmean;
-            an.add(s, 0, ts[s] * ts[s]);
+            an.template mac<FMA>(s, 0, ts[s], ts[s]);
         }
         an.finish();
         float tar_norm = std::sqrt(an.get(0));
@@ -1073,12 +1138,12 @@ static void icgn3d1_poi(const Images3D& im, int rx, int ry, int rz, float conv, 
             for (int j = 0; j < SY; j++)
                 for (int k = 0; k < SX; k++, s++) {
                     int xl = k - rx, yl = j - ry, zl = i - rz;
-                    float e = factor * ts[s] - rs[s];
-                    ae.add(s, 12, e * e);
+                    float e = mad<FMA>(factor, ts[s], -rs[s]);
+                    ae.template mac<FMA>(s, 12, e, e);
                     float g_x = sgx[s], g_y = sgy[s], g_z = sgz[s];
-                    ae.add(s, 0, g_x * e); ae.add(s, 1, (g_x * xl) * e); ae.add(s, 2, (g_x * yl) * e); ae.add(s, 3, (g_x * zl) * e);
-                    ae.add(s, 4, g_y * e); ae.add(s, 5, (g_y * xl) * e); ae.add(s, 6, (g_y * yl) * e); ae.add(s, 7, (g_y * zl) * e);
-                    ae.add(s, 8, g_z * e); ae.add(s, 9, (g_z * xl) * e); ae.add(s, 10, (g_z * yl) * e); ae.add(s, 11, (g_z * zl) * e);
+                    const float sd[12] = {g_x, g_x * xl, g_x * yl, g_x * zl, g_y, g_y * xl, g_y * yl, g_y * zl,
+                                          g_z, g_z * xl, g_z * yl, g_z * zl};
+                    for (int q = 0; q < 12; q++) ae.template mac<FMA>(s, q, sd[q], e);
                 }
         ae.finish();
         znssd = ae.get(12) / (ref_norm * ref_norm);
@@ -1375,6 +1440,32 @@ static int resolve_threads(int threads) {
 // ===========================================================================
 // C entry points
 // ===========================================================================
+// order = OC_ORDER_SEQ | OC_ORDER_LANES, optionally | OC_ARITH_FMA (oc_oracle.h)
+template <int DOF>
+static void icgn2d_queue(const Images2D& im, int rx, int ry, float conv, float stop, float* pois, long n, int stride_floats,
+                         int order, int lanes, int threads, const float* center_offsets, int self_adaptive,
+                         const LmDamping* lm) {
+    threads = resolve_threads(threads);
+    const bool fma = (order & OC_ARITH_FMA) != 0;
+    const int assoc = order & ~OC_ARITH_FMA;
+#pragma omp parallel num_threads(threads)
+    {
+        std::vector<float> scratch;
+#pragma omp for schedule(static)
+        for (long i = 0; i < n; i++) {
+            const float* off = center_offsets ? center_offsets + 2 * i : nullptr;
+            float* poi = pois + (size_t)i * stride_floats;
+            if (assoc == OC_ORDER_SEQ) {
+                if (fma) icgn2d_poi<DOF, AccSeq, true>(im, rx, ry, conv, stop, poi, lanes, scratch, off, self_adaptive, lm);
+                else icgn2d_poi<DOF, AccSeq, false>(im, rx, ry, conv, stop, poi, lanes, scratch, off, self_adaptive, lm);
+            } else {
+                if (fma) icgn2d_poi<DOF, AccLanes, true>(im, rx, ry, conv, stop, poi, lanes, scratch, off, self_adaptive, lm);
+                else icgn2d_poi<DOF, AccLanes, false>(im, rx, ry, conv, stop, poi, lanes, scratch, off, self_adaptive, lm);
+            }
+        }
+    }
+}
+
 extern "C" {
 
 int oc_oracle_max_threads(void) { return omp_get_max_threads(); }
@@ -1435,6 +1526,16 @@ void oc_oracle_bspline2d_lut(const float* img, int height, int width, float* lut
 
 float oc_oracle_bspline2d_eval(const float* lut, int height, int width, float x, float y) {
     return bspline2d_eval(lut, height, width, x, y);
+}
+float oc_oracle_bspline2d_eval_fma(const float* lut, int height, int width, float x, float y) {
+    return bspline2d_eval<true>(lut, height, width, x, y);
+}
+int oc_oracle_fma_is_hardware(void) {
+#ifdef __FMA__
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 void oc_oracle_fftcc2d(const float* ref, const float* tar, int height, int width, int rx, int ry, float* pois, long n,
@@ -1500,73 +1601,27 @@ void oc_oracle_fftcc2d(const float* ref, const float* tar, int height, int width
 void oc_oracle_icgn2d1_ex(const float* ref, const float* gx, const float* gy, const float* tar_lut, int height, int width,
                           int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes, int threads,
                           const float* center_offsets, int self_adaptive) {
-    threads = resolve_threads(threads);
     Images2D im = {ref, gx, gy, tar_lut, height, width};
-#pragma omp parallel num_threads(threads)
-    {
-        std::vector<float> scratch;
-#pragma omp for schedule(static)
-        for (long i = 0; i < n; i++) {
-            const float* off = center_offsets ? center_offsets + 2 * i : nullptr;
-            if (order == OC_ORDER_SEQ)
-                icgn2d_poi<6, AccSeq>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch, off, self_adaptive);
-            else
-                icgn2d_poi<6, AccLanes>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch, off, self_adaptive);
-        }
-    }
+    icgn2d_queue<6>(im, rx, ry, conv, stop, pois, n, OC_POI2D_FLOATS, order, lanes, threads, center_offsets, self_adaptive, nullptr);
 }
 
 void oc_oracle_icgn2d1(const float* ref, const float* gx, const float* gy, const float* tar_lut, int height, int width,
                        int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes, int threads) {
-    threads = resolve_threads(threads);
     Images2D im = {ref, gx, gy, tar_lut, height, width};
-#pragma omp parallel num_threads(threads)
-    {
-        std::vector<float> scratch;
-#pragma omp for schedule(static)
-        for (long i = 0; i < n; i++) {
-            if (order == OC_ORDER_SEQ)
-                icgn2d_poi<6, AccSeq>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch);
-            else
-                icgn2d_poi<6, AccLanes>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch);
-        }
-    }
+    icgn2d_queue<6>(im, rx, ry, conv, stop, pois, n, OC_POI2D_FLOATS, order, lanes, threads, nullptr, 0, nullptr);
 }
 
 void oc_oracle_icgn2d2_ex(const float* ref, const float* gx, const float* gy, const float* tar_lut, int height, int width,
                           int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes, int threads,
                           const float* center_offsets, int self_adaptive) {
-    threads = resolve_threads(threads);
     Images2D im = {ref, gx, gy, tar_lut, height, width};
-#pragma omp parallel num_threads(threads)
-    {
-        std::vector<float> scratch;
-#pragma omp for schedule(static)
-        for (long i = 0; i < n; i++) {
-            const float* off = center_offsets ? center_offsets + 2 * i : nullptr;
-            if (order == OC_ORDER_SEQ)
-                icgn2d_poi<12, AccSeq>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch, off, self_adaptive);
-            else
-                icgn2d_poi<12, AccLanes>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch, off, self_adaptive);
-        }
-    }
+    icgn2d_queue<12>(im, rx, ry, conv, stop, pois, n, OC_POI2D_FLOATS, order, lanes, threads, center_offsets, self_adaptive, nullptr);
 }
 
 void oc_oracle_icgn2d2(const float* ref, const float* gx, const float* gy, const float* tar_lut, int height, int width,
                        int rx, int ry, float conv, float stop, float* pois, long n, int order, int lanes, int threads) {
-    threads = resolve_threads(threads);
     Images2D im = {ref, gx, gy, tar_lut, height, width};
-#pragma omp parallel num_threads(threads)
-    {
-        std::vector<float> scratch;
-#pragma omp for schedule(static)
-        for (long i = 0; i < n; i++) {
-            if (order == OC_ORDER_SEQ)
-                icgn2d_poi<12, AccSeq>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch);
-            else
-                icgn2d_poi<12, AccLanes>(im, rx, ry, conv, stop, pois + i * OC_POI2D_FLOATS, lanes, scratch);
-        }
-    }
+    icgn2d_queue<12>(im, rx, ry, conv, stop, pois, n, OC_POI2D_FLOATS, order, lanes, threads, nullptr, 0, nullptr);
 }
 
 // ICLM2D1 / ICLM2D2 (src/oc_iclm.cpp): dof = 6 or 12; damping = {lambda, alpha, beta} (src/oc_iclm.h:33-38)
@@ -1575,26 +1630,8 @@ void oc_oracle_iclm2d(int dof, const float* ref, const float* gx, const float* g
                       int stride_floats, int order, int lanes, int threads) {
     Images2D im = {ref, gx, gy, tar_lut, height, width};
     const LmDamping lm = {std::log((double)damping[0]), damping[1], damping[2]};
-    const int nt = resolve_threads(threads);
-#pragma omp parallel num_threads(nt)
-    {
-        std::vector<float> scratch;
-#pragma omp for schedule(static)
-        for (long i = 0; i < n; i++) {
-            float* poi = pois + (size_t)i * stride_floats;
-            if (dof == 6) {
-                if (order == OC_ORDER_LANES)
-                    icgn2d_poi<6, AccLanes>(im, rx, ry, conv, stop, poi, lanes, scratch, nullptr, self_adaptive, &lm);
-                else
-                    icgn2d_poi<6, AccSeq>(im, rx, ry, conv, stop, poi, lanes, scratch, nullptr, self_adaptive, &lm);
-            } else {
-                if (order == OC_ORDER_LANES)
-                    icgn2d_poi<12, AccLanes>(im, rx, ry, conv, stop, poi, lanes, scratch, nullptr, self_adaptive, &lm);
-                else
-                    icgn2d_poi<12, AccSeq>(im, rx, ry, conv, stop, poi, lanes, scratch, nullptr, self_adaptive, &lm);
-            }
-        }
-    }
+    if (dof == 6) icgn2d_queue<6>(im, rx, ry, conv, stop, pois, n, stride_floats, order, lanes, threads, nullptr, self_adaptive, &lm);
+    else icgn2d_queue<12>(im, rx, ry, conv, stop, pois, n, stride_floats, order, lanes, threads, nullptr, self_adaptive, &lm);
 }
 
 void oc_oracle_strain2d(float* pois, long n, int stride_floats, float subregion_radius, int neighbor_number_min,
@@ -1726,6 +1763,9 @@ void oc_oracle_bspline3d_prefilter(const float* vol, int dz, int dy, int dx, flo
 float oc_oracle_bspline3d_eval(const float* coef, int dz, int dy, int dx, float x, float y, float z) {
     return bspline3d_eval(coef, dz, dy, dx, x, y, z);
 }
+float oc_oracle_bspline3d_eval_fma(const float* coef, int dz, int dy, int dx, float x, float y, float z) {
+    return bspline3d_eval<true>(coef, dz, dy, dx, x, y, z);
+}
 
 void oc_oracle_fftcc3d(const float* ref, const float* tar, int dz, int dy, int dx, int rx, int ry, int rz, float* pois,
                        long n, int threads) {
@@ -1796,12 +1836,18 @@ void oc_oracle_icgn3d1(const float* ref, const float* gx, const float* gy, const
         std::vector<float> scratch;
 #pragma omp for schedule(dynamic, 1)
         for (long i = 0; i < n; i++) {
-            if (order == OC_ORDER_SEQ)
-                icgn3d1_poi<AccSeq>(im, rx, ry, rz, conv, stop, pois + i * OC_POI3D_FLOATS, lanes, scratch);
-            else if (order == OC_ORDER_ROWS)
-                icgn3d1_poi<AccRows>(im, rx, ry, rz, conv, stop, pois + i * OC_POI3D_FLOATS, lanes, scratch);
-            else
-                icgn3d1_poi<AccLanes>(im, rx, ry, rz, conv, stop, pois + i * OC_POI3D_FLOATS, lanes, scratch);
+            float* poi = pois + i * OC_POI3D_FLOATS;
+            const bool fma = (order & OC_ARITH_FMA) != 0;
+            const int assoc = order & ~OC_ARITH_FMA;
+            if (assoc == OC_ORDER_SEQ) {
+                if (fma) icgn3d1_poi<AccSeq, true>(im, rx, ry, rz, conv, stop, poi, lanes, scratch);
+                else icgn3d1_poi<AccSeq, false>(im, rx, ry, rz, conv, stop, poi, lanes, scratch);
+            } else if (assoc == OC_ORDER_ROWS) {
+                icgn3d1_poi<AccRows, false>(im, rx, ry, rz, conv, stop, poi, lanes, scratch);  // (no fused form: oc_oracle.h)
+            } else {
+                if (fma) icgn3d1_poi<AccLanes, true>(im, rx, ry, rz, conv, stop, poi, lanes, scratch);
+                else icgn3d1_poi<AccLanes, false>(im, rx, ry, rz, conv, stop, poi, lanes, scratch);
+            }
         }
     }
 }

@@ -61,8 +61,25 @@
  *                     512 partials are combined by the same xor-butterfly.  With no
  *                     body (SX < 28) this IS OC_ORDER_LANES with lanes = 512.
  * Everything else (interpolation polynomial, warp algebra, LU inverse, guards,
- * flags) is identical in both modes.  No FMA contraction anywhere
+ * flags) is identical in both modes.  No COMPILER contraction anywhere
  * (-ffp-contract=off on both the oracle and the HIP side).
+ *
+ * Arithmetic contract (round 5): OR the flag OC_ARITH_FMA into `order` (OC_ORDER_LANES_FMA, OC_ORDER_SEQ_FMA) and every
+ * PER-SAMPLE multiply-add of ICGN2D1 / ICGN2D2 / ICLM2D1 / ICLM2D2 / ICGN3D1 is ONE explicit fmaf -- the contraction a
+ * compiler with FMA hardware enabled makes of the reference's own source expressions (the reference's build files fix no
+ * contraction mode: examples/ide_configuration/CMakeLists.txt), association unchanged:
+ *   - the 16-term bicubic polynomial (src/oc_cubic_bspline.cpp:159-177): v = fmaf(c * dy^k, dx^l, v), 15 fused of 15 adds;
+ *   - the tricubic basis polynomials (:35-53, Horner steps fused) and the 21 four-tap sums (:390-401): b0*r0, then 3 fmaf;
+ *   - the warps (src/oc_deformation.cpp:94-105, 268-282, 518-530): the first product stays, the following ones are fused,
+ *     the translation column is added last as the reference writes it;
+ *   - zero-mean norms (d*d into the running sum), the Hessian (sd[i]*sd[j]), the error e = fmaf(t, factor, -r), ZNSSD (e*e)
+ *     and the numerator (sd[i]*e) accumulations (src/oc_icgn.cpp:198-205, 260-276, 1314-1337, 1403-1433).
+ * NOT fused: the once-per-POI dense algebra (LU / cofactor inverses, warp products, dp = H^-1 b, convergence norm), the
+ * steepest-descent products g * x themselves, prepare() (gradients, tables, prefilter), FFTCC, NR2D1, Strain.
+ * IEEE-754 fusedMultiplyAdd is defined bit for bit, so the HIP kernels built with the same fused sites
+ * (oc_hip_set_tuning "arith_fma") are bit-identical to OC_ORDER_LANES_FMA; against the reference's separately rounded
+ * loop order (OC_ORDER_SEQ) the fused results differ by rounding only (tests/test_order_tolerance.py,
+ * tests/test_gpu_fullsize.py assert north_star's bars).  OC_ORDER_ROWS has no fused form.
  */
 #ifndef OC_ORACLE_H_
 #define OC_ORACLE_H_
@@ -74,6 +91,9 @@ extern "C" {
 #define OC_ORDER_SEQ 0
 #define OC_ORDER_LANES 1
 #define OC_ORDER_ROWS 2
+#define OC_ARITH_FMA 0x100
+#define OC_ORDER_SEQ_FMA (OC_ORDER_SEQ | OC_ARITH_FMA)
+#define OC_ORDER_LANES_FMA (OC_ORDER_LANES | OC_ARITH_FMA)
 
 #define OC_POI2D_FLOATS 25
 #define OC_POI3D_FLOATS 31
@@ -84,6 +104,8 @@ void oc_oracle_gradient2d(const float* img, int height, int width, float* gx, fl
 void oc_oracle_bspline2d_lut(const float* img, int height, int width, float* lut, int threads);
 /* src/oc_cubic_bspline.cpp:134-181 (single sample, for unit tests) */
 float oc_oracle_bspline2d_eval(const float* lut, int height, int width, float x, float y);
+/* the same under OC_ARITH_FMA */
+float oc_oracle_bspline2d_eval_fma(const float* lut, int height, int width, float x, float y);
 
 /* src/oc_fftcc.cpp:177-285.  If surface != NULL it receives, for POI 0 only,
  * the (2rx*2ry) float correlation surface (test hook for tie analysis). */
@@ -153,6 +175,10 @@ void oc_oracle_gradient3d(const float* vol, int dz, int dy, int dx, float* gx, f
 void oc_oracle_bspline3d_prefilter(const float* vol, int dz, int dy, int dx, float* coef, int threads);
 /* src/oc_cubic_bspline.cpp:353-405 */
 float oc_oracle_bspline3d_eval(const float* coef, int dz, int dy, int dx, float x, float y, float z);
+float oc_oracle_bspline3d_eval_fma(const float* coef, int dz, int dy, int dx, float x, float y, float z);
+/* 1 when this build executes fmaf as a hardware instruction (built with -mfma), 0 when it goes through libm's fmaf
+ * (same bits either way; only the speed differs) */
+int oc_oracle_fma_is_hardware(void);
 /* src/oc_fftcc.cpp:327-436 */
 void oc_oracle_fftcc3d(const float* ref, const float* tar, int dz, int dy, int dx,
                        int rx, int ry, int rz, float* pois, long n, int threads);

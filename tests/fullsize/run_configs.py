@@ -14,7 +14,11 @@ Checks per configuration
     infrastructure only): FFTCC -- integer displacement and guess identical, ZNCC of the peak within 1e-5 (2D) / 1e-4
     (32^3 windows); ICGN on the GPU's FFTCC output -- every bit of every record,
   * idempotence of the sharding: the first and second half of the queue computed separately
-    give the same bits as the whole queue.
+    give the same bits as the whole queue,
+  * the fused arithmetic contract (oc_hip_set_tuning "arith_fma", round 5): the same FFTCC output refined a second time by
+    the kernels whose per-sample multiply-adds are fused -- every bit equal to the oracle in OC_ORDER_LANES_FMA, and against
+    the REFERENCE's loop order (OC_ORDER_SEQ, separately rounded) the same bars as the default build; the record's "fma"
+    entry also carries the solver's time in both modes (the same queue, interleaved).
 """
 import argparse
 import json
@@ -64,7 +68,7 @@ def vs_reference_order(gpu, seq, cols_disp, col_zncc, col_iter):
                 seq_max_abs_d_zncc=float(dz.max()) if dz.size else 0.0, seq_sample=int(len(gpu)))
 
 
-def run_2d(name, side, r, nside, engine, oracle_sample, so=None):
+def run_2d(name, side, r, nside, engine, oracle_sample, so=None, with_fma=True):
     import torch
     import opencorr_amd as oc
     import oracle
@@ -121,6 +125,7 @@ def run_2d(name, side, r, nside, engine, oracle_sample, so=None):
     untouched = np.delete(np.arange(25), [2, 8, 14, 15, 16])
     fftcc_same = fftcc_same and bool(np.array_equal(fo[:, untouched].view(np.uint32), sample[:, untouched].view(np.uint32)))
     seq = sample.copy()  # the same FFTCC output, refined in the reference's own loop order
+    guess_sample = sample.copy()
     if engine == 3:
         prep = oracle.PreparedNR2D(ref_h, tar_h)
         oracle.nr2d1(prep, r, r, 0.001, 10.0, sample, order=oracle.ORDER_LANES, lanes=64)
@@ -130,10 +135,34 @@ def run_2d(name, side, r, nside, engine, oracle_sample, so=None):
         solve = oracle.icgn2d1 if engine == 1 else oracle.icgn2d2
         solve(prep, r, r, 0.001, 10.0, sample, order=oracle.ORDER_LANES, lanes=64)
         solve(prep, r, r, 0.001, 10.0, seq, order=oracle.ORDER_SEQ)
-    del prep
     bit_exact = bool(np.array_equal(sample.view(np.uint32), after[::step_s].view(np.uint32)))
     vs_seq = vs_reference_order(after[::step_s], seq, [2, 8], 16, 17)
-    return dict(config=name, engine="FFTCC2D+" + {1: "ICGN2D1", 2: "ICGN2D2", 3: "NR2D1"}[engine], image="%dx%d" % (side, side), radius=r, pois=n,
+    fma = None
+    if with_fma and engine != 3:
+        # the fused arithmetic contract on the same FFTCC output: GPU(arith_fma) == oracle(LANES_FMA) bit for bit, and
+        # GPU(arith_fma) against the reference's separately rounded loop order; solver time in both modes
+        def solve_only():
+            pois.copy_(fin)
+            g.compute(pois)
+        g.set_tuning("arith_fma", 1)
+        t_fma = timed(solve_only, torch.cuda.synchronize)
+        after_fma = pois.cpu().numpy()
+        g.set_tuning("arith_fma", 0)
+        t_sep = timed(solve_only, torch.cuda.synchronize)
+        g.set_tuning("arith_fma", 1)
+        t_fma = min(t_fma, timed(solve_only, torch.cuda.synchronize))
+        g.set_tuning("arith_fma", 0)
+        want_fma = guess_sample.copy()
+        solve(prep, r, r, 0.001, 10.0, want_fma, order=oracle.ORDER_LANES_FMA, lanes=64)
+        conv_f = after_fma[:, 16] >= 0
+        fma = dict(icgn_seconds_fma=t_fma, icgn_seconds_sep=t_sep, converged=int(conv_f.sum()),
+                   mean_iterations=float(after_fma[conv_f, 17].astype(np.float64).mean()),
+                   oracle_bit_exact=bool(np.array_equal(want_fma.view(np.uint32), after_fma[::step_s].view(np.uint32))),
+                   max_abs_d_disp_vs_default_build=float(np.abs(after_fma[conv_f & conv][:, [2, 8]].astype(np.float64)
+                                                                 - after[conv_f & conv][:, [2, 8]].astype(np.float64)).max()),
+                   **vs_reference_order(after_fma[::step_s], seq, [2, 8], 16, 17))
+    del prep
+    return dict(config=name, fma=fma, engine="FFTCC2D+" + {1: "ICGN2D1", 2: "ICGN2D2", 3: "NR2D1"}[engine], image="%dx%d" % (side, side), radius=r, pois=n,
                 seconds=secs, pois_per_s=float(conv.sum() / secs), converged=int(conv.sum()),
                 mean_iterations=float(after[conv, 17].astype(np.float64).mean()), prepare_s=prepare_s,
                 median_abs_err_u=float(np.median(du)), max_abs_err_u=float(du.max()), max_abs_err_v=float(dv.max()),
@@ -180,7 +209,7 @@ def run_strain(name, side, r, nside, radius, nmin):
                 oracle_bit_exact=bool(np.array_equal(got.view(np.uint32), want.view(np.uint32))))
 
 
-def run_3d(name, dim, r, nside, oracle_sample):
+def run_3d(name, dim, r, nside, oracle_sample, with_fma=True):
     import torch
     import opencorr_amd as oc
     import oracle
@@ -235,7 +264,26 @@ def run_3d(name, dim, r, nside, oracle_sample):
     oracle.icgn3d1(prep, r, r, r, 0.001, 20.0, seq, order=oracle.ORDER_SEQ)
     bit_exact = bool(np.array_equal(sample.view(np.uint32), after[::step_s].view(np.uint32)))
     vs_seq = vs_reference_order(after[::step_s], seq, [P["u"], P["v"], P["w"]], P["zncc"], P["iteration"])
-    return dict(config=name, engine="FFTCC3D+ICGN3D1", volume="%d^3" % dim, radius=r, pois=n, fftcc_seconds=t_f,
+    fma = None
+    if with_fma:
+        def solve_only():
+            pois.copy_(guess)
+            g.compute(pois)
+        g.set_tuning("arith_fma", 1)
+        t_fma = timed(solve_only, torch.cuda.synchronize, reps=2)
+        after_fma = pois.cpu().numpy()
+        g.set_tuning("arith_fma", 0)
+        want_fma = guess.cpu().numpy()[::step_s].copy()
+        oracle.icgn3d1(prep, r, r, r, 0.001, 20.0, want_fma, order=oracle.ORDER_LANES_FMA, lanes=LANES3D)
+        conv_f = after_fma[:, P["zncc"]] >= 0
+        cols = [P["u"], P["v"], P["w"]]
+        fma = dict(icgn_seconds_fma=t_fma, icgn_seconds_sep=t_g, converged=int(conv_f.sum()),
+                   mean_iterations=float(after_fma[conv_f, P["iteration"]].astype(np.float64).mean()),
+                   oracle_bit_exact=bool(np.array_equal(want_fma.view(np.uint32), after_fma[::step_s].view(np.uint32))),
+                   max_abs_d_disp_vs_default_build=float(np.abs(after_fma[conv_f & conv][:, cols].astype(np.float64)
+                                                                 - after[conv_f & conv][:, cols].astype(np.float64)).max()),
+                   **vs_reference_order(after_fma[::step_s], seq, cols, P["zncc"], P["iteration"]))
+    return dict(config=name, fma=fma, engine="FFTCC3D+ICGN3D1", volume="%d^3" % dim, radius=r, pois=n, fftcc_seconds=t_f,
                 icgn_seconds=t_g, pois_per_s=float(conv.sum() / (t_f + t_g)), converged=int(conv.sum()),
                 mean_iterations=float(after[conv, P["iteration"]].astype(np.float64).mean()), prepare_s=prepare_s, generate_s=gen_s,
                 median_abs_err=float(np.median(err)), max_abs_err=float(err.max()), oracle_sample=len(sample),
@@ -264,10 +312,10 @@ def main():
         elif c == "BST":
             rec = run_strain("B + Strain (4096^2, 500x500 POIs, subregion radius 40 px, >= 5 neighbours)", 4096, 16, 500, 40.0, 5)
         elif c == "E":
-            rec = run_3d("E on ONE GPU (512^3, r=16, 37^3 POIs)", 512, 16, 37, 96)
+            rec = run_3d("E on ONE GPU (512^3, r=16, 37^3 POIs)", 512, 16, 37, 2000)
         elif c == "E30":
             # the radius of the reference's own DVC example (examples/test_dvc_fftcc_icgn1.cpp:45-47)
-            rec = run_3d("DVC example shape (256^3, r=30, 8^3 POIs)", 256, 30, 8, 16)
+            rec = run_3d("DVC example shape (256^3, r=30, 8^3 POIs)", 256, 30, 8, 256)
         elif c == "Es":
             rec = run_3d("E-small (256^3, r=16, 12^3 POIs)", 256, 16, 12, 48)
         else:

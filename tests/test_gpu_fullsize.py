@@ -15,7 +15,10 @@ Size-independent properties + a strided oracle sample, the checks of tests/fulls
     second time in OC_ORDER_SEQ (bit-identical to the reference's own compiled sources, tests/test_oracle_vs_ref.py), and
     on that sample the GPU shows the same failure flags and codes, >= 99.5 % equal iteration counts, and on POIs with
     equal counts |d u, v(, w)| <= 1e-4 and |d ZNCC| <= 1e-5 (`_check_vs_reference_order`; the numbers travel into
-    profiles/*configs*.json through tests/fullsize/run_configs.py).
+    profiles/*configs*.json through tests/fullsize/run_configs.py),
+  * **the fused arithmetic contract (round 5, `oc_hip_set_tuning("arith_fma", 1)`) on every config**: the same FFTCC output
+    refined by the kernels whose per-sample multiply-adds are fused equals the oracle in OC_ORDER_LANES_FMA bit for bit on
+    the same sample, and meets the SAME bars against the reference's separately rounded loop order (`_check_fma`).
 """
 import importlib.util
 import os
@@ -40,8 +43,18 @@ def _check_vs_reference_order(rec):
     assert rec["seq_max_abs_d_disp"] <= 1e-4 and rec["seq_max_abs_d_zncc"] <= 1e-5, rec
 
 
+def _check_fma(rec, min_converged):
+    fma = rec["fma"]
+    assert fma is not None and fma["oracle_bit_exact"], fma
+    _check_vs_reference_order(fma)
+    assert fma["seq_sample"] == rec["oracle_sample"]
+    assert fma["converged"] >= min_converged * rec["pois"], fma
+    assert fma["max_abs_d_disp_vs_default_build"] <= 1e-3, fma   # (POIs may differ by one iteration between the builds)
+
+
 def _check(rec, min_converged, max_err):
     _check_vs_reference_order(rec)
+    _check_fma(rec, min_converged)
     assert rec["oracle_bit_exact"], rec
     assert rec["fftcc_oracle_same_integers"] and rec["fftcc_oracle_max_zncc_diff"] <= 5e-5, rec
     assert rec["split_queue_same_bits"], rec
@@ -80,11 +93,29 @@ def test_config_d_full_size_on_one_gpu():
 
 def test_config_e_full_size():
     """E (BASELINE configs[4]) on one MI355X: 512^3 volume pair, r = 16 (33^3 subvolume, 32^3 FFTCC window), 37^3 = 50 653
-    POIs, FFTCC3D -> ICGN3D1 (stop 20); >= 96 strided POIs against the oracle, 3D-affine field recovered."""
-    rec = _configs().run_3d("E", 512, 16, 37, 96)
-    assert rec["pois"] == 50653 and rec["oracle_sample"] >= 96
+    POIs, FFTCC3D -> ICGN3D1 (stop 20); >= 2 000 strided POIs (every 25th) against the oracle in BOTH orders and both arithmetic
+    modes, 3D-affine field recovered."""
+    rec = _configs().run_3d("E", 512, 16, 37, 2000)
+    assert rec["pois"] == 50653 and rec["oracle_sample"] >= 2000
     _check_vs_reference_order(rec)
+    _check_fma(rec, 0.999)
     assert rec["oracle_bit_exact"], rec
     assert rec["fftcc_oracle_same_integers"] and rec["fftcc_oracle_max_zncc_diff"] <= 1e-4, rec
     assert rec["converged"] >= 0.999 * rec["pois"], rec
+    assert rec["median_abs_err"] < 0.01 and rec["max_abs_err"] < 0.05, rec
+
+
+def test_dvc_example_shape_r30():
+    """The radius of the reference's own DVC example (examples/test_dvc_fftcc_icgn1.cpp:45-47: 61^3 subvolumes, 60^3 FFTCC
+    windows) on a 256^3 pair, 8^3 = 512 POIs: every second POI (256) against the oracle in both orders and both arithmetic
+    modes.  FFTCC3D's ZNCC at 60^3 is compared with the bar DESIGN.md section 3 / INTEGRATION.md state for windows beyond 32^3
+    (5e-4: the reference's own sequential float sums over 216 000 voxels, src/oc_fftcc.cpp:340-376, are what limits it; the
+    integers are exact and ICGN3D1 overwrites the value)."""
+    rec = _configs().run_3d("E30", 256, 30, 8, 256)
+    assert rec["pois"] == 512 and rec["oracle_sample"] >= 256
+    _check_vs_reference_order(rec)
+    _check_fma(rec, 0.99)
+    assert rec["oracle_bit_exact"], rec
+    assert rec["fftcc_oracle_same_integers"] and rec["fftcc_oracle_max_zncc_diff"] <= 5e-4, rec
+    assert rec["converged"] >= 0.99 * rec["pois"], rec
     assert rec["median_abs_err"] < 0.01 and rec["max_abs_err"] < 0.05, rec

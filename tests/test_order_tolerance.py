@@ -8,6 +8,10 @@ reference's OHT pair lives in tests/test_oracle_golden.py::test_lanes_order_clos
 >= 99.5 % equal iteration counts, and on POIs with equal iteration counts |d u, v(, w)| <= 1e-4, |d ZNCC| <= 1e-5
 (``north_star``: "match the reference CPU path's u/v/w and ZNCC per POI within 1e-4").  The same numbers are asserted
 GPU-vs-SEQ on all five BASELINE configs at full size in tests/test_gpu_fullsize.py.
+
+Round 5: the same three statements for the FUSED arithmetic contract (``OC_ORDER_LANES_FMA``: every per-sample
+multiply-add one fmaf, oracle/oc_oracle.h; what the kernels compute under ``oc_hip_set_tuning("arith_fma", 1)``)
+against the reference's separately rounded sequential order -- the bars do not move.
 """
 import importlib.util
 import os
@@ -36,7 +40,11 @@ def _assert_tolerance(rec):
     assert rec["seq_max_abs_d_zncc"] <= 1e-5, rec
 
 
-def test_icgn2d1_lanes_vs_seq_on_config_b_shaped_field():
+ORDERS = [oracle.ORDER_LANES, oracle.ORDER_LANES_FMA]
+
+
+@pytest.mark.parametrize("gpu_order", ORDERS)
+def test_icgn2d1_lanes_vs_seq_on_config_b_shaped_field(gpu_order):
     """ICGN2D1 (src/oc_icgn.cpp:144-341), r = 16, SURVEY 8(d)'s first-order field + noise (config A / B / D's generator)."""
     vs, _ = _vs_reference_order()
     ref, tar = synth.speckle_pair_2d(420, 440, seed=20260925)
@@ -45,14 +53,15 @@ def test_icgn2d1_lanes_vs_seq_on_config_b_shaped_field():
     oracle.fftcc2d(ref, tar, 16, 16, pois)
     prep = oracle.Prepared2D(ref, tar)
     a, b = pois.copy(), pois.copy()
-    oracle.icgn2d1(prep, 16, 16, 0.001, 10, a, order=oracle.ORDER_LANES, lanes=64)
+    oracle.icgn2d1(prep, 16, 16, 0.001, 10, a, order=gpu_order, lanes=64)
     oracle.icgn2d1(prep, 16, 16, 0.001, 10, b, order=oracle.ORDER_SEQ)
     rec = vs(a, b, [P2["u"], P2["v"]], P2["zncc"], P2["iteration"])
     assert rec["seq_sample"] == 1600
     _assert_tolerance(rec)
 
 
-def test_icgn2d2_lanes_vs_seq_on_config_c_shaped_field():
+@pytest.mark.parametrize("gpu_order", ORDERS)
+def test_icgn2d2_lanes_vs_seq_on_config_c_shaped_field(gpu_order):
     """ICGN2D2 (src/oc_icgn.cpp:685-898), r = 20 (41 x 41 subsets), config C's second-order field."""
     vs, _ = _vs_reference_order()
     so = dict(uxx=2e-6, vyy=-1e-6)
@@ -62,7 +71,7 @@ def test_icgn2d2_lanes_vs_seq_on_config_c_shaped_field():
     oracle.fftcc2d(ref, tar, 20, 20, pois)
     prep = oracle.Prepared2D(ref, tar)
     a, b = pois.copy(), pois.copy()
-    oracle.icgn2d2(prep, 20, 20, 0.001, 10, a, order=oracle.ORDER_LANES, lanes=64)
+    oracle.icgn2d2(prep, 20, 20, 0.001, 10, a, order=gpu_order, lanes=64)
     oracle.icgn2d2(prep, 20, 20, 0.001, 10, b, order=oracle.ORDER_SEQ)
     rec = vs(a, b, [P2["u"], P2["v"]], P2["zncc"], P2["iteration"])
     assert rec["seq_sample"] == 2025
@@ -73,8 +82,9 @@ def test_icgn2d2_lanes_vs_seq_on_config_c_shaped_field():
         assert np.abs(a[same, P2[key]] - b[same, P2[key]]).max() <= 1e-5, key
 
 
+@pytest.mark.parametrize("gpu_order", ORDERS)
 @pytest.mark.parametrize("r", [16])
-def test_icgn3d1_lanes_vs_seq_on_config_e_shaped_field(r):
+def test_icgn3d1_lanes_vs_seq_on_config_e_shaped_field(r, gpu_order):
     """ICGN3D1 (src/oc_icgn.cpp:1270-1490), r = 16 (33^3 subvolumes, 35 937 voxels per sum), config E's generator, with
     the lane count the HIP kernel uses."""
     vs, lanes3d = _vs_reference_order()
@@ -85,8 +95,37 @@ def test_icgn3d1_lanes_vs_seq_on_config_e_shaped_field(r):
     oracle.fftcc3d(ref, tar, r, r, r, pois)
     prep = oracle.Prepared3D(ref, tar)
     a, b = pois.copy(), pois.copy()
-    oracle.icgn3d1(prep, r, r, r, 0.001, 20, a, order=oracle.GPU_ORDER_3D, lanes=lanes3d)
+    oracle.icgn3d1(prep, r, r, r, 0.001, 20, a, order=gpu_order, lanes=lanes3d)
     oracle.icgn3d1(prep, r, r, r, 0.001, 20, b, order=oracle.ORDER_SEQ)
     rec = vs(a, b, [P3["u"], P3["v"], P3["w"]], P3["zncc"], P3["iteration"])
     assert rec["seq_sample"] == 64 and (a[:, P3["zncc"]] > 0.9).all()
     _assert_tolerance(rec)
+
+
+def test_fused_interpolation_is_a_rounding_change_only():
+    """BicubicBspline::compute / TricubicBspline::compute (src/oc_cubic_bspline.cpp:134-181, 353-405) with fused
+    multiply-adds against the separately rounded evaluation at random points: a few ulp of the grey range, never more."""
+    rng = np.random.default_rng(8)
+    img = rng.uniform(0, 255, (40, 44)).astype(np.float32)
+    lut = oracle.bspline2d_lut(img)
+    L = oracle.lib()
+    fp = oracle._fp
+    worst = 0.0
+    for _ in range(4000):
+        x, y = float(rng.uniform(1, 41.9)), float(rng.uniform(1, 37.9))
+        a = L.oc_oracle_bspline2d_eval(fp(lut), 40, 44, x, y)
+        b = L.oc_oracle_bspline2d_eval_fma(fp(lut), 40, 44, x, y)
+        worst = max(worst, abs(a - b))
+    assert 0 < worst <= 255 * 8 * 2.0 ** -23
+    # out of range: the same -1 sentinel
+    assert L.oc_oracle_bspline2d_eval_fma(fp(lut), 40, 44, 0.5, 3.0) == -1.0
+    vol = rng.uniform(0, 255, (20, 22, 24)).astype(np.float32)
+    coef = oracle.bspline3d_prefilter(vol)
+    worst = 0.0
+    for _ in range(4000):
+        x, y, z = float(rng.uniform(1, 21.9)), float(rng.uniform(1, 19.9)), float(rng.uniform(1, 17.9))
+        a = L.oc_oracle_bspline3d_eval(fp(coef), 20, 22, 24, x, y, z)
+        b = L.oc_oracle_bspline3d_eval_fma(fp(coef), 20, 22, 24, x, y, z)
+        worst = max(worst, abs(a - b))
+    assert 0 < worst <= 255 * 16 * 2.0 ** -23
+    assert L.oc_oracle_bspline3d_eval_fma(fp(coef), 20, 22, 24, 3.0, 3.0, 0.5) == -1.0
