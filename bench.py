@@ -97,6 +97,8 @@ TRAFFIC_JSON_OLD = os.path.join(ROOT, "profiles", "icgn2d1_hbm_traffic_configB.j
 # round 4: ONE script (tools/gpu_profiles.sh) collects kernel stats + PMC traffic of the dominant kernels of configs B, C and E;
 # its records fill roofline.traffic and roofline_secondary[*].traffic (tools/pmc_traffic.py --kernels: `per_kernel`)
 TRAFFIC_BY_CONFIG = {c: os.path.join(ROOT, "profiles", "traffic_config%s.json" % c) for c in "BCE"}
+# the same collection under the fused arithmetic contract (OC_BENCH_ARITH_FMA=1 tools/gpu_profiles.sh, round 5)
+TRAFFIC_BY_CONFIG_FMA = {c: os.path.join(ROOT, "profiles", "traffic_config%s_fma.json" % c) for c in "BCE"}
 # sweep of icgn2d_kernel<6> as a micro-benchmark: its gather pattern AND its VALU mix, nothing else (tools/ubench/coissue_ubench.hip)
 COISSUE_JSON = os.path.join(ROOT, "profiles", "coissue_ubench.json")
 # ds_read2_b32 serves 128 B per clock and CU (MI355X_MICROARCH.md, LDS table): 256 CUs x 128 B x 2.4 GHz
@@ -120,6 +122,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the side measurements (CPU baseline, host-queue rate): profiler runs")
     ap.add_argument("--cpu-sample", type=int, default=125000)
+    ap.add_argument("--arith", choices=["sep", "fma"], default="fma" if os.environ.get("OC_BENCH_ARITH_FMA") == "1" else "sep",
+                    help="arithmetic contract of the ICGN kernels in the TIMED region: sep = every multiply and add rounds on its own "
+                         "(the default build, oracle OC_ORDER_LANES), fma = the per-sample multiply-adds are fused "
+                         "(oc_hip_set_tuning arith_fma, oracle OC_ORDER_LANES_FMA).  The default line is `sep`; it reports the "
+                         "fused build next to it as `arith_fma`")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="strong: BASELINE config D (8192^2, 1414 x 1414 POIs) cut into N blocks, whatever N is")
     return ap.parse_args()
@@ -166,7 +173,53 @@ def sample_slots_icgn2d1(pois_np, rx, ry):
     return float(it[it > 0].sum() * ((n2 + 63) // 64) * 64)
 
 
-def roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof, sample_slots=None):
+# Mandated VALU work per sample of a subset (once | per iteration), every floating point INSTRUCTION the reference's
+# arithmetic needs -- no address arithmetic, no walks, no selects, no reductions:
+#   separately rounded (one instruction per multiply / add / subtract):
+#     2d1: 50 | 75     (algorithmic_flops_icgn2d1 below lists them)
+#     2d2: once  reference mean / zero-mean / norm 4, steepest-descent row 15 (x*x*0.5, x*y, y*y*0.5: 5; ten products), the
+#          78 Hessian terms 156 = 175; per iteration  warp 25 (three monomials + 2 x (6 products + 5 adds),
+#          src/oc_deformation.cpp:268-282) + centre 2, fractions 2, powers 4, polynomial 39, mean 1, zero-mean + norm 3, error 2,
+#          ZNSSD 2, numerator 24 = 104
+#     3d1: once  4 + 9 (steepest-descent products) + 156 = 169; per iteration  warp 18 + centre 3, floor / fraction 6, the four
+#          basis polynomials per axis 22 x 3 (src/oc_cubic_bspline.cpp:35-53), the 21 four-tap sums 147 (:390-401), mean 1,
+#          zero-mean + norm 3, error 2, ZNSSD 2, numerator 24 = 272
+#   fused contract (arith_fma: a multiply-add is ONE instruction): 2d1 28 | 49, 2d2 96 | 64, 3d1 90 | 167
+MANDATED_INSTR = {("2d1", False): (50, 75), ("2d1", True): (28, 49), ("2d2", False): (175, 104), ("2d2", True): (96, 64),
+                  ("3d1", False): (169, 272), ("3d1", True): (90, 167)}
+SIMDS = 256 * 4
+VALU_ISSUE_CYCLES = 2.0   # one wave64 VALU instruction occupies a SIMD32 for two cycles (MI355X_MICROARCH.md: 64 flop / clk / SIMD with FMA)
+
+
+def mandated_instr_icgn(pois_np, iter_col, samples, kind, fma):
+    """Lane-level floating point instructions the reference's arithmetic needs for this launch (MANDATED_INSTR x samples x
+    POIs / iterations that ran)."""
+    once, per_it = MANDATED_INSTR[(kind, bool(fma))]
+    it = pois_np[:, iter_col].astype(np.float64)
+    ran = it > 0
+    return float(ran.sum() * once * samples + it[ran].sum() * per_it * samples)
+
+
+def valu_hardware_block(mandated_lane_instr, retired_wave_instr, measured_ms):
+    """ceilings from HARDWARE rates only.  valu_floor_ms = the mandated arithmetic at the chip's VALU issue
+    rate (wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz)); valu_retired_ms = what the kernel actually retires (PMC
+    SQ_INSTS_VALU, committed profile of the same workload and arithmetic mode) at the same rate; overhead = retired / mandated."""
+    per_ms = SIMDS * CLOCK_GHZ * 1e9 / VALU_ISSUE_CYCLES * 1e-3          # wave-instructions per millisecond, whole chip
+    mandated_wave = mandated_lane_instr / 64.0
+    floor = mandated_wave / per_ms
+    blk = {"valu_floor_ms": floor, "valu_floor_frac": floor / measured_ms if measured_ms > 0 else None,
+           "mandated_wave_instr_per_launch": mandated_wave,
+           "valu_retired_ms": None, "valu_retired_frac": None, "overhead": None,
+           "issue_rate": "one wave64 VALU instruction per 2 cycles and SIMD32, 1024 SIMDs, 2.4 GHz"}
+    if retired_wave_instr:
+        blk["retired_wave_instr_per_launch"] = retired_wave_instr
+        blk["valu_retired_ms"] = retired_wave_instr / per_ms
+        blk["valu_retired_frac"] = blk["valu_retired_ms"] / measured_ms if measured_ms > 0 else None
+        blk["overhead"] = retired_wave_instr / mandated_wave
+    return blk
+
+
+def roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof, sample_slots=None, hw=None):
     """The `roofline` object of the JSON line (a function so that the CPU tests can exercise it)."""
     secs = icgn_avg_ms * 1e-3
     alg_rate = alg_bytes / secs / 1e9 if secs > 0 else 0.0      # GB/s
@@ -204,6 +257,11 @@ def roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof, sampl
         "valu": {"achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / VALU_PEAK_TFLOPS,
                  "algorithmic_flops_per_launch": alg_flops,
                  "note": "the reference's own fp32 operations over the chip's rate for separately rounded operations"},
+        # hardware-rate ceilings (round 5): the mandated arithmetic and the retired VALU stream at the chip's issue rate
+        "valu_hw": hw,
+        # the gather side of `combined` is a measured hardware ceiling (the sweep's own gather pattern, compute-free); its VALU
+        # side is an OWN-MIX ESTIMATE (the kernel's retired count x the cycles its own mix sustains) -- not a hardware ceiling:
+        # read `valu_hw` for that
         "combined": (combined_ceiling(icgn_avg_ms, sample_slots, (prof or {}).get("valu_wave_instr_per_launch"))
                      if sample_slots else None),
         "hbm_traffic_profiled": prof,
@@ -295,6 +353,8 @@ def main():
     icgn = opencorr_amd.ICGN2D1(RX, RY, CONV, STOP, device=local_rank)
     icgn.set_stream(stream)
     icgn.share_images(fftcc)
+    if args.arith == "fma":
+        icgn.set_tuning("arith_fma", 1)
     torch.cuda.synchronize()
     t0 = time.time()
     icgn.prepare()
@@ -395,7 +455,7 @@ def main():
         alg_bytes, mean_iter = algorithmic_bytes_icgn2d1(local_np, RX, RY)
         alg_flops = algorithmic_flops_icgn2d1(local_np, RX, RY)
         icgn_avg_ms = icgn_ms / max(icgn_launches, 1)
-        prof = pmc_profile(world)
+        prof = pmc_profile(world, args.arith == "fma")
         out = {
             "metric": "converged POIs/sec (FFTCC+ICGN2D1, 33x33 subset)",
             "value": value,
@@ -412,6 +472,10 @@ def main():
             "config": {
                 "workload": ("B: %dx%d speckle pair, r=16 (33x33 subset, 32x32 FFTCC window), %d POIs/GPU, "
                              "FFTCC2D init -> ICGN2D1 conv=1e-3 stop=10" % (width, height, hi - lo)),
+                "arithmetic": ("fp32, per-sample multiply-adds fused (arith_fma = 1; GPU == oracle OC_ORDER_LANES_FMA bit for bit)"
+                               if args.arith == "fma" else
+                               "fp32, every multiply and add rounded separately like the reference built for baseline x86-64 "
+                               "(GPU == oracle OC_ORDER_LANES bit for bit)"),
                 "total_pois": n_total,
                 "converged_pois": converged,
                 "mean_iterations": mean_iter,
@@ -419,7 +483,9 @@ def main():
                                if dist_on else "none"),
                 "all_gather_alone_ms": gather_alone_ms,
             },
-            "roofline": roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof, sample_slots_icgn2d1(local_np, RX, RY)),
+            "roofline": roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof, sample_slots_icgn2d1(local_np, RX, RY),
+                                       hw=valu_hardware_block(mandated_instr_icgn(local_np, 17, (2 * RX + 1) * (2 * RY + 1), "2d1", args.arith == "fma"),
+                                                              (prof or {}).get("valu_wave_instr_per_launch"), icgn_avg_ms)),
             "stage_ms": {
                 "fftcc_pipeline_avg": fftcc_ms / max(fftcc_launches, 1),
                 "icgn_kernel_avg": icgn_avg_ms,
@@ -436,6 +502,8 @@ def main():
         if world == 1 and not dist_on and not args.no_cpu_baseline:
             out["pcie_inclusive"] = host_queue_rate(fftcc, icgn, pristine, converged)
             out["value_pcie_inclusive"] = out["pcie_inclusive"]["value"]
+            out["arith_fma"] = other_arith_leg(torch, args, fftcc, icgn, queues[0], pristine, icgn_avg_ms, elapsed / args.steps * 1e3)
+            out["paths_8f_row1"] = variant_paths(torch, dev, local_rank, ref, tar, xs, ys, icgn_avg_ms, local_np)
             fftcc_block = secondary_block(
                 "fftcc2d_fused32x2_kernel (FFTCC2D, 32x32 window)", "B: 4096^2, r=16, 250 000 POIs",
                 (2 * (2 * RX) * (2 * RY) * 4 + 20) * float(hi - lo), fftcc_ms / max(fftcc_launches, 1), fftcc_launches,
@@ -511,9 +579,9 @@ def multi_gpu_check(args, dist, torch, dev, rank, world, local_rank, one_device,
             "ms_per_step_gather_not_overlapped": serial_ms}
 
 
-def kernel_traffic(config, kernel_regex):
+def kernel_traffic(config, kernel_regex, fma=False):
     """HBM / L2-side bytes per launch of one kernel from the committed PMC record of its config (tools/gpu_profiles.sh), or None."""
-    path = TRAFFIC_BY_CONFIG.get(config)
+    path = (TRAFFIC_BY_CONFIG_FMA if fma else TRAFFIC_BY_CONFIG).get(config)
     if not path or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -523,6 +591,7 @@ def kernel_traffic(config, kernel_regex):
         return None
     return {"hbm_bytes_per_launch": k.get("hbm_bytes_per_launch"), "l2_bytes_per_launch": k.get("l2_bytes_per_launch"),
             "l2_hit_rate": k.get("l2_hit_rate"), "rocprof_avg_ms": (k["avg_us"] * 1e-3 if k.get("avg_us") else None),
+            "valu_wave_instr_per_launch": k.get("SQ_INSTS_VALU_per_launch"),
             "rocprof_median_ms": (k["median_us"] * 1e-3 if k.get("median_us") else None), "scratch_bytes": k.get("scratch_bytes"),
             "vgpr": k.get("vgpr"), "source": os.path.relpath(path, ROOT) + (" (%s)" % rec["collected"] if rec.get("collected") else "")}
 
@@ -562,7 +631,8 @@ def combined_ceiling(icgn_avg_ms, sample_slots, valu_instr_per_launch):
     valu_ms = valu_instr_per_launch * cyc / (1024 * CLOCK_GHZ * 1e9) * 1e3 if (cyc and valu_instr_per_launch) else None
     ceiling = max(gather_ms, valu_ms or 0.0)
     return {"ceiling_ms": ceiling, "frac": ceiling / icgn_avg_ms if icgn_avg_ms > 0 else None,
-            "gather_side_ms": gather_ms, "valu_side_ms": valu_ms, "valu_cycles_per_instr_measured": cyc,
+            "gather_side_ms": gather_ms, "gather_side_frac": gather_ms / icgn_avg_ms if icgn_avg_ms > 0 else None,
+            "valu_side_own_mix_estimate_ms": valu_ms, "valu_cycles_per_instr_measured": cyc,
             "kernel_valu_wave_instr_per_launch": valu_instr_per_launch,
             "sweep_ubench": {"both_ms": lock["both_ms"], "gather_only_ms": lock["gather_only_ms"], "valu_only_ms": lock["valu_only_ms"],
                              "sample_slots": u["samples"]},
@@ -615,10 +685,14 @@ def secondary_rooflines(dev, device, reps=3):
     ran = it > 0
     n2 = (2 * r + 1) ** 2
     alg = float(ran.sum() * (3 * n2 * 4 + 200) + it[ran].sum() * n2 * 64 + (~ran).sum() * 200)
+    tr = kernel_traffic("C", "icgn2d_kernel")
     out.append(secondary_block("icgn2d_kernel<12,...> (ICGN2D2)", "C: 4096^2, r=20 (41x41), %d POIs" % len(xs), alg, avg, n, "l2",
                                L2_PEAK_GBS, "SURVEY 8(d): 3*N2*4 + k*N2*64 + 200 B per POI, N2 = 1681; same L1/L2 table gather as ICGN2D1",
-                               {"mean_iterations": float(it[ran].mean()), "converged": int((res[:, 16] >= 0).sum())},
-                               traffic=kernel_traffic("C", "icgn2d_kernel")))
+                               {"mean_iterations": float(it[ran].mean()), "converged": int((res[:, 16] >= 0).sum()),
+                                "valu_hw": valu_hardware_block(mandated_instr_icgn(res, 17, n2, "2d2", False),
+                                                               (tr or {}).get("valu_wave_instr_per_launch"), avg),
+                                "arith_fma": fused_leg(torch, g, q, guess, reps, 17, n2, "2d2", kernel_traffic("C", "icgn2d_kernel", fma=True), avg)},
+                               traffic=tr))
     del f, g, ref, tar, guess, q
     # ---- E: 512^3, r = 16, FFTCC3D + ICGN3D1, 37^3 POIs
     r = 16
@@ -646,12 +720,124 @@ def secondary_rooflines(dev, device, reps=3):
     ran = it > 0
     n3 = (2 * r + 1) ** 3
     alg = float(ran.sum() * (4 * n3 * 4 + 248) + it[ran].sum() * n3 * 256 + (~ran).sum() * 248)
+    tr = kernel_traffic("E", "icgn3d1")
     out.append(secondary_block("icgn3d1_kernel (ICGN3D1)", "E: 512^3, r=16 (33^3), %d POIs" % len(xs), alg, avg, n, "lds",
                                LDS_READ2_PEAK_GBS, "SURVEY 8(d): 4*N3*4 + k*N3*256 + 248 B per POI; the 256 B per sample and iteration are "
                                "the 64 tricubic taps, served from the LDS-staged coefficient box: judged against the LDS read rate "
                                "(ds_read2_b32: 128 B per clock and CU)",
-                               {"mean_iterations": float(it[ran].mean()), "converged": int((res[:, 18] >= 0).sum())},
-                               traffic=kernel_traffic("E", "icgn3d1")))
+                               {"mean_iterations": float(it[ran].mean()), "converged": int((res[:, 18] >= 0).sum()),
+                                "valu_hw": valu_hardware_block(mandated_instr_icgn(res, 19, n3, "3d1", False),
+                                                               (tr or {}).get("valu_wave_instr_per_launch"), avg),
+                                "arith_fma": fused_leg(torch, g, q, guess, max(2, reps - 1), 19, n3, "3d1", kernel_traffic("E", "icgn3d1", fma=True), avg)},
+                               traffic=tr))
+    return out
+
+
+def other_arith_leg(torch, args, fftcc, icgn, pois, pristine, this_kernel_ms, this_step_ms):
+    """The WHOLE step (reset, FFTCC2D, ICGN2D1) of the bench line once more under the other arithmetic contract -- the fused
+    build when the line is the default one, and vice versa -- same queue, same steps: what oc_hip_set_tuning("arith_fma") buys
+    on the metric, measured in the same process."""
+    fma = args.arith != "fma"
+    icgn.set_tuning("arith_fma", 1 if fma else 0)
+    try:
+        def step():
+            pois.copy_(pristine)
+            fftcc.compute(pois)
+            icgn.compute(pois)
+        for _ in range(max(2, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        icgn.profile_reset()
+        icgn.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ms, n = icgn.profile_read()
+        icgn.profile_enable(False)
+        res = pois.cpu().numpy()
+    finally:
+        icgn.set_tuning("arith_fma", 1 if args.arith == "fma" else 0)
+    conv = int((res[:, 16] >= 0).sum())
+    k_ms = ms / max(n, 1)
+    prof = pmc_profile(1, fma)
+    return {"contract": "fused per-sample multiply-adds (arith_fma = 1, oracle OC_ORDER_LANES_FMA)" if fma else "separately rounded (default build)",
+            "value": conv * args.steps / dt, "unit": "POI/s", "ms_per_step": dt / args.steps * 1e3, "icgn_kernel_avg_ms": k_ms,
+            "converged_pois": conv, "mean_iterations": float(res[res[:, 17] > 0, 17].astype(np.float64).mean()),
+            "kernel_time_ratio_to_the_line": k_ms / this_kernel_ms if this_kernel_ms > 0 else None,
+            "step_time_ratio_to_the_line": (dt / args.steps * 1e3) / this_step_ms if this_step_ms > 0 else None,
+            "valu_hw": valu_hardware_block(mandated_instr_icgn(res, 17, (2 * RX + 1) * (2 * RY + 1), "2d1", fma),
+                                           (prof or {}).get("valu_wave_instr_per_launch"), k_ms),
+            "traffic_source": (prof or {}).get("source"),
+            "why_not_the_default": "adopted as the default only if every parity bar holds AND ICGN3D1 gains >= 10 % (VERDICT r4 item 1): the "
+                                   "bars hold on all five configs, ICGN3D1 gains 5 % -- so the separately rounded build stays the default and "
+                                   "the fused one is one oc_hip_set_tuning call away (DESIGN.md section 3)"}
+
+
+def fused_leg(torch, eng, q, guess, reps, iter_col, samples, kind, traffic, sep_ms):
+    """The same launches under the fused arithmetic contract (oc_hip_set_tuning arith_fma = 1): kernel time, speed-up over the
+    default build measured a moment ago on the same queue, hardware-rate VALU figures of the fused instruction stream."""
+    eng.set_tuning("arith_fma", 1)
+    try:
+        avg, n = _timed_launches(torch, eng, lambda: (q.copy_(guess), eng.compute(q)), reps)
+        res = q.cpu().numpy()
+    finally:
+        eng.set_tuning("arith_fma", 0)
+    return {"avg_launch_ms": avg, "launches_timed": n, "speedup_over_default_build": sep_ms / avg if avg > 0 else None,
+            "valu_hw": valu_hardware_block(mandated_instr_icgn(res, iter_col, samples, kind, True),
+                                           (traffic or {}).get("valu_wave_instr_per_launch"), avg),
+            "traffic_source": (traffic or {}).get("source"),
+            "parity": "GPU == oracle OC_ORDER_LANES_FMA bit for bit; against the reference's separately rounded loop order the bars of "
+                      "tests/test_gpu_fullsize.py hold (flags equal, >= 99.5 % equal iteration counts, <= 1e-4 px, <= 1e-5 ZNCC)"}
+
+
+def variant_paths(torch, dev, device, ref, tar, xs, ys, base_ms, base_np, reps=3):
+    """SURVEY 8(f) row 1 on config B's grid: `B-OFF` = compute(poi_queue, center_offset_queue) with offsets
+    in [-2, 2] px; `B-SA` = setSelfAdaptive(true) with per-POI radii 12 ... 20 (src/oc_icgn.cpp:152-158, 353-557).  Self-adaptive
+    queues cannot share a per-workgroup coordinate table nor run lockstep sweeps, so they use the 4-wave table-free variant:
+    the cost per sample-iteration next to config B's is what this reports."""
+    import opencorr_amd
+    stream = torch.cuda.current_stream().cuda_stream
+    f = opencorr_amd.FFTCC2D(RX, RY, device=device)
+    f.set_stream(stream)
+    f.set_images(ref, tar)
+    g = opencorr_amd.ICGN2D1(RX, RY, CONV, STOP, device=device)
+    g.set_stream(stream)
+    g.share_images(f)
+    g.prepare()
+    guess = torch.from_numpy(opencorr_amd.make_pois2d(xs, ys)).to(dev)
+    f.compute(guess)
+    q = guess.clone()
+
+    def work(res):   # sample-iterations of a launch: what the interpolation sweeps and numerator passes scale with
+        it = res[:, 17].astype(np.float64)
+        ran = it > 0
+        n2 = (2 * res[ran, 23] + 1) * (2 * res[ran, 24] + 1)
+        return float((it[ran] * n2).sum()), float(it[ran].mean())
+
+    base_work, _ = work(base_np)
+    out = {}
+    rng = np.random.default_rng(20260927)
+    off = torch.from_numpy(rng.uniform(-2.0, 2.0, (len(xs), 2)).astype(np.float32)).to(dev)
+    avg, n = _timed_launches(torch, g, lambda: (q.copy_(guess), g.compute_with_offsets(q, off)), reps)
+    w, k = work(q.cpu().numpy())
+    out["B-OFF"] = {"what": "ICGN2D1::compute(poi_queue, center_offset_queue), offsets uniform in [-2, 2] px", "avg_launch_ms": avg,
+                    "launches_timed": n, "mean_iterations": k, "ns_per_sample_iteration": avg * 1e6 / w,
+                    "relative_to_config_B_per_sample_iteration": (avg / w) / (base_ms / base_work)}
+    sa = guess.clone()
+    radii = torch.from_numpy(rng.integers(12, 21, (len(xs), 2)).astype(np.float32)).to(dev)
+    sa[:, 23:25] = radii
+    g.set_self_adaptive(True)
+    try:
+        avg, n = _timed_launches(torch, g, lambda: (q.copy_(sa), g.compute(q)), reps)
+        w, k = work(q.cpu().numpy())
+    finally:
+        g.set_self_adaptive(False)
+    out["B-SA"] = {"what": "ICGN2D1 with setSelfAdaptive(true), per-POI radii uniform in 12 ... 20 (mean subset 33 x 33)",
+                   "avg_launch_ms": avg, "launches_timed": n, "mean_iterations": k, "ns_per_sample_iteration": avg * 1e6 / w,
+                   "relative_to_config_B_per_sample_iteration": (avg / w) / (base_ms / base_work)}
+    out["config_B"] = {"avg_launch_ms": base_ms, "ns_per_sample_iteration": base_ms * 1e6 / base_work}
     return out
 
 
@@ -681,12 +867,13 @@ def host_queue_rate(fftcc, icgn, pristine, converged, reps=3):
                     "unmodified call sequence fftcc->compute(q); icgn->compute(q); -- the queue crosses PCIe four times"}
 
 
-def pmc_profile(world):
+def pmc_profile(world, fma=False):
     """HBM bytes per ICGN launch from the COMMITTED PMC record of this workload (separate rocprofv3 --pmc passes,
     tools/gpu_round.sh); a constant read from profiles/, not something measured in this run."""
     if world != 1:
         return None
-    path = next((p for p in (TRAFFIC_BY_CONFIG["B"], TRAFFIC_JSON, TRAFFIC_JSON_OLD) if os.path.exists(p)), None)
+    cands = (TRAFFIC_BY_CONFIG_FMA["B"],) if fma else (TRAFFIC_BY_CONFIG["B"], TRAFFIC_JSON, TRAFFIC_JSON_OLD)
+    path = next((p for p in cands if os.path.exists(p)), None)
     if path is None:
         return None
     with open(path) as f:
@@ -697,7 +884,7 @@ def pmc_profile(world):
     if os.path.exists(second):
         with open(second) as f:
             spread = float(json.load(f)["hbm_bytes_per_launch"])
-    return {"hbm_bytes_per_launch": float(rec["hbm_bytes_per_launch"]),
+    return {"hbm_bytes_per_launch": (float(rec["hbm_bytes_per_launch"]) if rec.get("hbm_bytes_per_launch") else None),
             "hbm_bytes_per_launch_second_collection": spread,
             "l2_bytes_per_launch": (float(rec["l2_bytes_per_launch"]) if rec.get("l2_bytes_per_launch") else None),
             "l2_request_bytes_calibrated": rec.get("l2_request_bytes"), "l2_hit_rate": rec.get("l2_hit_rate"),
@@ -732,7 +919,7 @@ def cpu_baseline(ref, tar, xs, ys, sample):
         if best is None or (t2 - t0) < best[0]:
             best = (t2 - t0, t1 - t0, t2 - t1)
             conv = int((p[:, 16] >= 0).sum())
-    return {
+    out = {
         "value": conv / best[0],
         "unit": "POI/s",
         "cores": cores,
@@ -740,7 +927,33 @@ def cpu_baseline(ref, tar, xs, ys, sample):
         "build": build,
         "sample": "every %d-th POI of the same queue (%d POIs), FFTCC2D+ICGN2D1 compute, best of 3; "
                   "fftcc %.3f s, icgn %.3f s" % (stride, len(sx), best[1], best[2]),
+        "icgn_only_value": conv / best[2],
     }
+    # OpenCorr's OWN loops beside the port: oracle/_ref/liboc_ref.so = the reference's src/*.cpp compiled
+    # unmodified (its float**** table, per-thread instance pool and omp loop, src/oc_icgn.cpp:61-69, 343-351) against the
+    # stand-in Eigen of oracle/ref_stubs; prebuilt where the reference tree is mounted (it travels to this box, it cannot
+    # be rebuilt here), so -O2 -march=x86-64-v2 rather than this host's native flags.  ICGN leg only: the stand-in FFTW is
+    # an O(N^2) DFT, so the reference's FFTCC is not timed; the queue holds the port's FFTCC output.
+    try:
+        from oracle import ref as oracle_ref
+        if oracle_ref.available():
+            g = oracle.make_pois2d(sx, sy)
+            oracle.fftcc2d(ref_h, tar_h, RX, RY, g, threads=cores)
+            t = oracle_ref.time_icgn2d1(ref_h, tar_h, RX, RY, CONV, STOP, g, threads=cores, reps=3)
+            if t is not None:
+                rconv = int((g[:, 16] >= 0).sum())
+                same = bool(np.array_equal(g.view(np.uint32), p.view(np.uint32)))
+                out["reference_sources"] = {
+                    "icgn_only_value": rconv / t[1], "unit": "POI/s", "cores": cores, "kind": "reference",
+                    "icgn_seconds": t[1], "prepare_seconds": t[0],
+                    "build": "the reference's src/oc_{icgn,cubic_bspline,gradient,subset,deformation,...}.cpp unmodified, g++ -O2 "
+                             "-march=x86-64-v2 -fopenmp -ffp-contract=off (prebuilt: oracle/Makefile `ref`), stand-in Eigen",
+                    "sample": "the same %d POIs, ICGN2D1::compute(queue) only (initial guesses = the port's FFTCC output), best of 3" % len(sx),
+                    "bit_identical_to_the_port": same,
+                    "port_icgn_only_value": conv / best[2]}
+    except Exception as exc:   # the baseline leg never takes the bench line down
+        out["reference_sources"] = {"error": repr(exc)[:200]}
+    return out
 
 
 def oht_pair(device):

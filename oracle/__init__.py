@@ -140,6 +140,8 @@ def lib():
         L.oc_oracle_bspline3d_eval.argtypes = [fp, i, i, i, f, f, f]
         L.oc_oracle_bspline3d_eval.restype = f
         L.oc_oracle_fftcc3d.argtypes = [fp, fp, i, i, i, i, i, i, fp, l, i]
+        L.oc_oracle_fftcc3d_ex.argtypes = [fp, fp, i, i, i, i, i, i, fp, l, i, i]
+        L.oc_oracle_fftcc3d_ex.restype = None
         L.oc_oracle_icgn3d1.argtypes = [fp, fp, fp, fp, fp, i, i, i, i, i, i, f, f, fp, l, i, i, i]
         L.oc_oracle_max_threads.restype = i
         for name in ("oc_oracle_gradient2d", "oc_oracle_bspline2d_lut", "oc_oracle_fftcc2d", "oc_oracle_icgn2d1",
@@ -363,11 +365,15 @@ def bspline3d_eval(coef, x, y, z):
     return lib().oc_oracle_bspline3d_eval(_fp(coef), dz, dy, dx, float(x), float(y), float(z))
 
 
-def fftcc3d(ref, tar, rx, ry, rz, pois, threads=0):
+def fftcc3d(ref, tar, rx, ry, rz, pois, threads=0, exact_sums=False):
+    """FFTCC3D::compute(poi_queue) in place.  ``exact_sums``: means, norms and the ZNCC quotient in double instead of the
+    reference's sequential float32 running sums (src/oc_fftcc.cpp:340-376) -- the yardstick for the ZNCC of large windows,
+    where those running sums alone carry 1e-4 (32^3) ... 3e-4 (60^3)."""
     ref, tar = _img(ref), _img(tar)
     assert pois.dtype == np.float32 and pois.flags.c_contiguous and pois.shape[1] == POI3D_FLOATS
     dz, dy, dx = ref.shape
-    lib().oc_oracle_fftcc3d(_fp(ref), _fp(tar), dz, dy, dx, rx, ry, rz, _fp(pois), pois.shape[0], threads)
+    lib().oc_oracle_fftcc3d_ex(_fp(ref), _fp(tar), dz, dy, dx, rx, ry, rz, _fp(pois), pois.shape[0], threads,
+                               1 if exact_sums else 0)
 
 
 class Prepared3D:

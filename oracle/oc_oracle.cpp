@@ -1767,8 +1767,13 @@ float oc_oracle_bspline3d_eval_fma(const float* coef, int dz, int dy, int dx, fl
     return bspline3d_eval<true>(coef, dz, dy, dx, x, y, z);
 }
 
-void oc_oracle_fftcc3d(const float* ref, const float* tar, int dz, int dy, int dx, int rx, int ry, int rz, float* pois,
-                       long n, int threads) {
+// exact_sums = 0: the reference's own arithmetic -- means and norms as sequential float32 running sums over the window
+// (src/oc_fftcc.cpp:340-376).  exact_sums = 1: the same windows, the same first-maximum rule, but means, zero-mean values,
+// norms and the final quotient in double, rounded once: the ZNCC of the peak WITHOUT the rounding noise of a 10^4 ... 10^5-term
+// float running sum (which reaches 1e-4 at 32^3 and 3e-4 at 60^3 -- more than north_star's tolerance, and it is the
+// reference's own noise).  The integer displacements are the same in both modes whenever the peak is not a float-level tie.
+void oc_oracle_fftcc3d_ex(const float* ref, const float* tar, int /*dz*/, int dy, int dx, int rx, int ry, int rz, float* pois,
+                          long n, int threads, int exact_sums) {
     threads = resolve_threads(threads);
     const int sx = 2 * rx, sy = 2 * ry, sz = 2 * rz;
     const int size = sx * sy * sz;
@@ -1786,6 +1791,7 @@ void oc_oracle_fftcc3d(const float* ref, const float* tar, int dz, int dy, int d
             float px = poi[0], py = poi[1], pz = poi[2];
             float gu = poi[3], gv = poi[7], gw = poi[11];
             float ref_mean = 0.f, tar_mean = 0.f, ref_norm = 0.f, tar_norm = 0.f;
+            double ref_sum_d = 0.0, tar_sum_d = 0.0;
             for (int i = 0; i < sz; i++)
                 for (int j = 0; j < sy; j++)
                     for (int k = 0; k < sx; k++) {
@@ -1793,11 +1799,52 @@ void oc_oracle_fftcc3d(const float* ref, const float* tar, int dz, int dy, int d
                         float v = ref[((size_t)(int)rzp * dy + (int)ryp) * dx + (int)rxp];
                         rsub[(i * sy + j) * sx + k] = v;
                         ref_mean += v;
+                        ref_sum_d += v;
                         float txp = rxp + gu, typ = ryp + gv, tzp = rzp + gw;
                         v = tar[((size_t)(int)tzp * dy + (int)typ) * dx + (int)txp];
                         tsub[(i * sy + j) * sx + k] = v;
                         tar_mean += v;
+                        tar_sum_d += v;
                     }
+            if (exact_sums) {
+                const double rm = ref_sum_d / size, tm = tar_sum_d / size;
+                double rn = 0.0, tn = 0.0;
+                std::vector<cplx>& z = buf;
+                z.resize(size);
+                for (int k = 0; k < size; k++) {
+                    const double a = (double)rsub[k] - rm, b = (double)tsub[k] - tm;
+                    rn += a * a;
+                    tn += b * b;
+                    z[k] = cplx(a, b);
+                }
+                // the correlation surface of the double zero-mean windows (same transform as xcorr_nd)
+                fft_nd(z, dims, -1, cache);
+                spec.resize(size);
+                std::vector<size_t> strides = {(size_t)sy * sz, (size_t)sz, 1};
+                for (size_t q2 = 0; q2 < (size_t)size; q2++) {
+                    size_t rem = q2, neg = 0;
+                    for (size_t ax = 0; ax < 3; ax++) {
+                        const size_t kk = rem / strides[ax];
+                        rem -= kk * strides[ax];
+                        neg += ((dims[ax] - kk) % dims[ax]) * strides[ax];
+                    }
+                    const cplx zk = z[q2], znk = std::conj(z[neg]);
+                    spec[q2] = std::conj(0.5 * (zk + znk)) * (cplx(0.0, -0.5) * (zk - znk));
+                }
+                fft_nd(spec, dims, +1, cache);
+                double best = -2.0 * std::sqrt(rn * tn) * size;
+                int idx = 0;
+                for (int k = 0; k < size; k++)
+                    if (spec[k].real() > best) { best = spec[k].real(); idx = k; }
+                int du = idx % sx, dv = (idx / sx) % sy, dw = idx / (sx * sy);
+                if (du > rx) du -= sx;
+                if (dv > ry) dv -= sy;
+                if (dw > rz) dw -= sz;
+                poi[3] = (float)du + gu; poi[7] = (float)dv + gv; poi[11] = (float)dw + gw;
+                poi[15] = gu; poi[16] = gv; poi[17] = gw;
+                poi[18] = (float)(best / (std::sqrt(rn * tn) * size));
+                continue;
+            }
             ref_mean /= size;
             tar_mean /= size;
             for (int k = 0; k < size; k++) {
@@ -1824,6 +1871,11 @@ void oc_oracle_fftcc3d(const float* ref, const float* tar, int dz, int dy, int d
             poi[18] = max_zncc / (std::sqrt(ref_norm * tar_norm) * size);
         }
     }
+}
+
+void oc_oracle_fftcc3d(const float* ref, const float* tar, int dz, int dy, int dx, int rx, int ry, int rz, float* pois,
+                       long n, int threads) {
+    oc_oracle_fftcc3d_ex(ref, tar, dz, dy, dx, rx, ry, rz, pois, n, threads, 0);
 }
 
 void oc_oracle_icgn3d1(const float* ref, const float* gx, const float* gy, const float* gz, const float* tar_coef,

@@ -182,6 +182,10 @@ int oc_oracle_fma_is_hardware(void);
 /* src/oc_fftcc.cpp:327-436 */
 void oc_oracle_fftcc3d(const float* ref, const float* tar, int dz, int dy, int dx,
                        int rx, int ry, int rz, float* pois, long n, int threads);
+/* exact_sums = 1: means, norms and the ZNCC quotient in double (the peak's ZNCC without the rounding noise of the
+ * reference's sequential float32 running sums over 10^4 ... 10^5 voxels, src/oc_fftcc.cpp:340-376); 0 = oc_oracle_fftcc3d */
+void oc_oracle_fftcc3d_ex(const float* ref, const float* tar, int dz, int dy, int dx,
+                          int rx, int ry, int rz, float* pois, long n, int threads, int exact_sums);
 /* src/oc_icgn.cpp:1270-1500 */
 void oc_oracle_icgn3d1(const float* ref, const float* gx, const float* gy, const float* gz,
                        const float* tar_coef, int dz, int dy, int dx, int rx, int ry, int rz,

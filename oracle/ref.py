@@ -63,6 +63,11 @@ def lib():
         L.oc_ref_fftcc2d.argtypes = [fp, fp, i, i, i, i, fp, l, i]
         L.oc_ref_solve2d.argtypes = [i, fp, fp, i, i, i, i, f, f, fp, l, fp, i, fp, i]
         L.oc_ref_prepare2d.argtypes = [fp, fp, i, i, fp, fp, fp]
+        try:
+            dp = ctypes.POINTER(ctypes.c_double)
+            L.oc_ref_time_icgn2d1.argtypes = [fp, fp, i, i, i, i, f, f, fp, l, i, i, dp, dp]
+        except AttributeError:
+            pass   # a library built before round 5
         L.oc_ref_bspline2d_eval.argtypes = [fp, i, i, fp, l, fp]
         L.oc_ref_fftcc3d.argtypes = [fp, fp, i, i, i, i, i, i, fp, l, i]
         L.oc_ref_icgn3d1.argtypes = [fp, fp, i, i, i, i, i, i, f, f, fp, l, i]
@@ -100,6 +105,20 @@ def solve2d(engine, ref, tar, rx, ry, conv, stop, pois, center_offsets=None, sel
     dmp = None if damping is None else np.asarray(damping, dtype=np.float32)
     _check(lib().oc_ref_solve2d(engine, _fp(ref), _fp(tar), h, w, rx, ry, float(conv), float(stop), _fp(pois), pois.shape[0],
                                 _fp(off), 1 if self_adaptive else 0, _fp(dmp), threads), "2D solver %d" % engine)
+
+
+def time_icgn2d1(ref, tar, rx, ry, conv, stop, pois, threads=0, reps=3):
+    """The reference's own ICGN2D1 on a queue of initial guesses: (prepare seconds, best compute seconds); ``pois`` in place.
+    None when the library predates this entry point."""
+    L = lib()
+    if L is None or not hasattr(L, "oc_ref_time_icgn2d1"):
+        return None
+    ref, tar = _img(ref), _img(tar)
+    h, w = ref.shape
+    tp, tc = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    _check(L.oc_ref_time_icgn2d1(_fp(ref), _fp(tar), h, w, rx, ry, float(conv), float(stop), _fp(pois), pois.shape[0], threads,
+                                 reps, ctypes.byref(tp), ctypes.byref(tc)), "ICGN2D1 (timed)")
+    return tp.value, tc.value
 
 
 def gradient2d(img):

@@ -113,6 +113,38 @@ int oc_ref_solve2d(int engine, const float* ref, const float* tar, int height, i
     return 0;
 }
 
+// Timing leg of bench.py's cpu_baseline ("reference_sources"): the reference's OWN ICGN2D1 -- its float**** table, its
+// per-thread instance pool, its omp loop (src/oc_icgn.cpp:61-69, 343-351) -- on a queue that already holds initial guesses,
+// the way examples/test_2d_dic_fftcc_icgn1.cpp:93-104 runs it.  prepare() and compute(queue) are timed separately, compute
+// `reps` times on a fresh copy of the queue (best time returned); the last run's records are written back.
+int oc_ref_time_icgn2d1(const float* ref, const float* tar, int height, int width, int rx, int ry, float conv, float stop,
+                        float* pois, long n, int threads, int reps, double* prepare_seconds, double* compute_seconds) {
+    try {
+        Image2D ref_img(width, height), tar_img(width, height);
+        fill2d(ref_img, ref);
+        fill2d(tar_img, tar);
+        ICGN2D1 e(rx, ry, conv, stop, threads_or_all(threads));
+        e.setImages(ref_img, tar_img);
+        double t0 = omp_get_wtime();
+        e.prepare();
+        *prepare_seconds = omp_get_wtime() - t0;
+        double best = 1e30;
+        std::vector<POI2D> q;
+        for (int r = 0; r < (reps > 0 ? reps : 1); r++) {
+            q = load2d(pois, n);
+            t0 = omp_get_wtime();
+            e.compute(q);
+            const double dt = omp_get_wtime() - t0;
+            best = dt < best ? dt : best;
+        }
+        *compute_seconds = best;
+        if (n) std::memcpy(pois, static_cast<void*>(q.data()), sizeof(POI2D) * (size_t)n);
+    } catch (const std::string&) {
+        return 1;
+    }
+    return 0;
+}
+
 // what ICGN2D1::prepare() builds, for field-level comparison: Gradient2D4 (src/oc_gradient.cpp:37-79) of `ref` and the
 // BicubicBspline table (src/oc_cubic_bspline.cpp:84-132) of `tar`; lut is [y][x][k][l]
 int oc_ref_prepare2d(const float* ref, const float* tar, int height, int width, float* gx, float* gy, float* lut) {

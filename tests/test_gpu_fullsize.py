@@ -100,7 +100,10 @@ def test_config_e_full_size():
     _check_vs_reference_order(rec)
     _check_fma(rec, 0.999)
     assert rec["oracle_bit_exact"], rec
-    assert rec["fftcc_oracle_same_integers"] and rec["fftcc_oracle_max_zncc_diff"] <= 1e-4, rec
+    # FFTCC3D's ZNCC: north_star's 1e-4 against exactly summed means / norms; 2e-4 against the reference's own sequential
+    # float running sums over 32 768 voxels (src/oc_fftcc.cpp:340-376; 1.1e-4 measured on this sample)
+    assert rec["fftcc_exact_sums_same_integers"] and rec["fftcc_exact_sums_max_zncc_diff"] <= 1e-4, rec
+    assert rec["fftcc_oracle_same_integers"] and rec["fftcc_oracle_max_zncc_diff"] <= 2e-4, rec
     assert rec["converged"] >= 0.999 * rec["pois"], rec
     assert rec["median_abs_err"] < 0.01 and rec["max_abs_err"] < 0.05, rec
 
@@ -108,14 +111,15 @@ def test_config_e_full_size():
 def test_dvc_example_shape_r30():
     """The radius of the reference's own DVC example (examples/test_dvc_fftcc_icgn1.cpp:45-47: 61^3 subvolumes, 60^3 FFTCC
     windows) on a 256^3 pair, 8^3 = 512 POIs: every second POI (256) against the oracle in both orders and both arithmetic
-    modes.  FFTCC3D's ZNCC at 60^3 is compared with the bar DESIGN.md section 3 / INTEGRATION.md state for windows beyond 32^3
-    (5e-4: the reference's own sequential float sums over 216 000 voxels, src/oc_fftcc.cpp:340-376, are what limits it; the
-    integers are exact and ICGN3D1 overwrites the value)."""
+    modes.  FFTCC3D's ZNCC at 60^3: within north_star's 1e-4 of the exactly summed value, within 5e-4 of the reference's own
+    sequential float sums over 216 000 voxels (src/oc_fftcc.cpp:340-376; 3.1e-4 measured -- the reference's noise, stated in
+    DESIGN.md section 3 / INTEGRATION.md; the integers are exact and ICGN3D1 overwrites the value)."""
     rec = _configs().run_3d("E30", 256, 30, 8, 256)
     assert rec["pois"] == 512 and rec["oracle_sample"] >= 256
     _check_vs_reference_order(rec)
     _check_fma(rec, 0.99)
     assert rec["oracle_bit_exact"], rec
+    assert rec["fftcc_exact_sums_same_integers"] and rec["fftcc_exact_sums_max_zncc_diff"] <= 1e-4, rec
     assert rec["fftcc_oracle_same_integers"] and rec["fftcc_oracle_max_zncc_diff"] <= 5e-4, rec
     assert rec["converged"] >= 0.99 * rec["pois"], rec
     assert rec["median_abs_err"] < 0.01 and rec["max_abs_err"] < 0.05, rec

@@ -2,7 +2,7 @@
 # One parameterised GPU-box session (round 5; replaces the per-session gpu_r*.sh scripts of rounds 3 - 4):
 #   bash tools/gpu_session.sh <tag> <step> [<step> ...]          results under gpurun_out/<tag>/
 # steps:
-#   test:<pytest args>     python -m pytest <args> -x -q           (e.g. test:tests/test_gpu_arith_fma.py, test:-m_gpu -> "-m gpu")
+#   test:<pytest args>     python -m pytest <args> -x -q           ("+" stands for a space: test:tests/test_gpu_arith_fma.py, test:-m+gpu)
 #   configs:<A,B,..>       tests/fullsize/run_configs.py --configs ... (both arithmetic modes, oracle samples)  -> configs.json
 #   bench                  the driver's command line                                                              -> bench_n1.json
 #   benchtrace             rocprofv3 --kernel-trace --stats of the same command                                   -> bench_n1_kernel_stats.csv
@@ -20,7 +20,7 @@ for step in "$@"; do
   kind=${step%%:*}; arg=${step#*:}
   echo "== $step"
   case $kind in
-    test) timeout 1500 python -m pytest ${arg//_gpu/ gpu} -x -q 2>&1 | grep -v amdgpu.ids | tail -15;;
+    test) timeout 1500 python -m pytest ${arg//+/ } -x -q 2>&1 | grep -v amdgpu.ids | tail -15;;
     configs) timeout 2400 python tests/fullsize/run_configs.py --configs $arg --out $OUT/configs_${arg//,/_}.json 2>&1 | grep -v amdgpu | cut -c1-2500;;
     bench) timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench.err; cut -c1-600 $OUT/bench_n1.json; tail -3 $OUT/bench.err;;
     benchtrace)

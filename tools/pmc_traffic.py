@@ -70,20 +70,22 @@ def main():
 
 
 def one_kernel(a, rx):
-    fetch = per_dispatch(glob.glob(os.path.join(a.root, "pmc_fetch", "*_counter_collection.csv"))[0], "FETCH_SIZE", rx)
-    write = per_dispatch(glob.glob(os.path.join(a.root, "pmc_write", "*_counter_collection.csv"))[0], "WRITE_SIZE", rx)
-    fetch, write = fetch[-a.launches:], write[-a.launches:]
-    f_kb = sum(fetch) / len(fetch)
-    w_kb = sum(write) / len(write)
-    rec = {
-        "kernel_regex": rx.pattern,
-        "launches_averaged": len(fetch),
-        "FETCH_SIZE_kb_per_launch_raw": f_kb,
-        "WRITE_SIZE_kb_per_launch_raw": w_kb,
-        "fetch_correction": 2.0,
-        "hbm_bytes_per_launch": 2.0 * f_kb * 1024.0 + w_kb * 1024.0,
-        "note": a.note or "FETCH_SIZE x2 (gfx950 counts 128 B fabric requests as 64 B); WRITE_SIZE as reported",
-    }
+    fpath = glob.glob(os.path.join(a.root, "pmc_fetch", "*_counter_collection.csv"))
+    wpath = glob.glob(os.path.join(a.root, "pmc_write", "*_counter_collection.csv"))
+    rec = {"kernel_regex": rx.pattern, "launches_averaged": a.launches}
+    if fpath and wpath:   # (a collection limited to other counter sets -- OC_PROFILE_PASSES -- has no HBM record)
+        fetch = per_dispatch(fpath[0], "FETCH_SIZE", rx)[-a.launches:]
+        write = per_dispatch(wpath[0], "WRITE_SIZE", rx)[-a.launches:]
+        f_kb = sum(fetch) / len(fetch)
+        w_kb = sum(write) / len(write)
+        rec.update({
+            "launches_averaged": len(fetch),
+            "FETCH_SIZE_kb_per_launch_raw": f_kb,
+            "WRITE_SIZE_kb_per_launch_raw": w_kb,
+            "fetch_correction": 2.0,
+            "hbm_bytes_per_launch": 2.0 * f_kb * 1024.0 + w_kb * 1024.0,
+            "note": a.note or "FETCH_SIZE x2 (gfx950 counts 128 B fabric requests as 64 B); WRITE_SIZE as reported",
+        })
     rec["collected"] = datetime.date.today().isoformat()
     if a.command:
         rec["command"] = a.command

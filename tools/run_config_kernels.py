@@ -2,7 +2,7 @@
 """Runs the engines of one BASELINE config a few times and nothing else (no oracle, no checks): the command rocprofv3 wraps when
 tools/gpu_profiles.sh collects the kernel trace and the PMC traffic of configs C and E (config B is bench.py itself).
 
-    python tools/run_config_kernels.py C|E|E30 [--reps 3]
+    python tools/run_config_kernels.py C|E|E30 [--reps 3]          (OC_BENCH_ARITH_FMA=1: oc_hip_set_tuning arith_fma = 1)
 """
 import argparse
 import os
@@ -37,6 +37,8 @@ f.set_stream(stream)
 f.set_images(ref, tar)
 g.set_stream(stream)
 g.share_images(f)
+if os.environ.get("OC_BENCH_ARITH_FMA") == "1":   # the fused arithmetic contract (profiles/*_fma.*)
+    g.set_tuning("arith_fma", 1)
 g.prepare()
 q = pristine.clone()
 for _ in range(a.reps + a.warm):   # warm-up passes first (tools/pmc_traffic.py averages the last `reps` launches)
