@@ -1,6 +1,11 @@
 """Builds opencorr_amd/lib/libopencorr_hip.so (gfx950 only) with hipcc.
 
-    python -m opencorr_amd.build [--force]
+    python -m opencorr_amd.build [--force] [--ab]
+
+--ab additionally builds lib/ab/libopencorr_hip_ab.so: the SAME library plus the measured losers that are kept as A/B
+partners (-DOC_BUILD_AB=1: icgn2d variants 0 and 6, the ICGN3D1 row mapping icgn3d_rows.hip, the experiment environment
+knobs).  Test / experiment infrastructure: tests/ab/ and the tools/*_probe.py scripts load it through OPENCORR_HIP_LIB; the
+library that ships does not contain any of it.
 
 Flags that matter for parity: -ffp-contract=off (no FMA
 contraction; every multiply and add rounds separately, like the oracle) and no
@@ -15,7 +20,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libopencorr_hip.so")
-SOURCES = ["capi.hip", "prepare2d.hip", "icgn2d.hip", "nr2d.hip", "poi_order.hip", "poi_split.hip", "strain.hip", "fftcc2d.hip", "fftcc2d_fused.hip", "fftcc2d_fusedn.hip", "fftcc2d_fusedp.hip", "fftcc2d_fusedr.hip", "prepare3d.hip", "icgn3d.hip", "icgn3d_rows.hip", "fftcc3d.hip", "fftcc3d_fused.hip", "fftcc3d_fusedn.hip", "fftcc3d_planes.hip", "fftcc3d_planesb.hip"]
+SOURCES = ["capi.hip", "prepare2d.hip", "icgn2d.hip", "nr2d.hip", "poi_order.hip", "poi_split.hip", "strain.hip", "fftcc2d.hip", "fftcc2d_fused.hip", "fftcc2d_fusedn.hip", "fftcc2d_fusedp.hip", "fftcc2d_fusedr.hip", "prepare3d.hip", "icgn3d.hip", "fftcc3d.hip", "fftcc3d_fused.hip", "fftcc3d_fusedn.hip", "fftcc3d_planes.hip", "fftcc3d_planesb.hip"]
+# the A/B build: sources that exist only there, and the product sources whose code depends on OC_BUILD_AB (recompiled with
+# -DOC_BUILD_AB=1; every other object is shared with the product build)
+AB_ONLY_SOURCES = ["icgn3d_rows.hip"]
+AB_DEPENDENT = ["capi.hip", "icgn2d.hip", "icgn3d.hip"]
+AB_LIBDIR = os.path.join(LIBDIR, "ab")
+AB_LIB = os.path.join(AB_LIBDIR, "libopencorr_hip_ab.so")
 HEADERS = ["oc_device.h", "oc_kernels.h", "dic2d_device.h", "fft_device.h", "fftcc2d_fusedn_impl.h", "fftcc3d_planes_impl.h", "icgn3d_device.h", os.path.join("..", "..", "include", "opencorr_hip.h")]
 ARCH = "gfx950"
 # -fno-slp-vectorize: the SLP vectoriser pairs independent scalar fp32 operations into v_pk_mul_f32 / v_pk_add_f32.  On gfx950 a
@@ -45,17 +56,13 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    os.makedirs(LIBDIR, exist_ok=True)
+def _compile_and_link(units, lib, force, verbose, shared_objs=()):
+    """units: (source, object path, extra defines).  Compiles what is stale (in parallel) and links `lib`."""
     headers = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    objs = []
     cc = hipcc()
-    procs = []
-    units = [(src, src.replace(".hip", ".o"), []) for src in SOURCES]
-    units += [(src, src.replace(".hip", "_fma.o"), ["-DOC_FMA=1"]) for src in FMA_SOURCES]
-    for src, obj, defs in units:
+    objs, procs = list(shared_objs), []
+    for src, o, defs in units:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, obj)
         objs.append(o)
         if force or _stale(o, [s] + headers):
             cmd = [cc, "--offload-arch=" + ARCH, "-c", s, "-o", o] + FLAGS + EXTRA_FLAGS.get(src, []) + defs
@@ -65,14 +72,42 @@ def build(force=False, verbose=True):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
-    if force or procs or _stale(LIB, objs):
-        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrocfft", "-ldl", "-lpthread"]
+    if force or procs or _stale(lib, objs):
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrocfft", "-ldl", "-lpthread"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    return lib
+
+
+def _units(sources, libdir, defs):
+    units = [(src, os.path.join(libdir, src.replace(".hip", ".o")), list(defs)) for src in sources]
+    units += [(src, os.path.join(libdir, src.replace(".hip", "_fma.o")), list(defs) + ["-DOC_FMA=1"]) for src in sources if src in FMA_SOURCES]
+    return units
+
+
+def build(force=False, verbose=True, ab=False):
+    """The product library; ab=True: also the A/B build (see the module docstring).  Returns the product library's path."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    _compile_and_link(_units(SOURCES, LIBDIR, []), LIB, force, verbose)
+    if ab:
+        build_ab(force=force, verbose=verbose)
     return LIB
 
 
+def build_ab(force=False, verbose=True):
+    """lib/ab/libopencorr_hip_ab.so = the product objects that do not depend on OC_BUILD_AB + the dependent and A/B-only sources
+    compiled with -DOC_BUILD_AB=1.  Needs the product build's objects (build() first)."""
+    os.makedirs(AB_LIBDIR, exist_ok=True)
+    shared = [o for src, o, _ in _units([s for s in SOURCES if s not in AB_DEPENDENT], LIBDIR, [])]
+    missing = [o for o in shared if not os.path.exists(o)]
+    if missing:
+        raise RuntimeError("build_ab: the product build comes first (missing %s)" % ", ".join(os.path.basename(m) for m in missing))
+    return _compile_and_link(_units(AB_DEPENDENT + AB_ONLY_SOURCES, AB_LIBDIR, ["-DOC_BUILD_AB=1"]), AB_LIB, force, verbose, shared_objs=shared)
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, ab="--ab" in sys.argv)
     print(LIB)
+    if "--ab" in sys.argv:
+        print(AB_LIB)

@@ -170,6 +170,7 @@ struct oc_hip_engine {
     DevBuf poi_stage, off_stage;
     DevBuf cursors;  // small device scratch (batch maxima)
     DevBuf perm, tiles, perm_slots;  // locality schedule of the ICGN2D queue (poi_order.hip)
+    DevBuf setup_recs;               // icgn2d variant 8 (split launch shape): mean, norm, H^-1 per POI between the two kernels
     DevBuf split_scratch, split_tmp; // oc_hip_split_reliable / oc_hip_merge_recovered (poi_split.hip)
     // Strain (src/oc_strain.cpp:31-46: radius, min neighbours; ZNCC threshold 0.9, Cauchy approximation)
     float st_radius = 0.f, st_zncc = 0.9f;
@@ -534,7 +535,7 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
                              e->conv,      e->stop,            d_offsets,         nullptr,
                              e->self_adaptive ? 1 : 0,
                              lm ? std::log((double)e->lm_lambda) : 0.0,
-                             e->lm_alpha,  e->lm_beta,         e->arith_fma};
+                             e->lm_alpha,  e->lm_beta,         e->arith_fma,      nullptr};
     const long long N = (2LL * rx + 1) * (2LL * ry + 1);
     // fall back to the LDS-light single-wave variant when the tuned one cannot hold the subset
     int variant = e->icgn2d_variant;
@@ -548,18 +549,25 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
         // 3.65 against 3.81 ms on config C (profiles/r03q_icgn2d2_variant_ab_configC.json)
         variant = dof == 12 ? (passes <= 28 && count >= 32768 ? 4 : 3) : (passes <= 19 && count >= 32768 ? 5 : 2);
     }
-    if (e->self_adaptive && ochip::icgn2d_variant_uses_table(variant)) variant = 2;  // per-POI radii: no shared coordinate table
+    // per-POI radii: no shared coordinate table, and the per-wave arrays are sized for the LARGEST subset of the batch -- the
+    // target-array-only shape (variant 7) keeps four workgroups on a CU where variant 2 holds two (bench.py paths_8f_row1)
+    if (e->self_adaptive && (e->icgn2d_variant < 0 || ochip::icgn2d_variant_uses_table(variant))) variant = 7;
     if (lm) variant = 1;  // the IC-LM launch shape has the LDS footprint of variant 1
     if (N > ochip::icgn2d_max_samples(variant)) variant = 1;
     if (N > ochip::icgn2d_max_samples(variant))
         return fail(OC_HIP_ERR_UNSUPPORTED, "ICGN2D%d: subset %dx%d (%lld samples) exceeds the on-chip limit of %d samples",
                     dof == 6 ? 1 : 2, 2 * rx + 1, 2 * ry + 1, N, ochip::icgn2d_max_samples(variant));
+    if (variant == 8 && !lm) {
+        OC_TRY(e->setup_recs.reserve(count * (size_t)ochip::icgn2d_setup_record_floats(dof) * sizeof(float)));
+        P.setup = e->setup_recs.as<float>();
+    }
     // one wave per POI; grid.x is limited to 2^31-1
     const size_t kMaxGrid = 1u << 30;
     for (size_t first = 0; first < count; first += kMaxGrid) {
         const size_t n = (count - first) < kMaxGrid ? (count - first) : kMaxGrid;
         float* pois = d_pois + first * (size_t)stride_f;
         if (d_offsets) P.offsets = d_offsets + 2 * first;
+        if (P.setup) P.setup = e->setup_recs.as<float>() + first * (size_t)ochip::icgn2d_setup_record_floats(dof);
         OC_TRY(tile_order(e, pois, stride_f, n, &P.perm));
         ProfScope prof(e);  // the solver kernel alone (what rocprofv3 reports for it)
         hipError_t err;
@@ -684,9 +692,12 @@ int run_icgn3d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     const ImagePair& im = *e->img;
     int blocks = 0;
     size_t scratch = ochip::icgn3d1_scratch_floats(e->rx, e->ry, e->rz, &blocks);
-    // the row mapping (icgn3d_rows.hip, the default) keeps whole steps per thread: its slots are a little larger
+#if OC_BUILD_AB
+    // the row mapping (icgn3d_rows.hip, an A/B partner: only the A/B build contains it) keeps whole steps per thread: its
+    // slots are a little larger
     const size_t rows_scratch = ochip::icgn3d1_rows_slot_floats(e->rx, e->ry, e->rz) * (size_t)blocks;
     if (e->icgn3d_mapping != 0 && rows_scratch > scratch) scratch = rows_scratch;
+#endif
     if (scratch) OC_TRY(e->tmp.reserve(scratch * sizeof(float)));
     ochip::Icgn3dParams P = {im.ref_ptr(), e->gx.as<float>(), e->gy.as<float>(), e->gz.as<float>(), e->coef.as<float>(),
                              im.dz, im.dy, im.dx, e->rx, e->ry, e->rz, e->conv, e->stop,
@@ -704,8 +715,12 @@ int run_icgn3d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
         P.perm = e->perm.as<unsigned>();
     }
     ProfScope prof(e);
-    hipError_t err = e->icgn3d_mapping != 0 ? ochip::launch_icgn3d1_rows(P, d_pois, stride_f, count, e->stream)
+#if OC_BUILD_AB
+    hipError_t err = e->icgn3d_mapping != 0 ? ochip::launch_icgn3d1_rows(P, d_pois, stride_f, count, blocks, e->stream)
                                             : ochip::launch_icgn3d1(P, d_pois, stride_f, count, e->stream);
+#else
+    hipError_t err = ochip::launch_icgn3d1(P, d_pois, stride_f, count, e->stream);
+#endif
     if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "ICGN3D1 kernel launch failed: %s", hipGetErrorString(err));
     return OC_HIP_OK;
 }
@@ -1377,6 +1392,9 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
     if (k == "icgn2d_variant") {
         if (value < -1 || value >= ochip::icgn2d_variant_count())
             return fail(OC_HIP_ERR_INVALID, "icgn2d_variant %d out of range [-1 (automatic), %d)", value, ochip::icgn2d_variant_count());
+        if (value >= 0 && !ochip::icgn2d_variant_built(value))
+            return fail(OC_HIP_ERR_UNSUPPORTED, "icgn2d_variant %d is an A/B partner that only the A/B build of the library contains "
+                                               "(python -m opencorr_amd.build --ab)", value);
         e->icgn2d_variant = value;
     } else if (k == "icgn2d_xcd" || k == "xcd") {
         e->icgn2d_xcd = value != 0;
@@ -1395,6 +1413,11 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
         if (value < 0 || (value > 0 && value < 8)) return fail(OC_HIP_ERR_INVALID, "icgn3d_tile_vox must be 0 (off) or >= 8");
         e->icgn3d_tile_vox = value;
     } else if (k == "icgn3d_mapping") {
+#if !OC_BUILD_AB
+        if (value != 0)
+            return fail(OC_HIP_ERR_UNSUPPORTED, "icgn3d_mapping = 1 (the row mapping, measured 12 - 25 %% slower) is an A/B partner that only "
+                                               "the A/B build of the library contains (python -m opencorr_amd.build --ab)");
+#endif
         e->icgn3d_mapping = value != 0;
     } else if (k == "fftcc3d_planes_blocks") {
         if (value < 0 || value > 4096) return fail(OC_HIP_ERR_INVALID, "fftcc3d_planes_blocks must be 0 (default) ... 4096");
@@ -2180,6 +2203,16 @@ int oc_hip_merge_recovered(oc_hip_engine* e, void* pois, size_t count, size_t st
         OC_TRY(e->split_tmp.reserve(qb + ib));
         float* t_rec = e->split_tmp.as<float>();
         unsigned* t_idx = reinterpret_cast<unsigned*>(e->split_tmp.as<char>() + qb);
+        // the index list is checked on the device BEFORE the scatter may write anything of the caller's: a list
+        // with an entry outside the main queue is refused with `reliable`, `pois`, `unreliable` and the list itself untouched
+        {
+            unsigned* flag = e->split_scratch.as<unsigned>() + ochip::poi_split_scratch_words(n_unreliable) - 1;
+            OC_HIP_TRY(ochip::launch_poi_index_range(unreliable_index, n_unreliable, count, flag, e->stream));
+            unsigned bad = 0;
+            OC_HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof(bad), hipMemcpyDeviceToHost, e->stream));
+            OC_HIP_TRY(hipStreamSynchronize(e->stream));
+            if (bad) return fail(OC_HIP_ERR_INVALID, "merge_recovered: an unreliable_index entry is >= the main queue's %zu records (nothing was changed)", count);
+        }
         OC_HIP_TRY(ochip::launch_poi_split(static_cast<const float*>(unreliable), stride_f, n_unreliable, P, unreliable_index,
                                            static_cast<float*>(reliable), reliable_offset, nullptr, t_rec, t_idx, static_cast<float*>(pois),
                                            count, e->split_scratch.as<unsigned>(), e->stream));
@@ -2194,8 +2227,12 @@ int oc_hip_merge_recovered(oc_hip_engine* e, void* pois, size_t count, size_t st
         *n_remaining = totals[1];
         return finish_device_call(e);
     }
-    // host queues: the classification and both compactions run on the device; the host only moves the recovered records to
-    // where the device's index list says they go
+    // host queues: every index is checked BEFORE anything is enqueued or touched (the host knows the list)
+    for (size_t j = 0; j < n_unreliable; j++)
+        if (unreliable_index[j] >= count)
+            return fail(OC_HIP_ERR_INVALID, "merge_recovered: unreliable_index[%zu] = %u is >= the main queue's %zu records", j, unreliable_index[j], count);
+    // the classification and both compactions run on the device; the host only moves the recovered records to where the
+    // device's index list says they go
     OC_TRY(e->poi_stage.reserve(3 * qb + 3 * ib));
     char* base = e->poi_stage.as<char>();
     float* d_in = reinterpret_cast<float*>(base);
@@ -2206,11 +2243,6 @@ int oc_hip_merge_recovered(oc_hip_engine* e, void* pois, size_t count, size_t st
     unsigned* d_idx_rem = d_idx_rec + n_unreliable;
     OC_HIP_TRY(hipMemcpyAsync(d_in, unreliable, qb, hipMemcpyHostToDevice, e->stream));
     OC_HIP_TRY(hipMemcpyAsync(d_idx_in, unreliable_index, ib, hipMemcpyHostToDevice, e->stream));
-    // every index is checked BEFORE anything of the caller's is touched (the host knows the list; the device path has the
-    // kernel's own bound)
-    for (size_t j = 0; j < n_unreliable; j++)
-        if (unreliable_index[j] >= count)
-            return fail(OC_HIP_ERR_INVALID, "merge_recovered: unreliable_index[%zu] = %u is >= the main queue's %zu records", j, unreliable_index[j], count);
     OC_HIP_TRY(ochip::launch_poi_split(d_in, stride_f, n_unreliable, P, d_idx_in, d_rec, 0, d_idx_rec, d_rem, d_idx_rem, nullptr, 0,
                                        e->split_scratch.as<unsigned>(), e->stream));
     OC_TRY(read_split_totals(e, n_unreliable, totals));

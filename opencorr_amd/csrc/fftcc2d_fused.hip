@@ -32,10 +32,13 @@ using namespace fftdev;
 constexpr int FN = 32;               // window side (2 * radius)
 constexpr int FP = FN + 1;           // LDS row pitch in complex elements
 constexpr int FWAVE_LDS = FN * FP;   // float2 elements per wave
-// OC_FFTCC2D_X2 = 1 (the default since round 3) launches the two-POIs-per-wave kernel further down instead of this one
+// OC_FFTCC2D_X2 = 1 (the default since round 3) launches the two-POIs-per-wave kernel further down instead of this one.
+// The round-1 kernel is an A/B partner: it is COMPILED only with -DOC_FFTCC2D_X2=0 (tools/ab_build.py), the library that
+// ships does not contain it (round 5).
 #ifndef OC_FFTCC2D_X2
 #define OC_FFTCC2D_X2 1
 #endif
+#if !OC_FFTCC2D_X2
 #ifndef OC_FFTCC2D_WAVES
 #define OC_FFTCC2D_WAVES 4
 #endif
@@ -58,9 +61,11 @@ __device__ __forceinline__ void fft32_line(const c2* line, int step, int h, c2 (
     }
     fft16<INV>(v);
 }
+#endif  // !OC_FFTCC2D_X2
 
 }  // namespace
 
+#if !OC_FFTCC2D_X2
 __global__ __launch_bounds__(64 * kFusedWaves) void fftcc2d_fused32_kernel(Fftcc2dParams P, float* __restrict__ pois,
                                                                            int stride_f, unsigned long long count,
                                                                            int xcd_chunk) {
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void fftcc2d_fused32_kernel(Fftcc
         poi[poi2d::ZNCC] = best / (sqrtf(rn * tn) * M);
     }
 }
+#endif  // !OC_FFTCC2D_X2
 
 // ---------------------------------------------------------------------------------------------------------------
 // Second mapping (round 3): TWO POIs per wave, one lane per LINE.  Lane (q, l) of half-wave q gathers column l of its POI's
@@ -391,13 +397,14 @@ hipError_t launch_fftcc2d_fused(const Fftcc2dParams& p, float* pois, int stride_
                            (unsigned long long)count, chunk);
         return hipGetLastError();
     }
-#endif
+#else
     const size_t groups = (count + kFusedWaves - 1) / kFusedWaves;
     const int chunk = xcd ? (int)((groups + 7) / 8) : 0;
     const size_t grid = xcd ? (size_t)chunk * 8 : groups;
     hipLaunchKernelGGL(fftcc2d_fused32_kernel, dim3((unsigned)grid), dim3(64 * kFusedWaves), 0, stream, p, pois, stride_f,
                        (unsigned long long)count, chunk);
     return hipGetLastError();
+#endif
 }
 
 }  // namespace ochip

@@ -102,6 +102,9 @@ namespace ochip {
 //                             images in the numerator pass: half the LDS, twice the waves)
 //   MODE 3 = MODE 1 + TAB, MODE 4 = TAB + ts[NT*64] only (the zero-mean reference value is re-formed from the image in
 //                             the numerator pass as well).
+//   MODE 2 (round 5):         ts[NT*64] only, NO table -- MODE 4's footprint for queues that cannot share a table, i.e.
+//                             self-adaptive subsets: the arrays are sized for the LARGEST subset of the batch, so halving
+//                             them is what keeps four workgroups on a CU when radii reach 20 (27 passes).
 //   TAB: one table per WORKGROUP of what depends on (lane, pass) only -- the sample's local coordinates as a float
 //        pair and its byte offset from the subset origin -- filled once by the workgroup's waves: the per-sample
 //        walk (wrap test, selects) and the int -> float conversions of every pass become one or two LDS reads.
@@ -125,6 +128,11 @@ namespace ochip {
 //        505-731): same subset, Hessian and numerator code; the Hessian is kept (column j in lane j), damped and
 //        inverted every iteration, a step is only applied when the ZNSSD went down, out-of-range samples do not
 //        abort (they enter the subset as -1.f), and 2D2 weighs the convergence norm in float.
+// PHASE (round 5, VERDICT r4 item 3: "give the CU two kinds of agents") = the SPLIT launch shape: 0 = everything in one kernel;
+//        1 = the set-up alone (reference mean / norm, steepest-descent sweep, Hessian, inverse): no target array, no gathers ->
+//        the workgroup's LDS is the coordinate table only and the register budget admits more waves; it files
+//        { mean, norm, H^-1 (DOF x DOF, row-major) } per POI in P.setup; 2 = the Gauss-Newton iterations alone, which read
+//        that record instead of recomputing it.  Same operations on the same operands in the same order as PHASE 0: same bits.
 // Every variant performs the same floating-point operations in the same order, so all
 // of them are bit-identical to the oracle in OC_ORDER_LANES.
 // ---------------------------------------------------------------------------
@@ -146,21 +154,27 @@ struct GradSample {
     f2 xy = {0.f, 0.f};
 };
 
-template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC, int OFFS, int LM = 0>
+// floats of a POI's set-up record (PHASE 1 -> PHASE 2): mean, norm, H^-1 row-major
+constexpr int icgn2d_setup_floats(int dof) { return 2 + dof * dof; }
+
+template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC, int OFFS, int LM = 0, int PHASE = 0>
 __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, float* __restrict__ pois,
                                                                Icgn2dLaunch L) {
+    static_assert(PHASE == 0 || (LM == 0 && MODE == 4), "the split launch shape exists for the table variants of ICGN2D1 / ICGN2D2");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NH = DOF * (DOF + 1) / 2;
     constexpr bool TAB = MODE >= 3;
-    constexpr bool KEEP_RS = MODE != 4;  // the zero-mean reference subset is parked in LDS
-    constexpr int ARRAYS = MODE == 0 ? 4 : (MODE == 4 ? 1 : 2);
+    constexpr bool KEEP_RS = MODE != 4 && MODE != 2;  // the zero-mean reference subset is parked in LDS
+    constexpr int ARRAYS = MODE == 0 ? 4 : ((MODE == 4 || MODE == 2) ? 1 : 2);
     // ICGN2D1 in 8-wave workgroups: the eight 6 x 6 Hessians are inverted by ONE wave (coop_inverse6_x8); two more
     // barriers, which every wave passes exactly once -- also the ones that abandon their POI early (leave())
-    constexpr bool COOP = MODE == 4 && DOF == 6 && LM == 0 && WPB == 8;
+    constexpr bool COOP = MODE == 4 && DOF == 6 && LM == 0 && WPB == 8 && PHASE != 2;
+    constexpr bool kSetupOnly = PHASE == 1, kIterOnly = PHASE == 2;
+    constexpr int kSetupFloats = icgn2d_setup_floats(DOF);
     // lockstep sweeps (see OC_SWEEP_BARRIER above): the 8-wave table variants -- one subset size per launch, so every live
     // wave of a workgroup runs the same number of pass groups
     // (the 6-DoF kernel with only two workgroups per CU, variant 4, loses 6 % with them: it keeps them off by default)
-    constexpr int SWEEP_SYNC = (MODE == 4 && LM == 0 && (WPB == 8 || WPB == 4))
+    constexpr int SWEEP_SYNC = (MODE == 4 && LM == 0 && PHASE != 1 && (WPB == 8 || WPB == 4))
                                    ? (OC_SWEEP_BARRIER < 0 ? (DOF == 6 ? ((OCC >= 6 || WPB == 4) ? 2 : 0) : 3) : OC_SWEEP_BARRIER)
                                    : 0;
     // What keeps the sweep barriers deadlock-free although the waves of a workgroup run different iteration counts and may
@@ -296,7 +310,29 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     float ref_norm, ref_mean;
     const int x0r = (int)(px - rx), y0r = (int)(py - ry);
     const unsigned roff = (unsigned)__builtin_amdgcn_readfirstlane((y0r * width + x0r) * 4);
-    {
+    float* const setup_rec = (kSetupOnly || kIterOnly) ? P.setup + idx * (unsigned long long)kSetupFloats : nullptr;
+    if constexpr (kIterOnly) {
+        ref_mean = uni(setup_rec[0]);
+        ref_norm = uni(setup_rec[1]);
+    } else if constexpr (kSetupOnly) {
+        // no per-wave LDS array in the set-up kernel: the raw values are read a second time (coalesced, L2) for the norm
+        float acc = 0.f;
+        passes_batched<kSetupBatch>(
+            NF, NT, (NF * kWave + lane) < N,
+            [&](int t, bool valid) { return valid ? buf_f32(r_ref, off_at(t), roff) : 0.f; },
+            [&](int, bool valid, float v) { acc = valid ? acc + v : acc; });
+        const float mean = wave_allreduce_sum(acc) / fN;
+        ref_mean = uni(mean);
+        acc = 0.f;
+        passes_batched<kSetupBatch>(
+            NF, NT, (NF * kWave + lane) < N,
+            [&](int t, bool valid) { return valid ? buf_f32(r_ref, off_at(t), roff) : 0.f; },
+            [&](int, bool valid, float v) {
+                const float d = v - mean;
+                acc = valid ? mad(d, d, acc) : acc;
+            });
+        ref_norm = uni(sqrtf(wave_allreduce_sum(acc)));
+    } else {
         float acc = 0.f;
         SampleWalk w(lane, r0, c0, W, q64, r64);
         // (MODE 4 parks the raw values in the target array, which is idle until the first sweep)
@@ -331,7 +367,7 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     // ---- steepest-descent image + Hessian (src/oc_icgn.cpp:179-207; 2D2: 716-756), inverse (:210 / :759)
     float hinv_col[DOF];  // lane j < DOF: column j of H^-1
     float hcol[LM ? DOF : 1];  // LM: column j of H itself
-    {
+    if constexpr (!kIterOnly) {
         float h[NH];
 #pragma unroll
         for (int i = 0; i < NH; i++) h[i] = 0.f;
@@ -471,7 +507,26 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
     // dp[i] = sum_j H^-1(i,j) * num[j] is formed inside lane i (ascending j, as the reference's loop) and handed round
     // with DOF broadcasts, instead of DOF x DOF v_readlane per iteration (6.2 cycles each on gfx950).
     float hinv_row[LM ? 1 : DOF];
-    if constexpr (COOP) {
+    if constexpr (kSetupOnly) {
+        // file the POI's set-up record: mean, norm, H^-1 row-major -- the values PHASE 2 loads into hinv_row
+        if (lane == 0) {
+            setup_rec[0] = ref_mean;
+            setup_rec[1] = ref_norm;
+        }
+        if constexpr (COOP) {
+            if (lane < DOF * DOF) setup_rec[2 + lane] = coop_area[wave * 64 + 24 + lane];
+        } else {
+            if (lane < DOF) {
+#pragma unroll
+                for (int i = 0; i < DOF; i++) setup_rec[2 + i * DOF + lane] = hinv_col[i];  // H^-1(i, lane)
+            }
+        }
+        return;
+    } else if constexpr (kIterOnly) {
+        const float* __restrict__ row = setup_rec + 2 + min(lane, DOF - 1) * DOF;
+#pragma unroll
+        for (int j = 0; j < DOF; j++) hinv_row[j] = lane < DOF ? row[j] : 0.f;
+    } else if constexpr (COOP) {
         const float* __restrict__ row = coop_area + wave * 64 + 24 + min(lane, DOF - 1) * DOF;
 #pragma unroll
         for (int j = 0; j < DOF; j++) hinv_row[j] = lane < DOF ? row[j] : 0.f;
@@ -934,17 +989,20 @@ struct VariantInfo {
     int g, mode, pipe, wpb, occ;
 };
 
-template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC, int OFFS, int LM = 0>
+template <int DOF, int G, int MODE, int PIPE, int WPB, int OCC, int OFFS, int LM = 0, int PHASE = 0>
 static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int nt, bool xcd,
                            hipStream_t stream) {
-    constexpr int arrays = MODE == 0 ? 4 : (MODE == 4 ? 1 : 2);
+    constexpr int arrays = PHASE == 1 ? 0 : (MODE == 0 ? 4 : ((MODE == 4 || MODE == 2) ? 1 : 2));  // (the set-up kernel: table only)
     size_t lds = ((size_t)arrays * WPB + (MODE >= 3 ? 3 : 0)) * nt * kWave * sizeof(float);
     if (lds > (size_t)kLdsBudget) return hipErrorInvalidValue;
-    // experiments only (tools/icgn2d_occupancy_probe.py): OC_ICGN2D_LDS_PAD=<bytes> raises the workgroup's LDS request, i.e.
-    // lowers the number of workgroups a CU holds, with nothing else changed
+#if OC_BUILD_AB
+    // experiments only, A/B build only (tools/icgn2d_occupancy_probe.py): OC_ICGN2D_LDS_PAD=<bytes> raises the workgroup's LDS
+    // request, i.e. lowers the number of workgroups a CU holds, with nothing else changed
     static const size_t lds_pad = std::getenv("OC_ICGN2D_LDS_PAD") ? (size_t)std::atol(std::getenv("OC_ICGN2D_LDS_PAD")) : 0;
     if (lds_pad && lds_pad <= (size_t)kLdsBudget && lds_pad > lds) lds = lds_pad;
-    auto kern = icgn2d_kernel<DOF, G, MODE, PIPE, WPB, OCC, OFFS, LM>;
+#endif
+    if (PHASE != 0 && !p.setup) return hipErrorInvalidValue;
+    auto kern = icgn2d_kernel<DOF, G, MODE, PIPE, WPB, OCC, OFFS, LM, PHASE>;
     // the dynamic-LDS limit is a per-device property of the loaded function: raise it once on every
     // device this process launches on (one engine per device is a supported host layout)
     static std::atomic<unsigned long long> attr_devices{0};
@@ -979,20 +1037,34 @@ static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, siz
 //    G = 4 / G = 1 / 5 waves per SIMD lose 1 - 4 %.  The kernel is VALU-issue bound: occupancy barely matters.
 //    6 (round 4): variant 5's table and lockstep sweeps in 4-wave workgroups, four per CU (more independent workgroups per CU,
 //    fewer waves per SIMD): 3.47 against 3.30 ms (profiles/r4i_icgn2d1_variant_ab_4wave_lockstep.json) -- not selected automatically.
+//    7 (round 5): variant 2 with the target array only (MODE 2) -- the self-adaptive default: half the LDS, so that a batch
+//    whose largest subset is 41 x 41 still runs four 4-wave workgroups per CU instead of two.
 // Round 1's G = 2 and software-pipelined variants never won a sweep and are gone.
+// Variants 0 and 6 are measured losers kept as A/B partners: they are compiled only into the A/B build of the library
+// (-DOC_BUILD_AB=1, opencorr_amd/build.py build_ab(); tests that compare them load that build).
 //        id  G mode pipe wpb occ
-#define OC_ICGN2D_VARIANTS(X) \
-    X(0, 3, 0, 0, 1, 1)       \
+#define OC_ICGN2D_VARIANTS_PRODUCT(X) \
     X(1, 3, 1, 0, 1, 4)       \
     X(2, 3, 1, 0, 4, 4)       \
     X(3, 4, 1, 0, 1, 3)       \
     X(4, 3, 4, 0, 8, 4)       \
     X(5, OC_V5_G, 4, 0, 8, OC_V5_OCC) \
+    X(7, 3, 2, 0, 4, 4)
+#define OC_ICGN2D_VARIANTS_AB(X) \
+    X(0, 3, 0, 0, 1, 1)       \
     X(6, 2, 4, 0, 4, 4)
+#if OC_BUILD_AB
+#define OC_ICGN2D_VARIANTS(X) OC_ICGN2D_VARIANTS_PRODUCT(X) OC_ICGN2D_VARIANTS_AB(X)
+#else
+#define OC_ICGN2D_VARIANTS(X) OC_ICGN2D_VARIANTS_PRODUCT(X)
+#endif
+#define OC_ICGN2D_VARIANTS_ALL(X) OC_ICGN2D_VARIANTS_PRODUCT(X) OC_ICGN2D_VARIANTS_AB(X)
+
+constexpr int kSplitVariant = 8;
 
 template <int DOF>
 static hipError_t launch_dof(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
-                             hipStream_t stream) {
+                             hipStream_t stream, int phase = 0) {
     if (count == 0) return hipSuccess;
     // p.rx, p.ry: the engine's radius, or in self-adaptive mode the largest radii of the batch
     const int N = (2 * p.rx + 1) * (2 * p.ry + 1);
@@ -1004,18 +1076,33 @@ static hipError_t launch_dof(const Icgn2dParams& p, float* pois, int stride_f, s
                          : launch_t<DOF, GG, MM, PP, WW, OO, 0>(p, pois, stride_f, count, nt, xcd, stream);
         OC_ICGN2D_VARIANTS(X)
 #undef X
-        default: return hipErrorInvalidValue;
+        case kSplitVariant: {
+            // the split launch shape: the set-up kernel (table only in LDS, 8 / 4 waves per SIMD by registers) files
+            // mean, norm and H^-1 per POI in p.setup, the iteration kernel -- the big-queue default's shape, variant 5 for
+            // 6 DoF and variant 4 for 12 -- reads them.  Back to back on one stream here; capi.hip may instead feed the two
+            // kernels chunk-wise on two streams so that set-up workgroups of chunk k + 1 are co-resident with iteration
+            // workgroups of chunk k (`phase` = 1 / 2 launches one of them alone).
+            constexpr int SOCC = DOF == 6 ? 8 : 4, IG = DOF == 6 ? OC_V5_G : 3, IOCC = DOF == 6 ? OC_V5_OCC : 4;
+            hipError_t err = hipSuccess;
+            if (phase == 0 || phase == 1)
+                err = p.offsets ? launch_t<DOF, 1, 4, 0, 8, SOCC, 1, 0, 1>(p, pois, stride_f, count, nt, xcd, stream)
+                                : launch_t<DOF, 1, 4, 0, 8, SOCC, 0, 0, 1>(p, pois, stride_f, count, nt, xcd, stream);
+            if (err != hipSuccess || phase == 1) return err;
+            return p.offsets ? launch_t<DOF, IG, 4, 0, 8, IOCC, 1, 0, 2>(p, pois, stride_f, count, nt, xcd, stream)
+                             : launch_t<DOF, IG, 4, 0, 8, IOCC, 0, 0, 2>(p, pois, stride_f, count, nt, xcd, stream);
+        }
+        default: return hipErrorNotSupported;  // an A/B partner that this build does not contain, or an unknown id
     }
 }
 
 hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
-                          hipStream_t stream) {
-    return launch_dof<6>(p, pois, stride_f, count, variant, xcd, stream);
+                          hipStream_t stream, int phase) {
+    return launch_dof<6>(p, pois, stride_f, count, variant, xcd, stream, phase);
 }
 
 hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
-                          hipStream_t stream) {
-    return launch_dof<12>(p, pois, stride_f, count, variant, xcd, stream);
+                          hipStream_t stream, int phase) {
+    return launch_dof<12>(p, pois, stride_f, count, variant, xcd, stream, phase);
 }
 
 // IC-LM: one launch shape each (G = 3, gradients re-read, one wave per workgroup so the LDS limit is the
@@ -1037,25 +1124,40 @@ hipError_t launch_iclm2d2(const Icgn2dParams& p, float* pois, int stride_f, size
 #if !OC_FMA
 // ---- the arithmetic-independent part and the dispatch between the two builds (this translation unit only) ----
 using OC_ARITH::kLdsBudget;
-constexpr int kIcgn2dVariants = 7;
+constexpr int kIcgn2dVariants = 9;   // 0 ... 7: one kernel each; 8: the split launch shape (set-up kernel + iteration kernel)
 
 int icgn2d_variant_count() { return kIcgn2dVariants; }
 
+// the launch shape of a variant id, whether this build contains it or not
 int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int* occ) {
     switch (variant) {
 #define X(ID, GG, MM, PP, WW, OO) \
     case ID: *g = GG; *mode = MM; *pipe = PP; *wpb = WW; *occ = OO; return 0;
-        OC_ICGN2D_VARIANTS(X)
+        OC_ICGN2D_VARIANTS_ALL(X)
 #undef X
+        case 8: *g = OC_V5_G; *mode = 4; *pipe = 0; *wpb = 8; *occ = OC_V5_OCC; return 0;  // (the iteration kernel's shape at 6 DoF)
         default: return -1;
     }
 }
+
+bool icgn2d_variant_built(int variant) {
+    switch (variant) {
+#define X(ID, GG, MM, PP, WW, OO) \
+    case ID: return true;
+        OC_ICGN2D_VARIANTS(X)
+#undef X
+        case 8: return true;
+        default: return false;
+    }
+}
+
+int icgn2d_setup_record_floats(int dof) { return sep::icgn2d_setup_floats(dof); }
 
 // largest sample count a variant can hold in LDS
 int icgn2d_max_samples(int variant) {
     int g, mode, pipe, wpb, occ;
     if (icgn2d_variant_info(variant, &g, &mode, &pipe, &wpb, &occ)) return 0;
-    const int arrays = mode == 0 ? 4 : (mode == 4 ? 1 : 2);
+    const int arrays = mode == 0 ? 4 : ((mode == 4 || mode == 2) ? 1 : 2);
     return kLdsBudget / ((arrays * wpb + (mode >= 3 ? 3 : 0)) * (int)sizeof(float) * kWave) * kWave;
 }
 
@@ -1063,14 +1165,14 @@ int iclm2d_max_samples() { return kLdsBudget / (2 * (int)sizeof(float) * kWave) 
 
 // p.arith_fma selects the build whose per-sample multiply-adds are fused (oc_device.h; icgn2d_fma.o)
 hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
-                          hipStream_t stream) {
-    return p.arith_fma ? fma::launch_icgn2d1(p, pois, stride_f, count, variant, xcd, stream)
-                       : sep::launch_icgn2d1(p, pois, stride_f, count, variant, xcd, stream);
+                          hipStream_t stream, int phase) {
+    return p.arith_fma ? fma::launch_icgn2d1(p, pois, stride_f, count, variant, xcd, stream, phase)
+                       : sep::launch_icgn2d1(p, pois, stride_f, count, variant, xcd, stream, phase);
 }
 hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int variant, bool xcd,
-                          hipStream_t stream) {
-    return p.arith_fma ? fma::launch_icgn2d2(p, pois, stride_f, count, variant, xcd, stream)
-                       : sep::launch_icgn2d2(p, pois, stride_f, count, variant, xcd, stream);
+                          hipStream_t stream, int phase) {
+    return p.arith_fma ? fma::launch_icgn2d2(p, pois, stride_f, count, variant, xcd, stream, phase)
+                       : sep::launch_icgn2d2(p, pois, stride_f, count, variant, xcd, stream, phase);
 }
 hipError_t launch_iclm2d1(const Icgn2dParams& p, float* pois, int stride_f, size_t count, bool xcd, hipStream_t stream) {
     return p.arith_fma ? fma::launch_iclm2d1(p, pois, stride_f, count, xcd, stream) : sep::launch_iclm2d1(p, pois, stride_f, count, xcd, stream);

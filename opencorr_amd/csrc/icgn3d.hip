@@ -516,9 +516,11 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
 size_t icgn3d1_scratch_floats(int rx, int ry, int rz, int* blocks) {
     const size_t n = (size_t)(2 * rx + 1) * (2 * ry + 1) * (2 * rz + 1);
     *blocks = 512;
-    // experiments only (tools/icgn3d_occupancy_probe.py): OC_ICGN3D_BLOCKS=256 leaves ONE persistent workgroup per CU
+#if OC_BUILD_AB
+    // experiments only, A/B build only (tools/icgn3d_occupancy_probe.py): OC_ICGN3D_BLOCKS=256 leaves ONE persistent workgroup per CU
     static const int env_blocks = std::getenv("OC_ICGN3D_BLOCKS") ? std::atoi(std::getenv("OC_ICGN3D_BLOCKS")) : 0;
     if (env_blocks >= 8 && env_blocks <= 512) *blocks = env_blocks / 8 * 8;
+#endif
     return n * (size_t)*blocks;
 }
 

@@ -1,4 +1,6 @@
-// icgn3d_rows.hip -- ICGN3D1 with ONE HALF-WAVE PER SUBVOLUME ROW (round 4; the default mapping).
+// icgn3d_rows.hip -- ICGN3D1 with ONE HALF-WAVE PER SUBVOLUME ROW (round 4).  NOT the default mapping: measured 12 - 25 %
+// slower than icgn3d.hip, it is the A/B partner behind oc_hip_set_tuning("icgn3d_mapping", 1) and is compiled
+// only into the A/B build of the library (-DOC_BUILD_AB=1, opencorr_amd/build.py --ab).  Oracle order: OC_ORDER_ROWS.
 //
 // Replaces ICGN3D1::compute(POI3D*) (src/oc_icgn.cpp:1270-1490) for a whole POI queue (:1492-1500), like icgn3d.hip, whose
 // mapping (sample s owned by thread s mod 512) stays available behind oc_hip_set_tuning("icgn3d_mapping", 0) as the A/B
@@ -638,12 +640,13 @@ size_t icgn3d1_rows_slot_floats(int rx, int ry, int rz) {
     return mb * nch * kBlock3d + (nt + kBlock3d - 1) / kBlock3d * kBlock3d;
 }
 
-hipError_t launch_icgn3d1_rows(const Icgn3dParams& p, float* pois, int stride_f, size_t count, hipStream_t stream) {
+// `blocks` = persistent workgroups = scratch slots of icgn3d1_rows_slot_floats() floats each that p.scratch holds (the caller
+// sized the allocation with it: icgn3d1_scratch_floats)
+hipError_t launch_icgn3d1_rows(const Icgn3dParams& p, float* pois, int stride_f, size_t count, int blocks, hipStream_t stream) {
     if (count == 0) return hipSuccess;
-    if (!p.scratch) return hipErrorInvalidValue;
+    if (!p.scratch || blocks < 8) return hipErrorInvalidValue;
     // no row has 28 samples: everything is "tail", i.e. the mapping of icgn3d.hip itself (same bits: OC_ORDER_ROWS == OC_ORDER_LANES there)
     if (rows_body_chunks(2 * p.rx + 1) == 0) return launch_icgn3d1(p, pois, stride_f, count, stream);
-    const int blocks = 512;
     unsigned grid = (unsigned)(count < (size_t)blocks ? count : (size_t)blocks);
     grid = (grid + 7) / 8 * 8;  // whole XCD rounds (idle workgroups exit at once); never more than `blocks` slots
     Icgn3dParams q = p;

@@ -4,6 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+// OC_BUILD_AB = 1: the A/B build of the library (opencorr_amd/build.py --ab -> lib/ab/libopencorr_hip_ab.so) also contains the
+// measured losers kept as comparison partners -- icgn2d variants 0 and 6, the ICGN3D1 row mapping (icgn3d_rows.hip) -- and
+// honours the experiment environment knobs (OC_ICGN3D_BLOCKS, OC_ICGN2D_LDS_PAD).  The library that ships is built without it.
+#ifndef OC_BUILD_AB
+#define OC_BUILD_AB 0
+#endif
+
 namespace ochip {
 
 // ---- prepare2d.hip ---------------------------------------------------------
@@ -27,6 +34,8 @@ struct Icgn2dParams {
     double lm_log_lambda;
     float lm_alpha, lm_beta;
     int arith_fma;  // 1: the build whose per-sample multiply-adds are fused (oc_device.h OC_FMA; oracle OC_ORDER_LANES_FMA)
+    float* setup;   // variant 8 (split launch shape): icgn2d_setup_record_floats(dof) floats per POI -- mean, norm, H^-1 -- written by
+                    // the set-up kernel and read by the iteration kernel; nullptr otherwise
 };
 // writes max over the queue of (int)subset_radius.x / .y to out2[0], out2[1]
 hipError_t launch_poi2d_max_radius(const float* pois, int stride_floats, size_t count, int* out2, hipStream_t stream);
@@ -34,20 +43,23 @@ hipError_t launch_poi2d_max_radius(const float* pois, int stride_floats, size_t 
 // software pipelining, waves per workgroup; icgn2d.hip).  `variant` indexes that table,
 // `xcd` turns on the XCD-contiguous mapping of workgroups to the POI queue.
 // Returns hipErrorInvalidValue if the subset does not fit the variant's LDS budget.
+// phase (variant 8 only): 0 = set-up kernel then iteration kernel on `stream`, 1 = the set-up kernel alone, 2 = the iteration
+// kernel alone (the caller orders it behind the set-up of the same POIs)
 hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, int variant, bool xcd,
-                          hipStream_t stream);
+                          hipStream_t stream, int phase = 0);
 // ICLM2D1 / ICLM2D2 (src/oc_iclm.cpp): the same kernel with the Levenberg-Marquardt step
 hipError_t launch_iclm2d1(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
 hipError_t launch_iclm2d2(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
 int iclm2d_max_samples();
 hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, int variant, bool xcd,
-                          hipStream_t stream);
+                          hipStream_t stream, int phase = 0);
+int icgn2d_setup_record_floats(int dof);
 // the two builds of icgn2d.hip (oc_device.h: OC_FMA = 0 / 1) behind the four launchers above
 #define OC_DECLARE_ICGN2D_LAUNCHERS                                                                                          \
     hipError_t launch_icgn2d1(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, int variant, bool xcd,   \
-                              hipStream_t stream);                                                                          \
+                              hipStream_t stream, int phase);                                                               \
     hipError_t launch_icgn2d2(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, int variant, bool xcd,   \
-                              hipStream_t stream);                                                                          \
+                              hipStream_t stream, int phase);                                                               \
     hipError_t launch_iclm2d1(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream); \
     hipError_t launch_iclm2d2(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
 namespace sep {
@@ -59,6 +71,8 @@ OC_DECLARE_ICGN2D_LAUNCHERS
 #undef OC_DECLARE_ICGN2D_LAUNCHERS
 int icgn2d_variant_count();
 int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int* occ);
+// variants 0 and 6 are A/B partners that only the A/B build of the library contains (-DOC_BUILD_AB=1)
+bool icgn2d_variant_built(int variant);
 // variants with a per-workgroup coordinate table (mode >= 3) need one subset radius per launch
 inline bool icgn2d_variant_uses_table(int variant) {
     int g, mode, pipe, wpb, occ;
@@ -161,7 +175,7 @@ hipError_t launch_icgn3d1(const Icgn3dParams& p, float* pois, int stride_floats,
 // same solver with one half-wave per subvolume row (oracle order OC_ORDER_ROWS), measured 12 - 25 % slower; its scratch
 // slots are a little larger (whole steps): icgn3d1_rows_slot_floats floats per workgroup, 512 workgroups
 size_t icgn3d1_rows_slot_floats(int rx, int ry, int rz);
-hipError_t launch_icgn3d1_rows(const Icgn3dParams& p, float* pois, int stride_floats, size_t count, hipStream_t stream);
+hipError_t launch_icgn3d1_rows(const Icgn3dParams& p, float* pois, int stride_floats, size_t count, int blocks, hipStream_t stream);
 
 // ---- fftcc2d.hip -----------------------------------------------------------
 struct Fftcc2dParams {
@@ -233,6 +247,8 @@ struct PoiSplitParams {
     int zncc_at, conv_at;
     float zncc_low, zncc_high, conv;
 };
+// flag[0] <- 1 when any of the n device-resident indices is >= limit, else 0
+hipError_t launch_poi_index_range(const unsigned* index, size_t n, size_t limit, unsigned* flag, hipStream_t stream);
 // unsigned words of device scratch: per-block counts, then the two totals and the bad-index flag (the last three words)
 size_t poi_split_scratch_words(size_t count);
 // main_queue / main_count: class-0 records are also written back to main_queue[index_in[i]] -- never past main_count

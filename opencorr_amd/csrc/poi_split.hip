@@ -135,6 +135,26 @@ __global__ __launch_bounds__(kSplitBlock) void poi_split_scatter_kernel(const fl
 
 }  // namespace
 
+// flag[0] = 1 if any of the n indices is >= limit (cheap pre-pass of oc_hip_merge_recovered on DEVICE lists: nothing of the
+// caller's is written before the list is known to be clean)
+__global__ __launch_bounds__(256) void poi_index_range_kernel(const unsigned* __restrict__ index, unsigned n, unsigned limit,
+                                                              unsigned* __restrict__ flag) {
+    bool bad = false;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) bad = bad || index[i] >= limit;
+    if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) atomicOr(flag, 1u);
+}
+
+hipError_t launch_poi_index_range(const unsigned* index, size_t n, size_t limit, unsigned* flag, hipStream_t stream) {
+    hipError_t err = hipMemsetAsync(flag, 0, sizeof(unsigned), stream);
+    if (err != hipSuccess || n == 0) return err;
+    if (n > 0xffffffffull) return hipErrorInvalidValue;
+    if (limit > 0xffffffffull) return hipSuccess;  // 32-bit indices cannot exceed it
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(poi_index_range_kernel, dim3(blocks), dim3(256), 0, stream, index, (unsigned)n, (unsigned)limit, flag);
+    return hipGetLastError();
+}
+
 // per-block counts (2 per block) | totals[2] | bad-index flag
 size_t poi_split_scratch_words(size_t count) { return 2 * ((count + kSplitBlock - 1) / kSplitBlock) + 3; }
 

@@ -158,7 +158,9 @@ class _Engine:
         return ptr.value, blk.value
 
     def set_tuning(self, key, value):
-        """Performance knob of the C-ABI (``oc_hip_set_tuning``); results never change."""
+        """Knob of the C-ABI (``oc_hip_set_tuning``).  Every key but one selects among kernels that compute the same bits;
+        ``"arith_fma"`` = 1 switches the ICGN / IC-LM solvers to the fused arithmetic contract (one rounding fewer per
+        per-sample multiply-add: oracle order ``ORDER_LANES_FMA``; results move by rounding, inside the 1e-4 tolerance)."""
         capi.check(capi.lib().oc_hip_set_tuning(self._h, key.encode(), int(value)))
 
     def reset_stream(self):
@@ -275,7 +277,9 @@ class _Engine:
         """pointer of a queue-index list: one 32-bit integer per record, same memory kind as the queues"""
         if _is_torch(index):
             import torch
-            if index.dtype not in (torch.int32, torch.uint32) or not index.is_contiguous() or index.dim() != 1 or not index.is_cuda:
+            # (torch.uint32 exists from torch 2.3 on)
+            ok_dtypes = tuple(d for d in (torch.int32, getattr(torch, "uint32", None)) if d is not None)
+            if index.dtype not in ok_dtypes or not index.is_contiguous() or index.dim() != 1 or not index.is_cuda:
                 raise ValueError("%s must be a contiguous 1-d int32 CUDA tensor" % name)
             mem, n, p = capi.DEVICE, index.shape[0], ctypes.c_void_p(index.data_ptr())
         else:

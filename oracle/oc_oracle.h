@@ -49,7 +49,8 @@
  *                     xor-butterfly with ascending offsets 1,2,4,...,lanes/2.
  *                     The 2D HIP kernels (lanes = 64) and the ICGN3D1 kernel of
  *                     icgn3d.hip (lanes = 512) are bit-exact against this mode.
- *   OC_ORDER_ROWS   : ICGN3D1 only -- the association of the default 3D kernel
+ *   OC_ORDER_ROWS   : ICGN3D1 only -- the association of the row-mapping A/B kernel (NOT the
+ *                     default: that is icgn3d.hip / OC_ORDER_LANES with lanes = 512)
  *                     (icgn3d_rows.hip, one half-wave per subvolume row), `lanes`
  *                     = 512 threads: with SX = 2rx+1 samples per row and NCH =
  *                     (SX/32 >= 2 ? 2 : SX/32 + (SX%32 >= 28)) chunks of 32 columns,

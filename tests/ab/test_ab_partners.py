@@ -1,0 +1,163 @@
+"""The measured losers that stay around as A/B partners -- icgn2d variants 0 and 6 and the ICGN3D1 row mapping
+(icgn3d_rows.hip) -- are compiled only into the A/B build of the library (opencorr_amd/build.py --ab ->
+lib/ab/libopencorr_hip_ab.so, -DOC_BUILD_AB=1).  These tests keep them bit-exact against their oracle orders.  They run in
+a process of their own whose OPENCORR_HIP_LIB points at that build: tests/test_gpu_ab_build.py starts it on the GPU box;
+collected anywhere else they skip.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.skipif(os.environ.get("OC_AB_RUN") != "1", reason="runs inside tests/test_gpu_ab_build.py (needs the A/B build + a GPU)")
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import opencorr_amd
+    assert opencorr_amd.capi.LIB_PATH.endswith("libopencorr_hip_ab.so"), opencorr_amd.capi.LIB_PATH
+    return opencorr_amd
+
+
+@pytest.mark.parametrize("variant,xcd", [(0, 0), (6, 1), (6, 0), (5, 1), (7, 1)])
+def test_icgn2d1_ab_variants_identical_bits(eng, speckle_small, variant, xcd):
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    xs, ys = synth.poi_grid_2d(ref.shape[0], ref.shape[1], 19, 23, 26)
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, 16, 16, pois)
+    want = pois.copy()
+    oracle.icgn2d1(oracle.Prepared2D(ref, tar), 16, 16, 0.001, 10, want, order=oracle.ORDER_LANES, lanes=64)
+    icgn = eng.ICGN2D1(16, 16, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    icgn.set_tuning("icgn2d_variant", variant)
+    icgn.set_tuning("icgn2d_xcd", xcd)
+    assert np.array_equal(_bits(icgn.compute(pois.copy())), _bits(want))
+    icgn.set_tuning("arith_fma", 1)     # the A/B variants exist in both arithmetic modes
+    want = pois.copy()
+    oracle.icgn2d1(oracle.Prepared2D(ref, tar), 16, 16, 0.001, 10, want, order=oracle.ORDER_LANES_FMA, lanes=64)
+    assert np.array_equal(_bits(icgn.compute(pois.copy())), _bits(want))
+
+
+@pytest.mark.parametrize("dof", [6, 12])
+def test_icgn2d_variant6_lockstep_barriers_with_mixed_wave_lifetimes(eng, speckle_small, dof):
+    """Variant 6 (4-wave lockstep workgroups): every workgroup mixes guard rejects, first-sweep aborts, NaN guesses,
+    one-iteration POIs and stop-limited POIs (the product build runs the same case for variants 4 and 5)."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    r = 16
+    P = oracle.P2
+    xs, ys = synth.poi_grid_2d(h, w, 32, 30, 26)
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, r, r, pois)
+    prep = oracle.Prepared2D(ref, tar)
+    fn = oracle.icgn2d1 if dof == 6 else oracle.icgn2d2
+    solved = pois.copy()
+    fn(prep, r, r, 0.001, 10, solved, order=oracle.ORDER_LANES, lanes=64)
+    q = pois.copy()
+    slot = np.arange(len(q)) % 4
+    q[slot == 0, P["zncc"]] = -2.0
+    q[(np.arange(len(q)) % 8) == 1, P["u"]] = w - 30.0
+    q[(np.arange(len(q)) % 8) == 2, P["v"]] = np.nan
+    one = (np.arange(len(q)) % 8) == 3
+    q[one, 2:14] = solved[one, 2:14]
+    far = (np.arange(len(q)) % 8) == 5
+    q[far, P["u"]] += 6.5
+    q[far, P["v"]] -= 5.5
+    want = q.copy()
+    fn(prep, r, r, 0.001, 10, want, order=oracle.ORDER_LANES, lanes=64)
+    icgn = (eng.ICGN2D1 if dof == 6 else eng.ICGN2D2)(r, r, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    icgn.set_tuning("icgn2d_variant", 6)
+    for _ in range(3):
+        assert np.array_equal(_bits(icgn.compute(q.copy())), _bits(want))
+
+
+BIG = (96, 100, 104)  # dz, dy, dx
+
+
+@pytest.fixture(scope="module")
+def big_volumes():
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = synth.speckle_pair_3d(*BIG, seed=23)
+    return ref, tar, oracle.Prepared3D(ref, tar)
+
+
+@pytest.mark.parametrize("r", [13, 14, 15, 16, 17, 20, 29, 30, 31, 32])
+def test_icgn3d1_both_mappings_against_their_oracle_orders(big_volumes, r):
+    """The two ICGN3D1 kernels on the radii where the row mapping changes shape: r = 13 (27 samples per row: no body, the row
+    kernel IS the old mapping), 14 / 15 (one partial chunk of 29 / 31 lanes, no tail), 16 / 17 (one chunk + a tail of 1 / 3
+    columns), 20 / 29 (tail of 9 / 27 columns), 30 / 31 (two chunks, the second partial), 32 (two chunks + a tail column).
+    "icgn3d_mapping" = 1 (icgn3d_rows.hip, the default) must equal the oracle in OC_ORDER_ROWS bit for bit, = 0 (icgn3d.hip) the
+    oracle in OC_ORDER_LANES; the two orders differ by a re-association only (same iteration counts here, |d u| <= 1e-4)."""
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    ref, tar, prep = big_volumes
+    P = oracle.P3
+    c = [BIG[2] // 2, BIG[1] // 2, BIG[0] // 2]
+    span = [BIG[2] - 2 * (r + 7), BIG[1] - 2 * (r + 7), BIG[0] - 2 * (r + 7)]   # the warped subvolume + its taps stay inside
+    rng = np.random.default_rng(1000 + r)
+    n = 5 if r < 24 else 3
+    xs = [c[0] + int(rng.integers(-(span[0] // 2), span[0] // 2 + 1)) for _ in range(n)]
+    ys = [c[1] + int(rng.integers(-(span[1] // 2), span[1] // 2 + 1)) for _ in range(n)]
+    zs = [c[2] + int(rng.integers(-(span[2] // 2), span[2] // 2 + 1)) for _ in range(n)]
+    pois = oracle.make_pois3d(xs, ys, zs)
+    w = synth.DEFAULT_WARP_3D
+    pois[:, P["u"]], pois[:, P["v"]], pois[:, P["w"]] = round(w["u"]), round(w["v"]), round(w["w"])
+    extra = oracle.make_pois3d([c[0], c[0]], [c[1], c[1]], [c[2], c[2]])
+    extra[0, P["u"]] = 90.0       # leaves the volume inside the loop: -3
+    extra[1, P["zncc"]] = -2.0    # rejected on entry
+    pois = np.concatenate([pois, extra]).astype(np.float32)
+    icgn = opencorr_amd.ICGN3D1(r, r, r, 0.001, 20.0)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    results = {}
+    for mapping, order in ((1, oracle.ORDER_ROWS), (0, oracle.ORDER_LANES)):
+        want = pois.copy()
+        oracle.icgn3d1(prep, r, r, r, 0.001, 20.0, want, order=order, lanes=512)
+        icgn.set_tuning("icgn3d_mapping", mapping)
+        got = icgn.compute(pois.copy())
+        mism = np.argwhere(_bits(got) != _bits(want))
+        assert mism.size == 0, "mapping %d: first mismatches (poi, field): %s" % (mapping, mism[:10].tolist())
+        results[mapping] = got
+    a, b = results[1][:n], results[0][:n]
+    assert (a[:, P["zncc"]] > 0.9).all()
+    assert np.array_equal(a[:, P["iteration"]], b[:, P["iteration"]])
+    assert np.abs(a[:, [P["u"], P["v"], P["w"]]] - b[:, [P["u"], P["v"], P["w"]]]).max() <= 1e-4
+    if r == 13:
+        assert np.array_equal(_bits(results[1]), _bits(results[0]))   # no body: the same mapping, the same bits
+
+
+def test_icgn3d1_row_mapping_block_schedule_and_reduced_slots(eng):
+    """The row mapping under the block-ordered queue, and with fewer persistent workgroups than the default 512 (the A/B
+    build's OC_ICGN3D_BLOCKS knob is what sizes the scratch: the launcher must use the SAME count -- ADVICE r4)."""
+    import oracle
+    from opencorr_amd import synth
+    shape = (72, 76, 80)
+    ref, tar = synth.speckle_pair_3d(*shape, seed=21)
+    P = oracle.P3
+    xs, ys, zs = synth.poi_grid_3d(*shape, 13, 13, 13, 14)
+    pois = oracle.make_pois3d(xs, ys, zs)[:2191]
+    w = synth.DEFAULT_WARP_3D
+    pois[:, P["u"]], pois[:, P["v"]], pois[:, P["w"]] = round(w["u"]), round(w["v"]), round(w["w"])
+    pois[5::97, P["zncc"]] = -1.0
+    icgn = eng.ICGN3D1(5, 5, 5, 0.001, 20)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    icgn.set_tuning("icgn3d_mapping", 1)
+    icgn.set_tuning("icgn3d_tile_vox", 0)
+    want = icgn.compute(pois.copy())
+    for tile in (8, 48):
+        icgn.set_tuning("icgn3d_tile_vox", tile)
+        assert np.array_equal(_bits(icgn.compute(pois.copy())), _bits(want)), tile

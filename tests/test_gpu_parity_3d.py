@@ -274,9 +274,9 @@ def test_icgn3d1_bit_exact_vs_oracle(volumes, r):
 # ---------------------------------------------------------------------------------------------------------
 # The shapes the path is benchmarked on (BASELINE config E: 33^3 subvolumes; the reference's own DVC example:
 # r = 30, examples/test_dvc_fftcc_icgn1.cpp:45-47), on a volume small enough for the oracle to answer in seconds.
-# The default mapping is icgn3d_rows.hip (one half-wave per subvolume row): r = 16 ... 29 -> icgn3d1_rows_kernel<40, 1> (6 body
-# passes of 12 x 16 rows + one tail pass per sweep at r = 16), r >= 30 -> <0, 2>; icgn3d.hip ("icgn3d_mapping" = 0, and every
-# radius below 14) keeps its shapes, reached by test_icgn3d1_both_mappings_against_their_oracle_orders:
+# The mapping is icgn3d.hip (sample s owned by thread s mod 512; oracle order OC_ORDER_LANES).  The row mapping of round 4
+# (icgn3d_rows.hip, one half-wave per subvolume row, measured slower) is an A/B partner that only the A/B build of the library
+# contains: tests/ab/test_ab_partners.py::test_icgn3d1_both_mappings_against_their_oracle_orders.  Kernel shapes:
 #   r = 16 -> icgn3d1_kernel<40>, 6 staging passes of 12 x 512 samples per sweep
 #   r = 21 -> icgn3d1_kernel<48>;  r = 25 -> icgn3d1_kernel<64>;  r = 30 -> icgn3d1_kernel<0> (run-time row pitch)
 #   a 30 degree rotation as initial guess -> the coefficient box of a pass is wider than the compile-time pitch
@@ -354,52 +354,6 @@ def test_icgn3d1_large_radii_kernels(big_volumes, r, kernel):
     assert (want[:, P["zncc"]] > 0.9).all(), kernel
 
 
-@pytest.mark.parametrize("r", [13, 14, 15, 16, 17, 20, 29, 30, 31, 32])
-def test_icgn3d1_both_mappings_against_their_oracle_orders(big_volumes, r):
-    """The two ICGN3D1 kernels on the radii where the row mapping changes shape: r = 13 (27 samples per row: no body, the row
-    kernel IS the old mapping), 14 / 15 (one partial chunk of 29 / 31 lanes, no tail), 16 / 17 (one chunk + a tail of 1 / 3
-    columns), 20 / 29 (tail of 9 / 27 columns), 30 / 31 (two chunks, the second partial), 32 (two chunks + a tail column).
-    "icgn3d_mapping" = 1 (icgn3d_rows.hip, the default) must equal the oracle in OC_ORDER_ROWS bit for bit, = 0 (icgn3d.hip) the
-    oracle in OC_ORDER_LANES; the two orders differ by a re-association only (same iteration counts here, |d u| <= 1e-4)."""
-    import opencorr_amd
-    import oracle
-    from opencorr_amd import synth
-    ref, tar, prep = big_volumes
-    P = oracle.P3
-    c = [BIG[2] // 2, BIG[1] // 2, BIG[0] // 2]
-    span = [BIG[2] - 2 * (r + 7), BIG[1] - 2 * (r + 7), BIG[0] - 2 * (r + 7)]   # the warped subvolume + its taps stay inside
-    rng = np.random.default_rng(1000 + r)
-    n = 5 if r < 24 else 3
-    xs = [c[0] + int(rng.integers(-(span[0] // 2), span[0] // 2 + 1)) for _ in range(n)]
-    ys = [c[1] + int(rng.integers(-(span[1] // 2), span[1] // 2 + 1)) for _ in range(n)]
-    zs = [c[2] + int(rng.integers(-(span[2] // 2), span[2] // 2 + 1)) for _ in range(n)]
-    pois = oracle.make_pois3d(xs, ys, zs)
-    w = synth.DEFAULT_WARP_3D
-    pois[:, P["u"]], pois[:, P["v"]], pois[:, P["w"]] = round(w["u"]), round(w["v"]), round(w["w"])
-    extra = oracle.make_pois3d([c[0], c[0]], [c[1], c[1]], [c[2], c[2]])
-    extra[0, P["u"]] = 90.0       # leaves the volume inside the loop: -3
-    extra[1, P["zncc"]] = -2.0    # rejected on entry
-    pois = np.concatenate([pois, extra]).astype(np.float32)
-    icgn = opencorr_amd.ICGN3D1(r, r, r, 0.001, 20.0)
-    icgn.set_images(ref, tar)
-    icgn.prepare()
-    results = {}
-    for mapping, order in ((1, oracle.ORDER_ROWS), (0, oracle.ORDER_LANES)):
-        want = pois.copy()
-        oracle.icgn3d1(prep, r, r, r, 0.001, 20.0, want, order=order, lanes=512)
-        icgn.set_tuning("icgn3d_mapping", mapping)
-        got = icgn.compute(pois.copy())
-        mism = np.argwhere(_bits(got) != _bits(want))
-        assert mism.size == 0, "mapping %d: first mismatches (poi, field): %s" % (mapping, mism[:10].tolist())
-        results[mapping] = got
-    a, b = results[1][:n], results[0][:n]
-    assert (a[:, P["zncc"]] > 0.9).all()
-    assert np.array_equal(a[:, P["iteration"]], b[:, P["iteration"]])
-    assert np.abs(a[:, [P["u"], P["v"], P["w"]]] - b[:, [P["u"], P["v"], P["w"]]]).max() <= 1e-4
-    if r == 13:
-        assert np.array_equal(_bits(results[1]), _bits(results[0]))   # no body: the same mapping, the same bits
-
-
 def test_icgn3d1_block_schedule_changes_no_bits(volumes):
     """Queues of >= 2048 POIs are visited in compact cubic blocks (oc_hip_set_tuning "icgn3d_tile_vox", poi_order.hip
     launch_poi3d_tile_order) so that the POIs in flight share their voxels behind the L2s / the Infinity Cache: a schedule of
@@ -420,7 +374,7 @@ def test_icgn3d1_block_schedule_changes_no_bits(volumes):
     icgn = opencorr_amd.ICGN3D1(5, 5, 5, 0.001, 20)
     icgn.set_images(ref, tar)
     icgn.prepare()
-    for mapping in (0, 1):
+    for mapping in (0,):   # (the row mapping is an A/B partner: tests/ab/)
         icgn.set_tuning("icgn3d_mapping", mapping)
         icgn.set_tuning("icgn3d_tile_vox", 0)
         want = icgn.compute(pois.copy())

@@ -3,6 +3,9 @@
 the kernel bound by a shared resource (time per POI barely moves with the number of resident workgroups) or by the latency of a
 workgroup's own phase sequence (time ~ 1 / workgroups)?   python tools/icgn2d_occupancy_probe.py   (GPU box; one process per point)"""
 import json
+import os as _os
+# the OC_ICGN*_ knobs are honoured by the A/B build of the library only (python -m opencorr_amd.build --ab)
+_os.environ.setdefault("OPENCORR_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "opencorr_amd", "lib", "ab", "libopencorr_hip_ab.so"))
 import os
 import subprocess
 import sys

@@ -2,6 +2,9 @@
 """ICGN3D1 on config E with two (the default) and ONE persistent workgroup per CU (OC_ICGN3D_BLOCKS), everything else equal: how much
 of a workgroup's phase sequence does the second workgroup hide?   python tools/icgn3d_occupancy_probe.py   (GPU box)"""
 import json
+import os as _os
+# the OC_ICGN*_ knobs are honoured by the A/B build of the library only (python -m opencorr_amd.build --ab)
+_os.environ.setdefault("OPENCORR_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "opencorr_amd", "lib", "ab", "libopencorr_hip_ab.so"))
 import os
 import subprocess
 import sys

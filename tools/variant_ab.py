@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B timing of ICGN2D kernel variants on config B with HIP events, variants interleaved round by round so that clock
 drift hits all of them alike.  usage: [ENGINE=2 R=20 NS=316] python tools/variant_ab.py 2,4,5 [rounds] [launches]   (GPU box;
-ENGINE=2 R=20 NS=316 is config C: ICGN2D2)"""
+ENGINE=2 R=20 NS=316 is config C: ICGN2D2; ARITH_FMA=1: oc_hip_set_tuning arith_fma = 1)"""
 import json
 import os
 import sys
@@ -25,6 +25,8 @@ xs, ys = synth.poi_grid_2d(side, side, ns, ns, r + 8)
 stream = torch.cuda.current_stream().cuda_stream
 f = oc.FFTCC2D(r, r); f.set_stream(stream); f.set_images(ref, tar)
 g = (oc.ICGN2D1 if engine == 1 else oc.ICGN2D2)(r, r, 0.001, 10.0); g.set_stream(stream); g.share_images(f); g.prepare()
+if os.environ.get("ARITH_FMA") == "1":   # the fused arithmetic contract (every variant exists in both modes)
+    g.set_tuning("arith_fma", 1)
 guess = torch.from_numpy(oc.make_pois2d(xs, ys)).to(dev)
 f.compute(guess)
 q = guess.clone()
@@ -43,7 +45,7 @@ for rd in range(rounds + 1):
             times[v].append(tot / launches)
         bits[v] = q.cpu().numpy().view(np.uint32)
 first = bits[variants[0]]
-print(json.dumps({"workload": "4096^2, r = %d, %d x %d POIs, ICGN2D%d compute() incl. the tile-order kernels, HIP events" % (r, ns, ns, engine), "launches_per_round": launches,
+print(json.dumps({"workload": "4096^2, r = %d, %d x %d POIs, ICGN2D%d compute() incl. the tile-order kernels, HIP events%s" % (r, ns, ns, engine, ", arith_fma = 1" if os.environ.get("ARITH_FMA") == "1" else ""), "launches_per_round": launches,
                   "ms": {str(v): [round(t, 4) for t in ts] for v, ts in times.items()},
                   "mean_ms": {str(v): round(float(np.mean(ts)), 4) for v, ts in times.items()},
                   "same_bits": {str(v): bool(np.array_equal(bits[v], first)) for v in variants}}))
