@@ -202,6 +202,11 @@ struct oc_hip_engine {
     // host-queue pipeline (compute_host): the queue travels in chunks, copies of one chunk overlap the kernels of
     // its neighbours; one event per chunk orders the copy-out stream behind the kernels
     hipStream_t copy_stream = nullptr, copy_in_stream = nullptr;
+    // icgn2d variant 8 with "icgn2d_split_chunks" >= 2: the set-up kernels run on this second stream, one or two chunks ahead
+    // of the iteration kernels on the engine's stream, so that workgroups of both kinds are resident together
+    hipStream_t aux_stream = nullptr;
+    std::vector<hipEvent_t> split_ev;
+    int icgn2d_split_chunks = 0;
     std::vector<hipEvent_t> chunk_done, chunk_in;
     size_t chunks_fed = 0;  // chunks whose kernels (and event) are enqueued; (size_t)-1: the feeder failed.  Guarded by feed_mu
     std::mutex feed_mu;
@@ -571,6 +576,44 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
         OC_TRY(tile_order(e, pois, stride_f, n, &P.perm));
         ProfScope prof(e);  // the solver kernel alone (what rocprofv3 reports for it)
         hipError_t err;
+        if (variant == 8 && !lm && e->icgn2d_split_chunks >= 2 && n >= 16384) {
+            // the split launch shape as a two-stream pipeline over chunks of the visiting order: set-up kernel of chunk c on
+            // the auxiliary stream (at most two chunks ahead), iteration kernel of chunk c on the engine's stream behind it
+            const size_t C = (size_t)e->icgn2d_split_chunks;
+            const size_t m = ((n + C - 1) / C + 7) / 8 * 8;
+            if (!e->aux_stream) OC_HIP_TRY(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
+            while (e->split_ev.size() < 2 * C + 1) {
+                hipEvent_t ev;
+                OC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                e->split_ev.push_back(ev);
+            }
+            OC_HIP_TRY(hipEventRecord(e->split_ev[2 * C], e->stream));         // the queue, its visiting order, the previous call
+            OC_HIP_TRY(hipStreamWaitEvent(e->aux_stream, e->split_ev[2 * C], 0));
+            const size_t sf = (size_t)ochip::icgn2d_setup_record_floats(dof);
+            for (size_t c = 0; c * m < n; c++) {
+                const size_t lo = c * m, cnt = (n - lo) < m ? (n - lo) : m;
+                ochip::Icgn2dParams Pc = P;
+                float* pc = pois;
+                if (P.perm) {
+                    Pc.perm = P.perm + lo;   // the records, offsets and set-up records stay addressed by POI index
+                } else {
+                    pc = pois + lo * (size_t)stride_f;
+                    if (Pc.offsets) Pc.offsets += 2 * lo;
+                    Pc.setup += lo * sf;
+                }
+                if (c >= 2) OC_HIP_TRY(hipStreamWaitEvent(e->aux_stream, e->split_ev[2 * (c - 2) + 1], 0));
+                err = dof == 6 ? ochip::launch_icgn2d1(Pc, pc, stride_f, cnt, 8, e->icgn2d_xcd != 0, e->aux_stream, 1)
+                               : ochip::launch_icgn2d2(Pc, pc, stride_f, cnt, 8, e->icgn2d_xcd != 0, e->aux_stream, 1);
+                if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "ICGN2D set-up kernel launch failed: %s", hipGetErrorString(err));
+                OC_HIP_TRY(hipEventRecord(e->split_ev[2 * c], e->aux_stream));
+                OC_HIP_TRY(hipStreamWaitEvent(e->stream, e->split_ev[2 * c], 0));
+                err = dof == 6 ? ochip::launch_icgn2d1(Pc, pc, stride_f, cnt, 8, e->icgn2d_xcd != 0, e->stream, 2)
+                               : ochip::launch_icgn2d2(Pc, pc, stride_f, cnt, 8, e->icgn2d_xcd != 0, e->stream, 2);
+                if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "ICGN2D iteration kernel launch failed: %s", hipGetErrorString(err));
+                OC_HIP_TRY(hipEventRecord(e->split_ev[2 * c + 1], e->stream));
+            }
+            continue;
+        }
         if (lm)
             err = dof == 6 ? ochip::launch_iclm2d1(P, pois, stride_f, n, e->icgn2d_xcd != 0, e->stream)
                            : ochip::launch_iclm2d2(P, pois, stride_f, n, e->icgn2d_xcd != 0, e->stream);
@@ -1017,7 +1060,8 @@ int oc_hip_destroy(oc_hip_engine* e) {
     if (e->group_ev) (void)hipEventDestroy(e->group_ev);
     for (hipEvent_t ev : e->chunk_done) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->chunk_in) (void)hipEventDestroy(ev);
-    for (hipStream_t* st : {&e->copy_stream, &e->copy_in_stream})
+    for (hipEvent_t ev : e->split_ev) (void)hipEventDestroy(ev);
+    for (hipStream_t* st : {&e->copy_stream, &e->copy_in_stream, &e->aux_stream})
         if (*st) {
             (void)hipStreamSynchronize(*st);
             (void)hipStreamDestroy(*st);
@@ -1168,6 +1212,7 @@ static int clone_engine(const oc_hip_engine* e, int device, oc_hip_engine** out)
     r->self_adaptive = e->self_adaptive;
     r->icgn2d_xcd = e->icgn2d_xcd;
     r->arith_fma = e->arith_fma;
+    r->icgn2d_split_chunks = e->icgn2d_split_chunks;
     r->fftcc2d_fused = e->fftcc2d_fused;
     r->fftcc3d_fused = e->fftcc3d_fused;
     r->fftcc3d_planes_blocks = e->fftcc3d_planes_blocks;
@@ -1209,6 +1254,9 @@ static int rehome(oc_hip_engine* e, int device) {
     e->chunk_in.clear();
     if (e->copy_stream) { (void)hipStreamDestroy(e->copy_stream); e->copy_stream = nullptr; }
     if (e->copy_in_stream) { (void)hipStreamDestroy(e->copy_in_stream); e->copy_in_stream = nullptr; }
+    for (hipEvent_t ev : e->split_ev) (void)hipEventDestroy(ev);
+    e->split_ev.clear();
+    if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); e->aux_stream = nullptr; }
     (void)hipStreamDestroy(e->own_stream);
     e->own_stream = nullptr;
     OC_HIP_TRY(hipSetDevice(device));
@@ -1402,6 +1450,9 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
         if (value != 0 && !(e->is_icgn2d() || e->kind == OC_HIP_ICGN3D1))
             return fail(OC_HIP_ERR_UNSUPPORTED, "arith_fma: only the ICGN2D1 / ICGN2D2 / ICLM2D1 / ICLM2D2 / ICGN3D1 engines have a fused-arithmetic build");
         e->arith_fma = value != 0;
+    } else if (k == "icgn2d_split_chunks") {
+        if (value < 0 || value > 256) return fail(OC_HIP_ERR_INVALID, "icgn2d_split_chunks must be 0 (back to back) ... 256");
+        e->icgn2d_split_chunks = value;
     } else if (k == "icgn2d_tile_px") {
         if (value < 0 || (value > 0 && value < 16)) return fail(OC_HIP_ERR_INVALID, "icgn2d_tile_px must be 0 (off) or >= 16");
         e->icgn2d_tile_px = value;

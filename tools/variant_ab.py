@@ -13,7 +13,9 @@ sys.path.insert(0, ".")
 import opencorr_amd as oc
 from opencorr_amd import synth
 
-variants = [int(v) for v in sys.argv[1].split(",")]
+# "8/4" = variant 8 with icgn2d_split_chunks = 4 (the two-stream pipeline of the split launch shape)
+labels = sys.argv[1].split(",")
+variants = labels
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 launches = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 dev = torch.device("cuda", 0)
@@ -34,7 +36,8 @@ times = {v: [] for v in variants}
 bits = {}
 for rd in range(rounds + 1):
     for v in variants:
-        g.set_tuning("icgn2d_variant", v)
+        g.set_tuning("icgn2d_variant", int(v.split("/")[0]))
+        g.set_tuning("icgn2d_split_chunks", int(v.split("/")[1]) if "/" in v else 0)
         tot = 0.0
         for _ in range(launches):
             q.copy_(guess)
