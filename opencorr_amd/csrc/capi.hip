@@ -195,6 +195,7 @@ struct oc_hip_engine {
     int fftcc2d_fused = 1;    // single-kernel FFTCC2D when the window is 32 x 32
     int fftcc3d_fused = 1;    // single-kernel FFTCC3D for cubic windows of side 8 ... 64 (three kernels by size)
     int fftcc3d_planes_blocks = 0;  // persistent workgroups (= scratch volumes) of the plane-wise kernel; 0 = 256
+    int fftcc3d_tile_vox = 64; // FFTCC3D single-kernel paths: queues of >= 2048 POIs are visited in cubic blocks of this many voxels (0 = queue order)
     int icgn3d_tile_vox = 64; // ICGN3D1: queues of >= 2048 POIs are visited in cubic blocks of this many voxels (0 = queue order; config E: 78.8 -> 75.5 ms, profiles/r4g_icgn3d1_ab_block_schedule.txt)
     int icgn3d_mapping = 0;   // ICGN3D1: 0 = sample s owned by thread s mod 512 (icgn3d.hip; oracle order OC_ORDER_LANES) -- the default:
                               // 1 = one half-wave per subvolume row (icgn3d_rows.hip; OC_ORDER_ROWS), built and measured in round 4:
@@ -663,6 +664,20 @@ size_t fftcc3d_chunk_limit() {
     return 1024;
 }
 
+// visiting order of a POI3D queue in compact cubic blocks (poi_order.hip): FFTCC3D's single-kernel paths and ICGN3D1
+int tile_order3d(oc_hip_engine* e, const float* d_pois, int stride_f, size_t count, int tile_vox, const unsigned** perm) {
+    *perm = nullptr;
+    if (tile_vox <= 0 || count < 2048 || count > 0xffffffffull) return OC_HIP_OK;
+    const ImagePair& im = *e->img;
+    OC_TRY(e->perm.reserve(count * sizeof(unsigned)));
+    OC_TRY(e->perm_slots.reserve(count * sizeof(unsigned)));
+    OC_TRY(e->tiles.reserve(ochip::poi3d_tile_count(im.dz, im.dy, im.dx, tile_vox) * sizeof(unsigned)));
+    OC_HIP_TRY(ochip::launch_poi3d_tile_order(d_pois, stride_f, count, im.dz, im.dy, im.dx, tile_vox, e->tiles.as<unsigned>(),
+                                              e->perm_slots.as<unsigned>(), e->perm.as<unsigned>(), e->stream));
+    *perm = e->perm.as<unsigned>();
+    return OC_HIP_OK;
+}
+
 int run_fftcc3d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     if (!e->img || e->img->ndim != 3) return fail(OC_HIP_ERR_INVALID, "FFTCC3D: set_images3d has not been called");
     const ImagePair& im = *e->img;
@@ -674,6 +689,7 @@ int run_fftcc3d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
         blocks = (blocks + 7) / 8 * 8;
         if ((size_t)blocks > (count + 7) / 8 * 8) blocks = (int)((count + 7) / 8 * 8);
         OC_TRY(e->win.reserve(ochip::fftcc3d_planes_scratch_bytes(e->rx, blocks)));
+        OC_TRY(tile_order3d(e, d_pois, stride_f, count, e->fftcc3d_tile_vox, &P.perm));
         ProfScope prof(e);
         hipError_t err = ochip::launch_fftcc3d_planes(P, d_pois, stride_f, count, e->win.p, blocks, e->stream);
         if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "plane-wise FFTCC3D kernel launch failed: %s", hipGetErrorString(err));
@@ -681,6 +697,7 @@ int run_fftcc3d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     }
     if (e->fftcc3d_fused && (fused32 || ochip::fftcc3d_fusedn_supported(e->rx, e->ry, e->rz))) {
         ochip::Fftcc3dParams P = {im.ref_ptr(), im.tar_ptr(), im.dz, im.dy, im.dx, e->rx, e->ry, e->rz};
+        if (count <= (1u << 30)) OC_TRY(tile_order3d(e, d_pois, stride_f, count, e->fftcc3d_tile_vox, &P.perm));
         ProfScope prof(e);
         const size_t kMaxGrid = 1u << 30;
         for (size_t first = 0; first < count; first += kMaxGrid) {
@@ -749,14 +766,7 @@ int run_icgn3d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
         return fail(OC_HIP_ERR_UNSUPPORTED, "ICGN3D1: the row mapping (icgn3d_mapping = 1) has no fused-arithmetic build (arith_fma = 1)");
     // locality schedule: visit the queue in compact cubic blocks, so that the POIs in flight share their voxels behind the
     // L2s / the Infinity Cache (poi_order.hip); same bits for every POI
-    if (e->icgn3d_tile_vox > 0 && count >= 2048 && count <= 0xffffffffull) {
-        OC_TRY(e->perm.reserve(count * sizeof(unsigned)));
-        OC_TRY(e->perm_slots.reserve(count * sizeof(unsigned)));
-        OC_TRY(e->tiles.reserve(ochip::poi3d_tile_count(im.dz, im.dy, im.dx, e->icgn3d_tile_vox) * sizeof(unsigned)));
-        OC_HIP_TRY(ochip::launch_poi3d_tile_order(d_pois, stride_f, count, im.dz, im.dy, im.dx, e->icgn3d_tile_vox, e->tiles.as<unsigned>(),
-                                                  e->perm_slots.as<unsigned>(), e->perm.as<unsigned>(), e->stream));
-        P.perm = e->perm.as<unsigned>();
-    }
+    OC_TRY(tile_order3d(e, d_pois, stride_f, count, e->icgn3d_tile_vox, &P.perm));
     ProfScope prof(e);
 #if OC_BUILD_AB
     hipError_t err = e->icgn3d_mapping != 0 ? ochip::launch_icgn3d1_rows(P, d_pois, stride_f, count, blocks, e->stream)
@@ -1218,6 +1228,7 @@ static int clone_engine(const oc_hip_engine* e, int device, oc_hip_engine** out)
     r->fftcc3d_planes_blocks = e->fftcc3d_planes_blocks;
     r->icgn3d_mapping = e->icgn3d_mapping;
     r->icgn3d_tile_vox = e->icgn3d_tile_vox;
+    r->fftcc3d_tile_vox = e->fftcc3d_tile_vox;
     r->host_chunk = e->host_chunk;
     r->group_allgather = e->group_allgather;
     r->group_force_rccl = e->group_force_rccl;
@@ -1460,6 +1471,9 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
         e->fftcc2d_fused = value == 2 ? 2 : (value != 0);
     } else if (k == "fftcc3d_fused") {
         e->fftcc3d_fused = value != 0;
+    } else if (k == "fftcc3d_tile_vox") {
+        if (value < 0 || (value > 0 && value < 8)) return fail(OC_HIP_ERR_INVALID, "fftcc3d_tile_vox must be 0 (off) or >= 8");
+        e->fftcc3d_tile_vox = value;
     } else if (k == "icgn3d_tile_vox") {
         if (value < 0 || (value > 0 && value < 8)) return fail(OC_HIP_ERR_INVALID, "icgn3d_tile_vox must be 0 (off) or >= 8");
         e->icgn3d_tile_vox = value;

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dPa
     unsigned long long idx = blockIdx.x;
     if (xcd_chunk > 0) idx = (unsigned long long)(blockIdx.x & 7u) * xcd_chunk + (blockIdx.x >> 3);
     if (idx >= count) return;
+    if (P.perm) idx = P.perm[idx];
     float* poi = pois + idx * (unsigned long long)stride_f;
     constexpr int R = TN / 2;
     constexpr int M = TN * TN * TN;

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(Cube<N>::BLOCK) void fftcc3d_fusedn_kernel(Fftcc3dP
     unsigned long long idx = blockIdx.x;
     if (xcd_chunk > 0) idx = (unsigned long long)(blockIdx.x & 7u) * xcd_chunk + (blockIdx.x >> 3);
     if (idx >= count) return;
+    if (P.perm) idx = P.perm[idx];
     float* poi = pois + idx * (unsigned long long)stride_f;
 
     // ---- window coordinates -> voxel indices (src/oc_fftcc.cpp:349-358: Point3D(poi->x + k - rx, ...) truncated, the

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kPlThreads) void fftcc3d_planes_kernel(Fftcc3dParam
     const unsigned long long xcd_chunk = (count + 7) / 8, xcd_lo = (blockIdx.x & 7u) * xcd_chunk;
     const unsigned long long xcd_hi = min(count, xcd_lo + xcd_chunk);
     for (unsigned long long idx = xcd_lo + (blockIdx.x >> 3); idx < xcd_hi; idx += gridDim.x >> 3) {
-        float* poi = pois + idx * (unsigned long long)stride_f;
+        float* poi = pois + (P.perm ? (unsigned long long)P.perm[idx] : idx) * (unsigned long long)stride_f;
         __syncthreads();  // the previous POI is done with the tables and the tiles
 
         // ---- window coordinates -> voxel indices (src/oc_fftcc.cpp:349-358: Point3D(poi->x + k - rx, ...) truncated, the

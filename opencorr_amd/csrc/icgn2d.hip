@@ -1040,7 +1040,7 @@ static hipError_t launch_t(const Icgn2dParams& p, float* pois, int stride_f, siz
 //    7 (round 5): variant 2 with the target array only (MODE 2) -- the self-adaptive default: half the LDS, so that a batch
 //    whose largest subset is 41 x 41 still runs four 4-wave workgroups per CU instead of two.
 // Round 1's G = 2 and software-pipelined variants never won a sweep and are gone.
-// Variants 0 and 6 are measured losers kept as A/B partners: they are compiled only into the A/B build of the library
+// Variants 0, 6 and 8 are measured losers kept as A/B partners: they are compiled only into the A/B build of the library
 // (-DOC_BUILD_AB=1, opencorr_amd/build.py build_ab(); tests that compare them load that build).
 //        id  G mode pipe wpb occ
 #define OC_ICGN2D_VARIANTS_PRODUCT(X) \
@@ -1076,12 +1076,17 @@ static hipError_t launch_dof(const Icgn2dParams& p, float* pois, int stride_f, s
                          : launch_t<DOF, GG, MM, PP, WW, OO, 0>(p, pois, stride_f, count, nt, xcd, stream);
         OC_ICGN2D_VARIANTS(X)
 #undef X
+#if OC_BUILD_AB
         case kSplitVariant: {
             // the split launch shape: the set-up kernel (table only in LDS, 8 / 4 waves per SIMD by registers) files
             // mean, norm and H^-1 per POI in p.setup, the iteration kernel -- the big-queue default's shape, variant 5 for
             // 6 DoF and variant 4 for 12 -- reads them.  Back to back on one stream here; capi.hip may instead feed the two
             // kernels chunk-wise on two streams so that set-up workgroups of chunk k + 1 are co-resident with iteration
             // workgroups of chunk k (`phase` = 1 / 2 launches one of them alone).
+            // MEASURED in round 5 and SLOWER in every form (profiles/r5d_icgn2d_split_launch_shape_ab.json: config B 3.43 vs
+            // 3.39 ms back to back, 3.62 in four chunks on two streams; config C 3.87 vs 3.61): the fused kernel's phases of
+            // different workgroups already overlap on a CU, and three iteration workgroups leave no registers for a
+            // set-up workgroup to move in beside them.  A/B build only.
             constexpr int SOCC = DOF == 6 ? 8 : 4, IG = DOF == 6 ? OC_V5_G : 3, IOCC = DOF == 6 ? OC_V5_OCC : 4;
             hipError_t err = hipSuccess;
             if (phase == 0 || phase == 1)
@@ -1091,6 +1096,7 @@ static hipError_t launch_dof(const Icgn2dParams& p, float* pois, int stride_f, s
             return p.offsets ? launch_t<DOF, IG, 4, 0, 8, IOCC, 1, 0, 2>(p, pois, stride_f, count, nt, xcd, stream)
                              : launch_t<DOF, IG, 4, 0, 8, IOCC, 0, 0, 2>(p, pois, stride_f, count, nt, xcd, stream);
         }
+#endif
         default: return hipErrorNotSupported;  // an A/B partner that this build does not contain, or an unknown id
     }
 }
@@ -1146,7 +1152,7 @@ bool icgn2d_variant_built(int variant) {
     case ID: return true;
         OC_ICGN2D_VARIANTS(X)
 #undef X
-        case 8: return true;
+        case 8: return OC_BUILD_AB != 0;
         default: return false;
     }
 }

@@ -213,6 +213,10 @@ struct Fftcc3dParams {
     const float* tar;
     int dz, dy, dx;
     int rx, ry, rz;
+    // locality schedule of the single-kernel paths (poi_order.hip launch_poi3d_tile_order): the k-th window of the launch
+    // belongs to POI perm[k]; nullptr = queue order.  Round 5: the POIs in flight behind one L2 form a compact block of the
+    // volume instead of a 1 x 1 x 32 row of the queue, so that their overlapping windows are fetched from HBM once.
+    const unsigned* perm = nullptr;
 };
 hipError_t launch_fftcc3d_gather(const Fftcc3dParams& p, const float* pois, int stride_floats, size_t count,
                                  float* ref_win, float* tar_win, float* norms, hipStream_t stream);

@@ -23,7 +23,7 @@ def eng():
     return opencorr_amd
 
 
-@pytest.mark.parametrize("variant,xcd", [(0, 0), (6, 1), (6, 0), (5, 1), (7, 1)])
+@pytest.mark.parametrize("variant,xcd", [(0, 0), (6, 1), (6, 0), (8, 1), (8, 0), (5, 1), (7, 1)])
 def test_icgn2d1_ab_variants_identical_bits(eng, speckle_small, variant, xcd):
     import oracle
     from opencorr_amd import synth
@@ -161,3 +161,36 @@ def test_icgn3d1_row_mapping_block_schedule_and_reduced_slots(eng):
     for tile in (8, 48):
         icgn.set_tuning("icgn3d_tile_vox", tile)
         assert np.array_equal(_bits(icgn.compute(pois.copy())), _bits(want)), tile
+
+
+@pytest.mark.parametrize("dof", [6, 12])
+def test_icgn2d_split_launch_shape_pipeline_same_bits(eng, speckle_small, dof):
+    """Variant 8 -- the set-up kernel files mean, norm and H^-1 per POI, the iteration kernel reads them -- back to back and
+    as the two-stream pipeline over 3 and 7 chunks of the visiting order (`icgn2d_split_chunks`; set-up kernels one or two
+    chunks ahead of the iteration kernels): every bit equal to the single-kernel default, with centre offsets too, twice in
+    a row (the set-up records of the previous call are overwritten)."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    r = 16 if dof == 6 else 12
+    xs, ys = synth.poi_grid_2d(h, w, 150, 120, 24)  # 18000 POIs >= the 16384 of the tile schedule and of the pipeline
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, 12, 12, pois)
+    pois[7::101, oracle.P2["zncc"]] = -1.0
+    pois[11::103, oracle.P2["u"]] = 250.0
+    icgn = (eng.ICGN2D1 if dof == 6 else eng.ICGN2D2)(r, r, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    want = icgn.compute(pois.copy())
+    off = np.random.default_rng(3).uniform(-2, 2, (len(pois), 2)).astype(np.float32)
+    want_off = icgn.compute_with_offsets(pois.copy(), off)
+    sample = pois[::37].copy()
+    (oracle.icgn2d1 if dof == 6 else oracle.icgn2d2)(oracle.Prepared2D(ref, tar), r, r, 0.001, 10, sample, order=oracle.ORDER_LANES, lanes=64)
+    assert np.array_equal(_bits(sample), _bits(want[::37]))
+    icgn.set_tuning("icgn2d_variant", 8)
+    for chunks in (0, 3, 7):
+        icgn.set_tuning("icgn2d_split_chunks", chunks)
+        for _ in range(2):
+            assert np.array_equal(_bits(icgn.compute(pois.copy())), _bits(want)), chunks
+        assert np.array_equal(_bits(icgn.compute_with_offsets(pois.copy(), off)), _bits(want_off)), chunks

@@ -429,3 +429,27 @@ def test_compute_chain_3d_matches_separate_calls(volumes):
     torch.cuda.synchronize()
     assert np.array_equal(_bits(q.cpu().numpy()), _bits(want))
     assert (want[:, 18] > 0.9).mean() > 0.8
+
+
+@pytest.mark.parametrize("r", [6, 16, 15])
+def test_fftcc3d_block_schedule_changes_no_bits(volumes, r):
+    """Round 5: FFTCC3D's single-kernel paths (LDS kernel r = 6, register kernel r = 16, plane-wise kernel r = 15) visit queues
+    of >= 2048 POIs in compact cubic blocks (oc_hip_set_tuning "fftcc3d_tile_vox", the schedule ICGN3D1 uses) so that the
+    overlapping windows of the POIs in flight meet in one L2: independent per-POI work -- every record's bits are those of
+    the queue-order run; border windows (clamped) and integer initial guesses included."""
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = volumes
+    P = oracle.P3
+    xs, ys, zs = synth.poi_grid_3d(*SHAPE, 13, 13, 13, 6)
+    pois = oracle.make_pois3d(xs, ys, zs)[:2191]
+    pois[3::7, P["u"]] = 2.0
+    pois[5::11, P["w"]] = -1.0
+    f = opencorr_amd.FFTCC3D(r, r, r)
+    f.set_images(ref, tar)
+    f.set_tuning("fftcc3d_tile_vox", 0)
+    want = f.compute(pois.copy())
+    for tile in (8, 24, 64):
+        f.set_tuning("fftcc3d_tile_vox", tile)
+        assert np.array_equal(_bits(f.compute(pois.copy())), _bits(want)), tile

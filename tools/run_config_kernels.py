@@ -35,6 +35,8 @@ else:
     pristine = torch.from_numpy(oc.make_pois3d(xs, ys, zs)).to(dev)
 f.set_stream(stream)
 f.set_images(ref, tar)
+if os.environ.get("OC_FFTCC3D_TILE_VOX") and a.config != "C":   # A/B of the FFTCC3D visiting order (0 = queue order)
+    f.set_tuning("fftcc3d_tile_vox", int(os.environ["OC_FFTCC3D_TILE_VOX"]))
 g.set_stream(stream)
 g.share_images(f)
 if os.environ.get("OC_BENCH_ARITH_FMA") == "1":   # the fused arithmetic contract (profiles/*_fma.*)
