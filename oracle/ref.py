@@ -72,6 +72,8 @@ def lib():
         L.oc_ref_fftcc3d.argtypes = [fp, fp, i, i, i, i, i, i, fp, l, i]
         L.oc_ref_icgn3d1.argtypes = [fp, fp, i, i, i, i, i, i, f, f, fp, l, i]
         L.oc_ref_prepare3d.argtypes = [fp, fp, i, i, i, fp, fp, fp, fp, l, fp]
+        if hasattr(L, "oc_ref_epipolar_search"):
+            L.oc_ref_epipolar_search.argtypes = [fp, fp, i, i, fp, fp, fp, fp, i, i, fp, fp, i, i, f, f, fp, l, i, fp]
         L.oc_ref_strain.argtypes = [i, fp, l, f, i, f, i, i]
         L.oc_ref_region_fit.argtypes = [i, fp, l, fp, l, f, i, i]
         _lib = L
@@ -119,6 +121,24 @@ def time_icgn2d1(ref, tar, rx, ry, conv, stop, pois, threads=0, reps=3):
     _check(L.oc_ref_time_icgn2d1(_fp(ref), _fp(tar), h, w, rx, ry, float(conv), float(stop), _fp(pois), pois.shape[0], threads,
                                  reps, ctypes.byref(tp), ctypes.byref(tc)), "ICGN2D1 (timed)")
     return tp.value, tc.value
+
+
+def epipolar_search(ref, tar, cam1, cam2, search_radius, search_step, parallax_x, parallax_y, rx, ry, conv, stop, pois, threads=0):
+    """The reference's EpipolarSearch (src/oc_epipolar_search.cpp) end to end: cameras from (13 intrinsics, 6 extrinsics) each,
+    prepare(), compute(poi_queue) in place.  Returns the fundamental matrix it used (3 x 3, row-major float32), or None when
+    the library predates this entry point."""
+    L = lib()
+    if L is None or not hasattr(L, "oc_ref_epipolar_search"):
+        return None
+    ref, tar = _img(ref), _img(tar)
+    h, w = ref.shape
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (cam1[0], cam1[1], cam2[0], cam2[1], parallax_x, parallax_y)]
+    assert a[0].size == 13 and a[1].size == 6 and a[2].size == 13 and a[3].size == 6 and a[4].size == 3 and a[5].size == 3
+    F = np.zeros(9, dtype=np.float32)
+    _check(L.oc_ref_epipolar_search(_fp(ref), _fp(tar), h, w, _fp(a[0]), _fp(a[1]), _fp(a[2]), _fp(a[3]), int(search_radius),
+                                    int(search_step), _fp(a[4]), _fp(a[5]), rx, ry, float(conv), float(stop), _fp(pois), pois.shape[0],
+                                    threads, _fp(F)), "EpipolarSearch")
+    return F.reshape(3, 3)
 
 
 def gradient2d(img):

@@ -3,7 +3,8 @@
 // TEST INFRASTRUCTURE ONLY.  oracle/Makefile (target `ref`) compiles the reference's sources UNMODIFIED, where they lie
 // under /root/reference/src -- oc_fftcc.cpp, oc_icgn.cpp, oc_iclm.cpp, oc_nr.cpp, oc_cubic_bspline.cpp,
 // oc_gradient.cpp, oc_subset.cpp, oc_deformation.cpp, oc_dic.cpp, oc_image.cpp, and oc_strain.cpp,
-// oc_region_fit.cpp, oc_nearest_neighbor.cpp -- against the stand-in headers of oracle/ref_stubs (mini Eigen, FFTW,
+// oc_region_fit.cpp, oc_nearest_neighbor.cpp, and (round 5, the EpipolarSearch consumer) oc_calibration.cpp,
+// oc_epipolar_search.cpp, oc_stereovision.cpp -- against the stand-in headers of oracle/ref_stubs (mini Eigen, FFTW,
 // OpenCV and nanoflann), plus this file.  Nothing of the reference is copied into the
 // repository; the library exists only where /root/reference does (this container) and is what pins the oracle's
 // reading of the reference's loops: tests/test_oracle_vs_ref.py asserts oracle(OC_ORDER_SEQ) == liboc_ref.
@@ -15,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "oc_epipolar_search.h"
 #include "oc_fftcc.h"
 #include "oc_icgn.h"
 #include "oc_iclm.h"
@@ -138,6 +140,57 @@ int oc_ref_time_icgn2d1(const float* ref, const float* tar, int height, int widt
             best = dt < best ? dt : best;
         }
         *compute_seconds = best;
+        if (n) std::memcpy(pois, static_cast<void*>(q.data()), sizeof(POI2D) * (size_t)n);
+    } catch (const std::string&) {
+        return 1;
+    }
+    return 0;
+}
+
+// EpipolarSearch (src/oc_epipolar_search.cpp): two Calibration objects from their 13 intrinsics / 6 extrinsics
+// (src/oc_calibration.h:25-49), setSearch, createICGN, setParallax(coefficient_x, coefficient_y), setImages, prepare()
+// (-> updateMatrices of both cameras, updateFundementalMatrix, ICGN2D1::prepare) and compute(poi_queue) -- the loop of
+// :133-195 per POI: candidates along the epipolar line, icgn1->compute(&candidate) each, std::sort by ZNCC, candidates[0].
+// fundamental9_out (row-major) receives the matrix the search used.
+int oc_ref_epipolar_search(const float* ref, const float* tar, int height, int width, const float* cam1_intrinsics13,
+                           const float* cam1_extrinsics6, const float* cam2_intrinsics13, const float* cam2_extrinsics6,
+                           int search_radius, int search_step, const float* parallax_x3, const float* parallax_y3, int rx, int ry,
+                           float conv, float stop, float* pois, long n, int threads, float* fundamental9_out) {
+    try {
+        Image2D ref_img(width, height), tar_img(width, height);
+        fill2d(ref_img, ref);
+        fill2d(tar_img, tar);
+        CameraIntrinsics i1, i2;
+        CameraExtrinsics e1, e2;
+        std::memcpy(i1.cam_i, cam1_intrinsics13, sizeof(i1.cam_i));
+        std::memcpy(i2.cam_i, cam2_intrinsics13, sizeof(i2.cam_i));
+        std::memcpy(e1.cam_e, cam1_extrinsics6, sizeof(e1.cam_e));
+        std::memcpy(e2.cam_e, cam2_extrinsics6, sizeof(e2.cam_e));
+        Calibration cam1(i1, e1), cam2(i2, e2);
+        EpipolarSearch search(cam1, cam2, threads_or_all(threads));
+        search.setSearch(search_radius, search_step);
+        search.createICGN(rx, ry, conv, stop);
+        float px[3] = {parallax_x3[0], parallax_x3[1], parallax_x3[2]}, py[3] = {parallax_y3[0], parallax_y3[1], parallax_y3[2]};
+        search.setParallax(px, py);
+        search.setImages(ref_img, tar_img);
+        search.prepare();
+        // the matrix prepare() has just built (a protected member): the same four lines on the same two cameras (:99-118)
+        {
+            Calibration c1 = cam1, c2 = cam2;
+            c1.updateMatrices();
+            c2.updateMatrices();
+            Eigen::Matrix3f right_invK_t = c2.intrinsic_matrix.inverse().transpose();
+            Eigen::Matrix3f right_t_antisymmetric;
+            right_t_antisymmetric << 0, -c2.translation_vector(2), c2.translation_vector(1), c2.translation_vector(2), 0,
+                -c2.translation_vector(0), -c2.translation_vector(1), c2.translation_vector(0), 0;
+            Eigen::Matrix3f right_E = right_t_antisymmetric * c2.rotation_matrix;
+            Eigen::Matrix3f left_K = c1.intrinsic_matrix.inverse();
+            Eigen::Matrix3f F = right_invK_t * right_E * left_K;
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) fundamental9_out[r * 3 + c] = F(r, c);
+        }
+        std::vector<POI2D> q = load2d(pois, n);
+        search.compute(q);
         if (n) std::memcpy(pois, static_cast<void*>(q.data()), sizeof(POI2D) * (size_t)n);
     } catch (const std::string&) {
         return 1;

@@ -1,0 +1,68 @@
+"""The EpipolarSearch consumer on the GPU: host-side candidate generation
+(include/opencorr_compat/oc_epipolar.h) -> ONE ICGN2D1 launch over the trials of all POIs -> oc_hip_select_best.
+
+Bit for bit against the same batch solved by the oracle in the GPU's summation order; and -- where the reference's own
+compiled EpipolarSearch is at hand (oracle/_ref/liboc_ref.so travels to the GPU box) -- against the reference's loop:
+the same trial wins for (almost) every POI and the refined displacement agrees within north_star's tolerance.
+tests/test_oracle_vs_ref_epipolar.py (CPU) holds the bit-exact statement against the reference's loop order."""
+import numpy as np
+import pytest
+
+import epipolar_case as ec
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_batched_epipolar_search_on_the_gpu(tmp_path):
+    import torch
+    import opencorr_amd
+    import oracle
+    from oracle import ref as oref
+    from opencorr_amd import synth
+    ref, tar = synth.speckle_pair_2d(300, 320, seed=20260925)
+    h, w = ref.shape
+    xs, ys = synth.poi_grid_2d(h, w, 17, 15, 30)
+    xs = np.concatenate([xs, [w - 22.0, w - 19.0, 40.0]]).astype(np.float32)
+    ys = np.concatenate([ys, [150.0, 60.0, h - 18.0]]).astype(np.float32)
+    pois = oracle.make_pois2d(xs, ys)
+    pois[:, 20:23] = 7.5
+    cam1, cam2 = ec.cameras(w, h)
+    have_ref = oref.available() and hasattr(oref.lib(), "oc_ref_epipolar_search")
+    if have_ref:
+        ref_out = pois.copy()
+        F = oref.epipolar_search(ref, tar, cam1, cam2, ec.SEARCH_RADIUS, ec.SEARCH_STEP, ec.PARALLAX_X, ec.PARALLAX_Y, ec.RX, ec.RY,
+                                 ec.CONV, ec.STOP, ref_out)
+    else:
+        # the fundamental matrix of ec.cameras(320, 300) as the reference's updateFundementalMatrix builds it (float32,
+        # printed from a run with the reference library): any matrix would do for the GPU == oracle statement
+        F = np.array([[2.5001599e-09, 1.2496808e-09, 2.4999414e-02], [5.0003197e-09, 2.4993616e-09, 4.9998827e-02],
+                      [-2.5016150e-02, -4.9993075e-02, 2.1547318e-02]], dtype=np.float32)
+    cand, starts = ec.candidates(ec.candidate_lib(tmp_path), pois, F, w, h)
+    icgn = opencorr_amd.ICGN2D1(ec.RX, ec.RY, ec.CONV, ec.STOP)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    want_c = cand.copy()
+    oracle.icgn2d1(oracle.Prepared2D(ref, tar), ec.RX, ec.RY, ec.CONV, ec.STOP, want_c, order=oracle.ORDER_LANES, lanes=64)
+    want, _ = ec.select_like_the_reference(want_c, starts, pois)
+    got_c = icgn.compute(cand.copy())
+    assert np.array_equal(_bits(got_c), _bits(want_c))
+    got = icgn.select_best(got_c, starts, pois.copy())
+    assert np.array_equal(_bits(got), _bits(want))
+    # device-resident queues: one launch, one selection kernel, nothing crosses PCIe in between
+    d_c = torch.from_numpy(cand.copy()).cuda()
+    icgn.compute(d_c)
+    d = icgn.select_best(d_c, torch.from_numpy(starts.astype(np.int32)).cuda(), torch.from_numpy(pois.copy()).cuda())
+    assert np.array_equal(_bits(d.cpu().numpy()), _bits(want))
+    if have_ref:
+        # against the reference's own loop (its sequential summation order): same winner, same flags, displacement within 1e-4
+        same_trial = (got[:, 14] == ref_out[:, 14]) & (got[:, 15] == ref_out[:, 15])      # u0, v0 = the winning trial's guess
+        assert same_trial.mean() >= 0.98, same_trial.mean()
+        assert np.array_equal(got[:, 16] < 0, ref_out[:, 16] < 0)
+        m = same_trial & (got[:, 16] >= 0) & (got[:, 17] == ref_out[:, 17])
+        assert m.mean() > 0.9
+        assert np.abs(got[m][:, [2, 8]] - ref_out[m][:, [2, 8]]).max() <= 1e-4
+        assert np.abs(got[m, 16] - ref_out[m, 16]).max() <= 1e-5
