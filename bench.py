@@ -58,7 +58,7 @@ Besides the contract fields the JSON line carries
                   rate for separately rounded operations (256 CUs x 4 SIMD32 x 2.4 GHz = 78.6 Tflop/s, half the
                   157.3 Tflop/s FMA figure of MI355X_MICROARCH.md); `traffic` = HBM bytes per launch from PMC counters
                   (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) and `traffic_l2` = L2-side bytes (TCC_REQ x a request
-                  size calibrated on a gather of known byte count), both collected by tools/gpu_traffic.sh over THIS
+                  size calibrated on a gather of known byte count), both collected by tools/gpu_profiles.sh over THIS
                   command and committed as profiles/icgn2d1_traffic_configB.json (counters cannot be read from inside
                   the process; `traffic_source` names the file and its age),
   cpu_baseline -- the CPU oracle (float32 restatement of the reference, OpenMP; pinned bit for bit on the reference's
@@ -91,7 +91,7 @@ GATHER_UBENCH_FREE_GBS = 20350.0
 # what the CUs' vector L1 ports can deliver at 64 bytes per clock and CU (every byte of the gather passes through them)
 L1_PORT_PEAK_GBS = 256 * 64 * 2.4
 # HBM bytes per ICGN2D1 launch of THIS workload from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in their
-# own runs, corrected as the guide prescribes); written by tools/pmc_traffic.py, see tools/gpu_round.sh
+# own runs, corrected as the guide prescribes); written by tools/pmc_traffic.py, see tools/gpu_profiles.sh
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "icgn2d1_traffic_configB.json")
 TRAFFIC_JSON_OLD = os.path.join(ROOT, "profiles", "icgn2d1_hbm_traffic_configB.json")  # rounds 1-2: HBM side only
 # round 4: ONE script (tools/gpu_profiles.sh) collects kernel stats + PMC traffic of the dominant kernels of configs B, C and E;
@@ -233,7 +233,7 @@ def roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof, sampl
         "peak": L2_PEAK_GBS,
         "unit": "GB/s",
         "frac": alg_rate / L2_PEAK_GBS,
-        # HBM bytes per launch by PMC counters -- collected over this very command by tools/gpu_traffic.sh in separate
+        # HBM bytes per launch by PMC counters -- collected over this very command by tools/gpu_profiles.sh in separate
         # rocprofv3 passes (a process cannot read them itself) and committed; None when no record exists for the workload
         "traffic": (prof or {}).get("hbm_bytes_per_launch"),
         "traffic_l2": (prof or {}).get("l2_bytes_per_launch"),
@@ -869,7 +869,7 @@ def host_queue_rate(fftcc, icgn, pristine, converged, reps=3):
 
 def pmc_profile(world, fma=False):
     """HBM bytes per ICGN launch from the COMMITTED PMC record of this workload (separate rocprofv3 --pmc passes,
-    tools/gpu_round.sh); a constant read from profiles/, not something measured in this run."""
+    tools/gpu_profiles.sh); a constant read from profiles/, not something measured in this run."""
     if world != 1:
         return None
     cands = (TRAFFIC_BY_CONFIG_FMA["B"],) if fma else (TRAFFIC_BY_CONFIG["B"], TRAFFIC_JSON, TRAFFIC_JSON_OLD)
@@ -891,7 +891,7 @@ def pmc_profile(world, fma=False):
             "valu_wave_instr_per_launch": rec.get("SQ_INSTS_VALU_per_launch"),
             "rocprof_avg_ms": (rec["avg_us"] * 1e-3 if rec.get("avg_us") else None),
             "source": os.path.relpath(path, ROOT) + (" (%s)" % rec["collected"] if rec.get("collected") else ""),
-            "note": "PMC counters over `python bench.py --no-cpu-baseline`, one counter set per rocprofv3 run (tools/gpu_traffic.sh): "
+            "note": "PMC counters over `python bench.py --no-cpu-baseline`, one counter set per rocprofv3 run (tools/gpu_profiles.sh): "
                     "HBM = FETCH_SIZE x 2 + WRITE_SIZE; L2 side = TCC_REQ_sum x a request size calibrated on a gather of known byte "
                     "count; compulsory HBM traffic (images + table once) is 1.27 GB"}
 

@@ -248,17 +248,41 @@ int oc_hip_get_devices(const oc_hip_engine* engine, int* device_ids, int capacit
  * synchronised */
 int oc_hip_group_queue(const oc_hip_engine* engine, int member, const void** device_ptr, size_t* block_bytes);
 
-/* Performance knobs; every setting computes bit-identical results.
- *   "icgn2d_variant"  index into the ICGN2D kernel-variant table (gather depth, LDS footprint, per-workgroup
- *                     coordinate table, waves per workgroup); -1 (the default) lets the engine choose by subset size
- *   "icgn2d_xcd"      1: workgroups of one XCD serve a contiguous range of the POI queue
- *   "icgn2d_tile_px"  side of the square image tiles the ICGN2D queue is visited by (L1 / L2 locality; default 128;
- *                     0 = queue order)
- *   "fftcc2d_fused"   1: single-kernel FFTCC2D (LDS / register FFT) for square windows of side 16, 18, 20, 24, 30,
- *                     32, 36, 40, 48, 50, 60, 64 (radius 8, 9, 10, 12, 15, 16, 18, 20, 24, 25, 30, 32) and for rectangular
- *                     windows (radius_x != radius_y) with both sides out of 16, 20, 24, 32, 40, 48, 64; 0: rocFFT pipeline;
- *                     2: as 1, but 32 x 32 windows run the generic NR x NC kernel instead of their own (an A/B switch)
- *   "fftcc3d_fused"   1: single-kernel FFTCC3D (register/LDS FFT) for 32 x 32 x 32 windows; 0: rocFFT pipeline
+/* Knobs.  Every key but "arith_fma" selects among kernels that compute BIT-IDENTICAL results; unknown keys and values
+ * outside the stated range fail with OC_HIP_ERR_INVALID, values this build does not contain with OC_HIP_ERR_UNSUPPORTED.
+ *   "arith_fma"       ICGN2D1 / ICGN2D2 / ICLM2D1 / ICLM2D2 / ICGN3D1 only (other engines refuse 1).  0 (default): every
+ *                     multiply and add of the solver rounds on its own -- the reference built for baseline x86-64; GPU ==
+ *                     oracle OC_ORDER_LANES bit for bit.  1: every PER-SAMPLE multiply-add is one fused multiply-add -- what a
+ *                     compiler with FMA hardware makes of the reference's source expressions (src/oc_cubic_bspline.cpp:159-177,
+ *                     390-401; src/oc_icgn.cpp:198-205, 266-276, 1314-1445; the reference's build files fix no contraction
+ *                     mode); GPU == oracle OC_ORDER_LANES_FMA bit for bit.  Results of the two modes differ by rounding only:
+ *                     against the reference's separately rounded loop order both keep identical failure flags, >= 99.5 %
+ *                     identical iteration counts, |d u, v, w| <= 1e-4 and |d ZNCC| <= 1e-5 (all BASELINE configs:
+ *                     tests/test_gpu_fullsize.py).  Kernel time on one MI355X: ICGN2D1 -3 ... -9 %, ICGN2D2 -13 ... -17 %,
+ *                     ICGN3D1 -5 ... -7 %.  The once-per-POI dense algebra is never fused
+ *   "icgn2d_variant"  launch shape of the ICGN2D kernel (gather depth, LDS footprint, per-workgroup coordinate table, waves per
+ *                     workgroup); -1 (default) lets the engine choose: 5 / 4 (6 / 12 DoF: coordinate table, lockstep sweeps,
+ *                     8-wave workgroups) for queues >= 32768 POIs of subsets up to 35 x 34 / 41 x 41, 2 / 3 (no table) below,
+ *                     7 (target array only) for self-adaptive subsets, 1 (single-wave workgroups) for what fits nothing else.
+ *                     0, 6 and 8 (the split launch shape) are measured losers that only the A/B build of the library contains
+ *   "icgn2d_xcd"      1 (default): workgroups of one XCD serve a contiguous range of the POI queue
+ *   "icgn2d_tile_px"  side of the square image tiles the ICGN2D / NR2D1 queue is visited by (L1 / L2 locality; default 128;
+ *                     0 = queue order; applied to queues >= 16384 POIs)
+ *   "icgn2d_split_chunks"  A/B build, variant 8 only: chunks of the two-stream pipeline (0 = the two kernels back to back)
+ *   "fftcc2d_fused"   1 (default): single-kernel FFTCC2D (register / LDS FFT) for EVERY even square window side from 8 to 64
+ *                     (radius 4 ... 32) and for the 42 rectangular pairs (radius_x != radius_y) out of sides 16, 20, 24, 32, 40,
+ *                     48, 64; every other shape runs the rocFFT pipeline.  0: rocFFT pipeline always.  2: as 1, but 32 x 32
+ *                     windows run the generic NR x NC kernel instead of their own (an A/B switch)
+ *   "fftcc3d_fused"   1 (default): single-kernel FFTCC3D for every cubic window of even side 8 ... 64 (radius 4 ... 32): LDS kernel
+ *                     up to 26^3, register kernel at 32^3, plane-wise kernel for 28^3 ... 64^3; non-cubic windows and larger
+ *                     sides run the rocFFT pipeline.  0: rocFFT pipeline always
+ *   "fftcc3d_planes_blocks"  persistent workgroups (= private scratch volumes) of the plane-wise FFTCC3D kernel; 0 (default) = 256
+ *   "fftcc3d_tile_vox"  FFTCC3D single-kernel paths: queues >= 2048 POIs are visited in cubic blocks of this many voxels
+ *                     (default 64; 0 = queue order; >= 8)
+ *   "icgn3d_tile_vox" the same for ICGN3D1 (default 64; 0 = queue order; >= 8)
+ *   "icgn3d_mapping"  0 (default, the only value the shipped library accepts): sample s of a subvolume is owned by thread
+ *                     s mod 512 (icgn3d.hip; oracle OC_ORDER_LANES, lanes = 512); 1 (A/B build): one half-wave per subvolume row
+ *                     (oracle OC_ORDER_ROWS; 12 - 25 % slower; no fused-arithmetic form)
  *   "host_chunk"      POIs per chunk of the host-queue pipeline (copies of one chunk overlap the kernels of its
  *                     neighbours); 0 = whole queue at once; default 65536
  *   "group_allgather" 1: device groups leave the complete result queue on every member (see oc_hip_set_devices)
@@ -266,7 +290,8 @@ int oc_hip_group_queue(const oc_hip_engine* engine, int member, const void** dev
  *                     as a group of one, whose all-gather is an ncclAllGather on a one-rank communicator (queue ->
  *                     oc_hip_group_queue(engine, 0)); fails instead of falling back when librccl is unusable.  Exists
  *                     so that the RCCL binding (dlopen, version check, ncclCommInitAll, ncclAllGather) can be executed
- *                     on a one-GPU machine */
+ *                     on a one-GPU machine
+ * A device group (oc_hip_set_devices) hands every key on to its members. */
 int oc_hip_set_tuning(oc_hip_engine* engine, const char* key, int value);
 
 /* ---- precompute ----------------------------------------------------------- */

@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd $ROOT
 LIB=opencorr_amd/lib
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize"
-OBJS=$(ls $LIB/*.o | grep -v icgn3d)
+OBJS=$(ls $LIB/*.o | grep -v "/icgn3d\.o")   # (icgn3d_fma.o, the fused-arithmetic build of the same file, stays)
 cat > /tmp/time3d_ab.py <<'PY'
 import sys, time, json, os, numpy as np, torch
 sys.path.insert(0, ".")

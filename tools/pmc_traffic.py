@@ -9,7 +9,7 @@ WRITE_SIZE are kilobytes summed over the L2 channels; on gfx950 FETCH_SIZE count
 requests as 64 bytes, so it is doubled.  WRITE_SIZE is taken as reported (uncalibrated on gfx950).
 Warm-up launches are dropped: only the last `--launches` dispatches of the kernel are averaged.
 
-L2 side (when <dir> also holds pmc_tcc/ and pmc_calib/, tools/gpu_traffic.sh): TCC_REQ_sum of the kernel x the request
+L2 side (when <dir> also holds pmc_tcc/ and pmc_calib/, tools/gpu_profiles.sh): TCC_REQ_sum of the kernel x the request
 size measured on tools/ubench/l2_req_calib (a read-once stream of 2^30 bytes with the same 16-byte-per-lane loads:
 bytes / TCC_REQ_sum); FETCH_SIZE of that stream checks the x2 correction of the HBM side on this box.
 """
