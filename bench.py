@@ -679,7 +679,7 @@ def secondary_rooflines(dev, device, reps=3):
     guess = torch.from_numpy(opencorr_amd.make_pois2d(xs, ys)).to(dev)
     f.compute(guess)
     q = guess.clone()
-    avg, n = _timed_launches(torch, g, lambda: (q.copy_(guess), g.compute(q)), reps)
+    avg, n = _timed_launches(torch, g, lambda: (q.copy_(guess), g.compute(q)), 2 * reps)
     res = q.cpu().numpy()
     it = res[:, 17].astype(np.float64)
     ran = it > 0
@@ -691,7 +691,7 @@ def secondary_rooflines(dev, device, reps=3):
                                {"mean_iterations": float(it[ran].mean()), "converged": int((res[:, 16] >= 0).sum()),
                                 "valu_hw": valu_hardware_block(mandated_instr_icgn(res, 17, n2, "2d2", False),
                                                                (tr or {}).get("valu_wave_instr_per_launch"), avg),
-                                "arith_fma": fused_leg(torch, g, q, guess, reps, 17, n2, "2d2", kernel_traffic("C", "icgn2d_kernel", fma=True), avg)},
+                                "arith_fma": fused_leg(torch, g, q, guess, 2 * reps, 17, n2, "2d2", kernel_traffic("C", "icgn2d_kernel", fma=True), avg)},
                                traffic=tr))
     del f, g, ref, tar, guess, q
     # ---- E: 512^3, r = 16, FFTCC3D + ICGN3D1, 37^3 POIs

@@ -703,7 +703,8 @@ int run_fftcc3d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
         for (size_t first = 0; first < count; first += kMaxGrid) {
             const size_t n = (count - first) < kMaxGrid ? (count - first) : kMaxGrid;
             float* q = d_pois + first * (size_t)stride_f;
-            hipError_t err = fused32 ? ochip::launch_fftcc3d_fused(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream)
+            if (fused32) OC_TRY(e->flags.reserve(n));
+            hipError_t err = fused32 ? ochip::launch_fftcc3d_fused(P, q, stride_f, n, e->icgn2d_xcd != 0, e->flags.as<unsigned char>(), e->stream)
                                      : ochip::launch_fftcc3d_fusedn(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream);
             if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "fused FFTCC3D kernel launch failed: %s", hipGetErrorString(err));
         }

@@ -72,19 +72,25 @@ __device__ __forceinline__ void block_sum2(float& x, float& y, float* red, int l
     y = sy;
 }
 
-__global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dParams P, float* __restrict__ pois, int stride_f,
-                                                                      unsigned long long count, int xcd_chunk) {
+// One POI by one workgroup.  CLAMPED = false (the launch that does the work): windows whose x indices are contiguous in both
+// volumes -- every window that is not clamped at a volume border -- gathered with 16-byte loads; a workgroup that finds its
+// window clamped only raises needs_clamped[idx] and leaves.  CLAMPED = true (a second, small launch whose workgroups scan the
+// flags): the flagged POIs, gathered element by element through the index tables.  Two instantiations because the scalar
+// gather's 64 addresses raise the register pressure of the WHOLE kernel when both paths live in one: 104 B of scratch per
+// thread against 76 B for the contiguous-only instantiation -- and at 1 024 threads x 50 000 POIs every scratch byte is
+// 50 MB written to memory and read back (round 5, profiles/r5e_fftcc3d_block_schedule_ab.json: WRITE_SIZE 4.98 GB per launch
+// for 28 B of results per POI).
+template <bool CLAMPED>
+__device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, float* __restrict__ pois, int stride_f, unsigned long long idx,
+                                                    unsigned char* __restrict__ needs_clamped) {
     __shared__ c2 lds[kHalf];
     __shared__ int tab[6][TN];  // voxel index of window coordinate k: ref x, y, z, tar x, y, z
     __shared__ float red[2 * kWaves], red2[2 * kWaves];
     __shared__ int redi[kWaves];
+    __shared__ float norms[2];  // sums of squares of the two windows: formed early, needed by thread 0 at the very end
     const int tid = threadIdx.x;
     const int a = tid >> 5, b = tid & 31;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
-    unsigned long long idx = blockIdx.x;
-    if (xcd_chunk > 0) idx = (unsigned long long)(blockIdx.x & 7u) * xcd_chunk + (blockIdx.x >> 3);
-    if (idx >= count) return;
-    if (P.perm) idx = P.perm[idx];
     float* poi = pois + idx * (unsigned long long)stride_f;
     constexpr int R = TN / 2;
     constexpr int M = TN * TN * TN;
@@ -112,13 +118,17 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dPa
         mine_contig = rb == r0 + b && tb == t0 + b;
     }
     const bool contig = __syncthreads_and(mine_contig) != 0;
+    if constexpr (!CLAMPED) {
+        if (tid == 0) needs_clamped[idx] = contig ? 0 : 1;
+        if (!contig) return;
+    }
 
     // ---- gather: thread (z = a, y = b) reads its x-line of both windows; z = ref + i*tar
     c2 v[TN];
     {
         const float* __restrict__ rrow = P.ref + ((size_t)tab[2][a] * P.dy + tab[1][b]) * P.dx;
         const float* __restrict__ trow = P.tar + ((size_t)tab[5][a] * P.dy + tab[4][b]) * P.dx;
-        if (contig) {
+        if (!CLAMPED) {
             const float* __restrict__ rp = rrow + tab[0][0];
             const float* __restrict__ tp = trow + tab[3][0];
 #pragma unroll
@@ -136,8 +146,8 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dPa
         }
     }
     // means, zero-mean, sums of squares (src/oc_fftcc.cpp:360-376)
-    float rn, tn;
     {
+        float rn, tn;
         float rs = 0.f, ts = 0.f;
 #pragma unroll
         for (int k = 0; k < TN; k++) {
@@ -155,9 +165,11 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dPa
             tn += v[k].y * v[k].y;
         }
         block_sum2(rn, tn, red2, lane, wave);
-        // needed only at the very end: without this the compiler keeps the 32 partial sums it has just read from LDS
-        // alive (in scratch) across the whole transform and adds them up there
-        asm volatile("" : "+v"(rn), "+v"(tn));
+        // needed only at the very end, by thread 0: parked in LDS instead of two registers of every thread
+        if (tid == 0) {
+            norms[0] = rn;
+            norms[1] = tn;
+        }
     }
 
     const int zz = a & 15, half = a >> 4;
@@ -305,7 +317,30 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dPa
         poi[poi3d::U0] = gu;
         poi[poi3d::V0] = gv;
         poi[poi3d::W0] = gw;
-        poi[poi3d::ZNCC] = best / (sqrtf(rn * tn) * M);
+        poi[poi3d::ZNCC] = best / (sqrtf(norms[0] * norms[1]) * M);
+    }
+}
+
+// the launch that does the work: workgroup -> POI (XCD-contiguous ranges of the visiting order)
+__global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dParams P, float* __restrict__ pois, int stride_f,
+                                                                      unsigned long long count, int xcd_chunk,
+                                                                      unsigned char* __restrict__ needs_clamped) {
+    unsigned long long idx = blockIdx.x;
+    if (xcd_chunk > 0) idx = (unsigned long long)(blockIdx.x & 7u) * xcd_chunk + (blockIdx.x >> 3);
+    if (idx >= count) return;
+    if (P.perm) idx = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)P.perm[idx]);  // wave-uniform: the record's address stays in SGPRs
+    fftcc3d_fused32_poi<false>(P, pois, stride_f, idx, needs_clamped);
+}
+
+// the windows clamped at a volume border: a few persistent workgroups scan the flags the first launch left (normally none is set)
+__global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_clamped_kernel(Fftcc3dParams P, float* __restrict__ pois, int stride_f,
+                                                                              unsigned long long count,
+                                                                              unsigned char* __restrict__ needs_clamped) {
+    for (unsigned long long idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        if (needs_clamped[idx]) {   // uniform over the workgroup
+            fftcc3d_fused32_poi<true>(P, pois, stride_f, idx, needs_clamped);
+            __syncthreads();        // the next POI reuses the tables and the tile
+        }
     }
 }
 
@@ -313,14 +348,19 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dPa
 
 bool fftcc3d_fused_supported(int rx, int ry, int rz) { return rx == TN / 2 && ry == TN / 2 && rz == TN / 2; }
 
-hipError_t launch_fftcc3d_fused(const Fftcc3dParams& p, float* pois, int stride_f, size_t count, bool xcd, hipStream_t stream) {
+// needs_clamped: `count` bytes of device scratch (one flag per POI of the queue)
+hipError_t launch_fftcc3d_fused(const Fftcc3dParams& p, float* pois, int stride_f, size_t count, bool xcd, unsigned char* needs_clamped,
+                                hipStream_t stream) {
     if (count == 0) return hipSuccess;
-    if (!fftcc3d_fused_supported(p.rx, p.ry, p.rz)) return hipErrorInvalidValue;
+    if (!fftcc3d_fused_supported(p.rx, p.ry, p.rz) || !needs_clamped) return hipErrorInvalidValue;
     const int chunk = xcd ? (int)((count + 7) / 8) : 0;
     const size_t grid = xcd ? (size_t)chunk * 8 : count;
     (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
     hipLaunchKernelGGL(fftcc3d_fused32_kernel, dim3((unsigned)grid), dim3(kThreads3), 0, stream, p, pois, stride_f,
-                       (unsigned long long)count, chunk);
+                       (unsigned long long)count, chunk, needs_clamped);
+    const unsigned scan = (unsigned)(count < 256 ? count : 256);
+    hipLaunchKernelGGL(fftcc3d_fused32_clamped_kernel, dim3(scan), dim3(kThreads3), 0, stream, p, pois, stride_f,
+                       (unsigned long long)count, needs_clamped);
     return hipGetLastError();
 }
 

@@ -226,8 +226,10 @@ hipError_t launch_fftcc3d_argmax(const Fftcc3dParams& p, const float* surf, cons
 // ---- fftcc3d_fused.hip -----------------------------------------------------
 // all of FFTCC3D::compute(POI3D*) in one kernel for 32 x 32 x 32 windows (radius 16)
 bool fftcc3d_fused_supported(int rx, int ry, int rz);
+// needs_clamped: `count` bytes of device scratch (the first launch flags the POIs whose windows are clamped at a volume border,
+// the second one computes those)
 hipError_t launch_fftcc3d_fused(const Fftcc3dParams& p, float* pois, int stride_floats, size_t count, bool xcd,
-                                hipStream_t stream);
+                                unsigned char* needs_clamped, hipStream_t stream);
 
 // ---- fftcc3d_fusedn.hip ----------------------------------------------------
 // the same for cubic windows of side 8 ... 26 (radius 4 ... 13): the complex volume stays in LDS between the axis passes
