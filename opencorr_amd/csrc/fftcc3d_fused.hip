@@ -195,17 +195,38 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
         }
         __syncthreads();
     }
-    // ---- forward y (thread (z = a, x = b)), then LY -> LZ through LDS [y & 15][z][x], one y-half at a time
+    // ---- forward y (thread (z = a, x = b)), then LY -> LZ.  The (y, z) plane of every x is cut into four 16 x 16 blocks
+    // (y-half, z-half); the tile holds two of them: [z-half][y & 15][z & 15][x].  Round 0 moves the DIAGONAL blocks, round 1 the
+    // off-diagonal ones: a thread (z-half = its own `half` as a writer, y-half = `half` as a reader) hands over 16 values and
+    // receives 16 values per round, so it never holds more than one line's worth of data (64 registers).  Round 5: until
+    // then round g moved y-half g -- every thread wrote 16 values, half of the threads read 32 -- and a thread that had
+    // received its whole z-line in round 0 still held the 16 values it owed round 1: 96 live data registers of the 128 the
+    // workgroup size leaves, 16 of them in scratch (64 of the kernel's 76 B per thread).  `half` is uniform over a wave, so
+    // the two register-index patterns are two branches, not selects.
     fft32<false>(v);
     c2 w[TN];
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
+    for (int d = 0; d < 2; d++) {
+        {   // writer (z = a): block (y-half = half ^ d, z-half = half) -> slot `half`
+            c2* __restrict__ dst = lds + ((half * 16) * 16 + zz) * TP + b;
+            if ((half ^ d) == 0) {
 #pragma unroll
-        for (int yy = 0; yy < 16; yy++) lds[(yy * TN + a) * TP + b] = v[bitrev5(yy + 16 * g)];
+                for (int yy = 0; yy < 16; yy++) dst[yy * 16 * TP] = v[bitrev5(yy)];
+            } else {
+#pragma unroll
+                for (int yy = 0; yy < 16; yy++) dst[yy * 16 * TP] = v[bitrev5(yy + 16)];
+            }
+        }
         __syncthreads();
-        if (half == g) {
+        {   // reader (y = a): block (y-half = half, z-half = half ^ d) -> slot `half ^ d`
+            const c2* __restrict__ src = lds + (((half ^ d) * 16 + zz) * 16) * TP + b;
+            if ((half ^ d) == 0) {
 #pragma unroll
-            for (int z = 0; z < TN; z++) w[z] = lds[(zz * TN + z) * TP + b];
+                for (int z = 0; z < 16; z++) w[z] = src[z * TP];
+            } else {
+#pragma unroll
+                for (int z = 0; z < 16; z++) w[z + 16] = src[z * TP];
+            }
         }
         __syncthreads();
     }
@@ -240,15 +261,31 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
     for (int k = 0; k < TN; k++) t[k] = w[bitrev5(k)];
     fft32<true>(t);
     c2 u[TN];
+    // (the same two rounds of 16 x 16 blocks the other way round: writer y = a hands over its z-half `half ^ d`, reader z = a
+    // receives its y-half `half ^ d`)
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
-        if (half == g) {
+    for (int d = 0; d < 2; d++) {
+        {   // writer (y = a): block (y-half = half, z-half = half ^ d) -> slot `half ^ d`
+            c2* __restrict__ dst = lds + (((half ^ d) * 16 + zz) * 16) * TP + b;
+            if ((half ^ d) == 0) {
 #pragma unroll
-            for (int z = 0; z < TN; z++) lds[(zz * TN + z) * TP + b] = t[bitrev5(z)];
+                for (int z = 0; z < 16; z++) dst[z * TP] = t[bitrev5(z)];
+            } else {
+#pragma unroll
+                for (int z = 0; z < 16; z++) dst[z * TP] = t[bitrev5(z + 16)];
+            }
         }
         __syncthreads();
+        {   // reader (z = a): block (y-half = half ^ d, z-half = half) -> slot `half`
+            const c2* __restrict__ src = lds + ((half * 16) * 16 + zz) * TP + b;
+            if ((half ^ d) == 0) {
 #pragma unroll
-        for (int yy = 0; yy < 16; yy++) u[yy + 16 * g] = lds[(yy * TN + a) * TP + b];
+                for (int yy = 0; yy < 16; yy++) u[yy] = src[yy * 16 * TP];
+            } else {
+#pragma unroll
+                for (int yy = 0; yy < 16; yy++) u[yy + 16] = src[yy * 16 * TP];
+            }
+        }
         __syncthreads();
     }
     // ---- inverse y (thread (z = a, x = b)), LY -> LX
