@@ -32,6 +32,7 @@
 // phases.  Results of such a build are garbage; the product is always built with the mask at 0.
 //   1 = no coefficient staging (global -> LDS)   2 = no tap evaluation   4 = no Hessian sweep   8 = no numerator sweep
 //   32 = taps addressed with a row pitch of 33 floats (wrong rows, but no LDS bank conflicts: what a conflict-free layout is worth)
+//   64 = nothing left out, only the three forced iterations: the partner of the masks above
 //   16 = timeline: results stay valid, and the six strain floats of every POI record receive the shader-clock
 //        kilocycles its workgroup spent in  reference stats | Hessian sweep + reduction | LU inverse | warped-subvolume
 //        sweeps (boxes, staging, taps) | mean / norm / numerator sweeps + reductions | solve + warp update
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
             }
             lap(3);
             // src/oc_icgn.cpp:1396-1400
-            if (__syncthreads_or(out_of_range && !(OC_ABLATE & 47) ? 1 : 0)) {
+            if (__syncthreads_or(out_of_range && !(OC_ABLATE & 111) ? 1 : 0)) {
                 failed = true;
                 break;
             }
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(kBlock3d, 4) void icgn3d1_kernel(Icgn3dParams P, fl
             // src/oc_icgn.cpp:1445
             dp_norm = uni3(sqrtf(dp[0] * dp[0] + dp[4] * dp[4] + dp[8] * dp[8]));
             lap(5);
-        } while (iter < P.stop && ((OC_ABLATE & 47) ? iter < 3 : dp_norm >= P.conv));
+        } while (iter < P.stop && ((OC_ABLATE & 111) ? iter < 3 : dp_norm >= P.conv));
 
         if (failed) {
             if (tid == 0) poi[poi3d::ZNCC] = -3.f;

@@ -29,6 +29,8 @@ xs, ys, zs = synth.poi_grid_3d(dim, dim, dim, ns, ns, ns, r + 8)
 f = oc.FFTCC3D(r, r, r); f.set_images(ref, tar)
 g = oc.ICGN3D1(r, r, r, 0.001, 20.0)
 g.share_images(f); g.prepare()
+if os.environ.get("ARITH_FMA") == "1":   # variants built with tools/ab_build.py "icgn3d:fma" replace the fused-arithmetic object
+    g.set_tuning("arith_fma", 1)
 pristine = torch.from_numpy(oc.make_pois3d(xs, ys, zs)).to(dev)
 f.compute(pristine); torch.cuda.synchronize()
 q = pristine.clone()
