@@ -91,6 +91,13 @@ def test_fuzz_icgn2d1_icgn2d2_nr2d1_iclm(seed):
         solve(prep, rx, ry, conv, stop, want, order=oracle.ORDER_LANES, lanes=64)
         same = _same(got, want).all(axis=1)
         assert same.all(), (name, seed, rx, ry, np.flatnonzero(~same)[:5], got[~same][:2], want[~same][:2])
+        # the fused arithmetic contract on the same case (round 5): every bit equal to the oracle's LANES_FMA order
+        eng.set_tuning("arith_fma", 1)
+        got_f = eng.compute(pois.copy())
+        want_f = pois.copy()
+        solve(prep, rx, ry, conv, stop, want_f, order=oracle.ORDER_LANES_FMA, lanes=64)
+        same = _same(got_f, want_f).all(axis=1)
+        assert same.all(), (name + " fma", seed, rx, ry, np.flatnonzero(~same)[:5], got_f[~same][:2], want_f[~same][:2])
         # the cases are not all trivial: some POIs converge, some do not
         z = got[:, P["zncc"]]
         if seed < 6:   # (the fixed seeds were looked at; a soak seed may draw a case in which hardly anything converges)
@@ -171,6 +178,12 @@ def test_fuzz_icgn3d1(seed):
     assert same.all(), (seed, rx, ry, rz, np.flatnonzero(~same)[:5], got[~same][:2], want[~same][:2])
     if seed < 3:
         assert (got[:, P["zncc"]] > 0.5).sum() > 20
+    g.set_tuning("arith_fma", 1)     # the fused arithmetic contract on the same case (round 5)
+    got_f = g.compute(pois.copy())
+    want_f = pois.copy()
+    oracle.icgn3d1(oracle.Prepared3D(ref, tar), rx, ry, rz, conv, stop, want_f, order=oracle.ORDER_LANES_FMA, lanes=oracle.GPU_LANES_3D)
+    same = _same(got_f, want_f).all(axis=1)
+    assert same.all(), ("fma", seed, rx, ry, rz, np.flatnonzero(~same)[:5], got_f[~same][:2], want_f[~same][:2])
 
 
 @pytest.mark.parametrize("seed", range(4 + _EXTRA))
@@ -207,6 +220,10 @@ def test_fuzz_offsets_and_self_adaptive(seed):
         want = q.copy()
         solve(prep, rx, ry, 1e-3, 10, want, order=oracle.ORDER_LANES, lanes=64, center_offsets=off, self_adaptive=True)
         assert _same(eng.compute_with_offsets(q.copy(), off), want).all(), (seed, "both")
+        eng.set_tuning("arith_fma", 1)   # both at once under the fused arithmetic contract (round 5)
+        want = q.copy()
+        solve(prep, rx, ry, 1e-3, 10, want, order=oracle.ORDER_LANES_FMA, lanes=64, center_offsets=off, self_adaptive=True)
+        assert _same(eng.compute_with_offsets(q.copy(), off), want).all(), (seed, "both, fma")
 
 
 @pytest.mark.parametrize("seed", range(3 + _EXTRA))
