@@ -8,7 +8,8 @@
 // setIteration(float,float), setIteration(POI*), setImages, setSubset.
 // `thread_number` is kept for signature compatibility (the GPU parallelises internally);
 // the device is chosen with the extra setters setDevice() / setDevices() or the OC_HIP_DEVICE / OC_HIP_DEVICES
-// environment variables (OC_HIP_DEVICES=all: every engine spreads its queues over all GPUs of the node).  Failures of the engine (no GPU, bad call order, ...)
+// environment variables (OC_HIP_DEVICES=all: every engine spreads its queues over all GPUs of the node; OC_HIP_ARITH_FMA=1: the
+// ICGN / IC-LM solvers run under the fused arithmetic contract, see oc_hip_set_tuning "arith_fma").  Failures of the engine (no GPU, bad call order, ...)
 // are thrown as std::string like the reference does (src/oc_fftcc.cpp:145, src/oc_icgn.cpp:65).
 //
 // Differences a caller can observe (documented):
@@ -121,6 +122,16 @@ inline bool single_device(oc_hip_engine* e) {
 inline void apply_default_devices(oc_hip_engine* e) {
     const std::vector<int> ids = default_devices();
     if (ids.size() > 1) check(oc_hip_set_devices(e, ids.data(), (int)ids.size()));
+    // OC_HIP_ARITH_FMA=1: the ICGN / IC-LM solvers created through these classes use the fused arithmetic contract
+    // (oc_hip_set_tuning "arith_fma", include/opencorr_hip.h) -- an unmodified OpenCorr main opts in without a source change;
+    // engines without a fused build (FFTCC, NR2D1, Strain, RegionFit) are left alone
+    const char* fma = std::getenv("OC_HIP_ARITH_FMA");
+    if (fma && std::atoi(fma) != 0) {
+        int kind = 0;
+        if (oc_hip_get_kind(e, &kind) == OC_HIP_OK &&
+            (kind == OC_HIP_ICGN2D1 || kind == OC_HIP_ICGN2D2 || kind == OC_HIP_ICLM2D1 || kind == OC_HIP_ICLM2D2 || kind == OC_HIP_ICGN3D1))
+            check(oc_hip_set_tuning(e, "arith_fma", 1));
+    }
 }
 }  // namespace hipdetail
 

@@ -67,9 +67,10 @@ def _workdir(tmp_path, golden):
     return d
 
 
-def _run(exe, cwd):
+def _run(exe, cwd, env=None):
     # the examples end with cin.get(): give them an empty stdin
-    out = subprocess.run([exe], cwd=cwd, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = subprocess.run([exe], cwd=cwd, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                         env=dict(os.environ, **env) if env else None)
     assert out.returncode == 0, out.stdout.decode(errors="replace")[-2000:]
     return out.stdout.decode(errors="replace")
 
@@ -116,6 +117,45 @@ def test_reference_example_fftcc_icgn1_runs_unmodified(tmp_path, golden):
         shutil.copy(d / "oht_cfrp_4_fftcc_icgn1_r16_time.csv", os.path.join(keep, "example_test_2d_dic_fftcc_icgn1_time_mi355x.csv"))
         with open(os.path.join(keep, "example_test_2d_dic_fftcc_icgn1_stdout.txt"), "w") as f:
             f.write(log)
+
+
+@pytest.mark.gpu
+def test_reference_example_fftcc_icgn1_under_the_fused_contract(tmp_path, golden):
+    """The same unmodified main with OC_HIP_ARITH_FMA=1 in its environment (round 5): the shim switches its ICGN2D1 to the fused
+    arithmetic contract (oc_hip_set_tuning "arith_fma"), nothing else changes.  Its table equals what the Python mirror computes
+    in that mode at the CSV's print resolution (8 decimals), differs from the default mode's table, and meets the same bars
+    against the reference's own CSV."""
+    import opencorr_amd
+    exe = _exe("test_2d_dic_fftcc_icgn1")
+    d = _workdir(tmp_path, golden)
+    _run(exe, tmp_path, env={"OC_HIP_ARITH_FMA": "1"})
+    got = _table(d / "oht_cfrp_4_fftcc_icgn1_r16.csv", 9)   # x y u v u0 v0 zncc iteration convergence
+    tab = golden["table"].astype(np.float64)
+    # the example reads the 8-bit BMPs this test wrote from the fixture: the same pixels
+    pois = opencorr_amd.make_pois2d(tab[:, 0], tab[:, 1])
+    f = opencorr_amd.FFTCC2D(golden["rx"], golden["ry"])
+    f.set_images(golden["ref"], golden["tar"])
+    f.compute(pois)
+    g = opencorr_amd.ICGN2D1(golden["rx"], golden["ry"], golden["conv"], golden["stop"])
+    g.share_images(f)
+    g.prepare()
+    fused = pois.copy()
+    g.set_tuning("arith_fma", 1)
+    g.compute(fused)
+    plain = pois.copy()
+    g.set_tuning("arith_fma", 0)
+    g.compute(plain)
+    cols = [2, 8, 14, 15, 16, 17, 18]          # u v u0 v0 zncc iteration convergence
+    want = fused[:, cols].astype(np.float64)
+    ok = ~np.isnan(want).any(axis=1)
+    assert np.abs(got[ok][:, 2:9] - want[ok]).max() <= 6e-9            # "%.8f"
+    assert np.abs(got[ok][:, 2:9] - plain[ok][:, cols]).max() > 6e-9   # ... and it IS the other arithmetic mode
+    same = (got[:, 4] == tab[:, 4]) & (got[:, 5] == tab[:, 5])
+    m = (tab[:, 7] < golden["stop"]) & same
+    assert m.sum() > 28000
+    assert np.abs(got[m, 2] - tab[m, 2]).max() <= 2e-4 and np.abs(got[m, 3] - tab[m, 3]).max() <= 2e-4
+    assert np.abs(got[m, 6] - tab[m, 6]).max() <= 1e-5
+    assert (got[m, 7] == tab[m, 7]).mean() >= 0.99
 
 
 @pytest.mark.gpu
