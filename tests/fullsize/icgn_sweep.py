@@ -63,8 +63,8 @@ def main():
     torch.cuda.synchronize()
     pois = start.clone()
 
-    nvar = 6
-    variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(nvar))
+    # the variants the shipped library contains (0, 6 and 8 live in the A/B build: OPENCORR_HIP_LIB=.../lib/ab/libopencorr_hip_ab.so)
+    variants = [int(v) for v in args.variants.split(",")] if args.variants else [1, 2, 3, 4, 5, 7]
     xcds = [int(v) for v in args.xcd.split(",")]
     tiles = [int(v) for v in args.tile_px.split(",")] if args.tile_px else [None]
     base = None

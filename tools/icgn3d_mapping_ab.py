@@ -2,6 +2,9 @@
 interleaved on ONE volume pair and ONE FFTCC result:   python tools/icgn3d_mapping_ab.py [dim=512] [nside=37] [r=16] [reps=4]
 Prints one JSON object: ms per launch for both, iteration statistics, and how far apart the two results are (a re-association)."""
 import json
+import os as _os
+# the partners this script compares live in the A/B build of the library only (python -m opencorr_amd.build --ab)
+_os.environ.setdefault("OPENCORR_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "opencorr_amd", "lib", "ab", "libopencorr_hip_ab.so"))
 import sys
 
 import numpy as np

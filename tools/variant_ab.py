@@ -3,6 +3,9 @@
 drift hits all of them alike.  usage: [ENGINE=2 R=20 NS=316] python tools/variant_ab.py 2,4,5 [rounds] [launches]   (GPU box;
 ENGINE=2 R=20 NS=316 is config C: ICGN2D2; ARITH_FMA=1: oc_hip_set_tuning arith_fma = 1)"""
 import json
+import os as _os
+# the partners this script compares live in the A/B build of the library only (python -m opencorr_amd.build --ab)
+_os.environ.setdefault("OPENCORR_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "opencorr_amd", "lib", "ab", "libopencorr_hip_ab.so"))
 import os
 import sys
 
