@@ -274,8 +274,10 @@ int oc_hip_group_queue(const oc_hip_engine* engine, int member, const void** dev
  *                     48, 64; every other shape runs the rocFFT pipeline.  0: rocFFT pipeline always.  2: as 1, but 32 x 32
  *                     windows run the generic NR x NC kernel instead of their own (an A/B switch)
  *   "fftcc3d_fused"   1 (default): single-kernel FFTCC3D for every cubic window of even side 8 ... 64 (radius 4 ... 32): LDS kernel
- *                     up to 26^3, register kernel at 32^3, plane-wise kernel for 28^3 ... 64^3; non-cubic windows and larger
- *                     sides run the rocFFT pipeline.  0: rocFFT pipeline always
+ *                     up to 26^3, register kernel at 32^3, plane-wise kernel for 28^3 ... 64^3; and for every NON-cubic window
+ *                     with all three radii in 4 ... 16 whose complex volume [2rx][2ry][2rz + 1] fits 160 KB of LDS (one kernel,
+ *                     sides as run-time values: fftcc3d_box.hip); other non-cubic windows and larger sides run the rocFFT
+ *                     pipeline.  0: rocFFT pipeline always
  *   "fftcc3d_planes_blocks"  persistent workgroups (= private scratch volumes) of the plane-wise FFTCC3D kernel; 0 (default) = 256
  *   "fftcc3d_tile_vox"  FFTCC3D single-kernel paths: queues >= 2048 POIs are visited in cubic blocks of this many voxels
  *                     (default 64; 0 = queue order; >= 8)

@@ -695,7 +695,8 @@ int run_fftcc3d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
         if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "plane-wise FFTCC3D kernel launch failed: %s", hipGetErrorString(err));
         return OC_HIP_OK;
     }
-    if (e->fftcc3d_fused && (fused32 || ochip::fftcc3d_fusedn_supported(e->rx, e->ry, e->rz))) {
+    const bool box = ochip::fftcc3d_box_supported(e->rx, e->ry, e->rz);   // non-cubic windows (fftcc3d_box.hip)
+    if (e->fftcc3d_fused && (fused32 || box || ochip::fftcc3d_fusedn_supported(e->rx, e->ry, e->rz))) {
         ochip::Fftcc3dParams P = {im.ref_ptr(), im.tar_ptr(), im.dz, im.dy, im.dx, e->rx, e->ry, e->rz};
         if (count <= (1u << 30)) OC_TRY(tile_order3d(e, d_pois, stride_f, count, e->fftcc3d_tile_vox, &P.perm));
         ProfScope prof(e);
@@ -705,6 +706,7 @@ int run_fftcc3d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
             float* q = d_pois + first * (size_t)stride_f;
             if (fused32) OC_TRY(e->flags.reserve(n));
             hipError_t err = fused32 ? ochip::launch_fftcc3d_fused(P, q, stride_f, n, e->icgn2d_xcd != 0, e->flags.as<unsigned char>(), e->stream)
+                             : box   ? ochip::launch_fftcc3d_box(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream)
                                      : ochip::launch_fftcc3d_fusedn(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream);
             if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "fused FFTCC3D kernel launch failed: %s", hipGetErrorString(err));
         }

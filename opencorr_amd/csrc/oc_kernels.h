@@ -237,6 +237,12 @@ bool fftcc3d_fusedn_supported(int rx, int ry, int rz);
 hipError_t launch_fftcc3d_fusedn(const Fftcc3dParams& p, float* pois, int stride_floats, size_t count, bool xcd,
                                  hipStream_t stream);
 
+// ---- fftcc3d_box.hip ---------------------------------------------------------
+// the same for NON-cubic windows with every radius in 4 ... 16 whose complex volume fits the LDS: ONE kernel, the three sides
+// are run-time values (each axis pass switches to the line transform of its length)
+bool fftcc3d_box_supported(int rx, int ry, int rz);
+hipError_t launch_fftcc3d_box(const Fftcc3dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
+
 // ---- fftcc3d_planes.hip / fftcc3d_planesb.hip -------------------------------
 // the same for cubic windows of side 28 ... 64 (except 32): one persistent 512-thread workgroup per scratch slot, the complex
 // volume passes through a private N^3 scratch volume between the in-LDS plane transforms and the z pass

@@ -209,6 +209,99 @@ def test_fftcc3d_every_fused_cube(fftcc_volumes, r):
         assert (fused[:inner, P["zncc"]] > 0.5).mean() > 0.8, fused[:inner, P["zncc"]]
 
 
+# non-cubic windows (FFTCC3D's constructor takes three radii, src/oc_fftcc.cpp:48-74): ONE kernel, sides as run-time values
+# (fftcc3d_box.hip).  Every line length 8 ... 32 appears on every axis at least once; the extreme aspect ratios and the largest
+# volumes that still fit the LDS are among them.
+BOX_RADII = [(4, 5, 6), (6, 4, 5), (5, 6, 4), (7, 8, 9), (9, 7, 8), (8, 9, 7), (10, 11, 12), (12, 10, 11), (11, 12, 10),
+             (11, 12, 13), (13, 11, 12), (12, 13, 11), (14, 4, 15), (15, 14, 4), (4, 15, 14), (16, 4, 4), (4, 16, 4), (4, 4, 16),
+             (16, 16, 4), (4, 16, 16), (16, 4, 16), (16, 16, 8), (8, 16, 16), (16, 8, 16), (12, 12, 16), (16, 12, 12), (6, 8, 10),
+             (13, 13, 4), (16, 15, 9), (13, 14, 15)]
+
+
+def _box_kernel_takes(rx, ry, rz):
+    """fftcc3d_box_supported(): the [2rx][2ry][2rz + 1] complex volume and the kernel's tables within 160 KB of LDS."""
+    return 2 * rx * 2 * ry * (2 * rz + 1) * 8 + 6 * 32 * 4 + 3 * 16 * 4 <= 160 * 1024
+
+
+@pytest.mark.parametrize("r", BOX_RADII)
+def test_fftcc3d_box_kernel_non_cubic_windows(fftcc_volumes, r):
+    """Same integer peak as the oracle (inner POIs) and as the rocFFT pipeline (all POIs, clamped border windows included);
+    ZNCC within 2e-5 of the pipeline and within 1e-4 of the oracle with exactly summed means and norms (the bound against the
+    reference's sequential float sums grows with the voxel count as for the cubes); everything else in the records untouched.
+    "The oracle's peak" is the reference's: it plans FFTW as (2rx, 2ry, 2rz) over a buffer filled x-fastest
+    (src/oc_fftcc.cpp:68-70, 349-360), i.e. it correlates the RESHAPED window when the sides differ -- reproduced, not repaired."""
+    import opencorr_amd
+    import oracle
+    ref, tar = fftcc_volumes
+    dz, dy, dx = ref.shape
+    rx, ry, rz = r
+    P = oracle.P3
+    rng = np.random.default_rng(500 + 100 * rx + 10 * ry + rz)
+    n = 13
+    xs = rng.uniform(rx + 4, dx - rx - 4, n).astype(np.float32)
+    ys = rng.uniform(ry + 4, dy - ry - 4, n).astype(np.float32)
+    zs = rng.uniform(rz + 4, dz - rz - 4, n).astype(np.float32)
+    xs[::2], ys[::2], zs[::2] = np.floor(xs[::2]), np.floor(ys[::2]), np.floor(zs[::2])
+    pois = oracle.make_pois3d(xs, ys, zs)
+    pois[::3, P["u"]] = rng.integers(-2, 3, len(pois[::3]))  # integer initial guesses displace the target window
+    pois[1::3, P["w"]] = rng.integers(-2, 3, len(pois[1::3]))
+    inner = len(pois)
+    border = oracle.make_pois3d([3.0, 40.0, dx - 2.0], [40.0, 2.0, 40.0], [40.0, 40.0, dz - 3.0])
+    pois = np.concatenate([pois, border]).astype(np.float32)
+    want = pois.copy()
+    oracle.fftcc3d(ref, tar, rx, ry, rz, want)
+    exact = pois.copy()
+    oracle.fftcc3d(ref, tar, rx, ry, rz, exact, exact_sums=True)
+    f = opencorr_amd.FFTCC3D(rx, ry, rz)
+    f.set_images(ref, tar)
+    fused = f.compute(pois.copy())
+    again = f.compute(pois.copy())
+    assert np.array_equal(_bits(fused), _bits(again))
+    f.set_tuning("fftcc3d_fused", 0)
+    base = f.compute(pois.copy())
+    for key in ("u", "v", "w", "u0", "v0", "w0"):
+        assert np.array_equal(fused[:inner, P[key]], want[:inner, P[key]]), ("oracle", key, fused[:inner, P[key]], want[:inner, P[key]])
+        assert np.array_equal(fused[:, P[key]], base[:, P[key]]), ("pipeline", key)
+    vox = 8 * rx * ry * rz
+    dz_oracle = float(np.abs(fused[:inner, P["zncc"]] - want[:inner, P["zncc"]]).max())
+    dz_pipe = float(np.abs(fused[:, P["zncc"]] - base[:, P["zncc"]]).max())
+    dz_exact = float(np.abs(fused[:inner, P["zncc"]] - exact[:inner, P["zncc"]]).max())
+    assert dz_exact <= 1e-4, dz_exact
+    assert dz_oracle <= (1e-4 if vox <= 24 ** 3 else 2e-4), dz_oracle
+    assert dz_pipe <= 2e-5, dz_pipe
+    untouched = [c for c in range(31) if c not in (P["u"], P["v"], P["w"], P["u0"], P["v0"], P["w0"], P["zncc"])]
+    assert np.array_equal(_bits(fused[:, untouched]), _bits(pois[:, untouched]))
+    # two implementations, not one: the in-register transforms and rocFFT do not round alike over sixteen windows
+    # ((13, 14, 15) does not fit the LDS: the pipeline both times)
+    assert np.array_equal(_bits(fused[:, P["zncc"]]), _bits(base[:, P["zncc"]])) == (not _box_kernel_takes(rx, ry, rz))
+
+
+def test_fftcc3d_box_kernel_long_queue_in_block_order(volumes):
+    """2 500 POIs (above the 2 048 at which queues are visited in cubic blocks): the block schedule and the XCD-contiguous
+    dispatch change no bit of a non-cubic FFTCC3D either; a queue of one POI; an empty queue."""
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = volumes
+    xs, ys, zs = synth.poi_grid_3d(*SHAPE, 25, 10, 10, 20)
+    pois = oracle.make_pois3d(xs, ys, zs)
+    assert len(pois) == 2500
+    f = opencorr_amd.FFTCC3D(10, 6, 8)
+    f.set_images(ref, tar)
+    tiled = f.compute(pois.copy())
+    f.set_tuning("fftcc3d_tile_vox", 0)
+    plain = f.compute(pois.copy())
+    assert np.array_equal(_bits(tiled), _bits(plain))
+    one = f.compute(pois[7:8].copy())
+    assert np.array_equal(_bits(one), _bits(plain[7:8]))
+    assert f.compute(pois[:0].copy()).shape[0] == 0
+    want = pois[:200].copy()
+    oracle.fftcc3d(ref, tar, 10, 6, 8, want)
+    P = oracle.P3
+    for key in ("u", "v", "w"):
+        assert np.array_equal(plain[:200, P[key]], want[:, P[key]]), key
+
+
 def test_fftcc3d_planes_kernel_long_queue_and_block_counts(fftcc_volumes):
     """The plane-wise kernel is persistent: a queue longer than its workgroup count (every workgroup walks several POIs of
     its XCD's eighth) and three workgroup counts -- 8, 64, 256 scratch volumes -- give the same bits as the rocFFT pipeline's
