@@ -269,10 +269,11 @@ int oc_hip_group_queue(const oc_hip_engine* engine, int member, const void** dev
  *   "icgn2d_tile_px"  side of the square image tiles the ICGN2D / NR2D1 queue is visited by (L1 / L2 locality; default 128;
  *                     0 = queue order; applied to queues >= 16384 POIs)
  *   "icgn2d_split_chunks"  A/B build, variant 8 only: chunks of the two-stream pipeline (0 = the two kernels back to back)
- *   "fftcc2d_fused"   1 (default): single-kernel FFTCC2D (register / LDS FFT) for EVERY even square window side from 8 to 64
- *                     (radius 4 ... 32) and for the 42 rectangular pairs (radius_x != radius_y) out of sides 16, 20, 24, 32, 40,
- *                     48, 64; every other shape runs the rocFFT pipeline.  0: rocFFT pipeline always.  2: as 1, but 32 x 32
- *                     windows run the generic NR x NC kernel instead of their own (an A/B switch)
+ *   "fftcc2d_fused"   1 (default): single-kernel FFTCC2D (register / LDS FFT) for EVERY window with both radii in 4 ... 32 (even
+ *                     sides 8 ... 64): a template instance per square side and for the 42 rectangular pairs (radius_x !=
+ *                     radius_y) out of sides 16, 20, 24, 32, 40, 48, 64, one kernel with run-time sides (fftcc2d_rect.hip) for
+ *                     every other rectangular pair; larger windows run the rocFFT pipeline.  0: rocFFT pipeline always.  2: as
+ *                     1, but 32 x 32 windows run the generic NR x NC kernel instead of their own (an A/B switch)
  *   "fftcc3d_fused"   1 (default): single-kernel FFTCC3D for every cubic window of even side 8 ... 64 (radius 4 ... 32): LDS kernel
  *                     up to 26^3, register kernel at 32^3, plane-wise kernel for 28^3 ... 64^3; and for every NON-cubic window
  *                     with all three radii in 4 ... 16 whose complex volume [2rx][2ry][2rz + 1] fits 160 KB of LDS (one kernel,

@@ -434,7 +434,8 @@ int run_fftcc2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     const ImagePair& im = *e->img;
     // ("fftcc2d_fused" = 2: the generic NR x NC kernel also for 32 x 32 windows -- an A/B switch)
     const bool fused32 = e->fftcc2d_fused != 2 && ochip::fftcc2d_fused_supported(e->rx, e->ry);
-    if (e->fftcc2d_fused && (fused32 || ochip::fftcc2d_fusedn_supported(e->rx, e->ry))) {
+    const bool rect = ochip::fftcc2d_rect_supported(e->rx, e->ry);   // rectangular windows without an instantiation (fftcc2d_rect.hip)
+    if (e->fftcc2d_fused && (fused32 || rect || ochip::fftcc2d_fusedn_supported(e->rx, e->ry))) {
         ochip::Fftcc2dParams P = {im.ref_ptr(), im.tar_ptr(), im.dy, im.dx, e->rx, e->ry};
         ProfScope prof(e);
         const size_t kMaxBatch = 1u << 30;
@@ -442,6 +443,7 @@ int run_fftcc2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
             const size_t n = (count - first) < kMaxBatch ? (count - first) : kMaxBatch;
             float* q = d_pois + first * (size_t)stride_f;
             hipError_t err = fused32 ? ochip::launch_fftcc2d_fused(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream)
+                             : rect  ? ochip::launch_fftcc2d_rect(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream)
                                      : ochip::launch_fftcc2d_fusedn(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream);
             if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "fused FFTCC2D launch failed: %s", hipGetErrorString(err));
         }

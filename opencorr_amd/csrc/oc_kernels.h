@@ -201,6 +201,12 @@ bool fftcc2d_fusedn_supported(int rx, int ry);
 hipError_t launch_fftcc2d_fusedn(const Fftcc2dParams& p, float* pois, int stride_floats, size_t count, bool xcd,
                                  hipStream_t stream);
 
+// ---- fftcc2d_rect.hip ------------------------------------------------------
+// the same for every OTHER rectangular window with both radii in 4 ... 32: ONE kernel (two instantiations: sides <= 32, sides
+// <= 64), the two sides are run-time values (each axis pass switches to the line transform of its length)
+bool fftcc2d_rect_supported(int rx, int ry);
+hipError_t launch_fftcc2d_rect(const Fftcc2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
+
 // ---- fftcc2d_fused.hip -----------------------------------------------------
 // whole FFTCC2D::compute for 32 x 32 windows (rx == ry == 16) in one kernel, no rocFFT, no scratch
 bool fftcc2d_fused_supported(int rx, int ry);

@@ -231,9 +231,51 @@ def test_fftcc2d_fused_rectangular_windows(eng, speckle_small, rx, ry):
     assert np.array_equal(_bits(fused[-3:]), _bits(base[-3:]))
 
 
+# every radius 4 ... 32 once as rx and once as ry, paired with a different one (a rotation of the 29 radii)
+RECT_RADII = [(r, 4 + ((r - 4) + 11) % 29) for r in range(4, 33)]
+assert all(rx != ry for rx, ry in RECT_RADII) and sorted(ry for _, ry in RECT_RADII) == list(range(4, 33))
+
+
+@pytest.mark.parametrize("rx,ry", RECT_RADII + [(4, 32), (32, 4), (31, 32), (5, 4)])
+def test_fftcc2d_rect_kernel_every_line_length(eng, speckle_small, rx, ry):
+    """Rectangular windows outside the 42 instantiated pairs: ONE kernel with run-time sides (fftcc2d_rect.hip; the pairs that DO
+    have an instantiation take it, as before).  Same bars as the instantiated shapes: the reference's re-cut transform
+    reproduced -- identical integers against the oracle and the rocFFT pipeline, ZNCC to float rounding, guarded POIs
+    untouched -- on an odd-length queue (the last wave of the two-POIs-per-wave instantiation is half empty)."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    xs, ys = synth.poi_grid_2d(h, w, 11, 9, max(rx, ry) + 8)
+    xs = np.concatenate([xs, [3, w - 2, 150]]).astype(np.float32)
+    ys = np.concatenate([ys, [100, 100, 2]]).astype(np.float32)
+    base = eng.make_pois2d(xs, ys)
+    assert len(base) % 2 == 0
+    base = base[1:]
+    base[::7, 2] = 1.0
+    base[::5, 8] = -2.0
+    f = eng.FFTCC2D(rx, ry)
+    f.set_images(ref, tar)
+    fused = f.compute(base.copy())
+    assert np.array_equal(_bits(fused), _bits(f.compute(base.copy())))
+    f.set_tuning("fftcc2d_fused", 0)
+    piped = f.compute(base.copy())
+    want = base.copy()
+    oracle.fftcc2d(ref, tar, rx, ry, want)
+    for col in (2, 8, 14, 15):
+        assert np.array_equal(fused[:, col], piped[:, col]), col
+        assert np.array_equal(fused[:, col], want[:, col]), col
+    assert np.abs(fused[:, 16] - piped[:, 16]).max() <= 3e-6
+    assert np.abs(fused[:, 16] - want[:, 16]).max() <= 3e-5
+    other = [c for c in range(25) if c not in (2, 8, 14, 15, 16)]
+    assert np.array_equal(_bits(fused[:, other]), _bits(base[:, other]))
+    assert np.array_equal(_bits(fused[-3:]), _bits(base[-3:]))
+    assert not np.array_equal(_bits(fused[:, 16]), _bits(piped[:, 16]))   # two implementations, not the pipeline twice
+
+
 def test_fftcc2d_setsubset_replans(eng, speckle_small):
     """FFTCC2D::setSubset between computes (examples/test_3d_dic_epipolar_sift.cpp:188-190): the engine drops its FFT
-    plans / picks another kernel for the new window -- fused 32 -> rocFFT pipeline (rx != ry) -> fused 40 -> fused 32
+    plans / picks another kernel for the new window -- fused 32 -> the run-time-sides kernel (rx != ry) -> fused 40 -> fused 32
     again, each pass equal to a fresh engine of that radius and to the oracle."""
     import oracle
     from opencorr_amd import synth
