@@ -193,20 +193,26 @@ def test_gradient3d_and_tricubic_interpolation(volumes):
     assert (want == -1).sum() > 3 and (want > 0).sum() > 2000
 
 
-def test_fftcc3d_against_reference(volumes):
+@pytest.mark.parametrize("r", [(8, 8, 8), (5, 7, 4), (6, 4, 8), (4, 6, 7)])
+def test_fftcc3d_against_reference(volumes, r):
+    """Unequal radii too: the reference plans fftwf_plan_dft_r2c_3d(2rx, 2ry, 2rz) over a buffer it fills x-fastest
+    (src/oc_fftcc.cpp:68-70, 349-360), i.e. it correlates the window's floats read as an array [2rx][2ry][2rz] and decodes the
+    peak's buffer position as a window position (:401-403).  Its own code runs here (on the stand-in FFTW, which implements the
+    documented row-major meaning of n0, n1, n2); the oracle, the rocFFT pipeline and fftcc3d_box.hip reproduce that result."""
     from opencorr_amd import synth
     ref, tar, _ = volumes
     xs, ys, zs = synth.poi_grid_3d(*ref.shape, 3, 3, 2, 20)
     want = oracle.make_pois3d(xs, ys, zs)
     want[2, oracle.P3["w"]] = 2.0
     got = want.copy()
-    oref.fftcc3d(ref, tar, 8, 8, 8, want)
-    oracle.fftcc3d(ref, tar, 8, 8, 8, got)
+    oref.fftcc3d(ref, tar, r[0], r[1], r[2], want)
+    oracle.fftcc3d(ref, tar, r[0], r[1], r[2], got)
     P = oracle.P3
     for key in ("u", "v", "w", "u0", "v0", "w0"):
         assert np.array_equal(got[:, P[key]], want[:, P[key]]), key
     assert np.abs(got[:, P["zncc"]] - want[:, P["zncc"]]).max() <= 1e-4
-    assert (want[:, P["zncc"]] > 0.5).mean() > 0.9
+    if r[0] == r[2]:   # (a reshaped window correlates worse: no statement about its peak height)
+        assert (want[:, P["zncc"]] > 0.5).mean() > 0.9
 
 
 @pytest.mark.parametrize("r", [(6, 6, 6), (5, 7, 4)])
