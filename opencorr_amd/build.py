@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libopencorr_hip.so")
-SOURCES = ["capi.hip", "prepare2d.hip", "icgn2d.hip", "nr2d.hip", "poi_order.hip", "poi_split.hip", "strain.hip", "fftcc2d.hip", "fftcc2d_fused.hip", "fftcc2d_fusedn.hip", "fftcc2d_fusedp.hip", "fftcc2d_fusedr.hip", "fftcc2d_rect.hip", "prepare3d.hip", "icgn3d.hip", "fftcc3d.hip", "fftcc3d_fused.hip", "fftcc3d_fusedn.hip", "fftcc3d_box.hip", "fftcc3d_planes.hip", "fftcc3d_planesb.hip"]
+SOURCES = ["capi.hip", "prepare2d.hip", "icgn2d.hip", "icgn2d_band.hip", "nr2d.hip", "poi_order.hip", "poi_split.hip", "strain.hip", "fftcc2d.hip", "fftcc2d_fused.hip", "fftcc2d_fusedn.hip", "fftcc2d_fusedp.hip", "fftcc2d_fusedr.hip", "fftcc2d_rect.hip", "prepare3d.hip", "icgn3d.hip", "fftcc3d.hip", "fftcc3d_fused.hip", "fftcc3d_fusedn.hip", "fftcc3d_box.hip", "fftcc3d_planes.hip", "fftcc3d_planesb.hip"]
 # the A/B build: sources that exist only there, and the product sources whose code depends on OC_BUILD_AB (recompiled with
 # -DOC_BUILD_AB=1; every other object is shared with the product build)
 AB_ONLY_SOURCES = ["icgn3d_rows.hip"]
@@ -39,7 +39,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-
 EXTRA_FLAGS = {}
 # the solver files that exist in two arithmetic modes (csrc/oc_device.h): compiled a second time with -DOC_FMA=1 into
 # <name>_fma.o (kernels in ochip::fma; oc_hip_set_tuning("arith_fma", 1) launches them)
-FMA_SOURCES = ["icgn2d.hip", "icgn3d.hip"]
+FMA_SOURCES = ["icgn2d.hip", "icgn2d_band.hip", "icgn3d.hip"]
 
 
 def hipcc():

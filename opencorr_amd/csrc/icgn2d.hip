@@ -1130,7 +1130,8 @@ hipError_t launch_iclm2d2(const Icgn2dParams& p, float* pois, int stride_f, size
 #if !OC_FMA
 // ---- the arithmetic-independent part and the dispatch between the two builds (this translation unit only) ----
 using OC_ARITH::kLdsBudget;
-constexpr int kIcgn2dVariants = 9;   // 0 ... 7: one kernel each; 8: the split launch shape (set-up kernel + iteration kernel)
+constexpr int kIcgn2dVariants = 10;  // 0 ... 7: one kernel each; 8: the split launch shape (set-up kernel + iteration kernel);
+                                     // 9: the band kernel of icgn2d_band.hip (capi.hip launches it; listed here for the tuning key)
 
 int icgn2d_variant_count() { return kIcgn2dVariants; }
 
@@ -1142,6 +1143,7 @@ int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int
         OC_ICGN2D_VARIANTS_ALL(X)
 #undef X
         case 8: *g = OC_V5_G; *mode = 4; *pipe = 0; *wpb = 8; *occ = OC_V5_OCC; return 0;  // (the iteration kernel's shape at 6 DoF)
+        case 9: *g = 1; *mode = 5; *pipe = 0; *wpb = 8; *occ = 6; return 0;  // icgn2d_band.hip: table + LDS band, subset in registers
         default: return -1;
     }
 }
@@ -1153,6 +1155,7 @@ bool icgn2d_variant_built(int variant) {
         OC_ICGN2D_VARIANTS(X)
 #undef X
         case 8: return OC_BUILD_AB != 0;
+        case 9: return true;
         default: return false;
     }
 }
@@ -1163,6 +1166,7 @@ int icgn2d_setup_record_floats(int dof) { return sep::icgn2d_setup_floats(dof); 
 int icgn2d_max_samples(int variant) {
     int g, mode, pipe, wpb, occ;
     if (icgn2d_variant_info(variant, &g, &mode, &pipe, &wpb, &occ)) return 0;
+    if (variant == 9) return icgn2d_band_max_samples(6);  // (the 12-DoF instance holds more: capi.hip asks icgn2d_band_max_samples)
     const int arrays = mode == 0 ? 4 : ((mode == 4 || mode == 2) ? 1 : 2);
     return kLdsBudget / ((arrays * wpb + (mode >= 3 ? 3 : 0)) * (int)sizeof(float) * kWave) * kWave;
 }

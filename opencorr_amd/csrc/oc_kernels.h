@@ -69,6 +69,19 @@ namespace fma {
 OC_DECLARE_ICGN2D_LAUNCHERS
 }
 #undef OC_DECLARE_ICGN2D_LAUNCHERS
+// icgn2d_band.hip (round 6): the same solvers with the workgroup's band of the bicubic table staged in LDS and the warped subset in
+// registers; hipErrorInvalidValue when the subset has more passes than the kernel holds in registers or radii are per POI
+hipError_t launch_icgn2d1_band(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
+hipError_t launch_icgn2d2_band(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
+int icgn2d_band_max_samples(int dof);
+namespace sep {
+hipError_t launch_icgn2d1_band(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
+hipError_t launch_icgn2d2_band(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
+}
+namespace fma {
+hipError_t launch_icgn2d1_band(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
+hipError_t launch_icgn2d2_band(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
+}
 int icgn2d_variant_count();
 int icgn2d_variant_info(int variant, int* g, int* mode, int* pipe, int* wpb, int* occ);
 // variants 0 and 6 are A/B partners that only the A/B build of the library contains (-DOC_BUILD_AB=1)
