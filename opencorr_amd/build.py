@@ -3,8 +3,8 @@
     python -m opencorr_amd.build [--force] [--ab]
 
 --ab additionally builds lib/ab/libopencorr_hip_ab.so: the SAME library plus the measured losers that are kept as A/B
-partners (-DOC_BUILD_AB=1: icgn2d variants 0 and 6, the ICGN3D1 row mapping icgn3d_rows.hip, the experiment environment
-knobs).  Test / experiment infrastructure: tests/ab/ and the tools/*_probe.py scripts load it through OPENCORR_HIP_LIB; the
+partners (-DOC_BUILD_AB=1: icgn2d variants 0 and 6, the LDS-band kernel icgn2d_band.hip (variant 9), the ICGN3D1 row mapping
+icgn3d_rows.hip, the experiment environment knobs).  Test / experiment infrastructure: tests/ab/ and the tools/*_probe.py scripts load it through OPENCORR_HIP_LIB; the
 library that ships does not contain any of it.
 
 Flags that matter for parity: -ffp-contract=off (no FMA
@@ -20,10 +20,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libopencorr_hip.so")
-SOURCES = ["capi.hip", "prepare2d.hip", "icgn2d.hip", "icgn2d_band.hip", "nr2d.hip", "poi_order.hip", "poi_split.hip", "strain.hip", "fftcc2d.hip", "fftcc2d_fused.hip", "fftcc2d_fusedn.hip", "fftcc2d_fusedp.hip", "fftcc2d_fusedr.hip", "fftcc2d_rect.hip", "prepare3d.hip", "icgn3d.hip", "fftcc3d.hip", "fftcc3d_fused.hip", "fftcc3d_fusedn.hip", "fftcc3d_box.hip", "fftcc3d_planes.hip", "fftcc3d_planesb.hip"]
+SOURCES = ["capi.hip", "prepare2d.hip", "icgn2d.hip", "nr2d.hip", "poi_order.hip", "poi_split.hip", "strain.hip", "fftcc2d.hip", "fftcc2d_fused.hip", "fftcc2d_fusedn.hip", "fftcc2d_fusedp.hip", "fftcc2d_fusedr.hip", "fftcc2d_rect.hip", "prepare3d.hip", "icgn3d.hip", "fftcc3d.hip", "fftcc3d_fused.hip", "fftcc3d_fusedn.hip", "fftcc3d_box.hip", "fftcc3d_planes.hip", "fftcc3d_planesb.hip"]
 # the A/B build: sources that exist only there, and the product sources whose code depends on OC_BUILD_AB (recompiled with
 # -DOC_BUILD_AB=1; every other object is shared with the product build)
-AB_ONLY_SOURCES = ["icgn3d_rows.hip"]
+AB_ONLY_SOURCES = ["icgn3d_rows.hip", "icgn2d_band.hip"]
 AB_DEPENDENT = ["capi.hip", "icgn2d.hip", "icgn3d.hip"]
 AB_LIBDIR = os.path.join(LIBDIR, "ab")
 AB_LIB = os.path.join(AB_LIBDIR, "libopencorr_hip_ab.so")

@@ -561,9 +561,13 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
     // target-array-only shape (variant 7) keeps four workgroups on a CU where variant 2 holds two (bench.py paths_8f_row1)
     if (e->self_adaptive && (e->icgn2d_variant < 0 || ochip::icgn2d_variant_uses_table(variant))) variant = 7;
     if (lm) variant = 1;  // the IC-LM launch shape has the LDS footprint of variant 1
-    // variant 9 = icgn2d_band.hip (the workgroup's band of the table staged in LDS, the warped subset in registers): one radius per
-    // launch and at most the passes its instantiation unrolls -- the automatic choice serves everything else
-    const bool band = variant == 9 && !lm && !e->self_adaptive && N <= ochip::icgn2d_band_max_samples(dof);
+    // variant 9 = icgn2d_band.hip (A/B build only: the workgroup's band of the table staged in LDS, the warped subset in registers --
+    // bit-exact, measured 1.7 x slower than variant 5): one radius per launch and at most the passes it unrolls
+#if OC_BUILD_AB
+    const bool band = variant == 9 && !lm && !e->self_adaptive && ochip::icgn2d_band_supported(dof, rx, ry);
+#else
+    const bool band = false;
+#endif
     if (variant == 9 && !band) variant = dof == 12 ? 3 : 2;
     if (!band && N > ochip::icgn2d_max_samples(variant)) variant = 1;
     if (!band && N > ochip::icgn2d_max_samples(variant))
@@ -624,9 +628,11 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
         if (lm)
             err = dof == 6 ? ochip::launch_iclm2d1(P, pois, stride_f, n, e->icgn2d_xcd != 0, e->stream)
                            : ochip::launch_iclm2d2(P, pois, stride_f, n, e->icgn2d_xcd != 0, e->stream);
+#if OC_BUILD_AB
         else if (band)
             err = dof == 6 ? ochip::launch_icgn2d1_band(P, pois, stride_f, n, e->icgn2d_xcd != 0, e->stream)
                            : ochip::launch_icgn2d2_band(P, pois, stride_f, n, e->icgn2d_xcd != 0, e->stream);
+#endif
         else
             err = dof == 6 ? ochip::launch_icgn2d1(P, pois, stride_f, n, variant, e->icgn2d_xcd != 0, e->stream)
                            : ochip::launch_icgn2d2(P, pois, stride_f, n, variant, e->icgn2d_xcd != 0, e->stream);

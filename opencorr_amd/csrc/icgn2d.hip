@@ -594,6 +594,25 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
         // warped target subset (src/oc_icgn.cpp:230-242; 2D2: 784-796)
         bool negative = false;
         float acc = 0.f;
+        // Round 6: the range rule of BicubicBspline::compute (src/oc_cubic_bspline.cpp:137-142) hoisted out of the sweep for the
+        // AFFINE warp.  A sample's target coordinate is tc + ((W0 x + W1 y) + W2) with every float operation monotone in x and
+        // in y, so over the subset's index rectangle it takes its extremes at the four corner samples: all four inside
+        // [1, size - 2) <=> every sample inside.  A corner outside is a sample outside, i.e. a -1.f in the target subset, and the
+        // reference abandons the POI (:251-255, only zncc = -3 is written) -- which is decided here, before the sweep, from four
+        // lanes' worth of arithmetic instead of two subtractions, two compares and an or per sample (5 of the sweep's ~67 VALU
+        // instructions).  The quadratic warp of ICGN2D2 is not monotone and IC-LM keeps out-of-range samples as values: both keep
+        // the per-sample test.
+        constexpr bool kCornerTest = DOF == 6 && LM == 0 && !(OC_ABLATE2D & 6);
+        if constexpr (kCornerTest) {
+            const float cxl = (float)((lane & 1) ? rx : -rx) - offx, cyl = (float)((lane & 2) ? ry : -ry) - offy;
+            const float cax = tcx + (mad(Wm[1], cyl, Wm[0] * cxl) + Wm[2]), cay = tcy + (mad(Wm[4], cyl, Wm[3] * cxl) + Wm[5]);
+            const int cxi = floor_to_int(cax), cyi = floor_to_int(cay);
+            const bool cout = (unsigned)(cxi - 1) > (unsigned)(width - 4) || (unsigned)(cyi - 1) > (unsigned)(height - 4);
+            if (!(OC_ABLATE2D & 1) && wave_any(cout)) {
+                if (lane == 0) poi[poi2d::ZNCC] = -3.f;
+                return;
+            }
+        }
         {
             SampleWalk w(lane, r0, c0, W, q64, r64);
             constexpr bool kWarpV = (OC_UNIFORM_IN_VGPR & 1) != 0 && DOF == 6, kSizeV = (OC_UNIFORM_IN_VGPR & 2) != 0;
@@ -647,15 +666,21 @@ __global__ __launch_bounds__(64 * WPB, OCC) void icgn2d_kernel(Icgn2dParams P, f
                         ax = valid[g] ? ax : 1.f;
                         ay = valid[g] ? ay : 1.f;
                     }
-                    bool out;
-                    if constexpr ((OC_ABLATE2D & 6) != 0) {
+                    bool out = false;
+                    if constexpr (kCornerTest) {
+                        // every sample is inside the interpolatable range (the corner test above): no range test, no sentinel
+                        const int xi = floor_to_int(ax), yi = floor_to_int(ay);
+                        f[g].dx = __builtin_amdgcn_fractf(ax);
+                        f[g].dy = __builtin_amdgcn_fractf(ay);
+                        r_lut.load(f[g], (__umul24((unsigned)yi, (unsigned)widthv) + (unsigned)xi) << 4);
+                    } else if constexpr ((OC_ABLATE2D & 6) != 0) {
                         unsigned off = lut_locate<LM != 0>(f[g], heightv, widthv, ax, ay, out);
                         if (OC_ABLATE2D & 2) off = iter > 1 ? (off & 0x3ff0u) : off;
                         if (!(OC_ABLATE2D & 4) || iter == 1) r_lut.load(f[g], off);
                     } else {
                         lut_fetch<LM != 0>(f[g], r_lut, heightv, widthv, ax, ay, out);
                     }
-                    if constexpr (!LM) negative = negative || out;
+                    if constexpr (!LM && !kCornerTest) negative = negative || out;
                 }
             };
             auto consume = [&](const LutFetch(&f)[G], const bool(&valid)[G], int t0, auto checked) {
@@ -1155,7 +1180,7 @@ bool icgn2d_variant_built(int variant) {
         OC_ICGN2D_VARIANTS(X)
 #undef X
         case 8: return OC_BUILD_AB != 0;
-        case 9: return true;
+        case 9: return OC_BUILD_AB != 0;   // icgn2d_band.hip: measured 1.7 x slower, A/B build only
         default: return false;
     }
 }
@@ -1166,7 +1191,7 @@ int icgn2d_setup_record_floats(int dof) { return sep::icgn2d_setup_floats(dof); 
 int icgn2d_max_samples(int variant) {
     int g, mode, pipe, wpb, occ;
     if (icgn2d_variant_info(variant, &g, &mode, &pipe, &wpb, &occ)) return 0;
-    if (variant == 9) return icgn2d_band_max_samples(6);  // (the 12-DoF instance holds more: capi.hip asks icgn2d_band_max_samples)
+    if (variant == 9) return 0;  // (capi.hip asks icgn2d_band_supported instead)
     const int arrays = mode == 0 ? 4 : ((mode == 4 || mode == 2) ? 1 : 2);
     return kLdsBudget / ((arrays * wpb + (mode >= 3 ? 3 : 0)) * (int)sizeof(float) * kWave) * kWave;
 }

@@ -20,6 +20,7 @@
 // Launch shape: 512 threads, one POI per wave, XCD-contiguous groups, tile-ordered queue (poi_order.hip).  Not available for
 // self-adaptive radii (one subset size per launch), IC-LM, or subsets above NTMAX passes: icgn2d.hip serves those.
 #include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 #include "dic2d_device.h"
@@ -43,6 +44,9 @@ struct Icgn2dBandLaunch {
     int nt;                    // ceil(N / 64)
     int xcd_chunk;
     unsigned long long count;
+    int ablate;                // timing experiments (environment OC_BAND_ABLATE; results are NOT valid except for 0, 4, 16): 1 = no window
+                               // barriers, 2 = no staging loads, 4 = nothing staged (every sample takes the global gather: the launch
+                               // shape alone), 8 = no polynomial sweeps, 16 = exactly three iterations for every POI
 };
 
 __device__ __forceinline__ int dpp_quad_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }
@@ -405,7 +409,8 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
                 ux0 = ok ? nx0 : ux0; uy0 = ok ? ny0 : uy0; ux1 = ok ? nx1 : ux1; uy1 = ok ? ny1 : uy1;
             }
         }
-        const int ubw = ux1 >= ux0 ? ux1 - ux0 + 1 : 0, ubh = ux1 >= ux0 ? uy1 - uy0 + 1 : 0;
+        const bool none = ux1 < ux0 || (L.ablate & 4);
+        const int ubw = none ? 0 : ux1 - ux0 + 1, ubh = none ? 0 : uy1 - uy0 + 1;
 
         bool negative = false;
         float acc = 0.f;
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
 #pragma unroll
                 for (int j = 0; j < CAPR / 2; j++) {
                     const int row = 2 * j + st_row0;
-                    if (row < BH) {
+                    if (row < BH && !(L.ablate & 2)) {
                         const unsigned so = ((unsigned)(Y0 + row) * (unsigned)width + (unsigned)X0) << 4;
                         float4 sv[2];
 #pragma unroll
@@ -435,8 +440,8 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
                         }
                     }
                 }
-                __syncthreads();  // B2
-                if (active) {
+                if (!(L.ablate & 1)) __syncthreads();  // B2
+                if (active && !(L.ablate & 8)) {
 #pragma unroll
                     for (int g = 0; g < WP; g++) {
                         const int t = w * WP + g;
@@ -479,12 +484,12 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
                         }
                     }
                 }
-                if (w + 1 < nwin) __syncthreads();  // B3: the band may be overwritten
+                if (w + 1 < nwin && !(L.ablate & 1)) __syncthreads();  // B3: the band may be overwritten
             }
         }
         if (active) {
             // src/oc_icgn.cpp:251-255
-            if (wave_any(negative)) {
+            if (!(L.ablate & 16) && wave_any(negative)) {
                 if (lane == 0) {
                     poi[poi2d::ZNCC] = -3.f;
                     atomicSub(const_cast<int*>(ctrl), 1);
@@ -632,7 +637,7 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
                                 dp[11 % D] * dp[11 % D] * ry4 + dp[10 % D] * dp[10 % D] * rxy2;
                 dp_norm = uni(sqrtf(d));
             }
-            if (!(iter < P.stop && dp_norm >= P.conv)) {
+            if ((L.ablate & 16) ? iter >= 3 : !(iter < P.stop && dp_norm >= P.conv)) {
                 // ---- outputs (src/oc_icgn.cpp:310-340; 2D2: 860-897)
                 if (lane == 0) {
                     float zncc = 0.5f * (2 - znssd);
@@ -693,6 +698,7 @@ static hipError_t launch_band_t(const Icgn2dParams& p, float* pois, int stride_f
     L.nt = nt;
     L.count = count;
     L.xcd_chunk = xcd ? (int)((groups + 7) / 8) : 0;
+    L.ablate = std::getenv("OC_BAND_ABLATE") ? std::atoi(std::getenv("OC_BAND_ABLATE")) : 0;
     const size_t grid = xcd ? (size_t)L.xcd_chunk * 8 : groups;
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kBandWaves), lds, stream, p, pois, L);
@@ -721,7 +727,9 @@ hipError_t launch_icgn2d2_band(const Icgn2dParams& p, float* pois, int stride_f,
 }  // namespace OC_ARITH
 
 #if !OC_FMA
-int icgn2d_band_max_samples(int dof) { return (dof == 6 ? sep::kBandNtMax1 : sep::kBandNtMax2) * kWave; }
+bool icgn2d_band_supported(int dof, int rx, int ry) {
+    return (2 * rx + 1) * (2 * ry + 1) <= (dof == 6 ? sep::kBandNtMax1 : sep::kBandNtMax2) * kWave;
+}
 hipError_t launch_icgn2d1_band(const Icgn2dParams& p, float* pois, int stride_f, size_t count, bool xcd, hipStream_t stream) {
     return p.arith_fma ? fma::launch_icgn2d1_band(p, pois, stride_f, count, xcd, stream) : sep::launch_icgn2d1_band(p, pois, stride_f, count, xcd, stream);
 }

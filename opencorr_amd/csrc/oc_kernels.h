@@ -73,7 +73,7 @@ OC_DECLARE_ICGN2D_LAUNCHERS
 // registers; hipErrorInvalidValue when the subset has more passes than the kernel holds in registers or radii are per POI
 hipError_t launch_icgn2d1_band(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
 hipError_t launch_icgn2d2_band(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
-int icgn2d_band_max_samples(int dof);
+bool icgn2d_band_supported(int dof, int rx, int ry);  // an instantiation for this subset's pass count exists
 namespace sep {
 hipError_t launch_icgn2d1_band(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
 hipError_t launch_icgn2d2_band(const Icgn2dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);

@@ -1,5 +1,5 @@
-"""The measured losers that stay around as A/B partners -- icgn2d variants 0 and 6 and the ICGN3D1 row mapping
-(icgn3d_rows.hip) -- are compiled only into the A/B build of the library (opencorr_amd/build.py --ab ->
+"""The measured losers that stay around as A/B partners -- icgn2d variants 0 and 6, the LDS-band kernel (variant 9,
+icgn2d_band.hip, round 6) and the ICGN3D1 row mapping (icgn3d_rows.hip) -- are compiled only into the A/B build of the library (opencorr_amd/build.py --ab ->
 lib/ab/libopencorr_hip_ab.so, -DOC_BUILD_AB=1).  These tests keep them bit-exact against their oracle orders.  They run in
 a process of their own whose OPENCORR_HIP_LIB points at that build: tests/test_gpu_ab_build.py starts it on the GPU box;
 collected anywhere else they skip.
@@ -23,7 +23,7 @@ def eng():
     return opencorr_amd
 
 
-@pytest.mark.parametrize("variant,xcd", [(0, 0), (6, 1), (6, 0), (8, 1), (8, 0), (5, 1), (7, 1)])
+@pytest.mark.parametrize("variant,xcd", [(0, 0), (6, 1), (6, 0), (8, 1), (8, 0), (9, 1), (9, 0), (5, 1), (7, 1)])
 def test_icgn2d1_ab_variants_identical_bits(eng, speckle_small, variant, xcd):
     import oracle
     from opencorr_amd import synth
@@ -194,3 +194,86 @@ def test_icgn2d_split_launch_shape_pipeline_same_bits(eng, speckle_small, dof):
         for _ in range(2):
             assert np.array_equal(_bits(icgn.compute(pois.copy())), _bits(want)), chunks
         assert np.array_equal(_bits(icgn.compute_with_offsets(pois.copy(), off)), _bits(want_off)), chunks
+
+
+@pytest.mark.parametrize("dof", [6, 12])
+def test_icgn2d_band_kernel_trippers_offsets_rectangular(eng, speckle_small, dof):
+    """Variant 9 (icgn2d_band.hip: the workgroup's band of the bicubic table staged in LDS, the warped subset in registers, all
+    eight waves resident until the workgroup's last POI is done): guard trippers, rejected and NaN POIs, a far-off guess whose
+    samples leave the staged box (per-lane global gathers), a queue that does not fill its last workgroup, a non-square
+    subset, centre offsets -- bit-identical to the oracle in both arithmetic modes."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    rx, ry = (13, 9) if dof == 6 else (10, 12)
+    xs, ys = synth.poi_grid_2d(h, w, 11, 9, 24)
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, 12, 12, pois)
+    P = oracle.P2
+    extra = oracle.make_pois2d([3.0, 90.0, 90.0, 90.0, w - 12.0], [80.0, 80.0, 80.0, 80.0, 100.0])
+    extra[1, P["u"]] = 200.0
+    extra[2, P["zncc"]] = -1.0
+    extra[3, P["v"]] = np.nan
+    extra[4, P["u"]], extra[4, P["ux"]] = 1.0, 0.4
+    pois = np.concatenate([extra[:2], pois, extra[2:]]).astype(np.float32)
+    prep = oracle.Prepared2D(ref, tar)
+    fn = oracle.icgn2d1 if dof == 6 else oracle.icgn2d2
+    icgn = (eng.ICGN2D1 if dof == 6 else eng.ICGN2D2)(rx, ry, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    icgn.set_tuning("icgn2d_variant", 9)
+    off = np.random.default_rng(9).uniform(-2, 2, (len(pois), 2)).astype(np.float32)
+    for fma, order in ((0, oracle.ORDER_LANES), (1, oracle.ORDER_LANES_FMA)):
+        icgn.set_tuning("arith_fma", fma)
+        want = pois.copy()
+        fn(prep, rx, ry, 0.001, 10, want, order=order, lanes=64)
+        assert np.array_equal(_bits(icgn.compute(pois.copy())), _bits(want)), fma
+        want = pois.copy()
+        fn(prep, rx, ry, 0.001, 10, want, order=order, lanes=64, center_offsets=off)
+        assert np.array_equal(_bits(icgn.compute_with_offsets(pois.copy(), off)), _bits(want)), fma
+
+
+@pytest.mark.parametrize("dof", [6, 12])
+def test_icgn2d_band_kernel_mixed_wave_lifetimes_and_tile_schedule(eng, speckle_small, dof):
+    """Variant 9's workgroups keep all eight waves until the last POI is done (finished waves go on staging the band): every
+    workgroup mixes guard rejects, first-sweep aborts, NaN guesses, one-iteration POIs and stop-limited POIs; then a queue
+    long enough for the tile schedule (workgroups whose POIs straddle two grid rows: part of the waves gather globally)."""
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = speckle_small
+    h, w = ref.shape
+    r = 16
+    P = oracle.P2
+    xs, ys = synth.poi_grid_2d(h, w, 32, 30, 26)
+    pois = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, r, r, pois)
+    prep = oracle.Prepared2D(ref, tar)
+    fn = oracle.icgn2d1 if dof == 6 else oracle.icgn2d2
+    solved = pois.copy()
+    fn(prep, r, r, 0.001, 10, solved, order=oracle.ORDER_LANES, lanes=64)
+    q = pois.copy()
+    slot = np.arange(len(q)) % 8
+    q[slot == 0, P["zncc"]] = -2.0
+    q[slot == 1, P["u"]] = w - 30.0
+    q[slot == 2, P["v"]] = np.nan
+    q[slot == 3, 2:14] = solved[slot == 3, 2:14]
+    q[slot == 4, P["u"]] += 6.5
+    q[slot == 4, P["v"]] -= 5.5
+    want = q.copy()
+    fn(prep, r, r, 0.001, 10, want, order=oracle.ORDER_LANES, lanes=64)
+    icgn = (eng.ICGN2D1 if dof == 6 else eng.ICGN2D2)(r, r, 0.001, 10)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    icgn.set_tuning("icgn2d_variant", 9)
+    for _ in range(3):
+        assert np.array_equal(_bits(icgn.compute(q.copy())), _bits(want))
+    xs, ys = synth.poi_grid_2d(h, w, 150, 120, 24)  # 18000 POIs >= the 16384 of the tile schedule
+    big = oracle.make_pois2d(xs, ys)
+    oracle.fftcc2d(ref, tar, 12, 12, big)
+    got = icgn.compute(big.copy())
+    icgn.set_tuning("icgn2d_variant", -1)
+    assert np.array_equal(_bits(got), _bits(icgn.compute(big.copy())))
+    sample = big[::41].copy()
+    fn(prep, r, r, 0.001, 10, sample, order=oracle.ORDER_LANES, lanes=64)
+    assert np.array_equal(_bits(sample), _bits(got[::41]))

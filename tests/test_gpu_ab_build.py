@@ -1,4 +1,4 @@
-"""Runs tests/ab/ -- the bit-exactness checks of the A/B partners (icgn2d variants 0, 6 and 8 -- the split launch shape --, the ICGN3D1 row mapping) -- in a
+"""Runs tests/ab/ -- the bit-exactness checks of the A/B partners (icgn2d variants 0, 6, 8 -- the split launch shape -- and 9 -- the LDS-band kernel --, the ICGN3D1 row mapping) -- in a
 process of its own against the A/B build of the library (lib/ab/libopencorr_hip_ab.so, -DOC_BUILD_AB=1).  The library that
 ships contains none of them and refuses their tuning values, which is asserted here as well."""
 import os
@@ -27,7 +27,7 @@ def test_ab_partners_in_the_ab_build():
 def test_the_product_library_refuses_the_ab_partners():
     import opencorr_amd
     icgn = opencorr_amd.ICGN2D1(16, 16, 0.001, 10)
-    for v in (0, 6, 8):
+    for v in (0, 6, 8, 9):
         with pytest.raises(Exception, match="A/B"):
             icgn.set_tuning("icgn2d_variant", v)
     icgn.set_tuning("icgn2d_variant", 7)

@@ -42,7 +42,7 @@ def case2d(speckle_small):
     return ref, tar, pois, oracle.Prepared2D(ref, tar)
 
 
-@pytest.mark.parametrize("variant", [-1, 1, 2, 3, 4, 5, 7, 9])
+@pytest.mark.parametrize("variant", [-1, 1, 2, 3, 4, 5, 7])
 @pytest.mark.parametrize("dof", [6, 12])
 def test_icgn2d_fma_every_variant_equals_oracle_lanes_fma(eng, case2d, variant, dof):
     import oracle
