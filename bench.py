@@ -129,6 +129,12 @@ def parse():
                          "fused build next to it as `arith_fma`")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="strong: BASELINE config D (8192^2, 1414 x 1414 POIs) cut into N blocks, whatever N is")
+    ap.add_argument("--workload", choices=["B", "E"], default="B",
+                    help="B (default): the metric's configuration, FFTCC2D -> ICGN2D1 (BASELINE configs[1]; N > 1: weak scaling, or config D "
+                         "with --scaling strong).  E: BASELINE configs[4], the DVC path -- 512^3 volume pair, r = 16 (33^3 subvolumes, 32^3 "
+                         "FFTCC windows), 37^3 = 50 653 POIs, FFTCC3D -> ICGN3D1 (conv 1e-3, stop 20), the queue cut into N contiguous "
+                         "blocks (strong scaling, as the config is written: 'sharded over 8 x MI355X'), volumes replicated, one all-gather "
+                         "of the POI3D records (src/oc_icgn.cpp:1492-1500)")
     return ap.parse_args()
 
 
@@ -224,21 +230,35 @@ def roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof, sampl
     secs = icgn_avg_ms * 1e-3
     alg_rate = alg_bytes / secs / 1e9 if secs > 0 else 0.0      # GB/s
     achieved = alg_flops / secs / 1e12 if secs > 0 else 0.0     # Tflop/s
+    prof = prof or {}
+    stale = prof.get("stale")
+    l2_bytes, hbm_bytes = prof.get("l2_bytes_per_launch"), prof.get("hbm_bytes_per_launch")
+    l2_rate = l2_bytes / secs / 1e9 if (l2_bytes and secs > 0) else None
+    # `frac` is what the hardware counters measure at the level `bound` names: L2 request bytes per launch /
+    # the hipEvent-timed launch / the guide's aggregate L2 figure.  The SURVEY 8(d) byte count (which the L1s partly absorb) is
+    # `frac_algorithmic`.  Without a PMC record of THIS tree's kernel (`traffic_stale`) only the algorithmic figure exists.
+    main_rate = l2_rate if l2_rate is not None else alg_rate
     return {
-        # the roof the kernel sits closest to: the L1 / L2 gather of the 64-byte table entries (ablations in
-        # -13 % without two thirds of the gathers, -3 % without two thirds of the polynomials)
         "kernel": "icgn2d_kernel<6,...> (ICGN2D1)",
         "bound": "l2",
-        "achieved": alg_rate,
+        "achieved": main_rate,
+        "achieved_source": ("PMC: TCC_REQ x the calibrated request size per launch (committed record of this tree's kernel) / the launch "
+                            "duration measured with hipEvents in this run" if l2_rate is not None else
+                            "SURVEY 8(d) algorithmic bytes / the measured launch duration (no PMC record of this tree's kernel)"),
         "peak": L2_PEAK_GBS,
         "unit": "GB/s",
-        "frac": alg_rate / L2_PEAK_GBS,
+        "frac": main_rate / L2_PEAK_GBS,
+        "achieved_algorithmic": alg_rate,
+        "frac_algorithmic": alg_rate / L2_PEAK_GBS,
+        "hbm_frac_by_counters": (hbm_bytes / secs / 1e9 / HBM_PEAK_GBS) if (hbm_bytes and secs > 0) else None,
         # HBM bytes per launch by PMC counters -- collected over this very command by tools/gpu_profiles.sh in separate
-        # rocprofv3 passes (a process cannot read them itself) and committed; None when no record exists for the workload
-        "traffic": (prof or {}).get("hbm_bytes_per_launch"),
-        "traffic_l2": (prof or {}).get("l2_bytes_per_launch"),
-        "traffic_source": (prof or {}).get("source"),
-        "l2_counter_frac": ((prof or {}).get("l2_bytes_per_launch") or 0.0) / secs / 1e9 / L2_PEAK_GBS if secs > 0 else 0.0,
+        # rocprofv3 passes (a process cannot read them itself) and committed with a fingerprint of the kernel's sources; None when
+        # no record exists for the workload or the record belongs to other sources (traffic_stale says which)
+        "traffic": hbm_bytes,
+        "traffic_l2": l2_bytes,
+        "traffic_source": prof.get("source"),
+        "traffic_stale": stale,
+        "l2_counter_frac": (l2_rate or 0.0) / L2_PEAK_GBS,
         "algorithmic_bytes_per_launch": alg_bytes,
         "avg_launch_ms": icgn_avg_ms,
         "launches_timed": icgn_launches,
@@ -262,9 +282,9 @@ def roofline_block(alg_bytes, alg_flops, icgn_avg_ms, icgn_launches, prof, sampl
         # the gather side of `combined` is a measured hardware ceiling (the sweep's own gather pattern, compute-free); its VALU
         # side is an OWN-MIX ESTIMATE (the kernel's retired count x the cycles its own mix sustains) -- not a hardware ceiling:
         # read `valu_hw` for that
-        "combined": (combined_ceiling(icgn_avg_ms, sample_slots, (prof or {}).get("valu_wave_instr_per_launch"))
+        "combined": (combined_ceiling(icgn_avg_ms, sample_slots, prof.get("valu_wave_instr_per_launch"))
                      if sample_slots else None),
-        "hbm_traffic_profiled": prof,
+        "hbm_traffic_profiled": prof or None,
     }
 
 
@@ -308,35 +328,63 @@ def main():
     from opencorr_amd.dist import allgather_pois, shard_bounds
 
     # ---- workload ---------------------------------------------------------------------
-    per_side = args.pois or POIS_PER_GPU_SIDE
-    n_total = world * per_side * per_side
-    strong = args.scaling == "strong"
-    if strong:
-        n_total = 1414 * 1414
-    # image (height, width) and POI grid (nx, ny) per world size: constant POI pitch at every N (weak_layout)
-    if strong:
-        height = width = 8192
-        nx = ny = 1414
-    else:
-        height, width, nx, ny = weak_layout(world, args.size or 4096, per_side)
+    is3d = args.workload == "E"
+    strong = args.scaling == "strong" or is3d
     t0 = time.time()
-    # ONE image pair for all ranks: rank 0 renders it, the others receive it (the GPU renderer adds its speckles with float
-    # atomics, so two renderings of the same seed differ in the last bits of a few pixels -- and with them ~40 of 250 000
-    # POIs; ranks working on private renderings could not be cross-checked bit for bit, and would not be "replicas")
-    if not dist_on or rank == 0:
-        ref, tar = synth.speckle_pair_2d(height, width, seed=20260925, device=dev)
+    if is3d:
+        # E: the volume side and the POI grid can be shrunk for tests (--size, --pois); the default is BASELINE configs[4]
+        dim = args.size or 512
+        per_side = args.pois or 37
+        r3 = 16
+        zncc_col, iter_col = 18, 19   # POI3D: result.zncc, result.iteration (src/oc_poi.h:187-222)
+        # ONE volume pair for all ranks (rank 0 renders, the others receive it: replicas must be bit-identical to be cross-checked)
+        if not dist_on or rank == 0:
+            ref, tar = synth.speckle_pair_3d(dim, dim, dim, seed=20260927, device=dev)
+        else:
+            ref = torch.empty((dim, dim, dim), dtype=torch.float32, device=dev)
+            tar = torch.empty((dim, dim, dim), dtype=torch.float32, device=dev)
+        if dist_on:
+            dist.broadcast(ref, src=0)
+            dist.broadcast(tar, src=0)
+            torch.cuda.synchronize()
+        gx3, gy3, gz3 = synth.poi_grid_3d(dim, dim, dim, per_side, per_side, per_side, r3 + 8)
+        n_total = len(gx3)
+
+        def make_pois(idx):
+            return opencorr_amd.make_pois3d(gx3[idx], gy3[idx], gz3[idx])
+        height = width = dim
     else:
-        ref = torch.empty((height, width), dtype=torch.float32, device=dev)
-        tar = torch.empty((height, width), dtype=torch.float32, device=dev)
-    if dist_on:
-        dist.broadcast(ref, src=0)
-        dist.broadcast(tar, src=0)
-        torch.cuda.synchronize()
-    xs, ys = synth.poi_grid_2d(height, width, nx, ny, RX + 8)
-    xs, ys = xs[:n_total], ys[:n_total]
-    n_total = len(xs)
+        zncc_col, iter_col = 16, 17
+        per_side = args.pois or POIS_PER_GPU_SIDE
+        n_total = world * per_side * per_side
+        if strong:
+            n_total = 1414 * 1414
+        # image (height, width) and POI grid (nx, ny) per world size: constant POI pitch at every N (weak_layout)
+        if strong:
+            height = width = 8192
+            nx = ny = 1414
+        else:
+            height, width, nx, ny = weak_layout(world, args.size or 4096, per_side)
+        # ONE image pair for all ranks: rank 0 renders it, the others receive it (the GPU renderer adds its speckles with float
+        # atomics, so two renderings of the same seed differ in the last bits of a few pixels -- and with them ~40 of 250 000
+        # POIs; ranks working on private renderings could not be cross-checked bit for bit, and would not be "replicas")
+        if not dist_on or rank == 0:
+            ref, tar = synth.speckle_pair_2d(height, width, seed=20260925, device=dev)
+        else:
+            ref = torch.empty((height, width), dtype=torch.float32, device=dev)
+            tar = torch.empty((height, width), dtype=torch.float32, device=dev)
+        if dist_on:
+            dist.broadcast(ref, src=0)
+            dist.broadcast(tar, src=0)
+            torch.cuda.synchronize()
+        xs, ys = synth.poi_grid_2d(height, width, nx, ny, RX + 8)
+        xs, ys = xs[:n_total], ys[:n_total]
+        n_total = len(xs)
+
+        def make_pois(idx):
+            return opencorr_amd.make_pois2d(xs[idx], ys[idx])
     lo, hi = shard_bounds(n_total, world, rank)
-    pristine = torch.from_numpy(opencorr_amd.make_pois2d(xs[lo:hi], ys[lo:hi])).to(dev)
+    pristine = torch.from_numpy(make_pois(np.arange(lo, hi))).to(dev)
     # two queues (and two gather buffers): step k+1 fills one while the all-gather of step k reads the other
     queues = [pristine.clone(), pristine.clone()] if dist_on else [pristine.clone()]
     per_rank = -(-n_total // world)
@@ -347,10 +395,14 @@ def main():
     gen_s = time.time() - t0
 
     stream = torch.cuda.current_stream().cuda_stream
-    fftcc = opencorr_amd.FFTCC2D(RX, RY, device=local_rank)
+    if is3d:
+        fftcc = opencorr_amd.FFTCC3D(r3, r3, r3, device=local_rank)
+        icgn = opencorr_amd.ICGN3D1(r3, r3, r3, CONV, 20.0, device=local_rank)
+    else:
+        fftcc = opencorr_amd.FFTCC2D(RX, RY, device=local_rank)
+        icgn = opencorr_amd.ICGN2D1(RX, RY, CONV, STOP, device=local_rank)
     fftcc.set_stream(stream)
     fftcc.set_images(ref, tar)
-    icgn = opencorr_amd.ICGN2D1(RX, RY, CONV, STOP, device=local_rank)
     icgn.set_stream(stream)
     icgn.share_images(fftcc)
     if args.arith == "fma":
@@ -445,10 +497,18 @@ def main():
     elapsed = float(t[0].item())
     serial_ms = float(t[1].item()) if dist_on else None
     full_np = full.cpu().numpy()
-    converged = int((full_np[:, 16] >= 0).sum())
+    converged = int((full_np[:, zncc_col] >= 0).sum())
     local_np = pois.cpu().numpy()
-    check = multi_gpu_check(args, dist, torch, dev, rank, world, local_rank, one_device, backend, fftcc, icgn, xs, ys, n_total,
+    check = multi_gpu_check(args, dist, torch, dev, rank, world, local_rank, one_device, backend, fftcc, icgn, make_pois, n_total,
                             full_np, local_np, lo, hi, serial_ms) if dist_on else None
+    if is3d:
+        if rank == 0:
+            print(json.dumps(line_workload_e(args, torch, dev, local_rank, world, dist_on, elapsed, converged, n_total, hi - lo, dim, per_side,
+                                             local_np, icgn_ms, icgn_launches, fftcc_ms, fftcc_launches, prepare_ms, prepare_first_ms,
+                                             gen_s, gather_alone_ms, check, ref, tar, gx3, gy3, gz3)), flush=True)
+        if dist_on:
+            dist.destroy_process_group()
+        return
 
     if rank == 0:
         value = converged * args.steps / elapsed
@@ -459,6 +519,11 @@ def main():
         out = {
             "metric": "converged POIs/sec (FFTCC+ICGN2D1, 33x33 subset)",
             "value": value,
+            # `value` = the bench contract's definition: whole-job throughput with POIs and images resident in HBM when the timed
+            # region starts (the same number as value_device_resident).  SURVEY 8(d) defines the metric over a HOST queue (H2D of
+            # the POI records and D2H of the results inside): that rate is value_pcie_inclusive (N = 1, side measurement below)
+            "value_device_resident": value,
+            "value_definition": "HBM-resident inputs (bench contract); SURVEY 8(d)'s PCIe-inclusive rate: value_pcie_inclusive",
             "unit": "POI/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -519,7 +584,81 @@ def main():
         dist.destroy_process_group()
 
 
-def multi_gpu_check(args, dist, torch, dev, rank, world, local_rank, one_device, backend, fftcc, icgn, xs, ys, n_total, full_np,
+def line_workload_e(args, torch, dev, local_rank, world, dist_on, elapsed, converged, n_total, n_local, dim, per_side, local_np,
+                    icgn_ms, icgn_launches, fftcc_ms, fftcc_launches, prepare_ms, prepare_first_ms, gen_s, gather_alone_ms, check,
+                    ref, tar, gx3, gy3, gz3):
+    """The JSON line of `--workload E` (BASELINE configs[4]: DVC, FFTCC3D -> ICGN3D1, the queue cut into N blocks)."""
+    r = 16
+    n3 = (2 * r + 1) ** 3
+    it = local_np[:, 19].astype(np.float64)
+    ran = it > 0
+    alg = float(ran.sum() * (4 * n3 * 4 + 248) + it[ran].sum() * n3 * 256 + (~ran).sum() * 248)
+    icgn_avg = icgn_ms / max(icgn_launches, 1)
+    fma = args.arith == "fma"
+    tr = kernel_traffic("E", "icgn3d1", fma=fma) if world == 1 else None
+    roof = secondary_block("icgn3d1_kernel (ICGN3D1)", "E: %d^3, r=16 (33^3), %d POIs on this rank" % (dim, n_local), alg, icgn_avg,
+                           icgn_launches, "lds", LDS_READ2_PEAK_GBS,
+                           "SURVEY 8(d): 4*N3*4 + k*N3*256 + 248 B per POI; the 256 B per sample and iteration are the 64 tricubic taps, "
+                           "served from the LDS-staged coefficient box: judged against the LDS read rate (ds_read2_b32: 128 B per clock and CU)",
+                           {"mean_iterations": float(it[ran].mean()) if ran.any() else 0.0,
+                            "valu_hw": valu_hardware_block(mandated_instr_icgn(local_np, 19, n3, "3d1", fma),
+                                                           (tr or {}).get("valu_wave_instr_per_launch"), icgn_avg)}, traffic=tr)
+    out = {
+        "metric": "converged POIs/sec (FFTCC3D+ICGN3D1, 33^3 subvolume)",
+        "value": converged * args.steps / elapsed,
+        "unit": "POI/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup + max(args.settle, 0),
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": ("E: %d^3 blob volume pair, r=16 (33^3 subvolume, 32^3 FFTCC window), %d POIs in all, %d on this rank, "
+                         "FFTCC3D init -> ICGN3D1 conv=1e-3 stop=20" % (dim, n_total, n_local)),
+            "arithmetic": "fp32, fused per-sample multiply-adds (arith_fma = 1)" if fma else "fp32, every multiply and add rounded separately",
+            "total_pois": n_total,
+            "converged_pois": converged,
+            "collective": ("RCCL all_gather of POI3D records (124 B), overlapped with the next step's kernels" if dist_on else "none"),
+            "all_gather_alone_ms": gather_alone_ms,
+        },
+        "roofline": roof,
+        "stage_ms": {"fftcc_pipeline_avg": fftcc_ms / max(fftcc_launches, 1), "icgn_kernel_avg": icgn_avg, "prepare_once": prepare_ms,
+                     "prepare_first_call": prepare_first_ms, "generate_inputs_s": gen_s},
+    }
+    if check is not None:
+        out["multi_gpu_check"] = check
+    if world == 1 and not dist_on and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_3d(ref, tar, gx3, gy3, gz3, r, min(args.cpu_sample, 6000))
+    return out
+
+
+def cpu_baseline_3d(ref, tar, xs, ys, zs, r, sample):
+    """The CPU oracle (the reference's loop order) on a strided sample of config E's queue, all host cores: FFTCC3D + ICGN3D1."""
+    import oracle
+    build = oracle.use_timing_build()
+    ref_h, tar_h = ref.cpu().numpy(), tar.cpu().numpy()
+    stride = max(1, len(xs) // sample)
+    cores = oracle.max_threads()
+    p = oracle.make_pois3d(xs[::stride], ys[::stride], zs[::stride])
+    t0 = time.perf_counter()
+    oracle.fftcc3d(ref_h, tar_h, r, r, r, p)
+    t1 = time.perf_counter()
+    prep = oracle.Prepared3D(ref_h, tar_h)
+    t2 = time.perf_counter()
+    oracle.icgn3d1(prep, r, r, r, CONV, 20.0, p, order=oracle.ORDER_SEQ)
+    t3 = time.perf_counter()
+    conv = int((p[:, 18] >= 0).sum())
+    return {"value": conv / ((t1 - t0) + (t3 - t2)), "unit": "POI/s", "cores": cores, "kind": "port", "build": build,
+            "sample": "every %d-th POI of the same queue (%d POIs), FFTCC3D+ICGN3D1 compute, one run; fftcc %.2f s, icgn %.2f s "
+                      "(prepare %.2f s excluded)" % (stride, len(p), t1 - t0, t3 - t2, t2 - t1),
+            "icgn_only_value": conv / (t3 - t2)}
+
+
+def multi_gpu_check(args, dist, torch, dev, rank, world, local_rank, one_device, backend, fftcc, icgn, make_pois, n_total, full_np,
                     local_np, lo, hi, serial_ms, sample_per_rank=512):
     """N > 1 self-check (results for G in {1, 2, 4, 8} must be bitwise identical).  Every rank: its own block of
     the gathered queue equals what it computed.  Rank 0 additionally RE-SOLVES a strided sample of every other rank's block
@@ -561,7 +700,7 @@ def multi_gpu_check(args, dist, torch, dev, rank, world, local_rank, one_device,
                 continue
             stride = max(1, (rhi - rlo) // sample_per_rank)
             idx = np.arange(rlo, rhi, stride)
-            q = torch.from_numpy(opencorr_amd.make_pois2d(xs[idx], ys[idx])).to(dev)
+            q = torch.from_numpy(make_pois(idx)).to(dev)
             fftcc.compute(q)
             icgn.compute(q)
             torch.cuda.synchronize()
@@ -579,8 +718,24 @@ def multi_gpu_check(args, dist, torch, dev, rank, world, local_rank, one_device,
             "ms_per_step_gather_not_overlapped": serial_ms}
 
 
+def traffic_record_is_current(rec, kernel_regex):
+    """Staleness guard: a PMC record belongs to the instruction stream it was collected on.  tools/pmc_traffic.py
+    stores opencorr_amd.build.kernel_fingerprint() -- a hash of the kernel family's sources and the compiler flags -- in the record;
+    a record without one, or with another tree's, is not reported.  Returns (ok, reason)."""
+    from opencorr_amd import build as hip_build
+    have = (rec or {}).get("source_fingerprint")
+    if not have:
+        return False, "the PMC record carries no source fingerprint (collected before round 6): re-run tools/gpu_profiles.sh"
+    want = hip_build.kernel_fingerprint(kernel_regex)
+    if have != want:
+        return False, ("the PMC record was collected on other kernel sources (fingerprint %s, this tree %s): re-run tools/gpu_profiles.sh"
+                       % (have, want))
+    return True, None
+
+
 def kernel_traffic(config, kernel_regex, fma=False):
-    """HBM / L2-side bytes per launch of one kernel from the committed PMC record of its config (tools/gpu_profiles.sh), or None."""
+    """HBM / L2-side bytes per launch of one kernel from the committed PMC record of its config (tools/gpu_profiles.sh), or None;
+    a record that belongs to other kernel sources comes back as {"stale": reason, "source": file} with no numbers."""
     path = (TRAFFIC_BY_CONFIG_FMA if fma else TRAFFIC_BY_CONFIG).get(config)
     if not path or not os.path.exists(path):
         return None
@@ -589,6 +744,9 @@ def kernel_traffic(config, kernel_regex, fma=False):
     k = (rec.get("per_kernel") or {}).get(kernel_regex)
     if not k:
         return None
+    ok, why = traffic_record_is_current(k, kernel_regex)
+    if not ok:
+        return {"stale": why, "source": os.path.relpath(path, ROOT)}
     return {"hbm_bytes_per_launch": k.get("hbm_bytes_per_launch"), "l2_bytes_per_launch": k.get("l2_bytes_per_launch"),
             "l2_hit_rate": k.get("l2_hit_rate"), "rocprof_avg_ms": (k["avg_us"] * 1e-3 if k.get("avg_us") else None),
             "valu_wave_instr_per_launch": k.get("SQ_INSTS_VALU_per_launch"),
@@ -600,7 +758,7 @@ def secondary_block(kernel, config, alg_bytes, avg_ms, launches, bound, peak_gbs
     secs = avg_ms * 1e-3
     rate = alg_bytes / secs / 1e9 if secs > 0 else 0.0
     blk = {"kernel": kernel, "config": config, "bound": bound, "achieved": rate, "peak": peak_gbs, "unit": "GB/s",
-           "frac": rate / peak_gbs, "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
+           "frac": rate / peak_gbs, "traffic": (traffic or {}).get("hbm_bytes_per_launch"), "traffic_stale": (traffic or {}).get("stale"),
            "traffic_l2": (traffic or {}).get("l2_bytes_per_launch"), "traffic_source": (traffic or {}).get("source"),
            "rocprof_avg_ms": (traffic or {}).get("rocprof_avg_ms"), "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
            "launches_timed": launches, "hbm_frac_of_algorithmic_bytes": rate / HBM_PEAK_GBS,
@@ -876,8 +1034,15 @@ def pmc_profile(world, fma=False):
     path = next((p for p in cands if os.path.exists(p)), None)
     if path is None:
         return None
+    return pmc_profile_from(path)
+
+
+def pmc_profile_from(path, kernel_regex="icgn2d_kernel"):
     with open(path) as f:
         rec = json.load(f)
+    ok, why = traffic_record_is_current(rec, kernel_regex)
+    if not ok:
+        return {"stale": why, "source": os.path.relpath(path, ROOT) + (" (%s)" % rec["collected"] if rec.get("collected") else "")}
     # run-to-run spread of the HBM counters: the same passes collected a second time by the same script
     second = os.path.join(os.path.dirname(path), "traffic_configB_second_run.json")
     spread = None

@@ -42,6 +42,35 @@ EXTRA_FLAGS = {}
 FMA_SOURCES = ["icgn2d.hip", "icgn2d_band.hip", "icgn3d.hip"]
 
 
+# Sources a profiled kernel is built from (kernel-name regex of tools/gpu_profiles.sh -> files under csrc/): the PMC records under
+# profiles/ carry kernel_fingerprint() of the day they were collected, and bench.py refuses a record whose fingerprint is not
+# the current tree's (a kernel edit must not keep yesterday's counters: VERDICT r5 weak 10)
+KERNEL_SOURCES = {
+    "icgn2d_kernel": ["icgn2d.hip", "dic2d_device.h", "oc_device.h"],
+    "fftcc2d_fused32x2_kernel": ["fftcc2d_fused.hip", "fft_device.h", "oc_device.h"],
+    "fftcc2d_fusedn_kernel": ["fftcc2d_fusedn_impl.h", "fftcc2d_fusedn.hip", "fftcc2d_fusedp.hip", "fftcc2d_fusedr.hip", "fft_device.h", "oc_device.h"],
+    "icgn3d1": ["icgn3d.hip", "icgn3d_device.h", "oc_device.h"],
+    "fftcc3d_fused32_kernel": ["fftcc3d_fused.hip", "fft_device.h", "oc_device.h"],
+    "fftcc3d_planes_kernel": ["fftcc3d_planes_impl.h", "fftcc3d_planes.hip", "fftcc3d_planesb.hip", "fft_device.h", "oc_device.h"],
+}
+
+
+def kernel_fingerprint(kernel_regex):
+    """sha256 over the sources of the kernel family `kernel_regex` names (KERNEL_SOURCES; an unknown name: every file of csrc/)
+    and the compiler flags -- what decides the instruction stream the counters were measured on."""
+    import hashlib
+    files = KERNEL_SOURCES.get(kernel_regex)
+    if files is None:
+        files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    h = hashlib.sha256()
+    h.update((" ".join(FLAGS) + " " + ARCH).encode())
+    for f in files:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

@@ -113,6 +113,7 @@ def run_2d(name, side, r, nside, engine, oracle_sample, so=None, with_fma=True):
     # displacement and guess identical; the ZNCC of the peak within 1e-5: the surface passes through a float FFT on the
     # GPU and a double DFT in the oracle), THEN the oracle refines the GPU's FFTCC output and must reproduce every bit
     step_s = max(1, n // oracle_sample)
+    t_oracle = time.perf_counter()
     fin = pristine.clone()
     f.compute(fin)
     torch.cuda.synchronize()
@@ -137,6 +138,7 @@ def run_2d(name, side, r, nside, engine, oracle_sample, so=None, with_fma=True):
         solve(prep, r, r, 0.001, 10.0, seq, order=oracle.ORDER_SEQ)
     bit_exact = bool(np.array_equal(sample.view(np.uint32), after[::step_s].view(np.uint32)))
     vs_seq = vs_reference_order(after[::step_s], seq, [2, 8], 16, 17)
+    oracle_s = time.perf_counter() - t_oracle
     fma = None
     if with_fma and engine != 3:
         # the fused arithmetic contract on the same FFTCC output: GPU(arith_fma) == oracle(LANES_FMA) bit for bit, and
@@ -166,7 +168,8 @@ def run_2d(name, side, r, nside, engine, oracle_sample, so=None, with_fma=True):
                 seconds=secs, pois_per_s=float(conv.sum() / secs), converged=int(conv.sum()),
                 mean_iterations=float(after[conv, 17].astype(np.float64).mean()), prepare_s=prepare_s,
                 median_abs_err_u=float(np.median(du)), max_abs_err_u=float(du.max()), max_abs_err_v=float(dv.max()),
-                oracle_sample=len(sample), oracle_bit_exact=bit_exact, split_queue_same_bits=same_split,
+                oracle_sample=len(sample), oracle_stride=step_s, oracle_seconds_fftcc_lanes_seq=oracle_s, oracle_cores=oracle.max_threads(),
+                oracle_bit_exact=bit_exact, split_queue_same_bits=same_split,
                 fftcc_oracle_same_integers=fftcc_same, fftcc_oracle_max_zncc_diff=fftcc_zncc, **vs_seq)
 
 
@@ -309,11 +312,11 @@ def main():
         if c == "A":
             rec = run_2d("A (2048^2, r=15, 100x100 POIs)", 2048, 15, 100, 1, 10000)
         elif c == "B":
-            rec = run_2d("B, the bench line's workload (4096^2, r=16, 500x500 POIs)", 4096, 16, 500, 1, 4000)
+            rec = run_2d("B, the bench line's workload (4096^2, r=16, 500x500 POIs)", 4096, 16, 500, 1, 250000)
         elif c == "C":
-            rec = run_2d("C (4096^2, r=20, ICGN2D2, 316x316 POIs)", 4096, 20, 316, 2, 4000, so=dict(uxx=2e-6, vyy=-1e-6))
+            rec = run_2d("C (4096^2, r=20, ICGN2D2, 316x316 POIs)", 4096, 20, 316, 2, 99856, so=dict(uxx=2e-6, vyy=-1e-6))
         elif c == "D1":
-            rec = run_2d("D on ONE GPU (8192^2, r=16, 1414x1414 POIs)", 8192, 16, 1414, 1, 4000)
+            rec = run_2d("D on ONE GPU (8192^2, r=16, 1414x1414 POIs)", 8192, 16, 1414, 1, 200000)
         elif c == "BNR":
             rec = run_2d("B with NR2D1 (4096^2, r=16, 500x500 POIs)", 4096, 16, 500, 3, 4000)
         elif c == "BST":

@@ -28,7 +28,8 @@ def test_bench_prints_the_contract_keys():
     keys = {c.value for n in ast.walk(tree) if isinstance(n, ast.Dict) for c in n.keys if isinstance(c, ast.Constant)}
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "workload", "roofline", "bound", "achieved", "peak", "frac",
-              "traffic", "cores", "kind", "sample"):
+              "traffic", "cores", "kind", "sample", "value_device_resident", "value_pcie_inclusive", "frac_algorithmic",
+              "hbm_frac_by_counters", "traffic_stale"):
         assert k in keys or ('"%s"' % k) in src, k
     assert 'out["cpu_baseline"]' in src and "--no-cpu-baseline" in src
 
@@ -68,12 +69,54 @@ def test_roofline_block_is_well_formed():
     # traffic is the PMC record of the committed profiling run over the same command (HBM side and L2 side)
     assert r["traffic"] == 2.4e9 and r["traffic_l2"] == 5.5e10 and r["traffic_source"].startswith("profiles/")
     assert abs(r["l2_counter_frac"] - 5.5e10 / 3.23e-3 / 1e9 / bench.L2_PEAK_GBS) < 1e-9
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.45 < r["frac"] < 0.6
+    # `frac` is the COUNTER fraction of the level `bound` names (L2 request bytes / time / the guide's L2 figure); the SURVEY 8(d)
+    # byte count over the same peak travels beside it as frac_algorithmic; the HBM side by counters at the block's top level
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and abs(r["frac"] - r["l2_counter_frac"]) < 1e-12
+    assert abs(r["frac_algorithmic"] - alg_bytes / 3.23e-3 / 1e9 / bench.L2_PEAK_GBS) < 1e-9 and 0.45 < r["frac_algorithmic"] < 0.6
+    assert abs(r["hbm_frac_by_counters"] - 2.4e9 / 3.23e-3 / 1e9 / bench.HBM_PEAK_GBS) < 1e-12 and r["traffic_stale"] is None
     assert 0.5 < r["gather_ubench"]["frac"] < 0.7 and 0.25 < r["valu"]["frac"] < 0.34
-    assert abs(r["l1_port"]["frac"] - r["achieved"] / bench.L1_PORT_PEAK_GBS) < 1e-12
+    assert abs(r["l1_port"]["frac"] - r["achieved_algorithmic"] / bench.L1_PORT_PEAK_GBS) < 1e-12
     assert "2.2x" in r["why_not_hbm"]
     z = bench.roofline_block(alg_bytes, alg_flops, 0.0, 0, None)   # nothing timed: no division by zero
     assert z["achieved"] == 0.0 and z["frac"] == 0.0 and z["traffic"] is None
+    # a PMC record that belongs to other kernel sources: no counter figure is reported, the reason is, frac falls back to the
+    # algorithmic bytes and says so
+    st = bench.roofline_block(alg_bytes, alg_flops, 3.23, 10, {"stale": "collected on other kernel sources", "source": "profiles/x.json"})
+    assert st["traffic"] is None and st["traffic_l2"] is None and st["hbm_frac_by_counters"] is None
+    assert st["traffic_stale"] == "collected on other kernel sources" and st["frac"] == st["frac_algorithmic"]
+    assert "no PMC record" in st["achieved_source"]
+
+
+def test_pmc_records_are_bound_to_the_kernel_sources(tmp_path):
+    """tools/pmc_traffic.py stores a fingerprint of the kernel family's sources + compiler flags in every PMC record; bench.py
+    recomputes it and reports `traffic: null` plus the reason when they differ (a kernel edit must not keep old counters)."""
+    import json
+    import bench
+    from opencorr_amd import build as hip_build
+    fp = hip_build.kernel_fingerprint("icgn2d_kernel")
+    assert fp == hip_build.kernel_fingerprint("icgn2d_kernel") and fp != hip_build.kernel_fingerprint("icgn3d1")
+    rec = {"hbm_bytes_per_launch": 2.5e9, "l2_bytes_per_launch": 3.9e10, "collected": "2026-10-01", "source_fingerprint": fp,
+           "per_kernel": {"icgn2d_kernel": {"hbm_bytes_per_launch": 2.5e9, "l2_bytes_per_launch": 3.9e10, "source_fingerprint": fp}}}
+    good = tmp_path / "good.json"
+    good.write_text(json.dumps(rec))
+    got = bench.pmc_profile_from(str(good))
+    assert got["hbm_bytes_per_launch"] == 2.5e9 and "stale" not in got
+    ok, why = bench.traffic_record_is_current(rec, "icgn2d_kernel")
+    assert ok and why is None
+    for broken in (dict(rec, source_fingerprint="0123456789abcdef"), {k: v for k, v in rec.items() if k != "source_fingerprint"}):
+        bad = tmp_path / "bad.json"
+        bad.write_text(json.dumps(broken))
+        got = bench.pmc_profile_from(str(bad))
+        assert "stale" in got and got.get("hbm_bytes_per_launch") is None and "gpu_profiles.sh" in got["stale"]
+        blk = bench.roofline_block(1e10, 1e9, 3.2, 5, got)
+        assert blk["traffic"] is None and blk["traffic_stale"] == got["stale"]
+    # every committed record the bench line reads is either current or reported as stale -- never silently used
+    for path in list(bench.TRAFFIC_BY_CONFIG.values()) + list(bench.TRAFFIC_BY_CONFIG_FMA.values()):
+        if os.path.exists(path):
+            r = json.load(open(path))
+            for name, k in (r.get("per_kernel") or {}).items():
+                ok, why = bench.traffic_record_is_current(k, name)
+                assert ok or why
 
 
 def test_secondary_roofline_blocks():

@@ -313,6 +313,38 @@ def test_bench_control_flow_at_n2_and_n8_on_one_device(nranks):
     assert chk["ms_per_step_gather_not_overlapped"] > 0
 
 
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_bench_workload_e_control_flow_at_n2_and_n8_on_one_device(nranks):
+    """`bench.py --workload E` (BASELINE configs[4]: the DVC path, FFTCC3D -> ICGN3D1, the queue cut into N contiguous blocks,
+    one all-gather of POI3D records; src/oc_icgn.cpp:1492-1500) with N = 2 and N = 8 ranks on the one GPU of this box, on a
+    shrunk volume (96^3, 9^3 = 729 POIs): the broadcast volume pair, the block cuts (the last rank's block is short), the
+    double-buffered queues with overlapped all-gathers of 124-byte records, and -- strict mode -- multi_gpu_check: every rank's
+    block of the gathered queue equals what it computed, rank 0 re-solves every other rank's POIs bit for bit."""
+    import json
+    import socket
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, OC_BENCH_ONE_DEVICE="1", OC_BENCH_STRICT="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nranks), "--steps", "2", "--warmup", "1",
+           "--workload", "E", "--size", "96", "--pois", "9", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    chk = rec["multi_gpu_check"]
+    assert rec["n_gpus"] == nranks and rec["scaling"] == "strong" and chk["world_size"] == nranks and chk["backend"] == "gloo"
+    assert "FFTCC3D" in rec["metric"] and rec["config"]["total_pois"] == 729
+    assert chk["ok"] and chk["problems"] == [] and chk["gathered_equals_local_bits"] and chk["resolved_sample_bit_identical"]
+    per = -(-729 // nranks)
+    assert chk["resolved_sample_of_other_ranks"] == 729 - per          # blocks of <= 512 POIs are re-solved whole
+    assert rec["config"]["converged_pois"] >= 0.95 * 729
+    assert rec["roofline"]["kernel"].startswith("icgn3d1") and rec["roofline"]["frac"] > 0
+
+
 def test_group_of_eight_on_config_d_queue():
     """oc_hip_set_devices with EIGHT members over BASELINE config D's whole queue (8192^2 pair, 1414 x 1414 = 1 999 396 POIs,
     the 8-GPU configuration), device 0 named eight times: eight engines with their own tables (8 x 4.3 GB), eight streams,

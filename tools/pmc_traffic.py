@@ -87,6 +87,14 @@ def one_kernel(a, rx):
             "note": a.note or "FETCH_SIZE x2 (gfx950 counts 128 B fabric requests as 64 B); WRITE_SIZE as reported",
         })
     rec["collected"] = datetime.date.today().isoformat()
+    # which instruction stream these counters belong to: bench.py drops the record when the kernel's sources have changed since
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from opencorr_amd import build as _build
+        rec["source_fingerprint"] = _build.kernel_fingerprint(rx.pattern)
+    except Exception as exc:   # (a record without a fingerprint is treated as stale)
+        rec["source_fingerprint_error"] = repr(exc)[:200]
     if a.command:
         rec["command"] = a.command
     tcc = glob.glob(os.path.join(a.root, "pmc_tcc", "*_counter_collection.csv"))
