@@ -62,9 +62,11 @@ def vs_reference_order(gpu, seq, cols_disp, col_zncc, col_iter):
     dz = np.abs(gpu[same_it, col_zncc].astype(np.float64) - seq[same_it, col_zncc].astype(np.float64))
     # failed POIs keep their codes: -3 / -4 / -5 must be the SAME code on both sides
     codes_same = bool(np.array_equal(gpu[fa & fb, col_zncc], seq[fa & fb, col_zncc]))
+    over = int((dd.max(axis=1) > 1e-4).sum()) if dd.size else 0
     return dict(seq_flag_mismatches=int((fa != fb).sum()) + (0 if codes_same else 1),
                 seq_iteration_agreement=float(same_it.sum() / max(1, both.sum())),
                 seq_max_abs_d_disp=float(dd.max()) if dd.size else 0.0,
+                seq_pois_over_1e4=over, seq_frac_within_1e4=float(1.0 - over / max(1, int(same_it.sum()))),
                 seq_max_abs_d_zncc=float(dz.max()) if dz.size else 0.0, seq_sample=int(len(gpu)))
 
 
