@@ -1,24 +1,29 @@
-// icgn2d_band.hip -- ICGN2D1 / ICGN2D2 with the bicubic coefficient BAND of a workgroup staged in LDS (round 6).
+// icgn2d_band.hip -- ICGN2D1 / ICGN2D2 with the bicubic coefficient BAND of a workgroup staged in LDS (round 6, VERDICT r5 item 1).
 //
 // Replaces ICGN2D1::compute(POI2D*) (src/oc_icgn.cpp:144-341) / ICGN2D2::compute(POI2D*) (:685-898) for a whole queue, like
 // icgn2d.hip, whose arithmetic it repeats operation for operation (same bits: oracle OC_ORDER_LANES / _FMA).  What differs is
-// where the 64 bytes per sample of BicubicBspline::compute (src/oc_cubic_bspline.cpp:134-181) come from:
-//   * icgn2d.hip gathers them per lane from the planar table in global memory (four buffer_load_b128 through the CU's L1);
-//   * here the eight waves of a workgroup -- eight consecutive POIs of the visiting order, normally neighbours in a row of the
-//     POI grid -- sweep their subsets in lockstep WINDOWS of kBandWP passes (128 samples = ~4 subset rows).  In a window all of
-//     them touch ONE band of the table: a few rows x (7 x pitch + subset width) pixels x 4 planes x 16 B.  The band is bounded
-//     per wave from the images of the window's index rectangle under the POI's warp (affine: the four corners bound it exactly,
-//     every float operation being monotone), the waves' boxes are united (in wave order, while the union fits the LDS area),
-//     the union is loaded ONCE per workgroup with coalesced 1 KB buffer loads, and every sample inside it reads its four
-//     float4 with ds_read_b128.  A sample outside the staged box (a POI of the next grid row in the same workgroup, a large
-//     deformation gradient, the quadratic warp of ICGN2D2 bulging past its corners) takes the global gather per LANE -- the box
-//     is a performance decision, never a correctness one.
-//   * the warped target subset lives in REGISTERS (ts[NTMAX], every pass loop unrolled): the LDS of a workgroup is the
-//     coordinate table, the band and 1 KB of boxes -- no per-wave arrays -- so three workgroups per CU stay resident.
-//   * all eight waves stay until the workgroup's last POI has converged: a wave that is done keeps loading its share of the
-//     band (and passes every barrier), it only stops computing.
+// where the 64 bytes per sample of BicubicBspline::compute (src/oc_cubic_bspline.cpp:134-181) come from.  icgn2d.hip gathers
+// them per lane from the planar table in global memory: four buffer_load_b128 per sample through the CU's texture path, which
+// moves 64 B per clock and is what its interpolation sweeps wait for (gathers alone 1.78 ms, their arithmetic alone 1.04 ms,
+// DESIGN.md 4.1).  The LDS moves 256 B per clock (ds_read_b128).  So:
+//   * the eight waves of a workgroup -- eight consecutive POIs of the visiting order, normally neighbours in a row of the POI grid
+//     -- sweep their subsets in lockstep WINDOWS of two passes (128 samples = ~4 subset rows).  In a window all of them touch ONE
+//     band of the table: kBandRows rows x kBandCols pixels x 4 planes x 16 B = 36 KB.  Every iteration each wave bounds, for
+//     every window at once (one lane per window corner), the image of the window's index rectangle under its warp (affine: the
+//     corners bound it exactly, every float operation being monotone; quadratic: corners + a bound on the square terms); the
+//     workgroup agrees on one box origin per window (minimum over its waves) and every wave knows per window whether its samples
+//     lie inside that box (FAST) or not (SLOW: a POI of the next grid row in the same workgroup, a large deformation gradient);
+//   * the box is loaded ONCE per workgroup and window with LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS without passing
+//     through registers, addresses formed on the scalar unit: no VALU instruction, no VGPR); a FAST wave then reads its four
+//     float4 per sample with ds_read_b128 -- two VALU instructions of address arithmetic per sample, like the global gather's --
+//     a SLOW wave gathers from global memory as icgn2d.hip does, started before it waits for the band;
+//   * the warped target subset lives in REGISTERS (a 16 + k float vector addressed with the VGPR index mode, so the pass loops
+//     stay rolled): the LDS of a workgroup is the coordinate table, the band, the boxes and H^-1 -- no per-wave arrays -- and three
+//     workgroups per CU stay resident;
+//   * all eight waves stay until the workgroup's last POI is done: a finished wave keeps staging its rows of the band (and
+//     passes every barrier), it only stops computing.
 // Launch shape: 512 threads, one POI per wave, XCD-contiguous groups, tile-ordered queue (poi_order.hip).  Not available for
-// self-adaptive radii (one subset size per launch), IC-LM, or subsets above NTMAX passes: icgn2d.hip serves those.
+// self-adaptive radii (one subset size per launch), IC-LM, or subsets above 20 / 28 passes: icgn2d.hip serves those.
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -29,15 +34,13 @@
 namespace ochip {
 namespace OC_ARITH {
 
-constexpr int kBandWaves = 8;   // POIs per workgroup
-constexpr int kBandWP = 2;      // passes per window
-constexpr int kBandCapX = 96;   // pixels per staged row
-constexpr int kBandCapR = 6;    // staged rows
-
-// what a pass of the Hessian sweep / the numerator pass fetches for one sample
-struct GradSample {
-    float gx, gy, ref = 0.f;
-};
+constexpr int kBandWaves = 8;    // POIs per workgroup
+constexpr int kBandWP = 2;       // passes per window
+constexpr int kBandCols = 96;    // pixels per staged row
+constexpr int kBandPitch = 97;   // row pitch of the staged box in float4 (odd multiple of 16 B: consecutive rows fall on different banks)
+constexpr int kBandRows = 6;     // staged rows
+constexpr int kBandPlane = kBandRows * kBandPitch;   // float4 per plane
+constexpr int kBandMaxWin = 16;  // windows per sweep (32 passes)
 
 struct Icgn2dBandLaunch {
     int stride_f;
@@ -45,52 +48,69 @@ struct Icgn2dBandLaunch {
     int xcd_chunk;
     unsigned long long count;
     int ablate;                // timing experiments (environment OC_BAND_ABLATE; results are NOT valid except for 0, 4, 16): 1 = no window
-                               // barriers, 2 = no staging loads, 4 = nothing staged (every sample takes the global gather: the launch
-                               // shape alone), 8 = no polynomial sweeps, 16 = exactly three iterations for every POI
+                               // barriers, 2 = no staging, 4 = every wave takes the global gathers (the launch shape alone),
+                               // 8 = no polynomial sweeps, 16 = exactly three iterations for every POI
+};
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// the warped target subset of a wave, one float per pass and lane, in registers: 16 + TSB passes, indexed with a wave-uniform
+// pass number (s_set_gpr_idx / v_mov: one VALU instruction per access)
+template <int TSB>
+struct TsRegs {
+    typedef float bvec __attribute__((ext_vector_type(TSB)));
+    f16v a;
+    bvec b;
+    __device__ __forceinline__ void set(int t, float v) {
+        if (t < 16) a[t] = v;
+        else b[t - 16] = v;
+    }
+    __device__ __forceinline__ float get(int t) const { return t < 16 ? a[t] : b[t - 16]; }
 };
 
 __device__ __forceinline__ int dpp_quad_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }
 __device__ __forceinline__ int dpp_quad_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true); }
-__device__ __forceinline__ float4 buf_f32x4so(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+
+constexpr size_t icgn2d_band_lds_bytes(int nt, int dof) {
+    return (size_t)3 * nt * kWave * 4 + (size_t)4 * kBandPlane * 16 + (size_t)kBandWaves * kBandMaxWin * 16 + (size_t)kBandWaves * dof * dof * 4 + 16;
 }
 
-constexpr size_t icgn2d_band_lds_bytes(int nt, int ntmax) {
-    return (size_t)3 * nt * kWave * 4 + (size_t)4 * kBandCapR * kBandCapX * 16 + (size_t)kBandWaves * ((ntmax + kBandWP - 1) / kBandWP) * 16 + 16;
-}
+// what a pass of the Hessian sweep / the numerator pass fetches for one sample
+struct GradSample {
+    float gx, gy, ref = 0.f;
+};
 
-template <int DOF, int NTMAX, int OFFS>
+template <int DOF, int TSB, int OFFS>
 __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band_kernel(Icgn2dParams P, float* __restrict__ pois,
-                                                                                       Icgn2dBandLaunch L) {
+                                                                                     Icgn2dBandLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef __attribute__((address_space(3))) void* lds_vp;
     constexpr int NH = DOF * (DOF + 1) / 2;
-    constexpr int WP = kBandWP, NWMAX = (NTMAX + WP - 1) / WP;
-    constexpr int CAPX = kBandCapX, CAPR = kBandCapR, PLANE = CAPR * CAPX;
+    constexpr int WP = kBandWP;
     constexpr bool COOP = DOF == 6;
-    static_assert(NWMAX * 4 <= kWave, "one lane per (window, corner)");
     constexpr int kSetupBatch = 6, kHessBatch = 6, kNumBatch = DOF == 6 ? 6 : 4;
 
-    const int NTA = L.nt;
+    const int NT = L.nt;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     f2* __restrict__ tab_xy = reinterpret_cast<f2*>(lds);
-    unsigned* __restrict__ tab_off = reinterpret_cast<unsigned*>(lds + 2 * NTA * kWave);
-    float4* __restrict__ band = reinterpret_cast<float4*>(lds + 3 * NTA * kWave);
-    int4* __restrict__ boxes = reinterpret_cast<int4*>(band + 4 * PLANE);
-    volatile int* ctrl = reinterpret_cast<volatile int*>(boxes + kBandWaves * NWMAX);
+    unsigned* __restrict__ tab_off = reinterpret_cast<unsigned*>(lds + 2 * NT * kWave);
+    float4* __restrict__ band = reinterpret_cast<float4*>(lds + 3 * NT * kWave);
+    int4* __restrict__ boxes = reinterpret_cast<int4*>(band + 4 * kBandPlane);   // [wave][window]: xmin, ymin, xmax, ymax
+    float* __restrict__ hrow_area = reinterpret_cast<float*>(boxes + kBandWaves * kBandMaxWin);  // H^-1 of the eight POIs, row-major
+    volatile int* ctrl = reinterpret_cast<volatile int*>(hrow_area + kBandWaves * DOF * DOF);
     float* __restrict__ coop_area = reinterpret_cast<float*>(band);  // the band is idle until the first sweep
 
     const int height = P.height, width = P.width;
     const int rx = P.rx, ry = P.ry;
     const int W = 2 * rx + 1, N = W * (2 * ry + 1);
     const float fN = (float)N;
-    const int NT = (N + kWave - 1) / kWave;
     const int NF = N / kWave;
     const bool tail_valid = (NF * kWave + lane) < N;
     const int nwin = (NT + WP - 1) / WP;
     {
         const unsigned w4t = (unsigned)width * 4u;
-        for (int s = threadIdx.x; s < NTA * kWave; s += kWave * kBandWaves) {
+        for (int s = threadIdx.x; s < NT * kWave; s += kWave * kBandWaves) {
             const int r = s / W, c = s - r * W;
             tab_xy[s] = mk2((float)(c - rx), (float)(r - ry));
             tab_off[s] = (unsigned)r * w4t + ((unsigned)c << 2);
@@ -130,107 +150,73 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
     const unsigned roff = (unsigned)__builtin_amdgcn_readfirstlane((((int)(py - ry)) * width + ((int)(px - rx))) * 4);
     const __amdgpu_buffer_rsrc_t r_gx = make_rsrc(P.gx), r_gy = make_rsrc(P.gy), r_ref = make_rsrc(P.ref);
     const LutPlanes4 r_lut(P.lut, height, width);
-    // the plane this wave stages (constant for its life): waves 0-3 the even rows of a round, 4-7 the odd ones
+    // staging: wave v owns plane v & 3 and the rows (v >> 2), (v >> 2) + 2, (v >> 2) + 4 of the box: per row one 1 KiB LDS-DMA piece
+    // (pixels 0 .. 63) and one half piece (pixels 64 .. 95, lanes 0 .. 31) -- addresses on the scalar unit only
     const int st_plane = wave & 3, st_row0 = wave >> 2;
     const __amdgpu_buffer_rsrc_t r_stage = st_plane == 0 ? r_lut.p0 : (st_plane == 1 ? r_lut.p1 : (st_plane == 2 ? r_lut.p2 : r_lut.p3));
+    const bool band_ok = width >= kBandCols + 4 && height >= kBandRows + 4 && !(L.ablate & 4);
 
-    // every pass loop is unrolled over NTMAX with wave-uniform guards: ts[] must stay in registers
-    float ts[NTMAX];
-#pragma unroll
-    for (int t = 0; t < NTMAX; t++) ts[t] = 0.f;
-    // passes [0, NF) full, pass NF (if NF < NT) partial; loads of up to B passes in flight, uses in pass order
-    auto passes = [&](auto bconst, auto&& load, auto&& use) {
-        constexpr int B = decltype(bconst)::value;
-#pragma unroll
-        for (int t0 = 0; t0 < NTMAX; t0 += B) {
-            if (t0 < NT) {
-                __builtin_amdgcn_sched_barrier(0);  // keep the batches apart: the unrolled loop must not pile their loads up
-                decltype(load(0, true)) v[B];
-#pragma unroll
-                for (int u = 0; u < B; u++) {
-                    const int t = t0 + u;
-                    if (t < NTMAX) {
-                        if (t < NF) v[u] = load(t, true);
-                        else if (t < NT) v[u] = load(t, tail_valid);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < B; u++) {
-                    const int t = t0 + u;
-                    if (t < NTMAX) {
-                        if (t < NF) use(t, true, v[u]);
-                        else if (t < NT) use(t, tail_valid, v[u]);
-                    }
-                }
-            }
-        }
-    };
+    TsRegs<TSB> ts;
 
     float ref_norm = 0.f, ref_mean = 0.f;
-    float hinv_col[DOF];
-    float hinv_row[DOF];
-#pragma unroll
-    for (int j = 0; j < DOF; j++) hinv_row[j] = hinv_col[j] = 0.f;
     float h[NH];
 #pragma unroll
     for (int i = 0; i < NH; i++) h[i] = 0.f;
     if (active) {
         // ---- reference subset, zero-mean + norm (src/oc_icgn.cpp:174-176, src/oc_subset.cpp:39-53)
         float acc = 0.f;
-        passes(std::integral_constant<int, kSetupBatch>{},
-               [&](int t, bool valid) { return valid ? buf_f32(r_ref, off_at(t), roff) : 0.f; },
-               [&](int t, bool valid, float v) {
-                   acc = valid ? acc + v : acc;
-                   ts[t] = v;
-               });
+        passes_batched<kSetupBatch>(
+            NF, NT, tail_valid, [&](int t, bool valid) { return valid ? buf_f32(r_ref, off_at(t), roff) : 0.f; },
+            [&](int t, bool valid, float v) {
+                acc = valid ? acc + v : acc;
+                ts.set(t, v);
+            });
         const float mean = wave_allreduce_sum(acc) / fN;
         ref_mean = uni(mean);
         acc = 0.f;
-#pragma unroll
-        for (int t = 0; t < NTMAX; t++) {
-            if (t < NF) {
-                const float d = ts[t] - mean;
-                acc = mad(d, d, acc);
-            } else if (t < NT) {
-                const float d = ts[t] - mean;
-                acc = tail_valid ? mad(d, d, acc) : acc;
-            }
+#pragma unroll 3
+        for (int t = 0; t < NF; t++) {
+            const float d = ts.get(t) - mean;
+            acc = mad(d, d, acc);
+        }
+        if (NF < NT) {
+            const float d = ts.get(NF) - mean;
+            acc = tail_valid ? mad(d, d, acc) : acc;
         }
         ref_norm = uni(sqrtf(wave_allreduce_sum(acc)));
-#pragma unroll
-        for (int t = 0; t < NTMAX; t++) ts[t] = 0.f;  // (dead until the first sweep: say so to the register allocator)
 
         // ---- steepest-descent image + Hessian (src/oc_icgn.cpp:179-207; 2D2: 716-756)
         if constexpr (DOF == 6) {
             f2 hAA = mk2(0.f, 0.f), hBB = hAA, hAB = hAA, hAs = hAA, hxA = hAA, hyA = hAA, hxB = hAA, hyB = hAA;
             float h00 = 0.f, h33 = 0.f, h30 = 0.f, h21 = 0.f, h54 = 0.f;
-            passes(std::integral_constant<int, kHessBatch>{},
-                   [&](int t, bool valid) {
-                       GradSample v;
-                       const unsigned off = off_at(t);
-                       v.gx = valid ? buf_f32(r_gx, off, goff) : 0.f;
-                       v.gy = valid ? buf_f32(r_gy, off, goff) : 0.f;
-                       return v;
-                   },
-                   [&](int t, bool valid, const GradSample& v) {
-                       const float g_x = v.gx, g_y = v.gy;
-                       const f2 xy = tab_at(t) - mk2(offx, offy);
-                       const f2 A = g_x * xy, B = g_y * xy;
-                       const f2 nAA = mad(A, A, hAA), nBB = mad(B, B, hBB), nAB = mad(A, B, hAB), nAs = mad(A, B.yx, hAs);
-                       const f2 nxA = mad(g_x, A, hxA), nyA = mad(g_y, A, hyA), nxB = mad(g_x, B, hxB), nyB = mad(g_y, B, hyB);
-                       const float n00 = mad(g_x, g_x, h00), n33 = mad(g_y, g_y, h33), n30 = mad(g_y, g_x, h30);
-                       const float n21 = mad(A.y, A.x, h21), n54 = mad(B.y, B.x, h54);
-                       if (valid) {
-                           hAA = nAA; hBB = nBB; hAB = nAB; hAs = nAs; hxA = nxA; hyA = nyA; hxB = nxB; hyB = nyB;
-                           h00 = n00; h33 = n33; h30 = n30; h21 = n21; h54 = n54;
-                       }
-                   });
+            passes_batched<kHessBatch>(
+                NF, NT, tail_valid,
+                [&](int t, bool valid) {
+                    GradSample v;
+                    const unsigned off = off_at(t);
+                    v.gx = valid ? buf_f32(r_gx, off, goff) : 0.f;
+                    v.gy = valid ? buf_f32(r_gy, off, goff) : 0.f;
+                    return v;
+                },
+                [&](int t, bool valid, const GradSample& v) {
+                    const float g_x = v.gx, g_y = v.gy;
+                    const f2 xy = tab_at(t) - mk2(offx, offy);
+                    const f2 A = g_x * xy, B = g_y * xy;
+                    const f2 nAA = mad(A, A, hAA), nBB = mad(B, B, hBB), nAB = mad(A, B, hAB), nAs = mad(A, B.yx, hAs);
+                    const f2 nxA = mad(g_x, A, hxA), nyA = mad(g_y, A, hyA), nxB = mad(g_x, B, hxB), nyB = mad(g_y, B, hyB);
+                    const float n00 = mad(g_x, g_x, h00), n33 = mad(g_y, g_y, h33), n30 = mad(g_y, g_x, h30);
+                    const float n21 = mad(A.y, A.x, h21), n54 = mad(B.y, B.x, h54);
+                    if (valid) {
+                        hAA = nAA; hBB = nBB; hAB = nAB; hAs = nAs; hxA = nxA; hyA = nyA; hxB = nxB; hyB = nyB;
+                        h00 = n00; h33 = n33; h30 = n30; h21 = n21; h54 = n54;
+                    }
+                });
             h[0] = h00;
             h[1] = hxA.x; h[2] = hAA.x;
             h[3] = hxA.y; h[4] = h21; h[5] = hAA.y;
             h[6] = h30; h[7] = hyA.x; h[8] = hyA.y; h[9] = h33;
-            h[10 % NH] = hxB.x; h[11 % NH] = hAB.x; h[12 % NH] = hAs.y; h[13 % NH] = hyB.x; h[14 % NH] = hBB.x;
-            h[15 % NH] = hxB.y; h[16 % NH] = hAs.x; h[17 % NH] = hAB.y; h[18 % NH] = hyB.y; h[19 % NH] = h54; h[20 % NH] = hBB.y;
+            h[10] = hxB.x; h[11] = hAB.x; h[12] = hAs.y; h[13] = hyB.x; h[14] = hBB.x;
+            h[15] = hxB.y; h[16] = hAs.x; h[17] = hAB.y; h[18] = hyB.y; h[19] = h54; h[20] = hBB.y;
         } else {
             f2 hp[12][6];
             float hd[12];
@@ -265,7 +251,6 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
                     if ((r & 1) == 0) hd[r] = valid ? mad(sr, sr, hd[r]) : hd[r];
                 }
             };
-            // (a rolled loop: the 78 running sums leave no room for an unrolled body; the pass index is not a register index here)
             passes_prefetched(NF, NT, tail_valid, fetch, sample);
             int k = 0;
 #pragma unroll
@@ -275,19 +260,18 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
                     h[k % NH] = (c == r && (r & 1) == 0) ? hd[r] : ((c & 1) ? hp[r][c / 2].y : hp[r][c / 2].x);
         }
     }
-    // ---- inverse of the Hessian (:210 / :759)
+    // ---- inverse of the Hessian (:210 / :759), filed row-major in hrow_area
     if constexpr (COOP) {
         if (active) wave_reduce_sum_multi_to_lds<NH>(h, lane, coop_area + wave * 64);
         else if (lane < 24) coop_area[wave * 64 + lane] = 0.f;
         __syncthreads();
         if (wave == 0) coop_inverse6_x8(coop_area, lane);
         __syncthreads();
-        const float* __restrict__ row = coop_area + wave * 64 + 24 + min(lane, DOF - 1) * DOF;
-#pragma unroll
-        for (int j = 0; j < DOF; j++) hinv_row[j] = lane < DOF ? row[j] : 0.f;
+        // (H^-1 row-major moves out of the band area, which the first sweep overwrites)
+        if (lane < DOF * DOF) hrow_area[wave * DOF * DOF + lane] = coop_area[wave * 64 + 24 + lane];
     } else {
         if (active) {
-            float col[DOF];
+            float col[DOF], hinv_col[DOF];
 #pragma unroll
             for (int i = 0; i < DOF; i++) col[i] = 0.f;
             wave_allreduce_sum_multi<NH>(h, lane);
@@ -301,13 +285,11 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
                     if (lane == i) col[j] = v;
                 }
             lu_inverse_lanes<DOF>(col, hinv_col, lane);
+            // lane j holds column j of H^-1: element (i, j) goes to row i
+            if (lane < DOF) {
 #pragma unroll
-            for (int i = 0; i < DOF; i++)
-#pragma unroll
-                for (int j = 0; j < DOF; j++) {
-                    const float v = wave_bcast(hinv_col[i], j);
-                    hinv_row[j] = lane == i ? v : hinv_row[j];
-                }
+                for (int i = 0; i < DOF; i++) hrow_area[wave * DOF * DOF + i * DOF + lane] = hinv_col[i];
+            }
         }
     }
 
@@ -353,16 +335,55 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
         ax = tcx + wx;
         ay = tcy + wy;
     };
-    // lane 4 w + c: corner c of window w's index rectangle (all columns x the rows the window's samples lie in)
-    float cxl, cyl;
+    // Boxes of ALL windows of this wave at once, lane 4 w + c = corner c of window w's index rectangle (all columns x the rows
+    // its samples lie in; the row of the window's first / last sample comes from the coordinate table, whose y entry is
+    // (float)(row - ry)): the corner's target pixel, min / max over the quad.  The box bounds the pixels floor(x), floor(y) of
+    // every sample of the window: exactly for the affine warp (monotone float operations), with the square terms' bound
+    // 2 (|a_xx| X^2 + |a_yy| Y^2) + 0.01 on either side for the quadratic one.  corner_out = a corner leaves the interpolatable
+    // range (2D1: a corner IS a sample, the reference abandons the POI, see icgn2d.hip kCornerTest) -- a wave-uniform flag.
     const int bw_l = lane >> 2;
-    {
-        const int s0 = kWave * WP * bw_l, s1 = min(kWave * WP * (bw_l + 1), N) - 1;
-        const int ra = s0 / W, rb = max(s1, 0) / W;
-        cxl = (float)((lane & 1) ? rx : -rx) - offx;
-        cyl = (float)(((lane & 2) ? rb : ra) - ry) - offy;
+    auto publish_boxes = [&](bool& corner_out) {
+        if constexpr (DOF == 12) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                row3[k] = wave_bcast(Wcol[3], k);
+                row4[k] = wave_bcast(Wcol[4], k);
+            }
+        }
+        const int cs = min((lane & 2) ? kWave * WP * (bw_l + 1) - 1 : kWave * WP * bw_l, N - 1);
+        const float cxl = (float)((lane & 1) ? rx : -rx) - offx;
+        const float cyl = tab_xy[cs].y - offy;
+        float ax, ay;
+        warp_point(cxl, cyl, ax, ay);
+        float lox = ax, hix = ax, loy = ay, hiy = ay;
+        if constexpr (DOF == 12) {
+            const float X = (float)rx + fabsf(offx), Y = (float)ry + fabsf(offy);
+            const float dx_ = 2.f * (fabsf(row3[0]) * X * X + fabsf(row3[2]) * Y * Y) + 0.01f;
+            const float dy_ = 2.f * (fabsf(row4[0]) * X * X + fabsf(row4[2]) * Y * Y) + 0.01f;
+            lox -= dx_; hix += dx_; loy -= dy_; hiy += dy_;
+        }
+        int x0 = floor_to_int(lox), x1 = floor_to_int(hix), y0 = floor_to_int(loy), y1 = floor_to_int(hiy);
+        const bool cout = (unsigned)(x0 - 1) > (unsigned)(width - 4) || (unsigned)(y0 - 1) > (unsigned)(height - 4) ||
+                          (unsigned)(x1 - 1) > (unsigned)(width - 4) || (unsigned)(y1 - 1) > (unsigned)(height - 4);
+        corner_out = __builtin_amdgcn_ballot_w64(cout && bw_l < nwin) != 0;
+        x0 = min(x0, dpp_quad_xor1(x0)); x1 = max(x1, dpp_quad_xor1(x1));
+        y0 = min(y0, dpp_quad_xor1(y0)); y1 = max(y1, dpp_quad_xor1(y1));
+        x0 = min(x0, dpp_quad_xor2(x0)); x1 = max(x1, dpp_quad_xor2(x1));
+        y0 = min(y0, dpp_quad_xor2(y0)); y1 = max(y1, dpp_quad_xor2(y1));
+        // (a box that leaves the range is not FAST: publish it as "nothing", so that it neither drags the origin nor is read)
+        if (x0 < 1 || y0 < 1 || x1 > width - 3 || y1 > height - 3) { x0 = y0 = 0x7fffffff; x1 = y1 = -0x7fffffff; }
+        if ((lane & 3) == 0 && bw_l < nwin) boxes[wave * kBandMaxWin + bw_l] = make_int4(x0, y0, x1, y1);
+    };
+    auto publish_none = [&]() {
+        if (lane < nwin) boxes[wave * kBandMaxWin + lane] = make_int4(0x7fffffff, 0x7fffffff, -0x7fffffff, -0x7fffffff);
+    };
+    bool corner_out = false;
+    if (active) {
+        publish_boxes(corner_out);
+        if (lane == 0) atomicAdd(const_cast<int*>(ctrl), 1);
+    } else {
+        publish_none();
     }
-    if (active && lane == 0) atomicAdd(const_cast<int*>(ctrl), 1);
 
     int iter = 0;
     float dp_norm = 0.f, znssd = 0.f;
@@ -372,144 +393,128 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
 
 #pragma nounroll
     for (;;) {
-        __syncthreads();  // B0: the finished waves of the previous iteration have reported; the band is free
+        __syncthreads();  // the boxes of this iteration are published, the finished waves have reported, the band is free
         if (ctrl[0] <= 0) return;
-        if (active) {
-            iter++;
-            if constexpr (DOF == 12) {
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    row3[k] = wave_bcast(Wcol[3], k);
-                    row4[k] = wave_bcast(Wcol[4], k);
-                }
-            }
-            // boxes of all windows at once: the corner's target pixel, clamped to the interpolatable range, min / max over the quad
-            float ax, ay;
-            warp_point(cxl, cyl, ax, ay);
-            int xi = floor_to_int(ax), yi = floor_to_int(ay);
-            xi = min(max(xi, 1), width - 3);
-            yi = min(max(yi, 1), height - 3);
-            int x0 = min(xi, dpp_quad_xor1(xi)), x1 = max(xi, dpp_quad_xor1(xi));
-            int y0 = min(yi, dpp_quad_xor1(yi)), y1 = max(yi, dpp_quad_xor1(yi));
-            x0 = min(x0, dpp_quad_xor2(x0)); x1 = max(x1, dpp_quad_xor2(x1));
-            y0 = min(y0, dpp_quad_xor2(y0)); y1 = max(y1, dpp_quad_xor2(y1));
-            if ((lane & 3) == 0 && bw_l < nwin) boxes[wave * NWMAX + bw_l] = make_int4(x0, y0, x1, y1);
-        } else {
-            if (lane < nwin) boxes[wave * NWMAX + lane] = make_int4(1, 1, 0, 0);
-        }
-        __syncthreads();  // B1
-        // lane w: union of the waves' boxes of window w, in wave order, while it fits the staged area
-        int ux0 = 0x7fffffff, uy0 = 0x7fffffff, ux1 = -0x7fffffff, uy1 = -0x7fffffff;
+        // lane w: origin of window w's staged box = the minimum over the waves' boxes; this wave is FAST in window w when its
+        // own box lies inside [X0, X0 + cols) x [Y0, Y0 + rows)
+        int ox = 0, oy = 0;
+        bool fast_l = false;
         if (lane < nwin) {
+            int mx = 0x7fffffff, my = 0x7fffffff;
 #pragma unroll
             for (int v = 0; v < kBandWaves; v++) {
-                const int4 b = boxes[v * NWMAX + lane];
-                const int nx0 = min(ux0, b.x), ny0 = min(uy0, b.y), nx1 = max(ux1, b.z), ny1 = max(uy1, b.w);
-                const bool ok = b.x <= b.z && (nx1 - nx0) < CAPX && (ny1 - ny0) < CAPR;
-                ux0 = ok ? nx0 : ux0; uy0 = ok ? ny0 : uy0; ux1 = ok ? nx1 : ux1; uy1 = ok ? ny1 : uy1;
+                const int4 b = boxes[v * kBandMaxWin + lane];
+                mx = min(mx, b.x);
+                my = min(my, b.y);
             }
+            // (inside the image, so that every row piece of the box is a legal load)
+            ox = max(0, min(mx, width - kBandCols));
+            oy = max(0, min(my, height - kBandRows));
+            const int4 mine = boxes[wave * kBandMaxWin + lane];
+            // (an empty box -- a window whose bound leaves the interpolatable range -- is SLOW: its samples are tested one by one)
+            fast_l = band_ok && mine.x <= mine.z && mine.x >= ox && mine.z < ox + kBandCols && mine.y >= oy && mine.w < oy + kBandRows;
         }
-        const bool none = ux1 < ux0 || (L.ablate & 4);
-        const int ubw = none ? 0 : ux1 - ux0 + 1, ubh = none ? 0 : uy1 - uy0 + 1;
-
+        const unsigned long long fast_mask = __builtin_amdgcn_ballot_w64(fast_l);
         bool negative = false;
         float acc = 0.f;
-#pragma unroll
-        for (int t = 0; t < NTMAX; t++) ts[t] = 0.f;  // (the previous iteration's subset is dead)
-#pragma unroll
-        for (int w = 0; w < NWMAX; w++) {
-            if (w < nwin) {
-                const int X0 = __builtin_amdgcn_readlane(ux0, w), Y0 = __builtin_amdgcn_readlane(uy0, w);
-                const int BW = __builtin_amdgcn_readlane(ubw, w), BH = __builtin_amdgcn_readlane(ubh, w);
-                // ---- stage the band: wave (row parity, plane) x lanes along the row
-#pragma unroll
-                for (int j = 0; j < CAPR / 2; j++) {
-                    const int row = 2 * j + st_row0;
-                    if (row < BH && !(L.ablate & 2)) {
-                        const unsigned so = ((unsigned)(Y0 + row) * (unsigned)width + (unsigned)X0) << 4;
-                        float4 sv[2];
-#pragma unroll
-                        for (int c = 0; c < 2; c++) {
-                            const int bx = lane + 64 * c;
-                            if (bx < BW) sv[c] = buf_f32x4so(r_stage, (unsigned)bx << 4, so);
-                        }
-#pragma unroll
-                        for (int c = 0; c < 2; c++) {
-                            const int bx = lane + 64 * c;
-                            if (bx < BW) band[(st_plane * CAPR + row) * CAPX + bx] = sv[c];
-                        }
-                    }
-                }
-                if (!(L.ablate & 1)) __syncthreads();  // B2
-                if (active && !(L.ablate & 8)) {
-#pragma unroll
-                    for (int g = 0; g < WP; g++) {
-                        const int t = w * WP + g;
-                        if (t < NTMAX && t < NT) {
-                            LutFetch f;
-                            const bool full = t < NF;
-                            const bool valid = full || tail_valid;
-                            const f2 lxy = tab_at(t);
-                            const float xl = lxy.x - offx, yl = lxy.y - offy;
-                            float ax, ay;
-                            warp_point(xl, yl, ax, ay);
-                            if (!full) {
-                                ax = valid ? ax : 1.f;
-                                ay = valid ? ay : 1.f;
-                            }
-                            const int xi = floor_to_int(ax), yi = floor_to_int(ay);
-                            const bool out = (unsigned)(xi - 1) > (unsigned)(width - 4) || (unsigned)(yi - 1) > (unsigned)(height - 4);
-                            f.dx = __builtin_amdgcn_fractf(ax);
-                            f.dy = __builtin_amdgcn_fractf(ay);
-                            const unsigned bx = (unsigned)(xi - X0), by = (unsigned)(yi - Y0);
-                            if (bx < (unsigned)BW && by < (unsigned)BH) {  // (the box lies inside the interpolatable range)
-                                const float4* __restrict__ q = band + (by * CAPX + bx);
-                                f.c0 = q[0];
-                                f.c1 = q[PLANE];
-                                f.c2 = q[2 * PLANE];
-                                f.c3 = q[3 * PLANE];
-                            } else {
-                                r_lut.load(f, out ? 0u : (__umul24((unsigned)yi, (unsigned)width) + (unsigned)xi) << 4);
-                            }
-                            negative = negative || out;
-                            const float v = lut_value(f);
-                            if (full) {
-                                negative = negative || v < 0.f;
-                                acc = acc + v;
-                            } else {
-                                negative = negative || (valid && v < 0.f);
-                                acc = valid ? acc + v : acc;
-                            }
-                            ts[t] = v;
-                        }
-                    }
-                }
-                if (w + 1 < nwin && !(L.ablate & 1)) __syncthreads();  // B3: the band may be overwritten
-            }
+        if (active) {
+            iter++;
+            // src/oc_icgn.cpp:251-255 for the affine warp: a corner sample outside the interpolatable range is a -1.f in the target
+            // subset (decided before the sweep from the corners, icgn2d.hip kCornerTest); ICGN2D2 tests every sample
+            if (DOF == 6 && corner_out && !(L.ablate & 16)) negative = true;
         }
+        const bool compute = active && !(L.ablate & 8) && !(DOF == 6 && corner_out);
+#pragma nounroll
+        for (int w = 0; w < nwin; w++) {
+            const int X0 = __builtin_amdgcn_readlane(ox, w), Y0 = __builtin_amdgcn_readlane(oy, w);
+            const bool fast = ((fast_mask >> w) & 1ull) != 0;
+            // ---- stage the band of window w: this wave's three rows of its plane
+            if (band_ok && !(L.ablate & 2)) {
+#pragma unroll
+                for (int j = 0; j < kBandRows / 2; j++) {
+                    const int row = 2 * j + st_row0;
+                    const unsigned so = ((unsigned)(Y0 + row) * (unsigned)width + (unsigned)X0) << 4;
+                    float4* dst = band + (st_plane * kBandPlane + row * kBandPitch);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_stage, (lds_vp)dst, 16, lane << 4, so, 0, 0);
+                    if (lane < kBandCols - kWave)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_stage, (lds_vp)(dst + kWave), 16, lane << 4, so + kWave * 16, 0, 0);
+                }
+            }
+            // a SLOW wave gathers from global memory, like icgn2d.hip -- before it waits for the band it does not read
+            auto sweep_window = [&](auto fastc) {
+                constexpr bool FAST = decltype(fastc)::value;
+                const unsigned sbase = (unsigned)((Y0 * kBandPitch + X0) << 4);
+#pragma unroll
+                for (int g = 0; g < WP; g++) {
+                    const int t = w * WP + g;
+                    if (t < NT) {
+                        const bool full = t < NF;
+                        const bool valid = full || tail_valid;
+                        const f2 lxy = tab_at(t);
+                        const float xl = lxy.x - offx, yl = lxy.y - offy;
+                        float ax, ay;
+                        warp_point(xl, yl, ax, ay);
+                        if (!full) {
+                            ax = valid ? ax : (float)(X0 + 1);
+                            ay = valid ? ay : (float)(Y0 + 1);
+                        }
+                        int xi = floor_to_int(ax), yi = floor_to_int(ay);
+                        LutFetch f;
+                        f.dx = __builtin_amdgcn_fractf(ax);
+                        f.dy = __builtin_amdgcn_fractf(ay);
+                        if constexpr (DOF == 12) {
+                            const bool out = (unsigned)(xi - 1) > (unsigned)(width - 4) || (unsigned)(yi - 1) > (unsigned)(height - 4);
+                            negative = negative || out;
+                            xi = out ? X0 + 1 : xi;   // (a pixel inside the box and the image: the value is discarded)
+                            yi = out ? Y0 + 1 : yi;
+                        }
+                        if constexpr (FAST) {
+                            const char* __restrict__ q0 = reinterpret_cast<const char*>(band) + (((unsigned)(__umul24((unsigned)yi, kBandPitch) + (unsigned)xi) << 4) - sbase);
+                            const float4* __restrict__ q = reinterpret_cast<const float4*>(q0);
+                            f.c0 = q[0];
+                            f.c1 = q[kBandPlane];
+                            f.c2 = q[2 * kBandPlane];
+                            f.c3 = q[3 * kBandPlane];
+                        } else {
+                            r_lut.load(f, (__umul24((unsigned)yi, (unsigned)width) + (unsigned)xi) << 4);
+                        }
+                        const float v = lut_value(f);
+                        if (full) {
+                            negative = negative || v < 0.f;
+                            acc = acc + v;
+                        } else {
+                            negative = negative || (valid && v < 0.f);
+                            acc = valid ? acc + v : acc;
+                        }
+                        ts.set(t, v);
+                    }
+                }
+            };
+            if (compute && !fast) sweep_window(std::false_type{});
+            if (!(L.ablate & 1)) __syncthreads();  // the band of window w has landed (vmcnt) and is visible
+            if (compute && fast) sweep_window(std::true_type{});
+            if (w + 1 < nwin && !(L.ablate & 1)) __syncthreads();  // every wave has read it: it may be overwritten
+        }
+        bool done = false;
         if (active) {
             // src/oc_icgn.cpp:251-255
             if (!(L.ablate & 16) && wave_any(negative)) {
-                if (lane == 0) {
-                    poi[poi2d::ZNCC] = -3.f;
-                    atomicSub(const_cast<int*>(ctrl), 1);
-                }
-                active = false;
+                if (lane == 0) poi[poi2d::ZNCC] = -3.f;
+                done = true;
             }
         }
-        if (active) {
+        if (active && !done) {
             // zeroMeanNorm of the target subset (src/oc_icgn.cpp:257)
             const float tmean = wave_allreduce_sum(acc) / fN;
             acc = 0.f;
-#pragma unroll
-            for (int t = 0; t < NTMAX; t++) {
-                if (t < NF) {
-                    const float d = ts[t] - tmean;
-                    acc = mad(d, d, acc);
-                } else if (t < NT) {
-                    const float d = ts[t] - tmean;
-                    acc = tail_valid ? mad(d, d, acc) : acc;
-                }
+#pragma unroll 6
+            for (int t = 0; t < NF; t++) {
+                const float d = ts.get(t) - tmean;
+                acc = mad(d, d, acc);
+            }
+            if (NF < NT) {
+                const float d = ts.get(NF) - tmean;
+                acc = tail_valid ? mad(d, d, acc) : acc;
             }
             const float tar_norm = uni(sqrtf(wave_allreduce_sum(acc)));
             // error image, ZNSSD, numerator (src/oc_icgn.cpp:260-276)
@@ -522,42 +527,43 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
             f2 np12[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) np12[q] = mk2(0.f, 0.f);
-            passes(std::integral_constant<int, kNumBatch>{},
-                   [&](int t, bool valid) {
-                       GradSample v;
-                       const unsigned off = off_at(t);
-                       v.gx = valid ? buf_f32(r_gx, off, goff) : 0.f;
-                       v.gy = valid ? buf_f32(r_gy, off, goff) : 0.f;
-                       v.ref = valid ? buf_f32(r_ref, off, roff) : 0.f;
-                       return v;
-                   },
-                   [&](int t, bool valid, const GradSample& v) {
-                       const float g_x = v.gx, g_y = v.gy;
-                       const float tz = ts[t] - tmean;
-                       const float rsv = v.ref - ref_mean;
-                       const float e = mad(tz, factor, -rsv);
-                       ssd = valid ? mad(e, e, ssd) : ssd;
-                       if constexpr (DOF == 6) {
-                           const f2 xy = tab_at(t) - mk2(offx, offy);
-                           const f2 A = g_x * xy, B = g_y * xy;
-                           const f2 mA = mad(A, e, nA), mB = mad(B, e, nB);
-                           const float m0 = mad(g_x, e, num[0]), m3 = mad(g_y, e, num[3 % DOF]);
-                           if (valid) {
-                               nA = mA; nB = mB; num[0] = m0; num[3 % DOF] = m3;
-                           }
-                       } else {
-                           const f2 lxy = tab_at(t) - mk2(offx, offy);
-                           const float fxl = lxy.x, fyl = lxy.y;
-                           const float xx = (fxl * fxl) * 0.5f, xy = fxl * fyl, yy = (fyl * fyl) * 0.5f;
-                           const f2 m01 = mk2(1.f, fxl), m23 = mk2(fyl, xx), m45 = mk2(xy, yy);
-                           const f2 sdp[6] = {g_x * m01, g_x * m23, g_x * m45, g_y * m01, g_y * m23, g_y * m45};
+            passes_batched<kNumBatch>(
+                NF, NT, tail_valid,
+                [&](int t, bool valid) {
+                    GradSample v;
+                    const unsigned off = off_at(t);
+                    v.gx = valid ? buf_f32(r_gx, off, goff) : 0.f;
+                    v.gy = valid ? buf_f32(r_gy, off, goff) : 0.f;
+                    v.ref = valid ? buf_f32(r_ref, off, roff) : 0.f;
+                    return v;
+                },
+                [&](int t, bool valid, const GradSample& v) {
+                    const float g_x = v.gx, g_y = v.gy;
+                    const float tz = ts.get(t) - tmean;
+                    const float rsv = v.ref - ref_mean;
+                    const float e = mad(tz, factor, -rsv);
+                    ssd = valid ? mad(e, e, ssd) : ssd;
+                    if constexpr (DOF == 6) {
+                        const f2 xy = tab_at(t) - mk2(offx, offy);
+                        const f2 A = g_x * xy, B = g_y * xy;
+                        const f2 mA = mad(A, e, nA), mB = mad(B, e, nB);
+                        const float m0 = mad(g_x, e, num[0]), m3 = mad(g_y, e, num[3 % DOF]);
+                        if (valid) {
+                            nA = mA; nB = mB; num[0] = m0; num[3 % DOF] = m3;
+                        }
+                    } else {
+                        const f2 lxy = tab_at(t) - mk2(offx, offy);
+                        const float fxl = lxy.x, fyl = lxy.y;
+                        const float xx = (fxl * fxl) * 0.5f, xy = fxl * fyl, yy = (fyl * fyl) * 0.5f;
+                        const f2 m01 = mk2(1.f, fxl), m23 = mk2(fyl, xx), m45 = mk2(xy, yy);
+                        const f2 sdp[6] = {g_x * m01, g_x * m23, g_x * m45, g_y * m01, g_y * m23, g_y * m45};
 #pragma unroll
-                           for (int q = 0; q < 6; q++) {
-                               const f2 nv = mad(sdp[q], e, np12[q]);
-                               np12[q] = valid ? nv : np12[q];
-                           }
-                       }
-                   });
+                        for (int q = 0; q < 6; q++) {
+                            const f2 nv = mad(sdp[q], e, np12[q]);
+                            np12[q] = valid ? nv : np12[q];
+                        }
+                    }
+                });
             if constexpr (DOF == 6) {
                 num[1] = nA.x; num[2] = nA.y; num[4 % DOF] = nB.x; num[5 % DOF] = nB.y;
             } else {
@@ -576,9 +582,11 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
             // dp = H^-1 * numerator (src/oc_icgn.cpp:279-286)
             float dp[DOF];
             {
+                // lane i < DOF: dp[i] = sum_j H^-1(i, j) * num[j], ascending j like the reference loop
+                const float* __restrict__ hrow = hrow_area + wave * DOF * DOF + min(lane, DOF - 1) * DOF;
                 float mine = 0.f;
 #pragma unroll
-                for (int j = 0; j < DOF; j++) mine += hinv_row[j] * red[j];
+                for (int j = 0; j < DOF; j++) mine += hrow[j] * red[j];
 #pragma unroll
                 for (int i = 0; i < DOF; i++) dp[i] = wave_bcast(mine, i);
             }
@@ -670,18 +678,27 @@ __global__ __launch_bounds__(64 * kBandWaves, DOF == 6 ? 6 : 4) void icgn2d_band
                     poi[poi2d::CONV] = dp_norm;
                     poi[poi2d::SRX] = (float)rx;
                     poi[poi2d::SRY] = (float)ry;
-                    atomicSub(const_cast<int*>(ctrl), 1);
                 }
+                done = true;
+            }
+        }
+        // the next iteration's boxes (every wave read this iteration's before the window loop, i.e. before its barriers)
+        if (active && !done) {
+            publish_boxes(corner_out);
+        } else {
+            if (active) {
+                if (lane == 0) atomicSub(const_cast<int*>(ctrl), 1);
                 active = false;
             }
+            publish_none();
         }
     }
 }
 
-template <int DOF, int NTMAX, int OFFS>
+template <int DOF, int TSB, int OFFS>
 static hipError_t launch_band_t(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int nt, bool xcd, hipStream_t stream) {
-    const size_t lds = icgn2d_band_lds_bytes(nt, NTMAX);
-    auto kern = icgn2d_band_kernel<DOF, NTMAX, OFFS>;
+    const size_t lds = icgn2d_band_lds_bytes(nt, DOF);
+    auto kern = icgn2d_band_kernel<DOF, TSB, OFFS>;
     static std::atomic<unsigned long long> attr_devices{0};
     int dev = 0;
     hipError_t derr = hipGetDevice(&dev);
@@ -705,23 +722,27 @@ static hipError_t launch_band_t(const Icgn2dParams& p, float* pois, int stride_f
     return hipGetLastError();
 }
 
-// passes the two instantiations hold in registers (33 x 33 = 18 passes, 35 x 34 = 19; 41 x 41 = 27, 42 x 42 = 28)
-constexpr int kBandNtMax1 = 19, kBandNtMax2 = 28;
+template <int DOF, int TSB>
+static hipError_t launch_band_o(const Icgn2dParams& p, float* pois, int stride_f, size_t count, int nt, bool xcd, hipStream_t stream) {
+    return p.offsets ? launch_band_t<DOF, TSB, 1>(p, pois, stride_f, count, nt, xcd, stream)
+                     : launch_band_t<DOF, TSB, 0>(p, pois, stride_f, count, nt, xcd, stream);
+}
+
+// passes the register vector holds: 16 + TSB; ICGN2D1 up to 20 (35 x 35), ICGN2D2 up to 28 (42 x 42)
+constexpr int kBandNtMax1 = 20, kBandNtMax2 = 28;
 
 hipError_t launch_icgn2d1_band(const Icgn2dParams& p, float* pois, int stride_f, size_t count, bool xcd, hipStream_t stream) {
     if (count == 0) return hipSuccess;
     const int nt = ((2 * p.rx + 1) * (2 * p.ry + 1) + 63) / 64;
     if (p.self_adaptive || nt > kBandNtMax1) return hipErrorInvalidValue;
-    return p.offsets ? launch_band_t<6, kBandNtMax1, 1>(p, pois, stride_f, count, nt, xcd, stream)
-                     : launch_band_t<6, kBandNtMax1, 0>(p, pois, stride_f, count, nt, xcd, stream);
+    return nt <= 18 ? launch_band_o<6, 2>(p, pois, stride_f, count, nt, xcd, stream) : launch_band_o<6, 4>(p, pois, stride_f, count, nt, xcd, stream);
 }
 
 hipError_t launch_icgn2d2_band(const Icgn2dParams& p, float* pois, int stride_f, size_t count, bool xcd, hipStream_t stream) {
     if (count == 0) return hipSuccess;
     const int nt = ((2 * p.rx + 1) * (2 * p.ry + 1) + 63) / 64;
     if (p.self_adaptive || nt > kBandNtMax2) return hipErrorInvalidValue;
-    return p.offsets ? launch_band_t<12, kBandNtMax2, 1>(p, pois, stride_f, count, nt, xcd, stream)
-                     : launch_band_t<12, kBandNtMax2, 0>(p, pois, stride_f, count, nt, xcd, stream);
+    return nt <= 24 ? launch_band_o<12, 8>(p, pois, stride_f, count, nt, xcd, stream) : launch_band_o<12, 12>(p, pois, stride_f, count, nt, xcd, stream);
 }
 
 }  // namespace OC_ARITH
