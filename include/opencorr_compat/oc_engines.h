@@ -23,6 +23,7 @@
 //     with zncc = -3 (the reference would try to allocate a negative-sized subset).
 #pragma once
 
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -190,12 +191,15 @@ public:
 protected:
     oc_hip_engine* engine_ = nullptr;
     int device_ = hipdetail::default_device();
-    bool images_dirty_ = false;
+    std::atomic<bool> images_dirty_{false};   // (compute(POI*) may be entered by many threads at once: the upload happens once)
+    std::mutex upload_mu_;
     unsigned long long images_seq_ = 0;
 
     void uploadIfNeeded() {
         if (!engine_) throw std::string("engine not created");
-        if (!images_dirty_) return;
+        if (!images_dirty_.load(std::memory_order_acquire)) return;
+        std::lock_guard<std::mutex> lock(upload_mu_);
+        if (!images_dirty_.load(std::memory_order_relaxed)) return;
         if (!ref_img || !tar_img) throw std::string("setImages() has not been called");
         if (ref_img->height != tar_img->height || ref_img->width != tar_img->width)
             throw std::string("reference and target image sizes differ");
@@ -207,11 +211,16 @@ protected:
                                                  ref_img->width, OC_HIP_COL_MAJOR, OC_HIP_HOST));
             reg.publish(engine_, r, t, ref_img->height, ref_img->width, 1, device_);
         }
-        images_dirty_ = false;
+        images_dirty_.store(false, std::memory_order_release);
     }
     void computeBatch(POI2D* pois, size_t n) {
         uploadIfNeeded();
         hipdetail::check(oc_hip_compute(engine_, pois, n, sizeof(POI2D), OC_HIP_HOST));
+    }
+    // compute(POI2D*): the C-ABI's combining single-POI entry point (concurrent callers share a launch)
+    void computeOne(POI2D* poi) {
+        uploadIfNeeded();
+        hipdetail::check(oc_hip_compute_one(engine_, poi));
     }
 };
 
@@ -264,12 +273,15 @@ public:
 protected:
     oc_hip_engine* engine_ = nullptr;
     int device_ = hipdetail::default_device();
-    bool images_dirty_ = false;
+    std::atomic<bool> images_dirty_{false};   // (compute(POI*) may be entered by many threads at once: the upload happens once)
+    std::mutex upload_mu_;
     unsigned long long images_seq_ = 0;
 
     void uploadIfNeeded() {
         if (!engine_) throw std::string("engine not created");
-        if (!images_dirty_) return;
+        if (!images_dirty_.load(std::memory_order_acquire)) return;
+        std::lock_guard<std::mutex> lock(upload_mu_);
+        if (!images_dirty_.load(std::memory_order_relaxed)) return;
         if (!ref_img || !tar_img) throw std::string("setImages() has not been called");
         hipdetail::SnapshotRegistry& reg = hipdetail::SnapshotRegistry::get();
         const void* r = &ref_img->vol_mat[0][0][0];
@@ -279,11 +291,15 @@ protected:
                                                  ref_img->dim_x, ref_img->dim_y, ref_img->dim_z, OC_HIP_HOST));
             reg.publish(engine_, r, t, ref_img->dim_x, ref_img->dim_y, ref_img->dim_z, device_);
         }
-        images_dirty_ = false;
+        images_dirty_.store(false, std::memory_order_release);
     }
     void computeBatch(POI3D* pois, size_t n) {
         uploadIfNeeded();
         hipdetail::check(oc_hip_compute(engine_, pois, n, sizeof(POI3D), OC_HIP_HOST));
+    }
+    void computeOne(POI3D* poi) {
+        uploadIfNeeded();
+        hipdetail::check(oc_hip_compute_one(engine_, poi));
     }
 };
 
@@ -298,7 +314,7 @@ public:
         hipdetail::apply_default_devices(engine_);
     }
     void prepare() override {}  // empty in the reference too (src/oc_fftcc.cpp:175)
-    void compute(POI2D* poi) override { computeBatch(poi, 1); }
+    void compute(POI2D* poi) override { computeOne(poi); }
     void compute(std::vector<POI2D>& poi_queue) override { computeBatch(poi_queue.data(), poi_queue.size()); }
 };
 
@@ -313,7 +329,7 @@ public:
         hipdetail::apply_default_devices(engine_);
     }
     void prepare() override {}
-    void compute(POI3D* poi) override { computeBatch(poi, 1); }
+    void compute(POI3D* poi) override { computeOne(poi); }
     void compute(std::vector<POI3D>& poi_queue) override { computeBatch(poi_queue.data(), poi_queue.size()); }
 };
 
@@ -342,7 +358,8 @@ public:
         prepareRef();
         prepareTar();
     }
-    void compute(Poi* poi) override { this->computeBatch(poi, 1); }
+    // (callers inside their own OpenMP region -- src/oc_epipolar_search.cpp:184-188 -- are combined into one launch per batch)
+    void compute(Poi* poi) override { this->computeOne(poi); }
     void compute(std::vector<Poi>& poi_queue) override { this->computeBatch(poi_queue.data(), poi_queue.size()); }
     // initial guess and refinement in one call and ONE round trip of the queue over PCIe: `first` (an FFTCC engine, say)
     // processes every POI, then this engine -- the same bits as first.compute(poi_queue); compute(poi_queue);

@@ -286,6 +286,8 @@ int oc_hip_group_queue(const oc_hip_engine* engine, int member, const void** dev
  *   "icgn3d_mapping"  0 (default, the only value the shipped library accepts): sample s of a subvolume is owned by thread
  *                     s mod 512 (icgn3d.hip; oracle OC_ORDER_LANES, lanes = 512); 1 (A/B build): one half-wave per subvolume row
  *                     (oracle OC_ORDER_ROWS; 12 - 25 % slower; no fused-arithmetic form)
+ *   "single_combine"  1 (default): concurrent compute_one calls on an engine are combined into one launch per batch; 0: every
+ *                     call is a launch of its own (the behaviour up to round 5).  Same bits either way.
  *   "host_chunk"      POIs per chunk of the host-queue pipeline (copies of one chunk overlap the kernels of its
  *                     neighbours); 0 = whole queue at once; default 65536
  *   "group_allgather" 1: device groups leave the complete result queue on every member (see oc_hip_set_devices)
@@ -321,10 +323,16 @@ int oc_hip_compute(oc_hip_engine* engine, void* pois, size_t count, size_t strid
  * stream (device-ordered behind whatever their own streams still hold, and handed back afterwards).  Centre offsets,
  * device groups and Strain / RegionFit are not part of a chain. */
 int oc_hip_compute_chain(oc_hip_engine* const* engines, int n_engines, void* pois, size_t count, size_t stride_bytes, int memory);
-/* FFTCC2D::compute(POI2D*) / ICGN2D1::compute(POI2D*)  src/oc_fftcc.cpp:177, src/oc_icgn.cpp:144:
- * a mutex-guarded batch of one, safe to call from the caller's own OpenMP region
- * (src/oc_epipolar_search.cpp:184-188). */
+/* FFTCC2D::compute(POI2D*) / ICGN2D1::compute(POI2D*)  src/oc_fftcc.cpp:177, src/oc_icgn.cpp:144: safe to call from the
+ * caller's own OpenMP region (src/oc_epipolar_search.cpp:184-188; the reference keeps one scratch instance per thread,
+ * src/oc_icgn.cpp:61-69,147).  Calls that arrive while a launch is in flight are COMBINED: they queue up, one of the waiting
+ * threads hands the whole batch to the engine as one queue and every caller returns with its own record filled in -- T
+ * concurrent threads cost one launch per ~T POIs.  A POI's result does not depend on the batch it travels in.  A strictly
+ * sequential caller still pays a launch and two PCIe copies per POI.  Tuning key "single_combine" = 0 restores one launch per
+ * call. */
 int oc_hip_compute_one(oc_hip_engine* engine, void* poi);
+/* batches / POIs served by the combining front end of compute_one on this engine so far (either pointer may be null) */
+int oc_hip_single_stats(oc_hip_engine* engine, unsigned long long* batches, unsigned long long* pois);
 /* ICGN2D1::compute(std::vector<POI2D>&, std::vector<Point2D>& center_offset_queue)  src/oc_icgn.cpp:549-557
  * (ICGN2D2 :1128-1136): local subset coordinates are shifted by center_offsets[i] = {x, y} (two floats per POI,
  * the reference's Point2D) and the target subset is centred at POI + offset.  The offsets live in the same

@@ -20,14 +20,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libopencorr_hip.so")
-SOURCES = ["capi.hip", "prepare2d.hip", "icgn2d.hip", "nr2d.hip", "poi_order.hip", "poi_split.hip", "strain.hip", "fftcc2d.hip", "fftcc2d_fused.hip", "fftcc2d_fusedn.hip", "fftcc2d_fusedp.hip", "fftcc2d_fusedr.hip", "fftcc2d_rect.hip", "prepare3d.hip", "icgn3d.hip", "fftcc3d.hip", "fftcc3d_fused.hip", "fftcc3d_fusedn.hip", "fftcc3d_box.hip", "fftcc3d_planes.hip", "fftcc3d_planesb.hip"]
+SOURCES = ["capi.hip", "capi_host.hip", "capi_group.hip", "capi_strain.hip", "prepare2d.hip", "icgn2d.hip", "nr2d.hip", "poi_order.hip", "poi_split.hip", "strain.hip", "fftcc2d.hip", "fftcc2d_fused.hip", "fftcc2d_fusedn.hip", "fftcc2d_fusedp.hip", "fftcc2d_fusedr.hip", "fftcc2d_rect.hip", "prepare3d.hip", "icgn3d.hip", "fftcc3d.hip", "fftcc3d_fused.hip", "fftcc3d_fusedn.hip", "fftcc3d_box.hip", "fftcc3d_planes.hip", "fftcc3d_planesb.hip"]
 # the A/B build: sources that exist only there, and the product sources whose code depends on OC_BUILD_AB (recompiled with
 # -DOC_BUILD_AB=1; every other object is shared with the product build)
 AB_ONLY_SOURCES = ["icgn3d_rows.hip", "icgn2d_band.hip"]
 AB_DEPENDENT = ["capi.hip", "icgn2d.hip", "icgn3d.hip"]
 AB_LIBDIR = os.path.join(LIBDIR, "ab")
 AB_LIB = os.path.join(AB_LIBDIR, "libopencorr_hip_ab.so")
-HEADERS = ["oc_device.h", "oc_kernels.h", "dic2d_device.h", "fft_device.h", "fftcc2d_fusedn_impl.h", "fftcc3d_planes_impl.h", "icgn3d_device.h", os.path.join("..", "..", "include", "opencorr_hip.h")]
+HEADERS = ["capi_internal.h", "oc_device.h", "oc_kernels.h", "dic2d_device.h", "fft_device.h", "fftcc2d_fusedn_impl.h", "fftcc3d_planes_impl.h", "icgn3d_device.h", os.path.join("..", "..", "include", "opencorr_hip.h")]
 ARCH = "gfx950"
 # -fno-slp-vectorize: the SLP vectoriser pairs independent scalar fp32 operations into v_pk_mul_f32 / v_pk_add_f32.  On gfx950 a
 # packed op occupies a SIMD for 4.3 cycles against 2.4 for the plain one (profiles/r02b_valu_ubench.json) -- a 10 % gain that the

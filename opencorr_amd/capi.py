@@ -32,7 +32,7 @@ SYMBOLS = [
     "oc_hip_set_images2d", "oc_hip_set_images3d", "oc_hip_share_images", "oc_hip_set_subset",
     "oc_hip_set_iteration", "oc_hip_set_stream", "oc_hip_reset_stream", "oc_hip_set_tuning",
     "oc_hip_prepare", "oc_hip_prepare_ref", "oc_hip_prepare_tar",
-    "oc_hip_compute", "oc_hip_compute_chain", "oc_hip_compute_one", "oc_hip_compute_with_offsets", "oc_hip_compute_one_with_offset",
+    "oc_hip_compute", "oc_hip_compute_chain", "oc_hip_compute_one", "oc_hip_compute_with_offsets", "oc_hip_compute_one_with_offset", "oc_hip_single_stats",
     "oc_hip_set_self_adaptive", "oc_hip_synchronize", "oc_hip_select_best", "oc_hip_split_reliable", "oc_hip_merge_recovered",
     "oc_hip_get_kind", "oc_hip_get_field", "oc_hip_read_field",
     "oc_hip_profile_enable", "oc_hip_profile_read", "oc_hip_profile_reset",
@@ -154,6 +154,7 @@ def lib():
     L.oc_hip_compute_one.argtypes = [vp, vp]
     L.oc_hip_compute_with_offsets.argtypes = [vp, vp, vp, sz, sz, i]
     L.oc_hip_compute_one_with_offset.argtypes = [vp, vp, vp]
+    L.oc_hip_single_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
     L.oc_hip_set_self_adaptive.argtypes = [vp, i]
     L.oc_hip_synchronize.argtypes = [vp]
     L.oc_hip_get_kind.argtypes = [vp, ctypes.POINTER(i)]

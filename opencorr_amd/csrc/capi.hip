@@ -3,54 +3,9 @@
 // Host-side engine objects: device-resident image pair, precomputed fields,
 // POI staging, rocFFT plans, stream and profiling events.  No CPU compute path
 // exists here: every compute call ends in HIP kernel launches or fails.
-#include "../../include/opencorr_hip.h"
+#include "capi_internal.h"
 
-#include <hip/hip_runtime.h>
-#include <rocfft/rocfft.h>
-
-#include <dlfcn.h>
-
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <condition_variable>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <memory>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
-
-// RCCL: types and enumerators only -- the library itself is loaded with dlopen on first use (struct Rccl), and a
-// single-GPU host needs neither the library nor its development headers: without <rccl/rccl.h> the few declarations the
-// binding uses are restated here (the stable NCCL 2.x C API: opaque communicator handle, ncclResult_t with ncclSuccess = 0,
-// ncclUint8 = 1 in ncclDataType_t) and the version check against the loaded library is what guards them.
-#if __has_include(<rccl/rccl.h>)
-#include <rccl/rccl.h>
-#define OC_HIP_RCCL_HEADER 1
-#else
-#define OC_HIP_RCCL_HEADER 0
-extern "C" {
-typedef struct ncclComm* ncclComm_t;
-typedef enum { ncclSuccess = 0 } ncclResult_t;
-typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
-ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist);
-ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
-ncclResult_t ncclGroupStart();
-ncclResult_t ncclGroupEnd();
-ncclResult_t ncclCommDestroy(ncclComm_t comm);
-const char* ncclGetErrorString(ncclResult_t result);
-ncclResult_t ncclGetVersion(int* version);
-}
-#define NCCL_MAJOR 2
-#endif
-
-#include "oc_kernels.h"
-
-namespace {
+namespace ochip_capi {
 
 thread_local std::string g_last_error;
 
@@ -64,213 +19,10 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-#define OC_HIP_TRY(expr)                                                                              \
-    do {                                                                                              \
-        hipError_t err__ = (expr);                                                                    \
-        if (err__ != hipSuccess)                                                                      \
-            return fail(err__ == hipErrorOutOfMemory ? OC_HIP_ERR_NOMEM : OC_HIP_ERR_HIP,             \
-                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__), __FILE__, __LINE__); \
-    } while (0)
-
-#define OC_FFT_TRY(expr)                                                                               \
-    do {                                                                                               \
-        rocfft_status st__ = (expr);                                                                   \
-        if (st__ != rocfft_status_success)                                                             \
-            return fail(OC_HIP_ERR_ROCFFT, "%s failed: rocfft_status %d (%s:%d)", #expr, (int)st__, __FILE__, __LINE__); \
-    } while (0)
-
-#define OC_TRY(expr)                  \
-    do {                              \
-        int rc__ = (expr);            \
-        if (rc__ != OC_HIP_OK) return rc__; \
-    } while (0)
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    ~DevBuf() { release(); }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-    }
-    // grow-only allocation
-    int reserve(size_t n) {
-        if (n <= bytes) return OC_HIP_OK;
-        release();
-        hipError_t err = hipMalloc(&p, n);
-        if (err != hipSuccess) {
-            p = nullptr;
-            return fail(OC_HIP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(err));
-        }
-        bytes = n;
-        return OC_HIP_OK;
-    }
-    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
-// device copy of a reference/target image pair (2D) or volume pair (3D), row-major, x fastest
-struct ImagePair {
-    int ndim = 0;
-    int dx = 0, dy = 0, dz = 1;  // width, height, depth
-    DevBuf ref, tar;
-    const float* ref_ext = nullptr;  // used in place when the caller handed device memory
-    const float* tar_ext = nullptr;
-    const float* ref_ptr() const { return ref_ext ? ref_ext : ref.as<float>(); }
-    const float* tar_ptr() const { return tar_ext ? tar_ext : tar.as<float>(); }
-    size_t count() const { return (size_t)dx * dy * dz; }
-};
-
-struct FftPlans {
-    int n0 = 0, n1 = 0, n2 = 0;  // slowest .. fastest (n2 == 0 for 2D)
-    size_t chunk = 0;
-    rocfft_plan fwd = nullptr, inv = nullptr;
-    rocfft_execution_info info_fwd = nullptr, info_inv = nullptr;
-    DevBuf work_fwd, work_inv;
-    void destroy() {
-        if (fwd) rocfft_plan_destroy(fwd);
-        if (inv) rocfft_plan_destroy(inv);
-        if (info_fwd) rocfft_execution_info_destroy(info_fwd);
-        if (info_inv) rocfft_execution_info_destroy(info_inv);
-        fwd = inv = nullptr;
-        info_fwd = info_inv = nullptr;
-        chunk = 0;
-    }
-    ~FftPlans() { destroy(); }
-};
-
-std::once_flag g_rocfft_once;
+static std::once_flag g_rocfft_once;
 void rocfft_init_once() {
     std::call_once(g_rocfft_once, [] { rocfft_setup(); });
 }
-
-}  // namespace
-
-struct oc_hip_engine {
-    int kind = 0;
-    int device = 0;
-    int rx = 0, ry = 0, rz = 0;
-    float conv = 0.001f, stop = 10.f;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t order_ev = nullptr;  // orders the private stream behind the caller's default-stream work
-    // Orders a newly chosen stream behind the work this engine left on the previous one.  On a CALLER-owned stream the
-    // event is recorded at the end of every entry point that returns with work still enqueued (mark_tail): the caller may
-    // destroy its stream at any time afterwards, and HIP aborts the process when a destroyed stream is handed to ANY
-    // API call -- so a stream switch, destroy() and set_devices() never touch a caller's stream again, they wait for
-    // this event instead.
-    hipEvent_t switch_ev = nullptr;
-    bool tail_marked = false;  // switch_ev holds the tail of this engine's work on the current (caller-owned) stream
-    std::shared_ptr<ImagePair> img;
-    DevBuf gx, gy, gz, coef;  // coef: 2D LUT (16 floats / px) or 3D coefficient volume
-    DevBuf coef_gx, coef_gy;  // NR2D1: LUTs of the target gradients
-    DevBuf tmp;               // scratch for layout conversion / the warped subvolumes of ICGN3D1
-    DevBuf prefilter_tmp;     // second volume of the 3D B-spline prefilter (x pass -> here -> y pass -> coef -> z pass)
-    bool ref_ready = false, tar_ready = false;
-    DevBuf poi_stage, off_stage;
-    DevBuf cursors;  // small device scratch (batch maxima)
-    DevBuf perm, tiles, perm_slots;  // locality schedule of the ICGN2D queue (poi_order.hip)
-    DevBuf setup_recs;               // icgn2d variant 8 (split launch shape): mean, norm, H^-1 per POI between the two kernels
-    DevBuf split_scratch, split_tmp; // oc_hip_split_reliable / oc_hip_merge_recovered (poi_split.hip)
-    // Strain (src/oc_strain.cpp:31-46: radius, min neighbours; ZNCC threshold 0.9, Cauchy approximation)
-    float st_radius = 0.f, st_zncc = 0.9f;
-    int st_nmin = 0, st_approx = 1, st_ndim = 0;
-    size_t st_count = 0;  // queue length the grid was prepared for (0 = not prepared)
-    ochip::StrainGrid st_grid{};
-    DevBuf st_box, st_counts, st_start, st_cursor, st_slots, st_order, st_recs, st_fallback;
-    float lm_lambda = 100.f, lm_alpha = 0.1f, lm_beta = 10.f;  // DampingParameter defaults, src/oc_iclm.h:33-38
-    int icgn2d_tile_px = 128;  // 0 = visit the queue in its own order (64 until round 3; 128 suits the lockstep sweeps: 3.29 vs 3.34 ms)
-    // FFTCC working set
-    FftPlans fft;
-    DevBuf win, freq, norms, flags;
-    // kernel selection (oc_hip_set_tuning); every choice computes the same bits
-    int icgn2d_variant = -1;  // -1 = automatic (run_icgn2d; MI355X sweeps), else the variant oc_hip_set_tuning chose
-    bool self_adaptive = false;  // DIC::setSelfAdaptive
-    int icgn2d_xcd = 1;
-    // ICGN2D1 / ICGN2D2 / ICLM2D1 / ICLM2D2 / ICGN3D1: 0 = every multiply and add of the solver rounds on its own (oracle
-    // OC_ORDER_LANES; the reference built for baseline x86-64), 1 = the per-sample multiply-adds are fused (oc_device.h
-    // OC_FMA; oracle OC_ORDER_LANES_FMA) -- the only tuning key that changes result bits (by rounding, inside north_star's
-    // tolerance: DESIGN.md section 3)
-    int arith_fma = 0;
-    int fftcc2d_fused = 1;    // single-kernel FFTCC2D when the window is 32 x 32
-    int fftcc3d_fused = 1;    // single-kernel FFTCC3D for cubic windows of side 8 ... 64 (three kernels by size)
-    int fftcc3d_planes_blocks = 0;  // persistent workgroups (= scratch volumes) of the plane-wise kernel; 0 = 256
-    int fftcc3d_tile_vox = 64; // FFTCC3D single-kernel paths: queues of >= 2048 POIs are visited in cubic blocks of this many voxels (0 = queue order)
-    int icgn3d_tile_vox = 64; // ICGN3D1: queues of >= 2048 POIs are visited in cubic blocks of this many voxels (0 = queue order; config E: 78.8 -> 75.5 ms, profiles/r4g_icgn3d1_ab_block_schedule.txt)
-    int icgn3d_mapping = 0;   // ICGN3D1: 0 = sample s owned by thread s mod 512 (icgn3d.hip; oracle order OC_ORDER_LANES) -- the default:
-                              // 1 = one half-wave per subvolume row (icgn3d_rows.hip; OC_ORDER_ROWS), built and measured in round 4:
-                              // bit-exact against its own order, 12 - 25 % SLOWER -- kept as the A/B partner
-    // host-queue pipeline (compute_host): the queue travels in chunks, copies of one chunk overlap the kernels of
-    // its neighbours; one event per chunk orders the copy-out stream behind the kernels
-    hipStream_t copy_stream = nullptr, copy_in_stream = nullptr;
-    // icgn2d variant 8 with "icgn2d_split_chunks" >= 2: the set-up kernels run on this second stream, one or two chunks ahead
-    // of the iteration kernels on the engine's stream, so that workgroups of both kinds are resident together
-    hipStream_t aux_stream = nullptr;
-    std::vector<hipEvent_t> split_ev;
-    int icgn2d_split_chunks = 0;
-    std::vector<hipEvent_t> chunk_done, chunk_in;
-    size_t chunks_fed = 0;  // chunks whose kernels (and event) are enqueued; (size_t)-1: the feeder failed.  Guarded by feed_mu
-    std::mutex feed_mu;
-    std::condition_variable feed_cv;  // the copy-out thread sleeps here until the next chunk has been handed over
-    int host_chunk = 65536;  // POIs per chunk ("host_chunk" tuning key; 0 = the whole queue at once)
-    std::atomic<unsigned> single_calls{0};  // compute(POI*) calls on this engine (one hint on stderr when a caller loops over them)
-    // device group (oc_hip_set_devices): this engine leads, replicas[i] is a full engine of the same kind on
-    // group_devices[i + 1]; every setter, set_images, prepare and compute fans out
-    std::vector<oc_hip_engine*> replicas;
-    std::vector<int> group_devices;
-    bool is_replica = false;
-    int group_allgather = 0;     // DEVICE queues: leave the complete result queue in every member's mirror
-    int group_force_rccl = 0;    // the all-gather goes through RCCL even for a group of ONE (a one-rank communicator)
-    DevBuf group_mirror;         // full-size copy of a DEVICE queue (members other than the leader work in theirs)
-    DevBuf group_off_mirror;
-    size_t group_mirror_block = 0;  // bytes per member block of the last all-gathered queue
-    hipEvent_t group_ev = nullptr;
-    void* rccl_comm = nullptr;   // ncclComm_t of this member (group_allgather with distinct devices)
-    // profiling
-    bool prof = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    mutable std::mutex mu;
-
-    bool is3d() const { return kind == OC_HIP_FFTCC3D || kind == OC_HIP_ICGN3D1; }
-    bool is_iclm() const { return kind == OC_HIP_ICLM2D1 || kind == OC_HIP_ICLM2D2; }
-    bool is_icgn2d() const { return kind == OC_HIP_ICGN2D1 || kind == OC_HIP_ICGN2D2 || is_iclm(); }
-    bool is_icgn() const { return is_icgn2d() || kind == OC_HIP_ICGN3D1 || kind == OC_HIP_NR2D1; }
-    size_t poi_bytes() const { return is3d() ? OC_HIP_POI3D_BYTES : OC_HIP_POI2D_BYTES; }
-};
-
-namespace {
-
-void group_drop_comms(oc_hip_engine* e);  // RCCL communicators of a device group (defined with the group code)
-
-int check_engine(const oc_hip_engine* e) {
-    if (!e) return fail(OC_HIP_ERR_INVALID, "null engine handle");
-    return OC_HIP_OK;
-}
-
-int activate(const oc_hip_engine* e) {
-    OC_TRY(check_engine(e));
-    OC_HIP_TRY(hipSetDevice(e->device));
-    return OC_HIP_OK;
-}
-
-// Entry points make the engine's device current for the calling thread and give the caller's device back on the way
-// out (a host that drives several GPUs from one thread -- torch with more than one device, say -- must not find its
-// current device changed by a library call).
-struct DeviceScope {
-    int saved = -1;
-    DeviceScope() {
-        if (hipGetDevice(&saved) != hipSuccess) saved = -1;
-    }
-    ~DeviceScope() {
-        int now = -1;
-        if (saved >= 0 && hipGetDevice(&now) == hipSuccess && now != saved) (void)hipSetDevice(saved);
-    }
-    DeviceScope(const DeviceScope&) = delete;
-    DeviceScope& operator=(const DeviceScope&) = delete;
-};
-#define OC_ACTIVATE(e)        \
-    DeviceScope device_scope; \
-    OC_TRY(activate(e))
 
 int create_engine(int kind, int rx, int ry, int rz, float conv, float stop, int device, oc_hip_engine** out) {
     if (!out) return fail(OC_HIP_ERR_INVALID, "null output handle");
@@ -300,93 +52,22 @@ int create_engine(int kind, int rx, int ry, int rz, float conv, float stop, int 
     return OC_HIP_OK;
 }
 
-// The engine's private stream is non-blocking: nothing the caller enqueued is ordered against it.  Inputs that
-// live on the device (OC_HIP_DEVICE queues, offsets, images used in place) are usually produced on the legacy
-// default stream -- hipMemcpy, plain launches, torch unless told otherwise -- so every entry point that enqueues work
-// on the private stream first makes it wait for what the default stream holds at that moment.  Producers on OTHER
-// streams must be complete, or be named with oc_hip_set_stream (documented in opencorr_hip.h).
-int order_after_default_stream(oc_hip_engine* e) {
-    if (e->stream != e->own_stream) return OC_HIP_OK;  // caller-chosen stream: stream order is the caller's
-    if (!e->order_ev) OC_HIP_TRY(hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming));
-    OC_HIP_TRY(hipEventRecord(e->order_ev, nullptr));
-    OC_HIP_TRY(hipStreamWaitEvent(e->own_stream, e->order_ev, 0));
-    return OC_HIP_OK;
-}
+}  // namespace ochip_capi
 
-// See oc_hip_engine::switch_ev.  Entry points that return with work enqueued on a caller-owned stream end with this.
-int mark_tail(oc_hip_engine* e) {
-    if (e->stream == e->own_stream) return OC_HIP_OK;  // the engine's own stream can always be asked later
-    if (!e->switch_ev) OC_HIP_TRY(hipEventCreateWithFlags(&e->switch_ev, hipEventDisableTiming));
-    OC_HIP_TRY(hipEventRecord(e->switch_ev, e->stream));
-    e->tail_marked = true;
-    return OC_HIP_OK;
-}
-
-// Scope guard of the entry points that enqueue work: whatever way the function leaves -- also an error exit after some
-// kernels or copies were already enqueued on a CALLER-owned stream -- the engine's tail event covers that work, so a later
-// set_stream / destroy / set_devices drains it through the event instead of relying on hipFree's implicit device
-// synchronisation.  Quiet: a failure to record never replaces the error message the function itself reports, and the
-// success paths' own mark_tail (finish_device_call) simply records the same point twice.
-struct TailGuard {
-    oc_hip_engine* e;
-    explicit TailGuard(oc_hip_engine* engine) : e(engine) {}
-    TailGuard(const TailGuard&) = delete;
-    TailGuard& operator=(const TailGuard&) = delete;
-    ~TailGuard() {
-        if (!e || e->stream == e->own_stream) return;
-        if (!e->switch_ev && hipEventCreateWithFlags(&e->switch_ev, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            return;
-        }
-        if (hipEventRecord(e->switch_ev, e->stream) == hipSuccess) e->tail_marked = true;
-        else (void)hipGetLastError();
-    }
-};
-
-// Host-side wait for everything this engine has enqueued, without ever touching a caller's (possibly destroyed) stream.
-void drain_engine(oc_hip_engine* e) {
-    if (e->stream == e->own_stream) {
-        if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-    } else {
-        if (e->tail_marked && e->switch_ev) (void)hipEventSynchronize(e->switch_ev);
-        if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-    }
-    (void)hipGetLastError();
-}
-
-void clear_events(oc_hip_engine* e) {
-    for (auto& ev : e->events) {
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
-    }
-    e->events.clear();
-}
-
-struct ProfScope {
-    oc_hip_engine* e;
-    hipEvent_t stop = nullptr;
-    explicit ProfScope(oc_hip_engine* e_) : e(e_) {
-        if (!e->prof) return;
-        hipEvent_t start = nullptr;
-        if (hipEventCreate(&start) != hipSuccess) return;
-        if (hipEventCreate(&stop) != hipSuccess) { (void)hipEventDestroy(start); stop = nullptr; return; }
-        (void)hipEventRecord(start, e->stream);
-        e->events.emplace_back(start, stop);
-    }
-    ~ProfScope() {
-        if (stop) (void)hipEventRecord(stop, e->stream);
-    }
-};
+namespace {
 
 // ---------------------------------------------------------------------------
 // FFTCC2D pipeline
 // ---------------------------------------------------------------------------
 size_t fftcc_chunk_limit() {
+#if OC_BUILD_AB
+    // (experiments, A/B build only: POIs per batch of the rocFFT pipeline)
     const char* s = getenv("OC_HIP_FFTCC_CHUNK");
     if (s && *s) {
         long v = atol(s);
         if (v > 0) return (size_t)v;
     }
+#endif
     return 32768;
 }
 
@@ -671,11 +352,13 @@ int run_nr2d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
 // FFTCC3D pipeline / ICGN3D1
 // ---------------------------------------------------------------------------
 size_t fftcc3d_chunk_limit() {
+#if OC_BUILD_AB
     const char* s = getenv("OC_HIP_FFTCC3D_CHUNK");
     if (s && *s) {
         long v = atol(s);
         if (v > 0) return (size_t)v;
     }
+#endif
     return 1024;
 }
 
@@ -796,7 +479,9 @@ int run_icgn3d1(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
     return OC_HIP_OK;
 }
 
-int run_compute_device(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, const float* d_offsets = nullptr) {
+}  // namespace
+
+int ochip_capi::run_compute_device(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, const float* d_offsets) {
     if (d_offsets && e->kind != OC_HIP_ICGN2D1 && e->kind != OC_HIP_ICGN2D2)
         return fail(OC_HIP_ERR_INVALID, "center offsets are an ICGN2D1/ICGN2D2 feature (src/oc_icgn.h:75-76,130-131)");
     switch (e->kind) {
@@ -812,7 +497,7 @@ int run_compute_device(oc_hip_engine* e, float* d_pois, int stride_f, size_t cou
     }
 }
 
-}  // namespace
+
 
 // ===========================================================================
 // C entry points
@@ -866,199 +551,6 @@ int oc_hip_set_damping(oc_hip_engine* e, float lambda, float alpha, float beta) 
 // A call on a device-resident queue is asynchronous on a stream the CALLER chose (oc_hip_set_stream: stream-ordered
 // with the caller's other work, e.g. the next engine on the same stream).  On the engine's own private stream nobody
 // else could order against it, so the call completes before it returns.
-static int finish_device_call(oc_hip_engine* e) {
-    if (e->stream == e->own_stream) OC_HIP_TRY(hipStreamSynchronize(e->stream));
-    else OC_TRY(mark_tail(e));
-    return OC_HIP_OK;
-}
-
-// ---------------------------------------------------------------------------
-// Strain
-// ---------------------------------------------------------------------------
-static int strain_check(const oc_hip_engine* e, float radius, int nmin, int approximation) {
-    (void)e;
-    if (!(radius > 0.f)) return fail(OC_HIP_ERR_INVALID, "Strain: subregion radius must be > 0 (got %g)", (double)radius);
-    if (nmin < 1) return fail(OC_HIP_ERR_INVALID, "Strain: neighbor_number_min must be >= 1 (got %d)", nmin);
-    if (nmin > ochip::strain_knn_max())
-        return fail(OC_HIP_ERR_UNSUPPORTED, "Strain: neighbor_number_min %d exceeds the KNN path's limit of %d", nmin,
-                    ochip::strain_knn_max());
-    if (approximation != 1 && approximation != 2)
-        return fail(OC_HIP_ERR_INVALID, "Strain: approximation must be 1 (Cauchy) or 2 (Green), got %d", approximation);
-    return OC_HIP_OK;
-}
-
-int oc_hip_strain_create(float subregion_radius, int neighbor_number_min, int device, oc_hip_engine** out) {
-    if (out) *out = nullptr;
-    OC_TRY(strain_check(nullptr, subregion_radius, neighbor_number_min, 1));
-    OC_TRY(create_engine(OC_HIP_STRAIN, 1, 1, 0, 0.f, 0.f, device, out));
-    (*out)->st_radius = subregion_radius;
-    (*out)->st_nmin = neighbor_number_min;
-    return OC_HIP_OK;
-}
-
-int oc_hip_region_fit_create(float neighbor_search_radius, int neighbor_number_min, int device, oc_hip_engine** out) {
-    if (out) *out = nullptr;
-    OC_TRY(strain_check(nullptr, neighbor_search_radius, neighbor_number_min, 1));
-    OC_TRY(create_engine(OC_HIP_REGION_FIT, 1, 1, 0, 0.f, 0.f, device, out));
-    (*out)->st_radius = neighbor_search_radius;
-    (*out)->st_nmin = neighbor_number_min;
-    return OC_HIP_OK;
-}
-
-int oc_hip_region_fit_set(oc_hip_engine* e, float neighbor_search_radius, int neighbor_number_min) {
-    OC_TRY(check_engine(e));
-    if (e->kind != OC_HIP_REGION_FIT) return fail(OC_HIP_ERR_INVALID, "region_fit_set: not a RegionFit engine");
-    OC_TRY(strain_check(e, neighbor_search_radius, neighbor_number_min, 1));
-    std::lock_guard<std::mutex> lock(e->mu);
-    if (neighbor_search_radius != e->st_radius) e->st_count = 0;
-    e->st_radius = neighbor_search_radius;
-    e->st_nmin = neighbor_number_min;
-    return OC_HIP_OK;
-}
-
-int oc_hip_strain_set(oc_hip_engine* e, float subregion_radius, int neighbor_number_min, float zncc_threshold,
-                      int approximation) {
-    OC_TRY(check_engine(e));
-    if (e->kind != OC_HIP_STRAIN) return fail(OC_HIP_ERR_INVALID, "strain_set: not a Strain engine");
-    OC_TRY(strain_check(e, subregion_radius, neighbor_number_min, approximation));
-    std::lock_guard<std::mutex> lock(e->mu);
-    if (subregion_radius != e->st_radius) e->st_count = 0;  // the grid pitch follows the radius: prepare() again
-    e->st_radius = subregion_radius;
-    e->st_nmin = neighbor_number_min;
-    e->st_zncc = zncc_threshold;
-    e->st_approx = approximation;
-    return OC_HIP_OK;
-}
-
-static int strain_stage(oc_hip_engine* e, const void* pois, size_t count, size_t stride_bytes, int ndim, int memory,
-                        float** d_pois) {
-    if (e->kind != OC_HIP_STRAIN && e->kind != OC_HIP_REGION_FIT) return fail(OC_HIP_ERR_INVALID, "not a Strain / RegionFit engine");
-    if (ndim != 2 && ndim != 3) return fail(OC_HIP_ERR_INVALID, "ndim must be 2 (POI2D) or 3 (POI3D), got %d", ndim);
-    if (!pois) return fail(OC_HIP_ERR_INVALID, "null POI buffer");
-    const size_t rec = ndim == 2 ? OC_HIP_POI2D_BYTES : OC_HIP_POI3D_BYTES;
-    if (stride_bytes < rec || (stride_bytes & 3))
-        return fail(OC_HIP_ERR_INVALID, "bad POI stride %zu (record is %zu bytes, stride must be a multiple of 4)", stride_bytes, rec);
-    if (count > 0x7fffffffull) return fail(OC_HIP_ERR_UNSUPPORTED, "Strain: at most 2^31-1 POIs per queue");
-    if (memory == OC_HIP_DEVICE) {
-        *d_pois = static_cast<float*>(const_cast<void*>(pois));
-        return OC_HIP_OK;
-    }
-    OC_TRY(e->poi_stage.reserve(count * stride_bytes));
-    OC_HIP_TRY(hipMemcpyAsync(e->poi_stage.p, pois, count * stride_bytes, hipMemcpyHostToDevice, e->stream));
-    *d_pois = e->poi_stage.as<float>();
-    return OC_HIP_OK;
-}
-
-// neighbour search over a queue's coordinates; gather_records: also snapshot the fit records (RegionFit's cloud)
-static int plane_prepare(oc_hip_engine* e, int kind, const void* pois, size_t count, size_t stride_bytes, int ndim, int memory,
-                         bool gather_records) {
-    OC_ACTIVATE(e);
-    if (e->kind != kind) return fail(OC_HIP_ERR_INVALID, "prepare: wrong engine kind for this entry point");
-    std::lock_guard<std::mutex> lock(e->mu);
-    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
-    e->st_count = 0;
-    if (count == 0) return OC_HIP_OK;
-    OC_TRY(order_after_default_stream(e));
-    float* d_pois = nullptr;
-    OC_TRY(strain_stage(e, pois, count, stride_bytes, ndim, memory, &d_pois));
-    const int stride_f = (int)(stride_bytes / 4);
-    // bounding box -> grid (the cell count is needed on the host to size the tables)
-    OC_TRY(e->st_box.reserve(6 * sizeof(unsigned)));
-    OC_HIP_TRY(ochip::launch_strain_bbox(ndim, d_pois, stride_f, count, e->st_box.as<unsigned>(), e->stream));
-    unsigned box[6];
-    OC_HIP_TRY(hipMemcpyAsync(box, e->st_box.p, sizeof(box), hipMemcpyDeviceToHost, e->stream));
-    OC_HIP_TRY(hipStreamSynchronize(e->stream));
-    const ochip::StrainGrid g = ochip::strain_make_grid(ndim, box, e->st_radius);
-    const size_t ncell = ochip::strain_cell_count(g);
-    OC_TRY(e->st_counts.reserve(ncell * sizeof(unsigned)));
-    OC_TRY(e->st_cursor.reserve(ncell * sizeof(unsigned)));
-    OC_TRY(e->st_start.reserve((ncell + 1) * sizeof(unsigned)));
-    OC_TRY(e->st_slots.reserve(count * sizeof(unsigned)));
-    OC_TRY(e->st_order.reserve(count * sizeof(unsigned)));
-    OC_HIP_TRY(ochip::launch_strain_sort(ndim, d_pois, stride_f, count, g, e->st_counts.as<unsigned>(), e->st_start.as<unsigned>(),
-                                         e->st_cursor.as<unsigned>(), e->st_slots.as<unsigned>(), e->st_order.as<unsigned>(),
-                                         e->stream));
-    if (gather_records) {
-        OC_TRY(e->st_recs.reserve(count * 32));
-        OC_HIP_TRY(ochip::launch_strain_gather(ndim, d_pois, stride_f, count, e->st_order.as<unsigned>(), e->st_recs.p, e->stream));
-    }
-    if (memory == OC_HIP_HOST) OC_HIP_TRY(hipStreamSynchronize(e->stream));  // the staging buffer is reused by compute
-    else OC_TRY(finish_device_call(e));
-    e->st_grid = g;
-    e->st_ndim = ndim;
-    e->st_count = count;
-    return OC_HIP_OK;
-}
-
-int oc_hip_strain_prepare(oc_hip_engine* e, const void* pois, size_t count, size_t stride_bytes, int ndim, int memory) {
-    OC_TRY(check_engine(e));
-    return plane_prepare(e, OC_HIP_STRAIN, pois, count, stride_bytes, ndim, memory, false);
-}
-
-int oc_hip_region_fit_prepare(oc_hip_engine* e, const void* reliable_pois, size_t count, size_t stride_bytes, int ndim,
-                              int memory) {
-    OC_TRY(check_engine(e));
-    return plane_prepare(e, OC_HIP_REGION_FIT, reliable_pois, count, stride_bytes, ndim, memory, true);
-}
-
-int oc_hip_region_fit_compute(oc_hip_engine* e, void* pois, size_t count, size_t stride_bytes, int ndim, int memory) {
-    OC_ACTIVATE(e);
-    if (count == 0) return OC_HIP_OK;
-    std::lock_guard<std::mutex> lock(e->mu);
-    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
-    if (e->kind != OC_HIP_REGION_FIT) return fail(OC_HIP_ERR_INVALID, "not a RegionFit engine");
-    if (e->st_count == 0)
-        return fail(OC_HIP_ERR_INVALID, "RegionFit: setNeighbor + prepare has not been called (or the radius changed since)");
-    if (e->st_ndim != ndim) return fail(OC_HIP_ERR_INVALID, "RegionFit: prepared for POI%dD, compute() got POI%dD", e->st_ndim, ndim);
-    OC_TRY(order_after_default_stream(e));
-    float* d_pois = nullptr;
-    OC_TRY(strain_stage(e, pois, count, stride_bytes, ndim, memory, &d_pois));
-    const int stride_f = (int)(stride_bytes / 4);
-    OC_TRY(e->st_fallback.reserve((count + 1) * sizeof(unsigned)));
-    const ochip::StrainParams P = {e->st_radius * e->st_radius, 0.f, e->st_nmin, 1};
-    {
-        ProfScope prof(e);
-        OC_HIP_TRY(ochip::launch_region_fit_compute(ndim, d_pois, stride_f, count, e->st_grid, P, e->st_start.as<unsigned>(),
-                                                    e->st_recs.p, e->st_fallback.as<unsigned>(), e->stream));
-    }
-    if (memory == OC_HIP_HOST) {
-        OC_HIP_TRY(hipMemcpyAsync(pois, d_pois, count * stride_bytes, hipMemcpyDeviceToHost, e->stream));
-        OC_HIP_TRY(hipStreamSynchronize(e->stream));
-    } else {
-        OC_TRY(finish_device_call(e));
-    }
-    return OC_HIP_OK;
-}
-
-int oc_hip_strain_compute(oc_hip_engine* e, void* pois, size_t count, size_t stride_bytes, int ndim, int memory) {
-    OC_ACTIVATE(e);
-    if (count == 0) return OC_HIP_OK;
-    std::lock_guard<std::mutex> lock(e->mu);
-    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
-    if (e->kind != OC_HIP_STRAIN) return fail(OC_HIP_ERR_INVALID, "not a Strain engine");
-    if (e->st_count == 0) return fail(OC_HIP_ERR_INVALID, "Strain: prepare(poi_queue) has not been called (or the radius changed since)");
-    if (e->st_count != count || e->st_ndim != ndim)
-        return fail(OC_HIP_ERR_INVALID, "Strain: prepare() saw %zu POI%dD, compute() got %zu POI%dD", e->st_count, e->st_ndim, count, ndim);
-    OC_TRY(order_after_default_stream(e));
-    float* d_pois = nullptr;
-    OC_TRY(strain_stage(e, pois, count, stride_bytes, ndim, memory, &d_pois));
-    const int stride_f = (int)(stride_bytes / 4);
-    OC_TRY(e->st_recs.reserve(count * 32));
-    OC_TRY(e->st_fallback.reserve((count + 1) * sizeof(unsigned)));
-    const ochip::StrainParams P = {e->st_radius * e->st_radius, e->st_zncc, e->st_nmin, e->st_approx};
-    {
-        ProfScope prof(e);
-        OC_HIP_TRY(ochip::launch_strain_compute(ndim, d_pois, stride_f, count, e->st_grid, P, e->st_start.as<unsigned>(),
-                                                e->st_order.as<unsigned>(), e->st_recs.p, e->st_fallback.as<unsigned>(), e->stream));
-    }
-    if (memory == OC_HIP_HOST) {
-        OC_HIP_TRY(hipMemcpyAsync(pois, d_pois, count * stride_bytes, hipMemcpyDeviceToHost, e->stream));
-        OC_HIP_TRY(hipStreamSynchronize(e->stream));
-    } else {
-        OC_TRY(finish_device_call(e));
-    }
-    return OC_HIP_OK;
-}
 
 int oc_hip_nr2d1_create(int rx, int ry, float conv, float stop, int device, oc_hip_engine** out) {
     return create_engine(OC_HIP_NR2D1, rx, ry, 0, conv, stop, device, out);
@@ -1505,6 +997,8 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
     } else if (k == "fftcc3d_planes_blocks") {
         if (value < 0 || value > 4096) return fail(OC_HIP_ERR_INVALID, "fftcc3d_planes_blocks must be 0 (default) ... 4096");
         e->fftcc3d_planes_blocks = value;
+    } else if (k == "single_combine") {
+        e->single_combine = value != 0;
     } else if (k == "host_chunk") {
         if (value < 0 || (value > 0 && value < 16384)) return fail(OC_HIP_ERR_INVALID, "host_chunk must be 0 (off) or >= 16384 POIs");
         e->host_chunk = value;
@@ -1596,416 +1090,6 @@ int oc_hip_prepare(oc_hip_engine* e) {
 
 }  // extern "C"
 
-namespace {
-
-// ---------------------------------------------------------------------------
-// host queues: H2D of the AoS, kernels, D2H (the reference's CUDA module does the same,
-// examples/test_2d_dic_gpu_icgn.cpp:136-149) -- but chunk by chunk, so that the copies of one chunk overlap the
-// kernels of its neighbours:   H2D(0) K(0) | H2D(1) K(1) D2H(0) | H2D(2) K(2) D2H(1) | ... | D2H(last)
-// Kernels run on the engine's stream, copies out on a second stream behind a per-chunk event and from a second host
-// thread (copies to / from pageable memory block their thread; PCIe is full duplex); copies in are issued on the
-// engine's stream ahead of their kernels.  A POI's result does not depend on the chunk it travels in (tests: split
-// queue == whole queue), chunks are large enough for the ICGN2D tile schedule.
-// ---------------------------------------------------------------------------
-// `chain`: further engines that process the same records right after `e` (oc_hip_compute_chain: FFTCC then ICGN, say) --
-// per chunk ONE copy in, every engine's kernels in order on e's stream, ONE copy out, instead of a round trip per engine.
-// The callers have moved the chained engines onto e's stream for the duration of the call.
-int compute_host(oc_hip_engine* e, char* pois, const float* offsets, size_t count, size_t stride_bytes,
-                 oc_hip_engine* const* chain = nullptr, int n_chain = 0) {
-    const int stride_f = (int)(stride_bytes / 4);
-    auto run_all = [&](float* d_pois, size_t n, const float* d_off) -> int {
-        OC_TRY(run_compute_device(e, d_pois, stride_f, n, d_off));
-        for (int i = 0; i < n_chain; i++) OC_TRY(run_compute_device(chain[i], d_pois, stride_f, n, nullptr));
-        return OC_HIP_OK;
-    };
-    const size_t bytes = count * stride_bytes;
-    OC_TRY(e->poi_stage.reserve(bytes));
-    if (offsets) OC_TRY(e->off_stage.reserve(count * 2 * sizeof(float)));
-    // Chunk schedule.  What a pipeline cannot hide is the copy-in of its FIRST chunk and the copy-out of its LAST one, and
-    // every extra chunk costs a launch tail (the ICGN kernels' last workgroups run on a half-empty chip) plus an
-    // inter-stream hand-over.  So: small chunks at both ends (half of "host_chunk"), few large ones (three times
-    // "host_chunk") in between, whose copies hide behind the neighbours' kernels.  Measured on config B (250 000 POIs,
-    // chain of FFTCC2D + ICGN2D1): uniform chunks of 65 536: 4.76 ms, one piece: 5.36 ms, this schedule: see DESIGN 4.4.
-    std::vector<std::pair<size_t, size_t>> sched;  // (first POI, POIs)
-    {
-        const size_t unit = e->host_chunk > 0 ? (size_t)e->host_chunk : count;
-        if (count < 2 * unit) {
-            sched.emplace_back(0, count);  // not worth a pipeline
-        } else {
-            const size_t edge = std::max<size_t>(unit / 2, 1), mid_max = 3 * unit;
-            sched.emplace_back(0, edge);
-            size_t at = edge;
-            const size_t mid_total = count - 2 * edge;
-            const size_t nmid = (mid_total + mid_max - 1) / mid_max;
-            for (size_t i = 0; i < nmid; i++) {
-                const size_t n = mid_total / nmid + (i < mid_total % nmid ? 1 : 0);
-                sched.emplace_back(at, n);
-                at += n;
-            }
-            sched.emplace_back(at, count - at);
-        }
-    }
-    const size_t nchunk = sched.size();
-    if (nchunk > 1) {
-        if (!e->copy_stream) OC_HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-        if (!e->copy_in_stream) OC_HIP_TRY(hipStreamCreateWithFlags(&e->copy_in_stream, hipStreamNonBlocking));
-        // (two loops: a failed creation must not leave the lists at different lengths for the next call)
-        while (e->chunk_done.size() < nchunk) {
-            hipEvent_t ev = nullptr;
-            OC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            e->chunk_done.push_back(ev);
-        }
-        while (e->chunk_in.size() < nchunk) {
-            hipEvent_t ev = nullptr;
-            OC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            e->chunk_in.push_back(ev);
-        }
-    }
-    char* stage = e->poi_stage.as<char>();
-    if (nchunk == 1) {
-        OC_HIP_TRY(hipMemcpyAsync(stage, pois, bytes, hipMemcpyHostToDevice, e->stream));
-        const float* d_off = nullptr;
-        if (offsets) {
-            OC_HIP_TRY(hipMemcpyAsync(e->off_stage.p, offsets, count * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
-            d_off = e->off_stage.as<float>();
-        }
-        OC_TRY(run_all(reinterpret_cast<float*>(stage), count, d_off));
-        OC_HIP_TRY(hipMemcpyAsync(pois, stage, bytes, hipMemcpyDeviceToHost, e->stream));
-        OC_HIP_TRY(hipStreamSynchronize(e->stream));
-        return OC_HIP_OK;
-    }
-    // A copy between pageable host memory and the device blocks the calling thread, so the two directions get a thread
-    // each (PCIe is full duplex): this thread feeds chunks in and launches their kernels, the helper waits for each
-    // chunk's event and copies its records back.
-    const int device = e->device;
-    hipError_t out_err = hipSuccess;
-    {
-        std::lock_guard<std::mutex> hand(e->feed_mu);
-        e->chunks_fed = 0;
-    }
-    auto hand_over = [&](size_t fed) {
-        {
-            std::lock_guard<std::mutex> hand(e->feed_mu);
-            e->chunks_fed = fed;
-        }
-        e->feed_cv.notify_one();
-    };
-    auto copy_out = [&] {
-        if (hipSetDevice(device) != hipSuccess) {
-            out_err = hipErrorInvalidDevice;
-            return;
-        }
-        for (size_t c = 0; c < nchunk && out_err == hipSuccess; c++) {
-            const size_t first = sched[c].first, n = sched[c].second;
-            // the event is recorded by the feeding thread after chunk c's kernels were enqueued; until then
-            // hipStreamWaitEvent would see the event of an earlier call, so sleep until the hand-off
-            {
-                std::unique_lock<std::mutex> hand(e->feed_mu);
-                e->feed_cv.wait(hand, [&] { return e->chunks_fed > c; });
-                if (e->chunks_fed == (size_t)-1) break;  // the feeder failed: drain what was issued and stop
-            }
-            out_err = hipStreamWaitEvent(e->copy_stream, e->chunk_done[c], 0);
-            if (out_err == hipSuccess)
-                out_err = hipMemcpyAsync(pois + first * stride_bytes, stage + first * stride_bytes, n * stride_bytes, hipMemcpyDeviceToHost,
-                                         e->copy_stream);
-        }
-        if (out_err == hipSuccess) out_err = hipStreamSynchronize(e->copy_stream);
-    };
-    // std::thread's constructor throws std::system_error when the process is out of threads; nothing may unwind through
-    // the extern "C" boundary, so the helper is optional: without it this thread copies out after feeding
-    std::thread out_thread;
-    bool helper = true;
-    try {
-        out_thread = std::thread(copy_out);
-    } catch (...) {
-        helper = false;
-    }
-    int rc = OC_HIP_OK;
-    auto feed = [&]() -> int {
-        // the staging buffer may still be read by kernels of an earlier call on the engine's stream
-        OC_HIP_TRY(hipEventRecord(e->chunk_in[0], e->stream));
-        OC_HIP_TRY(hipStreamWaitEvent(e->copy_in_stream, e->chunk_in[0], 0));
-        for (size_t c = 0; c < nchunk; c++) {
-            const size_t first = sched[c].first, n = sched[c].second;
-            // copies in travel on their own stream: on the kernels' stream a pageable copy would queue behind the
-            // previous chunk's kernels and nothing would overlap
-            OC_HIP_TRY(hipMemcpyAsync(stage + first * stride_bytes, pois + first * stride_bytes, n * stride_bytes, hipMemcpyHostToDevice,
-                                      e->copy_in_stream));
-            const float* d_off = nullptr;
-            if (offsets) {
-                float* o = e->off_stage.as<float>() + 2 * first;
-                OC_HIP_TRY(hipMemcpyAsync(o, offsets + 2 * first, n * 2 * sizeof(float), hipMemcpyHostToDevice, e->copy_in_stream));
-                d_off = o;
-            }
-            OC_HIP_TRY(hipEventRecord(e->chunk_in[c], e->copy_in_stream));
-            OC_HIP_TRY(hipStreamWaitEvent(e->stream, e->chunk_in[c], 0));
-            OC_TRY(run_all(reinterpret_cast<float*>(stage + first * stride_bytes), n, d_off));
-            OC_HIP_TRY(hipEventRecord(e->chunk_done[c], e->stream));
-            hand_over(c + 1);
-        }
-        return OC_HIP_OK;
-    };
-    rc = feed();
-    const std::string feed_error = g_last_error;
-    if (rc != OC_HIP_OK) hand_over((size_t)-1);
-    if (helper) out_thread.join();
-    else copy_out();
-    OC_HIP_TRY(hipStreamSynchronize(e->stream));
-    if (rc != OC_HIP_OK) return fail(rc, "%s", feed_error.c_str());
-    if (out_err != hipSuccess) return fail(OC_HIP_ERR_HIP, "copying results back failed: %s", hipGetErrorString(out_err));
-    return OC_HIP_OK;
-}
-
-// ---------------------------------------------------------------------------
-// device groups (oc_hip_set_devices): contiguous blocks of the queue, one per member (the loop that is
-// being replaced is src/oc_icgn.cpp:343-351).  Member g takes POIs [g * ceil(n / G), (g + 1) * ceil(n / G)).
-// ---------------------------------------------------------------------------
-struct GroupBlock {
-    oc_hip_engine* e;
-    size_t first, n;
-};
-
-std::vector<GroupBlock> group_blocks(oc_hip_engine* e, size_t count) {
-    const size_t G = e->replicas.size() + 1, per = (count + G - 1) / G;
-    std::vector<GroupBlock> b;
-    for (size_t g = 0; g < G; g++) {
-        const size_t first = std::min(g * per, count), n = std::min(per, count - first);
-        b.push_back({g == 0 ? e : e->replicas[g - 1], first, n});
-    }
-    return b;
-}
-
-// RCCL, loaded on first use: the single-GPU path never needs it and should not pay for loading it (nor fail to start
-// on a machine without it).  Types and enumerators come from <rccl/rccl.h> at compile time -- the datatype passed to
-// ncclAllGather is the header's ncclUint8, not a number typed in here -- and the loaded library must report the same
-// major version as that header.
-struct Rccl {
-    decltype(&ncclCommInitAll) comm_init_all = nullptr;
-    decltype(&ncclAllGather) all_gather = nullptr;
-    decltype(&ncclGroupStart) group_start = nullptr;
-    decltype(&ncclGroupEnd) group_end = nullptr;
-    decltype(&ncclCommDestroy) comm_destroy = nullptr;
-    decltype(&ncclGetErrorString) err = nullptr;
-    decltype(&ncclGetVersion) get_version = nullptr;
-    int version = 0;
-    std::string why;  // why the library is unusable
-    bool ok = false;
-    const char* text(ncclResult_t rc) const { return err ? err(rc) : "?"; }
-    static Rccl& get() {
-        static Rccl r;
-        static std::once_flag once;
-        std::call_once(once, [] {
-            // OC_HIP_RCCL_LIB names a specific build; otherwise the ROCm soname, then the unversioned name
-            const char* names[3] = {getenv("OC_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so"};
-            void* h = nullptr;
-            for (const char* name : names)
-                if (!h && name && *name) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (!h) {
-                const char* d = dlerror();
-                r.why = std::string("librccl.so.1 could not be loaded: ") + (d ? d : "?");
-                return;
-            }
-            r.comm_init_all = (decltype(r.comm_init_all))dlsym(h, "ncclCommInitAll");
-            r.all_gather = (decltype(r.all_gather))dlsym(h, "ncclAllGather");
-            r.group_start = (decltype(r.group_start))dlsym(h, "ncclGroupStart");
-            r.group_end = (decltype(r.group_end))dlsym(h, "ncclGroupEnd");
-            r.comm_destroy = (decltype(r.comm_destroy))dlsym(h, "ncclCommDestroy");
-            r.err = (decltype(r.err))dlsym(h, "ncclGetErrorString");
-            r.get_version = (decltype(r.get_version))dlsym(h, "ncclGetVersion");
-            if (!(r.comm_init_all && r.all_gather && r.group_start && r.group_end && r.comm_destroy && r.get_version)) {
-                r.why = "librccl lacks one of ncclCommInitAll / ncclAllGather / ncclGroupStart / ncclGroupEnd / ncclCommDestroy / ncclGetVersion";
-                return;
-            }
-            if (r.get_version(&r.version) != ncclSuccess || r.version / 10000 != NCCL_MAJOR) {
-                r.why = "librccl reports version " + std::to_string(r.version) + ", built against major " + std::to_string(NCCL_MAJOR);
-                return;
-            }
-            r.ok = true;
-        });
-        return r;
-    }
-};
-
-void group_drop_comms(oc_hip_engine* e) {
-    bool any = e->rccl_comm != nullptr;
-    for (oc_hip_engine* r : e->replicas) any = any || r->rccl_comm != nullptr;
-    if (!any) return;  // never load RCCL just to find out there is nothing to drop
-    Rccl& R = Rccl::get();
-    auto drop = [&](oc_hip_engine* m) {
-        if (m->rccl_comm && R.ok) {
-            (void)hipSetDevice(m->device);
-            (void)R.comm_destroy((ncclComm_t)m->rccl_comm);
-        }
-        m->rccl_comm = nullptr;
-    };
-    drop(e);
-    for (oc_hip_engine* r : e->replicas) drop(r);
-}
-
-// Can this group's all-gather be ONE ncclAllGather?  Yes when its members sit on distinct devices (a communicator
-// cannot hold a device twice) and there is more than one of them -- or exactly one and "group_force_rccl" is set, which
-// runs the identical code (ncclCommInitAll over one device, ncclAllGather on a one-rank communicator) so that the RCCL
-// binding executes on a one-GPU machine.
-bool group_uses_rccl(oc_hip_engine* e, const std::vector<GroupBlock>& blocks) {
-    const int G = (int)blocks.size();
-    for (int a = 0; a < G; a++)
-        for (int b = a + 1; b < G; b++)
-            if (blocks[a].e->device == blocks[b].e->device) return false;
-    if (G == 1 && !e->group_force_rccl) return false;
-    return true;
-}
-
-// Every member's mirror ends up holding the whole queue (blocks of `block` bytes, the last one padded): ONE
-// ncclAllGather over xGMI when the members sit on distinct devices, peer copies otherwise (a group may name a device
-// twice -- that is how the sharding logic is exercised on a one-GPU box).  RCCL: every member sends its own block from
-// where it lies -- the leader straight from the caller's queue (`leader_block`), the others from their slot of their
-// mirror (an in-place all-gather for them).
-int group_allgather(oc_hip_engine* e, const std::vector<GroupBlock>& blocks, size_t block, const char* leader_block) {
-    const int G = (int)blocks.size();
-    if (group_uses_rccl(e, blocks)) {
-        Rccl& R = Rccl::get();
-        if (!R.ok) {
-            if (e->group_force_rccl) return fail(OC_HIP_ERR_HIP, "group_force_rccl: %s", R.why.c_str());
-        } else {
-            if (!e->rccl_comm) {
-                std::vector<ncclComm_t> comms(G, nullptr);
-                std::vector<int> devs;
-                for (const GroupBlock& b : blocks) devs.push_back(b.e->device);
-                const ncclResult_t rc = R.comm_init_all(comms.data(), G, devs.data());
-                (void)hipSetDevice(e->device);
-                if (rc != ncclSuccess) return fail(OC_HIP_ERR_HIP, "ncclCommInitAll over %d devices failed: %s", G, R.text(rc));
-                for (int g = 0; g < G; g++) blocks[g].e->rccl_comm = comms[g];
-            }
-            // whatever happens between ncclGroupStart and ncclGroupEnd, ncclGroupEnd is reached: an open group would
-            // poison this thread's later RCCL calls and the cached communicators
-            ncclResult_t rc = R.group_start();
-            hipError_t herr = hipSuccess;
-            if (rc == ncclSuccess) {
-                for (int g = 0; g < G && rc == ncclSuccess && herr == hipSuccess; g++) {
-                    oc_hip_engine* m = blocks[g].e;
-                    herr = hipSetDevice(m->device);
-                    if (herr != hipSuccess) break;
-                    char* mirror = m->group_mirror.as<char>();
-                    const char* mine = g == 0 ? leader_block : mirror + (size_t)g * block;
-                    rc = R.all_gather(mine, mirror, block, ncclUint8, (ncclComm_t)m->rccl_comm, m->stream);
-                }
-                const ncclResult_t rc2 = R.group_end();
-                if (rc == ncclSuccess) rc = rc2;
-            }
-            (void)hipSetDevice(e->device);
-            if (herr != hipSuccess) return fail(OC_HIP_ERR_HIP, "hipSetDevice inside the all-gather failed: %s", hipGetErrorString(herr));
-            if (rc != ncclSuccess) return fail(OC_HIP_ERR_HIP, "ncclAllGather failed: %s", R.text(rc));
-            return OC_HIP_OK;
-        }
-    }
-    // peer copies: the leader's block joins its mirror, then member g fetches every other member's block once that
-    // member is done (its event)
-    OC_HIP_TRY(hipMemcpyAsync(e->group_mirror.p, leader_block, block, hipMemcpyDeviceToDevice, e->stream));  // blocks[0] is a full block
-    OC_HIP_TRY(hipEventRecord(e->group_ev, e->stream));
-    for (int g = 0; g < G; g++) {
-        oc_hip_engine* m = blocks[g].e;
-        OC_HIP_TRY(hipSetDevice(m->device));
-        for (int h = 0; h < G; h++) {
-            if (h == g) continue;
-            oc_hip_engine* src = blocks[h].e;
-            OC_HIP_TRY(hipStreamWaitEvent(m->stream, src->group_ev, 0));
-            OC_HIP_TRY(hipMemcpyPeerAsync(m->group_mirror.as<char>() + (size_t)h * block, m->device,
-                                          src->group_mirror.as<char>() + (size_t)h * block, src->device, block, m->stream));
-        }
-    }
-    OC_HIP_TRY(hipSetDevice(e->device));
-    return OC_HIP_OK;
-}
-
-// DEVICE queue of a group: the queue lives on the leader's device.  Every other member pulls its block into its own
-// mirror (peer copy over xGMI), solves it there on its own stream and pushes the records back; the leader solves
-// block 0 in place.  All of it is stream-ordered: members wait for the leader's stream to reach this call, the
-// leader's stream waits for the members' completion events.
-int compute_group_device(oc_hip_engine* e, char* pois, const float* offsets, size_t count, size_t stride_bytes) {
-    const std::vector<GroupBlock> blocks = group_blocks(e, count);
-    const int stride_f = (int)(stride_bytes / 4);
-    const size_t per = blocks[0].n, block = per * stride_bytes;  // blocks[0] is the largest
-    auto event_of = [](oc_hip_engine* m) -> int {
-        if (!m->group_ev) OC_HIP_TRY(hipEventCreateWithFlags(&m->group_ev, hipEventDisableTiming));
-        return OC_HIP_OK;
-    };
-    OC_TRY(event_of(e));
-    OC_HIP_TRY(hipEventRecord(e->group_ev, e->stream));  // the queue is ready when the leader's stream gets here
-    hipEvent_t ready = e->group_ev;
-    for (size_t g = 1; g < blocks.size(); g++) {
-        oc_hip_engine* m = blocks[g].e;
-        const size_t first = blocks[g].first, n = blocks[g].n;
-        std::lock_guard<std::mutex> lock(m->mu);
-        OC_HIP_TRY(hipSetDevice(m->device));
-        OC_TRY(event_of(m));
-        OC_TRY(m->group_mirror.reserve(blocks.size() * block));
-        OC_HIP_TRY(hipStreamWaitEvent(m->stream, ready, 0));
-        if (n) {
-            char* mine = m->group_mirror.as<char>() + g * block;
-            OC_HIP_TRY(hipMemcpyPeerAsync(mine, m->device, pois + first * stride_bytes, e->device, n * stride_bytes, m->stream));
-            const float* d_off = nullptr;
-            if (offsets) {
-                OC_TRY(m->group_off_mirror.reserve(per * 2 * sizeof(float)));
-                OC_HIP_TRY(hipMemcpyPeerAsync(m->group_off_mirror.p, m->device, offsets + 2 * first, e->device, n * 2 * sizeof(float), m->stream));
-                d_off = m->group_off_mirror.as<float>();
-            }
-            OC_TRY(run_compute_device(m, reinterpret_cast<float*>(mine), stride_f, n, d_off));
-            OC_HIP_TRY(hipMemcpyPeerAsync(pois + first * stride_bytes, e->device, mine, m->device, n * stride_bytes, m->stream));
-        }
-        OC_HIP_TRY(hipEventRecord(m->group_ev, m->stream));
-    }
-    OC_HIP_TRY(hipSetDevice(e->device));
-    // the members are busy; now the leader's own block, in place
-    if (blocks[0].n) OC_TRY(run_compute_device(e, reinterpret_cast<float*>(pois), stride_f, blocks[0].n, offsets));
-    if (e->group_allgather) {
-        // one all-gather: every member ends up with every block
-        OC_TRY(e->group_mirror.reserve(blocks.size() * block));
-        OC_TRY(group_allgather(e, blocks, block, pois));
-        for (const GroupBlock& b : blocks) {
-            b.e->group_mirror_block = block;
-            if (b.e != e) {
-                OC_HIP_TRY(hipSetDevice(b.e->device));
-                OC_HIP_TRY(hipEventRecord(b.e->group_ev, b.e->stream));
-            }
-        }
-        OC_HIP_TRY(hipSetDevice(e->device));
-    }
-    for (size_t g = 1; g < blocks.size(); g++) OC_HIP_TRY(hipStreamWaitEvent(e->stream, blocks[g].e->group_ev, 0));
-    return OC_HIP_OK;
-}
-
-// HOST queue of a group: every member moves and solves its own block (its own host thread, its own PCIe link), the
-// results land directly in the caller's vector -- no exchange step is needed for a host-resident queue.
-int compute_group_host(oc_hip_engine* e, char* pois, const float* offsets, size_t count, size_t stride_bytes) {
-    const std::vector<GroupBlock> blocks = group_blocks(e, count);
-    std::vector<int> rc(blocks.size(), OC_HIP_OK);
-    std::vector<std::string> msg(blocks.size());
-    auto work = [&](size_t g) {
-        oc_hip_engine* m = blocks[g].e;
-        if (blocks[g].n == 0) return;
-        if (hipSetDevice(m->device) != hipSuccess) {
-            rc[g] = OC_HIP_ERR_HIP;
-            msg[g] = "hipSetDevice failed";
-            return;
-        }
-        rc[g] = compute_host(m, pois + blocks[g].first * stride_bytes, offsets ? offsets + 2 * blocks[g].first : nullptr, blocks[g].n,
-                             stride_bytes);
-        if (rc[g] != OC_HIP_OK) msg[g] = g_last_error;  // thread-local in the worker
-    };
-    std::vector<std::thread> threads;
-    for (size_t g = 1; g < blocks.size(); g++) threads.emplace_back([&, g] {
-        std::lock_guard<std::mutex> lock(blocks[g].e->mu);
-        work(g);
-    });
-    work(0);
-    for (std::thread& t : threads) t.join();
-    OC_HIP_TRY(hipSetDevice(e->device));
-    for (size_t g = 0; g < blocks.size(); g++)
-        if (rc[g] != OC_HIP_OK) return fail(rc[g], "group member %zu (device %d): %s", g, blocks[g].e->device, msg[g].c_str());
-    return OC_HIP_OK;
-}
-
-}  // namespace
 
 extern "C" {
 
@@ -2120,22 +1204,156 @@ static void hint_single_poi_loop(oc_hip_engine* e) {
     static std::atomic<bool> said{false};
     const char* q = getenv("OC_HIP_QUIET");
     if ((q && *q && *q != '0') || said.exchange(true)) return;
-    fprintf(stderr, "opencorr_hip: compute(POI*) was called 4096 times on one engine -- every call is a GPU launch plus two PCIe copies. "
-                    "Hand the POIs over as one queue (compute(std::vector<POI>&), or computeBestOf() for trial positions per POI) for "
-                    "~1000x the throughput.  OC_HIP_QUIET=1 silences this hint.\n");
+    fprintf(stderr, "opencorr_hip: compute(POI*) was called 4096 times on one engine -- calls from concurrent threads are combined into one "
+                    "launch per batch, but a sequential loop still pays a GPU launch plus two PCIe copies per POI.  Hand the POIs over as "
+                    "one queue (compute(std::vector<POI>&), or computeBestOf() for trial positions per POI) for ~1000x the throughput.  "
+                    "OC_HIP_QUIET=1 silences this hint.\n");
+}
+
+// One batch of combined single-POI requests through the engine's host-queue path: records gathered into one buffer, ONE
+// compute call, records scattered back.  Requests with and without a centre offset cannot share a launch (the engine takes
+// an offset queue or none): the leader serves them as two sub-batches.
+static void serve_single_batch(oc_hip_engine* e, std::vector<oc_hip_engine::SingleRequest*>& batch) {
+    const size_t rec = e->poi_bytes();
+    for (int with_off = 0; with_off < 2; with_off++) {
+        std::vector<oc_hip_engine::SingleRequest*> part;
+        for (auto* r : batch)
+            if ((r->offset != nullptr) == (with_off != 0)) part.push_back(r);
+        if (part.empty()) continue;
+        int rc;
+        const auto t_begin = std::chrono::steady_clock::now();
+        if (part.size() == 1) {
+            rc = compute_impl(e, part[0]->poi, part[0]->offset, 1, rec, OC_HIP_HOST);
+        } else {
+            rc = e->single_buf.reserve(part.size() * rec);
+            char* buf = static_cast<char*>(e->single_buf.p);
+            float* off = nullptr;
+            if (rc == OC_HIP_OK && with_off) {
+                rc = e->single_off.reserve(2 * part.size() * sizeof(float));
+                off = static_cast<float*>(e->single_off.p);
+            }
+            if (rc == OC_HIP_OK) {
+                for (size_t i = 0; i < part.size(); i++) {
+                    memcpy(buf + i * rec, part[i]->poi, rec);
+                    if (off) {
+                        off[2 * i] = part[i]->offset[0];
+                        off[2 * i + 1] = part[i]->offset[1];
+                    }
+                }
+                rc = compute_impl(e, buf, off, part.size(), rec, OC_HIP_HOST);
+            }
+            if (rc == OC_HIP_OK)
+                for (size_t i = 0; i < part.size(); i++) memcpy(part[i]->poi, buf + i * rec, rec);
+        }
+        e->single_engine_ns.fetch_add((unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count(),
+                                      std::memory_order_relaxed);
+        e->single_batches.fetch_add(1, std::memory_order_relaxed);
+        e->single_batched_pois.fetch_add(part.size(), std::memory_order_relaxed);
+        for (auto* r : part) {
+            r->rc = rc;
+            if (rc != OC_HIP_OK) r->error = g_last_error;   // (thread-local in the leader: handed to the request's owner)
+        }
+    }
+}
+
+// compute(POI*) / compute(POI*, center_offset): queue the request.  Whoever finds no leader becomes one: it takes everything
+// that is queued as ONE batch, serves it, wakes the owners of the served requests (each on its own condition variable) and
+// goes on with what has arrived meanwhile -- back to back, so the GPU never waits for a thread to wake up.  Its own request
+// sits in its first batch; after kSingleExtraBatches further batches it promotes the owner of a queued request to leader and
+// returns (no caller serves the others for ever).  A POI's result does not depend on the batch it travels in (the per-POI
+// solves are independent: tests/test_gpu_parity_2d.py::test_host_pipeline_chunks_change_no_bits).
+constexpr int kSingleExtraBatches = 32;
+
+static int compute_single(oc_hip_engine* e, void* poi, const float* offset) {
+    if (!poi) return fail(OC_HIP_ERR_INVALID, "null POI");
+    if (!e->single_combine) return compute_impl(e, poi, offset, 1, e->poi_bytes(), OC_HIP_HOST);
+    oc_hip_engine::SingleRequest req(poi, offset);
+    bool lead;
+    {
+        std::lock_guard<std::mutex> lk(e->single_mu);
+        e->single_pending.push_back(&req);
+        lead = !e->single_leader;
+        if (lead) e->single_leader = true;
+    }
+    // Publishing a request's new state is the leader's LAST access to it (the owner may return at once).  Owners whose spin
+    // budget ran out sleep on the engine's condition variable: they register under its mutex and re-check their state there, the
+    // leader takes the same mutex after its stores -- no wake-up is lost, and nobody pays a futex call while everyone spins.
+    auto wake_sleepers = [&]() {
+        if (e->single_sleepers.load(std::memory_order_acquire) > 0) {
+            std::lock_guard<std::mutex> ls(e->single_sleep_mu);
+            e->single_sleep_cv.notify_all();
+        }
+    };
+    if (!lead) {
+        // a short busy wait (the batch in flight is usually ~50 us from done), then polite polling -- yielding the core between
+        // looks, so that 60 waiting threads do not crowd out the leader and the HIP runtime's own threads --, then sleep
+        for (int spin = 0; spin < 1500 && req.state.load(std::memory_order_acquire) == 0; spin++) __builtin_ia32_pause();
+        if (req.state.load(std::memory_order_acquire) == 0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (req.state.load(std::memory_order_acquire) == 0 && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(400))
+                std::this_thread::yield();
+        }
+        if (req.state.load(std::memory_order_acquire) == 0) {
+            std::unique_lock<std::mutex> ls(e->single_sleep_mu);
+            e->single_sleepers.fetch_add(1, std::memory_order_acq_rel);
+            e->single_sleep_cv.wait(ls, [&] { return req.state.load(std::memory_order_acquire) != 0; });
+            e->single_sleepers.fetch_sub(1, std::memory_order_acq_rel);
+        }
+        lead = req.state.load(std::memory_order_acquire) == 2;   // promoted while still queued: this thread leads now
+    }
+    if (lead) {
+        std::vector<oc_hip_engine::SingleRequest*> batch;
+        bool own_done = false;
+        for (int served = 0;; served++) {
+            {
+                std::lock_guard<std::mutex> lk(e->single_mu);
+                if (e->single_pending.empty()) {
+                    e->single_leader = false;   // (its own request was queued before this thread became leader: it is done)
+                    break;
+                }
+                if (own_done && served > kSingleExtraBatches) {
+                    e->single_pending.front()->state.store(2, std::memory_order_release);   // its owner takes over; the request stays queued
+                    wake_sleepers();
+                    break;
+                }
+                batch.clear();
+                batch.swap(e->single_pending);
+            }
+            serve_single_batch(e, batch);
+            for (auto* r : batch) {
+                if (r == &req) own_done = true;
+                else r->state.store(1, std::memory_order_release);
+            }
+            wake_sleepers();
+        }
+    }
+    if (req.rc != OC_HIP_OK) return fail(req.rc, "%s", req.error.c_str());
+    return OC_HIP_OK;
 }
 
 int oc_hip_compute_one(oc_hip_engine* e, void* poi) {
     OC_TRY(check_engine(e));
     hint_single_poi_loop(e);
-    return compute_impl(e, poi, nullptr, 1, e->poi_bytes(), OC_HIP_HOST);
+    return compute_single(e, poi, nullptr);
 }
 
 int oc_hip_compute_one_with_offset(oc_hip_engine* e, void* poi, const float* center_offset) {
     OC_TRY(check_engine(e));
     hint_single_poi_loop(e);
     if (!center_offset) return fail(OC_HIP_ERR_INVALID, "null center offset");
-    return compute_impl(e, poi, center_offset, 1, e->poi_bytes(), OC_HIP_HOST);
+    if (e->kind != OC_HIP_ICGN2D1 && e->kind != OC_HIP_ICGN2D2)
+        return fail(OC_HIP_ERR_INVALID, "center offsets are an ICGN2D1/ICGN2D2 feature (src/oc_icgn.h:75-76,130-131)");
+    return compute_single(e, poi, center_offset);
+}
+
+// batches / POIs the combining front end has served on this engine (tests, diagnostics)
+int oc_hip_single_stats(oc_hip_engine* e, unsigned long long* batches, unsigned long long* pois) {
+    OC_TRY(check_engine(e));
+    if (batches) *batches = e->single_batches.load();
+    if (pois) *pois = e->single_batched_pois.load();
+    if (getenv("OC_HIP_SINGLE_DEBUG")) fprintf(stderr, "opencorr_hip: single-POI front end: %llu batches, %llu POIs, %.3f ms inside the engine\n",
+                                               e->single_batches.load(), e->single_batched_pois.load(), e->single_engine_ns.load() * 1e-6);
+    return OC_HIP_OK;
 }
 
 int oc_hip_select_best(oc_hip_engine* e, const void* candidates, size_t n_candidates, size_t candidate_stride_bytes,
@@ -2175,176 +1393,6 @@ int oc_hip_select_best(oc_hip_engine* e, const void* candidates, size_t n_candid
         return OC_HIP_OK;
     }
     return finish_device_call(e);
-}
-
-// ---------------------------------------------------------------------------
-// reliable / unreliable selection of the RegionFit -> re-ICGN loop (poi_split.hip)
-// ---------------------------------------------------------------------------
-static int split_params(int ndim, size_t stride_bytes, float low, float high, float conv, int mode, ochip::PoiSplitParams* P) {
-    if (ndim != 2 && ndim != 3) return fail(OC_HIP_ERR_INVALID, "ndim must be 2 (POI2D) or 3 (POI3D), got %d", ndim);
-    const size_t rec = ndim == 2 ? OC_HIP_POI2D_BYTES : OC_HIP_POI3D_BYTES;
-    if (stride_bytes < rec || (stride_bytes & 3)) return fail(OC_HIP_ERR_INVALID, "bad POI stride %zu (record is %zu bytes, stride must be a multiple of 4)", stride_bytes, rec);
-    P->mode = mode;
-    P->rec_floats = (int)(rec / 4);
-    P->zncc_at = ndim == 2 ? 16 : 18;  // result.zncc / result.convergence, src/oc_poi.h:102-136, 187-222
-    P->conv_at = ndim == 2 ? 18 : 20;
-    P->zncc_low = low;
-    P->zncc_high = high;
-    P->conv = conv;
-    return OC_HIP_OK;
-}
-
-// totals[0], totals[1]: records of class 0 / 1; totals[2]: a main-queue index was out of range (merge_recovered)
-static int read_split_totals(oc_hip_engine* e, size_t count, size_t totals[3]) {
-    unsigned host[3] = {0, 0, 0};
-    const unsigned* d = e->split_scratch.as<unsigned>() + ochip::poi_split_scratch_words(count) - 3;
-    OC_HIP_TRY(hipMemcpyAsync(host, d, sizeof(host), hipMemcpyDeviceToHost, e->stream));
-    OC_HIP_TRY(hipStreamSynchronize(e->stream));
-    totals[0] = host[0];
-    totals[1] = host[1];
-    totals[2] = host[2];
-    return OC_HIP_OK;
-}
-
-// device records (stride_bytes apart) -> the caller's host queue: only the record's own bytes travel, so whatever the
-// caller keeps between records (stride_bytes > record size) stays as it was -- like on the DEVICE path, whose scatter
-// writes rec_floats per record
-static hipError_t copy_records_to_host(void* dst, const void* src, size_t n, size_t stride_bytes, size_t rec_bytes, hipStream_t stream) {
-    if (n == 0) return hipSuccess;
-    if (stride_bytes == rec_bytes) return hipMemcpyAsync(dst, src, n * stride_bytes, hipMemcpyDeviceToHost, stream);
-    return hipMemcpy2DAsync(dst, stride_bytes, src, stride_bytes, rec_bytes, n, hipMemcpyDeviceToHost, stream);
-}
-
-int oc_hip_split_reliable(oc_hip_engine* e, const void* pois, size_t count, size_t stride_bytes, int ndim, float zncc_threshold_low,
-                          float zncc_threshold_high, float conv_criterion, void* reliable, size_t reliable_offset, void* unreliable,
-                          unsigned* unreliable_index, size_t* n_reliable, size_t* n_unreliable, int memory) {
-    OC_ACTIVATE(e);
-    if (!n_reliable || !n_unreliable) return fail(OC_HIP_ERR_INVALID, "split_reliable: null count pointer");
-    *n_reliable = *n_unreliable = 0;
-    if (count == 0) return OC_HIP_OK;
-    if (!pois || !reliable || !unreliable || !unreliable_index) return fail(OC_HIP_ERR_INVALID, "split_reliable: null buffer");
-    ochip::PoiSplitParams P;
-    OC_TRY(split_params(ndim, stride_bytes, zncc_threshold_low, zncc_threshold_high, conv_criterion, 0, &P));
-    std::lock_guard<std::mutex> lock(e->mu);
-    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
-    OC_TRY(order_after_default_stream(e));
-    OC_TRY(e->split_scratch.reserve(ochip::poi_split_scratch_words(count) * sizeof(unsigned)));
-    const int stride_f = (int)(stride_bytes / 4);
-    const size_t rec_bytes = (size_t)P.rec_floats * 4;
-    size_t totals[3];
-    if (memory == OC_HIP_DEVICE) {
-        OC_HIP_TRY(ochip::launch_poi_split(static_cast<const float*>(pois), stride_f, count, P, nullptr, static_cast<float*>(reliable),
-                                           reliable_offset, nullptr, static_cast<float*>(unreliable), unreliable_index, nullptr, 0,
-                                           e->split_scratch.as<unsigned>(), e->stream));
-        OC_TRY(read_split_totals(e, count, totals));
-    } else {
-        const size_t qb = count * stride_bytes;
-        OC_TRY(e->poi_stage.reserve(3 * qb + count * sizeof(unsigned)));
-        char* base = e->poi_stage.as<char>();
-        float* d_in = reinterpret_cast<float*>(base);
-        float* d_rel = reinterpret_cast<float*>(base + qb);
-        float* d_unr = reinterpret_cast<float*>(base + 2 * qb);
-        unsigned* d_idx = reinterpret_cast<unsigned*>(base + 3 * qb);
-        OC_HIP_TRY(hipMemcpyAsync(d_in, pois, qb, hipMemcpyHostToDevice, e->stream));
-        OC_HIP_TRY(ochip::launch_poi_split(d_in, stride_f, count, P, nullptr, d_rel, 0, nullptr, d_unr, d_idx, nullptr, 0,
-                                           e->split_scratch.as<unsigned>(), e->stream));
-        OC_TRY(read_split_totals(e, count, totals));
-        OC_HIP_TRY(copy_records_to_host(static_cast<char*>(reliable) + reliable_offset * stride_bytes, d_rel, totals[0], stride_bytes, rec_bytes, e->stream));
-        if (totals[1]) {
-            OC_HIP_TRY(copy_records_to_host(unreliable, d_unr, totals[1], stride_bytes, rec_bytes, e->stream));
-            OC_HIP_TRY(hipMemcpyAsync(unreliable_index, d_idx, totals[1] * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-        }
-        OC_HIP_TRY(hipStreamSynchronize(e->stream));
-    }
-    *n_reliable = totals[0];
-    *n_unreliable = totals[1];
-    return OC_HIP_OK;
-}
-
-int oc_hip_merge_recovered(oc_hip_engine* e, void* pois, size_t count, size_t stride_bytes, int ndim, void* unreliable,
-                           unsigned* unreliable_index, size_t n_unreliable, float zncc_threshold_high, float conv_criterion, void* reliable,
-                           size_t reliable_offset, size_t* n_recovered, size_t* n_remaining, int memory) {
-    OC_ACTIVATE(e);
-    if (!n_recovered || !n_remaining) return fail(OC_HIP_ERR_INVALID, "merge_recovered: null count pointer");
-    *n_recovered = 0;
-    *n_remaining = 0;
-    if (n_unreliable == 0) return OC_HIP_OK;
-    if (!pois || !reliable || !unreliable || !unreliable_index) return fail(OC_HIP_ERR_INVALID, "merge_recovered: null buffer");
-    ochip::PoiSplitParams P;
-    OC_TRY(split_params(ndim, stride_bytes, 0.f, zncc_threshold_high, conv_criterion, 1, &P));
-    std::lock_guard<std::mutex> lock(e->mu);
-    TailGuard tail(e);  // also the error exits leave the enqueued work covered by the tail event
-    OC_TRY(order_after_default_stream(e));
-    OC_TRY(e->split_scratch.reserve(ochip::poi_split_scratch_words(n_unreliable) * sizeof(unsigned)));
-    const int stride_f = (int)(stride_bytes / 4);
-    const size_t qb = n_unreliable * stride_bytes, ib = n_unreliable * sizeof(unsigned);
-    const size_t rec_bytes = (size_t)P.rec_floats * 4;
-    size_t totals[3];
-    if (memory == OC_HIP_DEVICE) {
-        // the POIs that stay unreliable are compacted into a scratch copy first (an in-place compaction would overwrite
-        // records other threads still have to read), then moved back to the front of the caller's arrays
-        OC_TRY(e->split_tmp.reserve(qb + ib));
-        float* t_rec = e->split_tmp.as<float>();
-        unsigned* t_idx = reinterpret_cast<unsigned*>(e->split_tmp.as<char>() + qb);
-        // the index list is checked on the device BEFORE the scatter may write anything of the caller's: a list
-        // with an entry outside the main queue is refused with `reliable`, `pois`, `unreliable` and the list itself untouched
-        {
-            unsigned* flag = e->split_scratch.as<unsigned>() + ochip::poi_split_scratch_words(n_unreliable) - 1;
-            OC_HIP_TRY(ochip::launch_poi_index_range(unreliable_index, n_unreliable, count, flag, e->stream));
-            unsigned bad = 0;
-            OC_HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof(bad), hipMemcpyDeviceToHost, e->stream));
-            OC_HIP_TRY(hipStreamSynchronize(e->stream));
-            if (bad) return fail(OC_HIP_ERR_INVALID, "merge_recovered: an unreliable_index entry is >= the main queue's %zu records (nothing was changed)", count);
-        }
-        OC_HIP_TRY(ochip::launch_poi_split(static_cast<const float*>(unreliable), stride_f, n_unreliable, P, unreliable_index,
-                                           static_cast<float*>(reliable), reliable_offset, nullptr, t_rec, t_idx, static_cast<float*>(pois),
-                                           count, e->split_scratch.as<unsigned>(), e->stream));
-        OC_TRY(read_split_totals(e, n_unreliable, totals));
-        // an index outside the main queue: the kernel wrote nothing through it; the caller's lists are left as they were
-        if (totals[2]) return fail(OC_HIP_ERR_INVALID, "merge_recovered: an unreliable_index entry is >= the main queue's %zu records", count);
-        if (totals[1]) {
-            OC_HIP_TRY(hipMemcpyAsync(unreliable, t_rec, totals[1] * stride_bytes, hipMemcpyDeviceToDevice, e->stream));
-            OC_HIP_TRY(hipMemcpyAsync(unreliable_index, t_idx, totals[1] * sizeof(unsigned), hipMemcpyDeviceToDevice, e->stream));
-        }
-        *n_recovered = totals[0];
-        *n_remaining = totals[1];
-        return finish_device_call(e);
-    }
-    // host queues: every index is checked BEFORE anything is enqueued or touched (the host knows the list)
-    for (size_t j = 0; j < n_unreliable; j++)
-        if (unreliable_index[j] >= count)
-            return fail(OC_HIP_ERR_INVALID, "merge_recovered: unreliable_index[%zu] = %u is >= the main queue's %zu records", j, unreliable_index[j], count);
-    // the classification and both compactions run on the device; the host only moves the recovered records to where the
-    // device's index list says they go
-    OC_TRY(e->poi_stage.reserve(3 * qb + 3 * ib));
-    char* base = e->poi_stage.as<char>();
-    float* d_in = reinterpret_cast<float*>(base);
-    float* d_rec = reinterpret_cast<float*>(base + qb);
-    float* d_rem = reinterpret_cast<float*>(base + 2 * qb);
-    unsigned* d_idx_in = reinterpret_cast<unsigned*>(base + 3 * qb);
-    unsigned* d_idx_rec = d_idx_in + n_unreliable;
-    unsigned* d_idx_rem = d_idx_rec + n_unreliable;
-    OC_HIP_TRY(hipMemcpyAsync(d_in, unreliable, qb, hipMemcpyHostToDevice, e->stream));
-    OC_HIP_TRY(hipMemcpyAsync(d_idx_in, unreliable_index, ib, hipMemcpyHostToDevice, e->stream));
-    OC_HIP_TRY(ochip::launch_poi_split(d_in, stride_f, n_unreliable, P, d_idx_in, d_rec, 0, d_idx_rec, d_rem, d_idx_rem, nullptr, 0,
-                                       e->split_scratch.as<unsigned>(), e->stream));
-    OC_TRY(read_split_totals(e, n_unreliable, totals));
-    std::vector<unsigned> rec_idx(totals[0]);
-    char* rel_dst = static_cast<char*>(reliable) + reliable_offset * stride_bytes;
-    if (totals[0]) {
-        OC_HIP_TRY(copy_records_to_host(rel_dst, d_rec, totals[0], stride_bytes, rec_bytes, e->stream));
-        OC_HIP_TRY(hipMemcpyAsync(rec_idx.data(), d_idx_rec, totals[0] * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-    }
-    if (totals[1]) {
-        OC_HIP_TRY(copy_records_to_host(unreliable, d_rem, totals[1], stride_bytes, rec_bytes, e->stream));
-        OC_HIP_TRY(hipMemcpyAsync(unreliable_index, d_idx_rem, totals[1] * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-    }
-    OC_HIP_TRY(hipStreamSynchronize(e->stream));
-    for (size_t j = 0; j < totals[0]; j++)
-        std::memcpy(static_cast<char*>(pois) + (size_t)rec_idx[j] * stride_bytes, rel_dst + j * stride_bytes, rec_bytes);
-    *n_recovered = totals[0];
-    *n_remaining = totals[1];
-    return OC_HIP_OK;
 }
 
 int oc_hip_set_self_adaptive(oc_hip_engine* e, int enable) {

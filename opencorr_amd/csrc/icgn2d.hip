@@ -89,6 +89,13 @@
 #ifndef OC_UNIFORM_IN_VGPR
 #define OC_UNIFORM_IN_VGPR 0
 #endif
+// The experiment macros above change what the kernels compute or how they are scheduled: they exist for the A/B build of the
+// library and the ablation scripts (tools/ablate_icgn2d.sh, tools/ab_icgn2d.sh: -DOC_BUILD_AB=1); the library that ships is
+// built with every one of them at its default.
+#if !OC_BUILD_AB && (OC_ABLATE2D != 0 || OC_SWEEP_PRIO != 0 || OC_UNIFORM_IN_VGPR != 0 || OC_SWEEP_BARRIER != -1 || OC_SETUP_BATCH != 6 || \
+                     OC_HESS_BATCH != 6 || OC_NUM_BATCH != 6 || OC_V5_G != 2 || OC_V5_OCC != 6)
+#error "icgn2d.hip: experiment macros are honoured in the A/B build only (-DOC_BUILD_AB=1)"
+#endif
 
 namespace ochip {
 

@@ -367,4 +367,60 @@ int oc_ref_region_fit(int ndim, const float* reliable, long n_reliable, float* p
     return 0;
 }
 
+// The reference's host-side Deformation classes (src/oc_deformation.{h,cpp}) for tests/test_oracle_vs_ref_deformation.py:
+// kind 1 = Deformation2D1 (6 parameters, 3 x 3), 2 = Deformation2D2 (12, 6 x 6), 3 = Deformation3D1 (12, 4 x 4).
+// mat_out <- warp_matrix after setDeformation(p); warped <- warp(pt); p_back <- the parameters setDeformation() reads back
+// from a warp_matrix overwritten with mat_in (row-major).
+int oc_ref_deformation(int kind, const float* p, const float* pt, const float* mat_in, float* mat_out, float* warped, float* p_back) {
+    try {
+        if (kind == 1) {
+            float q[6];
+            std::memcpy(q, p, sizeof(q));
+            Deformation2D1 d(q);
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) mat_out[i * 3 + j] = d.warp_matrix(i, j);
+            Point2D a(pt[0], pt[1]);
+            Point2D b = d.warp(a);
+            warped[0] = b.x; warped[1] = b.y;
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) d.warp_matrix(i, j) = mat_in[i * 3 + j];
+            d.setDeformation();
+            const float back[6] = {d.u, d.ux, d.uy, d.v, d.vx, d.vy};
+            std::memcpy(p_back, back, sizeof(back));
+        } else if (kind == 2) {
+            float q[12];
+            std::memcpy(q, p, sizeof(q));
+            Deformation2D2 d(q);
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 6; j++) mat_out[i * 6 + j] = d.warp_matrix(i, j);
+            Point2D b = d.warp(Point2D(pt[0], pt[1]));
+            warped[0] = b.x; warped[1] = b.y;
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 6; j++) d.warp_matrix(i, j) = mat_in[i * 6 + j];
+            d.setDeformation();
+            const float back[12] = {d.u, d.ux, d.uy, d.uxx, d.uxy, d.uyy, d.v, d.vx, d.vy, d.vxx, d.vxy, d.vyy};
+            std::memcpy(p_back, back, sizeof(back));
+        } else if (kind == 3) {
+            float q[12];
+            std::memcpy(q, p, sizeof(q));
+            Deformation3D1 d(q);
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 4; j++) mat_out[i * 4 + j] = d.warp_matrix(i, j);
+            Point3D a(pt[0], pt[1], pt[2]);
+            Point3D b = d.warp(a);
+            warped[0] = b.x; warped[1] = b.y; warped[2] = b.z;
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 4; j++) d.warp_matrix(i, j) = mat_in[i * 4 + j];
+            d.setDeformation();
+            const float back[12] = {d.u, d.ux, d.uy, d.uz, d.v, d.vx, d.vy, d.vz, d.w, d.wx, d.wy, d.wz};
+            std::memcpy(p_back, back, sizeof(back));
+        } else {
+            return 2;
+        }
+    } catch (const std::string&) {
+        return 1;
+    }
+    return 0;
+}
+
 }  // extern "C"

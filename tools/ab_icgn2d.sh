@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 LIB=opencorr_amd/lib
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize"
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -DOC_BUILD_AB=1"
 SRC=${AB_SRC:-icgn2d}   # the source file the variants rebuild (icgn2d | nr2d)
 OBJS=$(ls $LIB/*.o | grep -v "/$SRC\.o")
 cat > /tmp/time2d_ab.py <<'PY'

@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 LIB=opencorr_amd/lib
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize ${EXTRA_FLAGS}"
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -DOC_BUILD_AB=1 ${EXTRA_FLAGS}"
 OBJS=$(ls $LIB/*.o | grep -v "icgn2d\.o")
 cat > /tmp/time2d.py <<'PY'
 import sys, time, json, os, numpy as np, torch
