@@ -24,6 +24,7 @@
 #pragma once
 
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -120,6 +121,12 @@ inline bool single_device(oc_hip_engine* e) {
     return oc_hip_get_devices(e, nullptr, 0, &n) == OC_HIP_OK && n == 1;
 }
 // applied by every shim constructor right after the engine exists
+// true when OC_HIP_ARITH_FMA switches the solvers created through these classes to the fused arithmetic contract
+inline bool arithFmaFromEnvironment() {
+    const char* fma = std::getenv("OC_HIP_ARITH_FMA");
+    return fma && std::atoi(fma) != 0;
+}
+
 inline void apply_default_devices(oc_hip_engine* e) {
     const std::vector<int> ids = default_devices();
     if (ids.size() > 1) check(oc_hip_set_devices(e, ids.data(), (int)ids.size()));
@@ -130,8 +137,17 @@ inline void apply_default_devices(oc_hip_engine* e) {
     if (fma && std::atoi(fma) != 0) {
         int kind = 0;
         if (oc_hip_get_kind(e, &kind) == OC_HIP_OK &&
-            (kind == OC_HIP_ICGN2D1 || kind == OC_HIP_ICGN2D2 || kind == OC_HIP_ICLM2D1 || kind == OC_HIP_ICLM2D2 || kind == OC_HIP_ICGN3D1))
+            (kind == OC_HIP_ICGN2D1 || kind == OC_HIP_ICGN2D2 || kind == OC_HIP_ICLM2D1 || kind == OC_HIP_ICLM2D2 || kind == OC_HIP_ICGN3D1)) {
             check(oc_hip_set_tuning(e, "arith_fma", 1));
+            // the one knob that changes result bits, set from outside the program: say so once per process;
+            // arithFmaFromEnvironment() tells a caller which mode its engines run in
+            static std::atomic<bool> said{false};
+            const char* quiet = std::getenv("OC_HIP_QUIET");
+            if (!(quiet && *quiet && *quiet != '0') && !said.exchange(true))
+                std::fprintf(stderr, "opencorr_hip: OC_HIP_ARITH_FMA=%s -- the ICGN / IC-LM solvers of this process use the fused arithmetic contract "
+                                     "(per-sample multiply-adds fused; results differ from the default build by rounding, inside 1e-4 px).  "
+                                     "OC_HIP_QUIET=1 silences this note.\n", fma);
+        }
     }
 }
 }  // namespace hipdetail

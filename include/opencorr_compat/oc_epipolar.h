@@ -8,9 +8,14 @@
 //     ICGN2D1::computeBestOf(candidates, segment_starts, poi_queue)   (oc_engines.h: one launch + one selection kernel)
 // Only plain floats cross this header: the fundamental matrix (row-major, what EpipolarSearch::updateFundementalMatrix
 // builds from the two cameras' calibration, :99-118) comes from the caller's calibration code -- Calibration / Stereovision
-// are outside this library's scope.  Every expression below is the reference's, operand for operand (its Eigen product
-// fundamental_matrix * view1_vector is the coefficient-wise sum with ascending inner index), so the candidates are the
-// reference's own bit for bit (tests/test_oracle_vs_ref_epipolar.py runs the reference's compiled EpipolarSearch beside it).
+// are outside this library's scope.  Every expression below is the reference's, operand for operand; its Eigen product
+// fundamental_matrix * view1_vector is restated as the coefficient-wise sum with ascending inner index, (a0 + a1) + a2.  The
+// candidates equal those of the reference's compiled EpipolarSearch bit for bit where that reference is built against
+// oracle/ref_stubs' stand-in Eigen (tests/test_oracle_vs_ref_epipolar.py) -- which sums the three terms in the same order.  Real
+// Eigen 3.4 may associate a 3-term row product differently (a0 + (a1 + a2)): a one-ulp change of the line's coefficients, and
+// since x_view2 / y_view2 are truncated to int (src/oc_epipolar_search.cpp:166-179) a trial position can then move by a pixel for
+// a POI that sits exactly on a truncation boundary.  No real Eigen exists in this image to decide it; ICGN refines every trial to
+// the same sub-pixel minimum either way.
 #pragma once
 
 #include <vector>

@@ -240,7 +240,14 @@ int run_icgn2d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count, cons
     }
     // per-POI radii: no shared coordinate table, and the per-wave arrays are sized for the LARGEST subset of the batch -- the
     // target-array-only shape (variant 7) keeps four workgroups on a CU where variant 2 holds two (bench.py paths_8f_row1)
-    if (e->self_adaptive && (e->icgn2d_variant < 0 || ochip::icgn2d_variant_uses_table(variant))) variant = 7;
+    // -- when variant 2's two arrays per wave would leave a CU at most two workgroups (subsets from 26 passes = 41 x 40 up: the
+    // measured case, radii 12 ... 20: 4.91 -> 3.98 ms); smaller batches keep variant 2, which is 4 % ahead at equal occupancy
+    // (3.49 vs 3.61 ms on a uniform r = 16: one image read per sample fewer).  ADVICE r5.
+    if (e->self_adaptive && (e->icgn2d_variant < 0 || ochip::icgn2d_variant_uses_table(variant))) {
+        const long long passes_sa = (N + 63) / 64;
+        const bool crowded = 3 * (2 * 4 * passes_sa * 256) > (160 * 1024 - 2048);   // three workgroups of variant 2 no longer fit
+        variant = crowded ? 7 : (dof == 12 ? 3 : 2);
+    }
     if (lm) variant = 1;  // the IC-LM launch shape has the LDS footprint of variant 1
     // variant 9 = icgn2d_band.hip (A/B build only: the workgroup's band of the table staged in LDS, the warped subset in registers --
     // bit-exact, measured 1.7 x slower than variant 5): one radius per launch and at most the passes it unrolls
@@ -399,10 +406,10 @@ int run_fftcc3d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
         if (count <= (1u << 30)) OC_TRY(tile_order3d(e, d_pois, stride_f, count, e->fftcc3d_tile_vox, &P.perm));
         ProfScope prof(e);
         const size_t kMaxGrid = 1u << 30;
+        if (fused32) OC_TRY(e->flags.reserve(ochip::fftcc3d_fused_flag_bytes(count < kMaxGrid ? count : kMaxGrid)));   // once, before anything is enqueued
         for (size_t first = 0; first < count; first += kMaxGrid) {
             const size_t n = (count - first) < kMaxGrid ? (count - first) : kMaxGrid;
             float* q = d_pois + first * (size_t)stride_f;
-            if (fused32) OC_TRY(e->flags.reserve(n));
             hipError_t err = fused32 ? ochip::launch_fftcc3d_fused(P, q, stride_f, n, e->icgn2d_xcd != 0, e->flags.as<unsigned char>(), e->stream)
                              : box   ? ochip::launch_fftcc3d_box(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream)
                                      : ochip::launch_fftcc3d_fusedn(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream);
@@ -972,6 +979,12 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
             return fail(OC_HIP_ERR_UNSUPPORTED, "arith_fma: only the ICGN2D1 / ICGN2D2 / ICLM2D1 / ICLM2D2 / ICGN3D1 engines have a fused-arithmetic build");
         e->arith_fma = value != 0;
     } else if (k == "icgn2d_split_chunks") {
+#if !OC_BUILD_AB
+        // (the split launch shape, variant 8, exists in the A/B build only: the key would have no effect here -- ADVICE r5)
+        if (value != 0)
+            return fail(OC_HIP_ERR_UNSUPPORTED, "icgn2d_split_chunks belongs to icgn2d_variant 8, an A/B partner that only the A/B build of the "
+                                                "library contains (python -m opencorr_amd.build --ab)");
+#endif
         if (value < 0 || value > 256) return fail(OC_HIP_ERR_INVALID, "icgn2d_split_chunks must be 0 (back to back) ... 256");
         e->icgn2d_split_chunks = value;
     } else if (k == "icgn2d_tile_px") {

@@ -82,7 +82,7 @@ __device__ __forceinline__ void block_sum2(float& x, float& y, float* red, int l
 // for 28 B of results per POI).
 template <bool CLAMPED>
 __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, float* __restrict__ pois, int stride_f, unsigned long long idx,
-                                                    unsigned char* __restrict__ needs_clamped) {
+                                                    unsigned char* __restrict__ needs_clamped, unsigned* __restrict__ any_clamped) {
     __shared__ c2 lds[kHalf];
     __shared__ int tab[6][TN];  // voxel index of window coordinate k: ref x, y, z, tar x, y, z
     __shared__ float red[2 * kWaves], red2[2 * kWaves];
@@ -119,7 +119,10 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
     }
     const bool contig = __syncthreads_and(mine_contig) != 0;
     if constexpr (!CLAMPED) {
-        if (tid == 0) needs_clamped[idx] = contig ? 0 : 1;
+        if (tid == 0) {
+            needs_clamped[idx] = contig ? 0 : 1;
+            if (!contig) atomicOr(any_clamped, 1u);
+        }
         if (!contig) return;
     }
 
@@ -366,16 +369,18 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_kernel(Fftcc3dPa
     if (xcd_chunk > 0) idx = (unsigned long long)(blockIdx.x & 7u) * xcd_chunk + (blockIdx.x >> 3);
     if (idx >= count) return;
     if (P.perm) idx = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)P.perm[idx]);  // wave-uniform: the record's address stays in SGPRs
-    fftcc3d_fused32_poi<false>(P, pois, stride_f, idx, needs_clamped);
+    fftcc3d_fused32_poi<false>(P, pois, stride_f, idx, needs_clamped, reinterpret_cast<unsigned*>(needs_clamped + ((count + 3) & ~3ull)));
 }
 
 // the windows clamped at a volume border: a few persistent workgroups scan the flags the first launch left (normally none is set)
 __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_clamped_kernel(Fftcc3dParams P, float* __restrict__ pois, int stride_f,
                                                                               unsigned long long count,
                                                                               unsigned char* __restrict__ needs_clamped) {
+    // (the first launch raises the word behind the flags when ANY window was clamped -- normally none: nothing to scan)
+    if (*reinterpret_cast<const unsigned*>(needs_clamped + ((count + 3) & ~3ull)) == 0u) return;
     for (unsigned long long idx = blockIdx.x; idx < count; idx += gridDim.x) {
         if (needs_clamped[idx]) {   // uniform over the workgroup
-            fftcc3d_fused32_poi<true>(P, pois, stride_f, idx, needs_clamped);
+            fftcc3d_fused32_poi<true>(P, pois, stride_f, idx, needs_clamped, nullptr);
             __syncthreads();        // the next POI reuses the tables and the tile
         }
     }
@@ -385,7 +390,9 @@ __global__ __launch_bounds__(kThreads3, 4) void fftcc3d_fused32_clamped_kernel(F
 
 bool fftcc3d_fused_supported(int rx, int ry, int rz) { return rx == TN / 2 && ry == TN / 2 && rz == TN / 2; }
 
-// needs_clamped: `count` bytes of device scratch (one flag per POI of the queue)
+// needs_clamped: fftcc3d_fused_flag_bytes(count) bytes of device scratch (one flag per POI of the queue + one "any" word)
+size_t fftcc3d_fused_flag_bytes(size_t count) { return ((count + 3) & ~(size_t)3) + 4; }
+
 hipError_t launch_fftcc3d_fused(const Fftcc3dParams& p, float* pois, int stride_f, size_t count, bool xcd, unsigned char* needs_clamped,
                                 hipStream_t stream) {
     if (count == 0) return hipSuccess;
@@ -393,8 +400,12 @@ hipError_t launch_fftcc3d_fused(const Fftcc3dParams& p, float* pois, int stride_
     const int chunk = xcd ? (int)((count + 7) / 8) : 0;
     const size_t grid = xcd ? (size_t)chunk * 8 : count;
     (void)hipGetLastError();  // drop stale errors of earlier, unrelated calls
+    hipError_t err = hipMemsetAsync(needs_clamped + ((count + 3) & ~(size_t)3), 0, 4, stream);
+    if (err != hipSuccess) return err;
     hipLaunchKernelGGL(fftcc3d_fused32_kernel, dim3((unsigned)grid), dim3(kThreads3), 0, stream, p, pois, stride_f,
                        (unsigned long long)count, chunk, needs_clamped);
+    err = hipGetLastError();
+    if (err != hipSuccess) return err;   // (nothing to scan behind a launch that failed)
     const unsigned scan = (unsigned)(count < 256 ? count : 256);
     hipLaunchKernelGGL(fftcc3d_fused32_clamped_kernel, dim3(scan), dim3(kThreads3), 0, stream, p, pois, stride_f,
                        (unsigned long long)count, needs_clamped);

@@ -245,8 +245,9 @@ hipError_t launch_fftcc3d_argmax(const Fftcc3dParams& p, const float* surf, cons
 // ---- fftcc3d_fused.hip -----------------------------------------------------
 // all of FFTCC3D::compute(POI3D*) in one kernel for 32 x 32 x 32 windows (radius 16)
 bool fftcc3d_fused_supported(int rx, int ry, int rz);
-// needs_clamped: `count` bytes of device scratch (the first launch flags the POIs whose windows are clamped at a volume border,
-// the second one computes those)
+// needs_clamped: fftcc3d_fused_flag_bytes(count) bytes of device scratch (the first launch flags the POIs whose windows are clamped at
+// a volume border and raises one "any" word behind the flags, the second one computes those -- and returns at once when the word is 0)
+size_t fftcc3d_fused_flag_bytes(size_t count);
 hipError_t launch_fftcc3d_fused(const Fftcc3dParams& p, float* pois, int stride_floats, size_t count, bool xcd,
                                 unsigned char* needs_clamped, hipStream_t stream);
 

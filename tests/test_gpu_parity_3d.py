@@ -364,6 +364,36 @@ def test_icgn3d1_bit_exact_vs_oracle(volumes, r):
         assert (want[:-4, P["zncc"]] > 0.97).all()
 
 
+def test_icgn3d1_overwrites_the_zncc_fftcc3d_left(volumes):
+    """FFTCC3D's ZNCC carries the reference's own summation noise at large windows (the stated, volume-dependent bar of
+    tests/test_gpu_fullsize.py / INTEGRATION.md); what a DVC pipeline reports is ICGN3D1's ZNCC, which replaces it on EVERY exit
+    -- converged, stop-limited (-4), left the volume (-3), NaN (-5) -- and a guard reject keeps only a flag that was already
+    negative (src/oc_icgn.cpp:1279-1286, 1396-1400, 1449-1489).  A sentinel in the field before the call must be gone."""
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    ref, tar = volumes
+    xs, ys, zs = synth.poi_grid_3d(*SHAPE, 4, 3, 3, 26)
+    pois = oracle.make_pois3d(xs, ys, zs)
+    oracle.fftcc3d(ref, tar, 8, 8, 8, pois)
+    P = oracle.P3
+    extra = oracle.make_pois3d([3, 40, 40, 40], [38, 38, 38, 38], [36, 36, 36, 36])   # guard reject, leaves the volume, far-off, NaN
+    extra[1, P["u"]] = 60.0
+    extra[2, P["u"]], extra[2, P["v"]] = 5.5, -4.5
+    extra[3, P["w"]] = np.nan
+    pois = np.concatenate([pois, extra]).astype(np.float32)
+    sentinel = np.float32(0.123456)
+    pois[:, P["zncc"]] = sentinel
+    icgn = opencorr_amd.ICGN3D1(8, 8, 8, 0.001, 20)
+    icgn.set_images(ref, tar)
+    icgn.prepare()
+    for fma in (0, 1):
+        icgn.set_tuning("arith_fma", fma)
+        got = icgn.compute(pois.copy())
+        assert not (got[:, P["zncc"]] == sentinel).any(), np.argwhere(got[:, P["zncc"]] == sentinel).ravel().tolist()
+        assert (got[:-4, P["zncc"]] > 0.9).all() and got[-4, P["zncc"]] == -3.0 and got[-3, P["zncc"]] == -3.0 and got[-1, P["zncc"]] == -3.0
+
+
 # ---------------------------------------------------------------------------------------------------------
 # The shapes the path is benchmarked on (BASELINE config E: 33^3 subvolumes; the reference's own DVC example:
 # r = 30, examples/test_dvc_fftcc_icgn1.cpp:45-47), on a volume small enough for the oracle to answer in seconds.
