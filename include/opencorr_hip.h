@@ -263,8 +263,10 @@ int oc_hip_group_queue(const oc_hip_engine* engine, int member, const void** dev
  *   "icgn2d_variant"  launch shape of the ICGN2D kernel (gather depth, LDS footprint, per-workgroup coordinate table, waves per
  *                     workgroup); -1 (default) lets the engine choose: 5 / 4 (6 / 12 DoF: coordinate table, lockstep sweeps,
  *                     8-wave workgroups) for queues >= 32768 POIs of subsets up to 35 x 34 / 41 x 41, 2 / 3 (no table) below,
- *                     7 (target array only) for self-adaptive subsets, 1 (single-wave workgroups) for what fits nothing else.
- *                     0, 6 and 8 (the split launch shape) are measured losers that only the A/B build of the library contains
+ *                     7 (target array only) for self-adaptive subsets from 27 passes up (2 / 3 below), 1 (single-wave
+ *                     workgroups) for what fits nothing else.  0, 6, 8 (the split launch shape) and 9 (the workgroup's
+ *                     coefficient band staged in LDS, icgn2d_band.hip) are measured losers that only the A/B build of the
+ *                     library contains
  *   "icgn2d_xcd"      1 (default): workgroups of one XCD serve a contiguous range of the POI queue
  *   "icgn2d_tile_px"  side of the square image tiles the ICGN2D / NR2D1 queue is visited by (L1 / L2 locality; default 128;
  *                     0 = queue order; applied to queues >= 16384 POIs)

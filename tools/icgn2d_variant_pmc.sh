@@ -1,4 +1,5 @@
-# usage: bash tools/r6_prof.sh <tag> <variant list e.g. "5 9">   (GPU box)
+# PMC counter sets (four passes) + a kernel trace per icgn2d launch shape, via tools/variant_ab.py (GPU box; the A/B library for variants 0, 6, 8, 9).
+# usage: bash tools/icgn2d_variant_pmc.sh <tag> "<variants, e.g. 5 9>"   -> gpurun_out/<tag>/   (profiles/r6c_icgn2d_band_vs_variant5_pmc.txt)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; VARS=${2:-"5 9"}
 export OPENCORR_HIP_LIB=$ROOT/opencorr_amd/lib/libopencorr_hip.so

@@ -1,3 +1,5 @@
+# Builds tests/cpp/omp_single_poi.cpp and runs it with 8 / 16 / 64 OpenMP threads (GPU box): the combining front end of oc_hip_compute_one against one
+# launch per call (profiles/r6k_omp_single_poi_combining_front_end.txt).
 set -e
 python - <<'PY'
 import struct, numpy as np, sys

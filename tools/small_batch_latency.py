@@ -1,3 +1,5 @@
+"""What a small batch costs end to end (host queue and device queue, n = 1 ... 1024 POIs): the per-call floor that the combining front end of
+oc_hip_compute_one amortises.  GPU box: python tools/small_batch_latency.py"""
 import sys, time, numpy as np
 sys.path.insert(0, ".")
 import opencorr_amd as oc, torch
