@@ -28,6 +28,15 @@
 #define OC_FUSED32_WAVE_XY 1
 #endif
 
+#if defined(OC_F32_ABL) && (OC_F32_ABL & 1)   // timing experiment (results invalid): no workgroup barriers
+#define __syncthreads() __builtin_amdgcn_wave_barrier()
+#endif
+// OC_FUSED32_HERM (round 6): 1 = the decomposition described under "Round 6" below (mirror-closed waves, the spectrum product's
+// partner line fetched with ds_bpermute, the inverse on the kx <= 16 half of the Hermitian product); 0 = rounds 1 - 5.
+#ifndef OC_FUSED32_HERM
+#define OC_FUSED32_HERM 1
+#endif
+
 namespace ochip {
 
 namespace {
@@ -39,6 +48,9 @@ constexpr int TP = TN + 1;                // LDS row pitch in complex elements
 constexpr int kThreads3 = TN * TN;        // one line per thread
 constexpr int kWaves = kThreads3 / kWave;  // 16
 constexpr int kHalf = 16 * TN * TP;       // complex elements of half a volume in LDS
+constexpr int HP = TN / 2 + 1;            // kx = 0 ... 16: the half of the Hermitian product the inverse works on; also its row pitch
+constexpr int kTileH = TN * TN * HP;      // [z][y][kx <= 16] complex: the whole half-spectrum at once (136 KB)
+constexpr int kLdsC = OC_FUSED32_HERM ? (kTileH > kHalf ? kTileH : kHalf) : kHalf;
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned 16-byte load
 
@@ -83,7 +95,7 @@ __device__ __forceinline__ void block_sum2(float& x, float& y, float* red, int l
 template <bool CLAMPED>
 __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, float* __restrict__ pois, int stride_f, unsigned long long idx,
                                                     unsigned char* __restrict__ needs_clamped, unsigned* __restrict__ any_clamped) {
-    __shared__ c2 lds[kHalf];
+    __shared__ c2 lds[kLdsC];
     __shared__ int tab[6][TN];  // voxel index of window coordinate k: ref x, y, z, tar x, y, z
     __shared__ float red[2 * kWaves], red2[2 * kWaves];
     __shared__ int redi[kWaves];
@@ -167,6 +179,17 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
             rn += v[k].x * v[k].x;
             tn += v[k].y * v[k].y;
         }
+#if OC_FUSED32_HERM
+        // needed only at the very end, by thread 0: the waves' partial sums are parked in LDS now and added up there, in
+        // block_sum2's order, behind the arg-max barrier -- no barrier of their own
+        rn = wave_allreduce_sum(rn);
+        tn = wave_allreduce_sum(tn);
+        if (lane == 0) {
+            red2[wave] = rn;
+            red2[kWaves + wave] = tn;
+        }
+    }
+#else
         block_sum2(rn, tn, red2, lane, wave);
         // needed only at the very end, by thread 0: parked in LDS instead of two registers of every thread
         if (tid == 0) {
@@ -174,8 +197,132 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
             norms[1] = tn;
         }
     }
+#endif
 
     const int zz = a & 15, half = a >> 4;
+#if OC_FUSED32_HERM
+    // ---- Round 6.  What changed against rounds 1 - 5 (the #else branch), and why: 22 % of the kernel were its 22 workgroup
+    // barriers (one 16-wave workgroup per CU: nothing else runs while they drain; profiles/r6o_*), another half LDS traffic.
+    //  (1) The thread that transforms the z-line (ky, kx) is chosen so that a WAVE is closed under k -> -k: wave W holds
+    //      ky = W and 32 - W (wave 0: ky = 0 and 16), all kx.  Z(-k) for the spectrum product then sits in a lane of the same
+    //      wave and comes through ds_bpermute: no LDS memory, no barrier (was: a full-volume exchange, 4 barriers).
+    //  (2) The two half-waves of such a wave have DIFFERENT y-halves, which would turn the register index of the 16 x 16 block
+    //      scheme into a per-lane select.  Instead a thread of the upper y-half keeps its z-line rotated by 16: round d fills
+    //      w[16 d ...] for every lane, the transform of the rotated line is (-1)^kz times the transform of the line -- exactly,
+    //      bit for bit: the first butterfly level pairs n with n + 16, a + b commutes, a - b changes sign, and everything
+    //      behind it is odd in its input -- and a sign flip of the odd outputs restores it.
+    //  (3) conj(R) T is Hermitian, so the inverse needs the lines kx = 0 ... 16 only; after the z and y passes
+    //      D(z, y, -kx) = conj D(z, y, kx) completes the x-line inside the thread.  The half-spectrum [z][y][kx <= 16] fits the
+    //      LDS at once: one barrier for z -> y, the y-pass writes its column back IN PLACE, and y -> x stays inside the
+    //      half-wave that owns the z-plane.  (The correlation values change in their last bits; the arg-max does not.)
+    //  (4) The sums of squares wait in LDS for thread 0 (above).
+    // Barriers: 10.  LDS accesses per thread: 64 + 64 + (32 + 32 + 32 on 17 of 32 lanes) + 17, and 64 ds_bpermute.
+    // ---- forward x, then LX -> LY through LDS [z & 15][y][x], one z-half at a time (a z-plane is written and read by the 32
+    // threads of ONE half-wave: a wave-level fence inside, the workgroup barrier only where the z-halves hand the slots over)
+    fft32<false>(v);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (half == h) {
+#pragma unroll
+            for (int k = 0; k < TN; k++) lds[(zz * TN + b) * TP + k] = v[bitrev5(k)];
+            wave_lds_fence();
+#pragma unroll
+            for (int j = 0; j < TN; j++) v[j] = lds[(zz * TN + j) * TP + b];
+        }
+        __syncthreads();
+    }
+    // ---- forward y (thread (z = a, x = b)), then LY -> LZ in 16 x 16 blocks of the (y, z) plane as before (round 0: diagonal
+    // blocks, round 1: the others); the READER is thread (ky(a), kx = b) of the mirror-closed layout
+    fft32<false>(v);
+    const int mw = a >> 1, ms = a & 1;
+    const int ky = mw == 0 ? (ms << 4) : (ms ? TN - mw : mw);
+    const int yh = ky >> 4, yl = ky & 15;
+    c2 w[TN];
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        {   // writer (z = a): block (y-half = half ^ d, z-half = half) -> slot `half`
+            c2* __restrict__ dst = lds + ((half * 16) * 16 + zz) * TP + b;
+            if ((half ^ d) == 0) {
+#pragma unroll
+                for (int yy = 0; yy < 16; yy++) dst[yy * 16 * TP] = v[bitrev5(yy)];
+            } else {
+#pragma unroll
+                for (int yy = 0; yy < 16; yy++) dst[yy * 16 * TP] = v[bitrev5(yy + 16)];
+            }
+        }
+        __syncthreads();
+        {   // reader (y = ky): block (y-half = yh, z-half = yh ^ d) sits in slot yh ^ d; it becomes w[16 d ...]: z = i ^ (16 yh)
+            const c2* __restrict__ src = lds + ((((yh ^ d) * 16 + yl) * 16)) * TP + b;
+#pragma unroll
+            for (int z = 0; z < 16; z++) w[z + 16 * d] = src[z * TP];
+        }
+        __syncthreads();
+    }
+    // ---- forward z: Z(kz, ky, kx = b) in w[bitrev5(kz)] (the odd kz -- registers 16 ... 31 -- with the sign of (2))
+    fft32<false>(w);
+    {
+        const unsigned flip = yh ? 0x80000000u : 0u;
+#pragma unroll
+        for (int i = 16; i < TN; i++) w[i] = mkc(__uint_as_float(__float_as_uint(w[i].x) ^ flip), __uint_as_float(__float_as_uint(w[i].y) ^ flip));
+    }
+    // ---- spectra of the two real windows and their product conj(R) * T (src/oc_fftcc.cpp:378-386); Z(-k) is register
+    // bitrev5(-kz) of the lane that holds line (-ky, -kx)
+    {
+        const int plane = ((mw == 0 ? ms : (ms ^ 1)) << 5) | ((TN - b) & (TN - 1));
+        const int paddr = plane << 2;
+        auto from_partner = [&](c2 x) {
+            return mkc(__int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(x.x))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(x.y))));
+        };
+        auto product = [](c2 zk, c2 zm) {
+            const float rr = 0.5f * (zk.x + zm.x), ri = 0.5f * (zk.y - zm.y);
+            const float tr = 0.5f * (zk.y + zm.y), ti = -0.5f * (zk.x - zm.x);
+            return mkc((rr * tr) + (ri * ti), (rr * ti) - (ri * tr));
+        };
+#pragma unroll
+        for (int z = 0; z <= TN / 2; z++) {
+            const int zc = (TN - z) & (TN - 1);            // -kz
+            const c2 zk = w[bitrev5(z)], zk2 = w[bitrev5(zc)];
+            const c2 zm = from_partner(zk2);               // the partner's Z at -kz: what this lane needs at kz = z
+            if (zc != z) {
+                const c2 zm2 = from_partner(zk);           // ... and at kz = -z
+                w[bitrev5(zc)] = product(zk2, zm2);
+            }
+            w[bitrev5(z)] = product(zk, zm);
+        }
+    }
+    // ---- inverse z on the lines kx <= 16, LZ -> LY through the half-spectrum tile [z][ky][kx]
+    if (b < HP) {
+        c2 t[TN];
+#pragma unroll
+        for (int k = 0; k < TN; k++) t[k] = w[bitrev5(k)];
+        fft32<true>(t);
+#pragma unroll
+        for (int z = 0; z < TN; z++) lds[(z * TN + ky) * HP + b] = t[bitrev5(z)];
+    }
+    __syncthreads();
+    // ---- inverse y by thread (z = a, kx = b <= 16), written back in place (every thread owns its column)
+    if (b < HP) {
+        c2 u[TN];
+#pragma unroll
+        for (int j = 0; j < TN; j++) u[j] = lds[(a * TN + j) * HP + b];
+        fft32<true>(u);
+#pragma unroll
+        for (int j = 0; j < TN; j++) lds[(a * TN + j) * HP + b] = u[bitrev5(j)];
+    }
+    wave_lds_fence();
+    // ---- LY -> LX inside the half-wave that owns plane z = a; D(z, y, 32 - kx) = conj D(z, y, kx); inverse x
+    c2 q[TN];
+    {
+        const c2* __restrict__ row = lds + (a * TN + b) * HP;
+#pragma unroll
+        for (int k = 0; k < HP; k++) q[k] = row[k];
+#pragma unroll
+        for (int k = 1; k < TN / 2; k++) q[TN - k] = mkc(q[k].x, -q[k].y);
+    }
+    fft32<true>(q);
+
+#else
     // ---- forward x, then LX -> LY through LDS [z & 15][y][x], one z-half at a time
     fft32<false>(v);
     // (a z-plane is written and read by the 32 threads of ONE half-wave: inside the plane a wave-level fence orders its
@@ -314,6 +461,7 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
     // ---- inverse x (thread (z = a, y = b)): the correlation volume, real part
     fft32<true>(q);
 
+#endif
     // ---- arg-max with "strict >, scanning from index 0" (src/oc_fftcc.cpp:391-400): the thread's 32 values sit at
     // linear indices (a*32 + b)*32 + x, ascending in x
     float best = -2.f;
@@ -357,7 +505,16 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
         poi[poi3d::U0] = gu;
         poi[poi3d::V0] = gv;
         poi[poi3d::W0] = gw;
+#if OC_FUSED32_HERM
+        float rn = 0.f, tn = 0.f;
+        for (int i = 0; i < kWaves; i++) {
+            rn += red2[i];
+            tn += red2[kWaves + i];
+        }
+        poi[poi3d::ZNCC] = best / (sqrtf(rn * tn) * M);
+#else
         poi[poi3d::ZNCC] = best / (sqrtf(norms[0] * norms[1]) * M);
+#endif
     }
 }
 

@@ -51,6 +51,10 @@ for rep in (1, 2):
             if first is None:
                 first = a
             rec["same_bits_as_first"] = bool(np.array_equal(a.view(np.uint32), first.view(np.uint32)))
+            zc = 18  # POI3D: ZNCC (opencorr_amd/io.py TABLE3D); everything else FFTCC3D writes is an integer-valued float
+            other = [c for c in range(a.shape[1]) if c != zc]
+            rec["same_integers_as_first"] = bool(np.array_equal(a[:, other].view(np.uint32), first[:, other].view(np.uint32)))
+            rec["max_abs_d_zncc_vs_first"] = float(np.abs(a[:, zc] - first[:, zc]).max())
         rec.update({"lib": name, "run": rep})
         out.append(rec)
         print(json.dumps(rec), flush=True)
