@@ -110,26 +110,30 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
     // ---- window coordinates -> voxel indices (src/oc_fftcc.cpp:349-358: Point3D(poi->x + k - rx, ...) truncated, the
     // target window displaced by the initial guess).  Separable, so one table per axis and window.  The reference has
     // no bounds guard in 3D; indices are clamped like in fftcc3d_gather_kernel.
-    if (tid < 6 * TN) {
-        const int axis = tid >> 5, k = tid & 31, which = axis % 3;
+    constexpr bool kOwnIndices = OC_FUSED32_HERM && !CLAMPED;   // (round 6) no table, no barrier: see below
+    auto voxel = [&](int axis, int k) {   // axis 0 ... 2: reference x, y, z; 3 ... 5: target
+        const int which = axis % 3;
         const float p = poi[which == 0 ? poi3d::X : which == 1 ? poi3d::Y : poi3d::Z];
         const float g = poi[which == 0 ? poi3d::U : which == 1 ? poi3d::V : poi3d::W];
         const int D = which == 0 ? P.dx : which == 1 ? P.dy : P.dz;
         float c = p + k - R;
         if (axis >= 3) c = c + g;
-        tab[axis][k] = clampi3((int)c, 0, D - 1);
+        return clampi3((int)c, 0, D - 1);
+    };
+    if constexpr (!kOwnIndices) {
+        if (tid < 6 * TN) tab[tid >> 5][tid & 31] = voxel(tid >> 5, tid & 31);
     }
     // both windows' x indices contiguous (true unless a window is clamped at the border): 16-byte loads.  Every thread forms
     // the four table entries the test needs itself, so that the vote's barrier is also the one that publishes `tab`
-    bool mine_contig;
-    {
-        const float p = poi[poi3d::X], g = poi[poi3d::U];
-        const float c0 = p + 0 - R, cb = p + b - R;
-        const int r0 = clampi3((int)c0, 0, P.dx - 1), rb = clampi3((int)cb, 0, P.dx - 1);
-        const int t0 = clampi3((int)(c0 + g), 0, P.dx - 1), tb = clampi3((int)(cb + g), 0, P.dx - 1);
-        mine_contig = rb == r0 + b && tb == t0 + b;
+    const bool mine_contig = voxel(0, b) == voxel(0, 0) + b && voxel(3, b) == voxel(3, 0) + b;
+    bool contig;
+    if constexpr (kOwnIndices) {
+        // the test depends on b alone and every wave holds every b: a vote inside the wave gives the workgroup's answer, and a
+        // thread needs six table entries only, which it forms itself -- neither table nor barrier
+        contig = __builtin_amdgcn_ballot_w64(mine_contig) == ~0ull;
+    } else {
+        contig = __syncthreads_and(mine_contig) != 0;
     }
-    const bool contig = __syncthreads_and(mine_contig) != 0;
     if constexpr (!CLAMPED) {
         if (tid == 0) {
             needs_clamped[idx] = contig ? 0 : 1;
@@ -141,11 +145,13 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
     // ---- gather: thread (z = a, y = b) reads its x-line of both windows; z = ref + i*tar
     c2 v[TN];
     {
-        const float* __restrict__ rrow = P.ref + ((size_t)tab[2][a] * P.dy + tab[1][b]) * P.dx;
-        const float* __restrict__ trow = P.tar + ((size_t)tab[5][a] * P.dy + tab[4][b]) * P.dx;
+        const int rz = kOwnIndices ? voxel(2, a) : tab[2][a], ry = kOwnIndices ? voxel(1, b) : tab[1][b];
+        const int tz = kOwnIndices ? voxel(5, a) : tab[5][a], ty = kOwnIndices ? voxel(4, b) : tab[4][b];
+        const float* __restrict__ rrow = P.ref + ((size_t)rz * P.dy + ry) * P.dx;
+        const float* __restrict__ trow = P.tar + ((size_t)tz * P.dy + ty) * P.dx;
         if (!CLAMPED) {
-            const float* __restrict__ rp = rrow + tab[0][0];
-            const float* __restrict__ tp = trow + tab[3][0];
+            const float* __restrict__ rp = rrow + (kOwnIndices ? voxel(0, 0) : tab[0][0]);
+            const float* __restrict__ tp = trow + (kOwnIndices ? voxel(3, 0) : tab[3][0]);
 #pragma unroll
             for (int q = 0; q < TN / 4; q++) {
                 const float4u r4 = *reinterpret_cast<const float4u*>(rp + 4 * q);
@@ -216,24 +222,31 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
     //      LDS at once: one barrier for z -> y, the y-pass writes its column back IN PLACE, and y -> x stays inside the
     //      half-wave that owns the z-plane.  (The correlation values change in their last bits; the arg-max does not.)
     //  (4) The sums of squares wait in LDS for thread 0 (above).
-    // Barriers: 10.  LDS accesses per thread: 64 + 64 + (32 + 32 + 32 on 17 of 32 lanes) + 17, and 64 ds_bpermute.
+    // Barriers: 8 (means, x -> y done, 4 in y -> z, z -> y, arg-max).  LDS accesses per thread: 128 four-byte ones, 64 + (32 + 32 + 32 on
+    // 17 of 32 lanes) + 17 eight-byte ones, and 64 ds_bpermute.
     // ---- forward x, then LX -> LY through LDS [z & 15][y][x], one z-half at a time (a z-plane is written and read by the 32
     // threads of ONE half-wave: a wave-level fence inside, the workgroup barrier only where the z-halves hand the slots over)
     fft32<false>(v);
+    {
+        // (5) real parts first, then imaginary parts: 32 planes x 32 x 33 FLOATS are the 132 KB that held 16 complex planes, so
+        // every half-wave has a slot of its own for its plane and the whole exchange needs no workgroup barrier
+        float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        if (half == h) {
+        for (int k = 0; k < TN; k++) ldsf[(a * TN + b) * TP + k] = v[bitrev5(k)].x;
+        wave_lds_fence();
 #pragma unroll
-            for (int k = 0; k < TN; k++) lds[(zz * TN + b) * TP + k] = v[bitrev5(k)];
-            wave_lds_fence();
+        for (int j = 0; j < TN; j++) v[j].x = ldsf[(a * TN + j) * TP + b];
+        wave_lds_fence();
 #pragma unroll
-            for (int j = 0; j < TN; j++) v[j] = lds[(zz * TN + j) * TP + b];
-        }
-        __syncthreads();
+        for (int k = 0; k < TN; k++) ldsf[(a * TN + b) * TP + k] = v[bitrev5(k)].y;
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < TN; j++) v[j].y = ldsf[(a * TN + j) * TP + b];
     }
     // ---- forward y (thread (z = a, x = b)), then LY -> LZ in 16 x 16 blocks of the (y, z) plane as before (round 0: diagonal
     // blocks, round 1: the others); the READER is thread (ky(a), kx = b) of the mirror-closed layout
     fft32<false>(v);
+    __syncthreads();   // every plane has left its slot
     const int mw = a >> 1, ms = a & 1;
     const int ky = mw == 0 ? (ms << 4) : (ms ? TN - mw : mw);
     const int yh = ky >> 4, yl = ky & 15;
