@@ -50,7 +50,8 @@ constexpr int kWaves = kThreads3 / kWave;  // 16
 constexpr int kHalf = 16 * TN * TP;       // complex elements of half a volume in LDS
 constexpr int HP = TN / 2 + 1;            // kx = 0 ... 16: the half of the Hermitian product the inverse works on; also its row pitch
 constexpr int kTileH = TN * TN * HP;      // [z][y][kx <= 16] complex: the whole half-spectrum at once (136 KB)
-constexpr int kLdsC = OC_FUSED32_HERM ? (kTileH > kHalf ? kTileH : kHalf) : kHalf;
+constexpr int kSlotZ = 16 * TN * HP + 16;  // one slot of the exchange to z-lines: [z & 15][ky][kx & 15 (+1)], the second one skewed by 16 elements
+constexpr int kLdsC = OC_FUSED32_HERM ? (2 * kSlotZ > kHalf ? 2 * kSlotZ : kHalf) : kHalf;
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned 16-byte load
 
@@ -106,6 +107,18 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
     float* poi = pois + idx * (unsigned long long)stride_f;
     constexpr int R = TN / 2;
     constexpr int M = TN * TN * TN;
+#if defined(OC_F32_TIMELINE)   // timing experiment (A/B builds): thread 0 leaves the cycles (s_memtime) between its marks in the record's unused fields 19 ... 30
+    unsigned long long tl_mark = __builtin_readcyclecounter();
+    int tl_slot = 19;
+    auto stamp = [&]() {
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (tid == 0 && tl_slot < 31) poi[tl_slot] = (float)(now - tl_mark);
+        tl_slot++;
+        tl_mark = now;
+    };
+#else
+    auto stamp = [] {};
+#endif
 
     // ---- window coordinates -> voxel indices (src/oc_fftcc.cpp:349-358: Point3D(poi->x + k - rx, ...) truncated, the
     // target window displaced by the initial guess).  Separable, so one table per axis and window.  The reference has
@@ -142,13 +155,46 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
         if (!contig) return;
     }
 
+#if defined(OC_F32_ABL) && (OC_F32_ABL & 2)   // timing experiment: what launching 50 000 sixteen-wave workgroups with 137 KB of LDS costs by itself
+    if (tid == 0) lds[0] = mkc(poi[poi3d::X], 0.f);
+    if (P.dx > 0) return;
+#endif
+#if defined(OC_F32_TIMELINE) && OC_F32_TIMELINE == 2
+    stamp();   // fine: record loads, indices, vote
+#endif
+#if OC_FUSED32_HERM
+    // ---- gather (round 6): thread (z = a, x = b) reads its Y-line of both windows; z = ref + i*tar.  A load instruction of a wave
+    // then covers two 128-byte rows (the 32 lanes of a half-wave sit side by side in x) instead of 64 rows, one per lane: the
+    // texture path handles one cache line per cycle whatever the lanes take from it, and the x-line form cost 27 % of the kernel
+    // there (profiles/r6o_*).  The y-pass therefore comes first, the x-pass second.
+    c2 v[TN];
+    {
+        const int my_ry = kOwnIndices ? voxel(1, b) : tab[1][b], my_ty = kOwnIndices ? voxel(4, b) : tab[4][b];   // lane y holds row y's index
+        const int rz = kOwnIndices ? voxel(2, a) : tab[2][a], tz = kOwnIndices ? voxel(5, a) : tab[5][a];
+        const int rx = CLAMPED ? tab[0][b] : voxel(0, 0) + b, tx = CLAMPED ? tab[3][b] : voxel(3, 0) + b;
+        const float* __restrict__ rp = P.ref + (size_t)rz * P.dy * P.dx + rx;
+        const float* __restrict__ tp = P.tar + (size_t)tz * P.dy * P.dx + tx;
+#pragma unroll
+        for (int y = 0; y < TN; y++) {
+            const int ry = __builtin_amdgcn_readlane(my_ry, y), ty = __builtin_amdgcn_readlane(my_ty, y);   // wave-uniform row offsets
+#if defined(OC_F32_ABL) && (OC_F32_ABL & 4)   // timing experiment (results invalid): every thread gathers the same two rows
+            v[y] = mkc(P.ref[y], P.tar[y]);
+#else
+            v[y] = mkc(rp[(size_t)ry * P.dx], tp[(size_t)ty * P.dx]);
+#endif
+        }
+    }
+#else
     // ---- gather: thread (z = a, y = b) reads its x-line of both windows; z = ref + i*tar
     c2 v[TN];
     {
         const int rz = kOwnIndices ? voxel(2, a) : tab[2][a], ry = kOwnIndices ? voxel(1, b) : tab[1][b];
         const int tz = kOwnIndices ? voxel(5, a) : tab[5][a], ty = kOwnIndices ? voxel(4, b) : tab[4][b];
-        const float* __restrict__ rrow = P.ref + ((size_t)rz * P.dy + ry) * P.dx;
-        const float* __restrict__ trow = P.tar + ((size_t)tz * P.dy + ty) * P.dx;
+        const float* rrow = P.ref + ((size_t)rz * P.dy + ry) * P.dx;
+        const float* trow = P.tar + ((size_t)tz * P.dy + ty) * P.dx;
+#if defined(OC_F32_ABL) && (OC_F32_ABL & 4)   // timing experiment (results invalid): every thread gathers the same two rows
+        rrow = P.ref; trow = P.tar;
+#endif
         if (!CLAMPED) {
             const float* __restrict__ rp = rrow + (kOwnIndices ? voxel(0, 0) : tab[0][0]);
             const float* __restrict__ tp = trow + (kOwnIndices ? voxel(3, 0) : tab[3][0]);
@@ -166,6 +212,7 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
             for (int k = 0; k < TN; k++) v[k] = mkc(rrow[tab[0][k]], trow[tab[3][k]]);
         }
     }
+#endif
     // means, zero-mean, sums of squares (src/oc_fftcc.cpp:360-376)
     {
         float rn, tn;
@@ -175,7 +222,13 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
             rs += v[k].x;
             ts += v[k].y;
         }
+#if defined(OC_F32_TIMELINE) && OC_F32_TIMELINE == 2
+        stamp();   // fine: gather arrived, 64 additions
+#endif
         block_sum2(rs, ts, red, lane, wave);
+#if defined(OC_F32_TIMELINE) && OC_F32_TIMELINE == 2
+        stamp();   // fine: wave sums, barrier, 32 LDS reads
+#endif
         const c2 mean = mkc(rs / M, ts / M);
         rn = 0.f;
         tn = 0.f;
@@ -205,6 +258,7 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
     }
 #endif
 
+    stamp();   // 19: indices, gather, means, zero-mean, sums of squares
     const int zz = a & 15, half = a >> 4;
 #if OC_FUSED32_HERM
     // ---- Round 6.  What changed against rounds 1 - 5 (the #else branch), and why: 22 % of the kernel were its 22 workgroup
@@ -224,9 +278,9 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
     //  (4) The sums of squares wait in LDS for thread 0 (above).
     // Barriers: 8 (means, x -> y done, 4 in y -> z, z -> y, arg-max).  LDS accesses per thread: 128 four-byte ones, 64 + (32 + 32 + 32 on
     // 17 of 32 lanes) + 17 eight-byte ones, and 64 ds_bpermute.
-    // ---- forward x, then LX -> LY through LDS [z & 15][y][x], one z-half at a time (a z-plane is written and read by the 32
-    // threads of ONE half-wave: a wave-level fence inside, the workgroup barrier only where the z-halves hand the slots over)
+    // ---- forward y (thread (z = a, x = b)), then LY -> LX inside the half-wave that owns plane z = a
     fft32<false>(v);
+    stamp();   // 20: forward y
     {
         // (5) real parts first, then imaginary parts: 32 planes x 32 x 33 FLOATS are the 132 KB that held 16 complex planes, so
         // every half-wave has a slot of its own for its plane and the whole exchange needs no workgroup barrier
@@ -243,38 +297,44 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
 #pragma unroll
         for (int j = 0; j < TN; j++) v[j].y = ldsf[(a * TN + j) * TP + b];
     }
-    // ---- forward y (thread (z = a, x = b)), then LY -> LZ in 16 x 16 blocks of the (y, z) plane as before (round 0: diagonal
-    // blocks, round 1: the others); the READER is thread (ky(a), kx = b) of the mirror-closed layout
+    stamp();   // 21: y -> x exchange (real planes, imaginary planes)
+    // ---- forward x (thread (z = a, ky = b)), then -> LZ in 16 x 16 blocks of the (kx, z) plane: slot s is written by the z-half s
+    // (round d: its kx-half s ^ d) as [z & 15][ky][kx & 15], row pitch 17; the READER is thread (ky(a), kx = b) of the
+    // mirror-closed layout, whose kx-half p = b >> 4 differs from lane to lane: it finds its block in slot p ^ d (the second slot
+    // starts 16 elements late, so that the two 16-lane groups of a half-wave meet different banks)
     fft32<false>(v);
     __syncthreads();   // every plane has left its slot
+    stamp();   // 22: forward x, barrier
     const int mw = a >> 1, ms = a & 1;
     const int ky = mw == 0 ? (ms << 4) : (ms ? TN - mw : mw);
-    const int yh = ky >> 4, yl = ky & 15;
+    const int xh = b >> 4, xl = b & 15;
     c2 w[TN];
 #pragma unroll
     for (int d = 0; d < 2; d++) {
-        {   // writer (z = a): block (y-half = half ^ d, z-half = half) -> slot `half`
-            c2* __restrict__ dst = lds + ((half * 16) * 16 + zz) * TP + b;
+        {   // writer (z = a, ky = b): block (kx-half = half ^ d, z-half = half) -> slot `half`
+            c2* __restrict__ dst = lds + half * kSlotZ + (zz * TN + b) * HP;
             if ((half ^ d) == 0) {
 #pragma unroll
-                for (int yy = 0; yy < 16; yy++) dst[yy * 16 * TP] = v[bitrev5(yy)];
+                for (int x = 0; x < 16; x++) dst[x] = v[bitrev5(x)];
             } else {
 #pragma unroll
-                for (int yy = 0; yy < 16; yy++) dst[yy * 16 * TP] = v[bitrev5(yy + 16)];
+                for (int x = 0; x < 16; x++) dst[x] = v[bitrev5(x + 16)];
             }
         }
         __syncthreads();
-        {   // reader (y = ky): block (y-half = yh, z-half = yh ^ d) sits in slot yh ^ d; it becomes w[16 d ...]: z = i ^ (16 yh)
-            const c2* __restrict__ src = lds + ((((yh ^ d) * 16 + yl) * 16)) * TP + b;
+        {   // reader (ky, kx = b): block (kx-half = xh, z-half = xh ^ d) sits in slot xh ^ d; it becomes w[16 d ...]: z = i ^ (16 xh)
+            const c2* __restrict__ src = lds + (xh ^ d) * kSlotZ + ky * HP + xl;
 #pragma unroll
-            for (int z = 0; z < 16; z++) w[z + 16 * d] = src[z * TP];
+            for (int z = 0; z < 16; z++) w[z + 16 * d] = src[z * TN * HP];
         }
         __syncthreads();
     }
+    stamp();   // 23: -> z exchange (two rounds, four barriers)
     // ---- forward z: Z(kz, ky, kx = b) in w[bitrev5(kz)] (the odd kz -- registers 16 ... 31 -- with the sign of (2))
     fft32<false>(w);
+    stamp();   // 24: forward z
     {
-        const unsigned flip = yh ? 0x80000000u : 0u;
+        const unsigned flip = xh ? 0x80000000u : 0u;
 #pragma unroll
         for (int i = 16; i < TN; i++) w[i] = mkc(__uint_as_float(__float_as_uint(w[i].x) ^ flip), __uint_as_float(__float_as_uint(w[i].y) ^ flip));
     }
@@ -304,6 +364,7 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
             w[bitrev5(z)] = product(zk, zm);
         }
     }
+    stamp();   // 25: sign flip, partner values through ds_bpermute, spectrum product
     // ---- inverse z on the lines kx <= 16, LZ -> LY through the half-spectrum tile [z][ky][kx]
     if (b < HP) {
         c2 t[TN];
@@ -314,6 +375,7 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
         for (int z = 0; z < TN; z++) lds[(z * TN + ky) * HP + b] = t[bitrev5(z)];
     }
     __syncthreads();
+    stamp();   // 26: inverse z (kx <= 16), tile write, barrier
     // ---- inverse y by thread (z = a, kx = b <= 16), written back in place (every thread owns its column)
     if (b < HP) {
         c2 u[TN];
@@ -333,7 +395,9 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
 #pragma unroll
         for (int k = 1; k < TN / 2; k++) q[TN - k] = mkc(q[k].x, -q[k].y);
     }
+    stamp();   // 27: inverse y on the column, written back, fence, row read + Hermitian completion
     fft32<true>(q);
+    stamp();   // 28: inverse x
 
 #else
     // ---- forward x, then LX -> LY through LDS [z & 15][y][x], one z-half at a time
@@ -501,6 +565,7 @@ __device__ __forceinline__ void fftcc3d_fused32_poi(const Fftcc3dParams& P, floa
         redi[wave] = bidx;
     }
     __syncthreads();
+    stamp();   // 29: arg-max inside the thread and the wave, barrier
     if (tid == 0) {
         for (int i = 1; i < kWaves; i++)
             if (red[i] > best || (red[i] == best && redi[i] < bidx)) {

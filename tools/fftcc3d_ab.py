@@ -55,6 +55,8 @@ for rep in (1, 2):
             other = [c for c in range(a.shape[1]) if c != zc]
             rec["same_integers_as_first"] = bool(np.array_equal(a[:, other].view(np.uint32), first[:, other].view(np.uint32)))
             rec["max_abs_d_zncc_vs_first"] = float(np.abs(a[:, zc] - first[:, zc]).max())
+            if os.environ.get("OC_AB_TIMELINE"):   # builds with -DOC_F32_TIMELINE leave thread 0's cycles per phase in fields 19 ... 30
+                rec["timeline_mean_cycles"] = [round(float(x), 1) for x in a[:, 19:31].mean(axis=0)]
         rec.update({"lib": name, "run": rep})
         out.append(rec)
         print(json.dumps(rec), flush=True)
