@@ -23,7 +23,7 @@ LIB = os.path.join(LIBDIR, "libopencorr_hip.so")
 SOURCES = ["capi.hip", "capi_host.hip", "capi_group.hip", "capi_strain.hip", "prepare2d.hip", "icgn2d.hip", "nr2d.hip", "poi_order.hip", "poi_split.hip", "strain.hip", "fftcc2d.hip", "fftcc2d_fused.hip", "fftcc2d_fusedn.hip", "fftcc2d_fusedp.hip", "fftcc2d_fusedr.hip", "fftcc2d_rect.hip", "prepare3d.hip", "icgn3d.hip", "fftcc3d.hip", "fftcc3d_fused.hip", "fftcc3d_fusedn.hip", "fftcc3d_box.hip", "fftcc3d_planes.hip", "fftcc3d_planesb.hip"]
 # the A/B build: sources that exist only there, and the product sources whose code depends on OC_BUILD_AB (recompiled with
 # -DOC_BUILD_AB=1; every other object is shared with the product build)
-AB_ONLY_SOURCES = ["icgn3d_rows.hip", "icgn2d_band.hip"]
+AB_ONLY_SOURCES = ["icgn3d_rows.hip", "icgn2d_band.hip", "fftcc3d_fused_r5.hip"]
 AB_DEPENDENT = ["capi.hip", "icgn2d.hip", "icgn3d.hip"]
 AB_LIBDIR = os.path.join(LIBDIR, "ab")
 AB_LIB = os.path.join(AB_LIBDIR, "libopencorr_hip_ab.so")

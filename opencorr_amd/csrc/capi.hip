@@ -406,11 +406,18 @@ int run_fftcc3d(oc_hip_engine* e, float* d_pois, int stride_f, size_t count) {
         if (count <= (1u << 30)) OC_TRY(tile_order3d(e, d_pois, stride_f, count, e->fftcc3d_tile_vox, &P.perm));
         ProfScope prof(e);
         const size_t kMaxGrid = 1u << 30;
-        if (fused32) OC_TRY(e->flags.reserve(ochip::fftcc3d_fused_flag_bytes(count < kMaxGrid ? count : kMaxGrid)));   // once, before anything is enqueued
+#if OC_BUILD_AB
+        const bool fused32_r5 = fused32 && e->fftcc3d_fused == 2;   // the decomposition of rounds 1 - 5 (fftcc3d_fused_r5.hip)
+        if (fused32_r5) OC_TRY(e->flags.reserve(ochip::fftcc3d_fused_flag_bytes(count < kMaxGrid ? count : kMaxGrid)));   // once, before anything is enqueued
+#endif
         for (size_t first = 0; first < count; first += kMaxGrid) {
             const size_t n = (count - first) < kMaxGrid ? (count - first) : kMaxGrid;
             float* q = d_pois + first * (size_t)stride_f;
-            hipError_t err = fused32 ? ochip::launch_fftcc3d_fused(P, q, stride_f, n, e->icgn2d_xcd != 0, e->flags.as<unsigned char>(), e->stream)
+            hipError_t err =
+#if OC_BUILD_AB
+                             fused32_r5 ? ochip::launch_fftcc3d_fused_r5(P, q, stride_f, n, e->icgn2d_xcd != 0, e->flags.as<unsigned char>(), e->stream) :
+#endif
+                             fused32 ? ochip::launch_fftcc3d_fused(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream)
                              : box   ? ochip::launch_fftcc3d_box(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream)
                                      : ochip::launch_fftcc3d_fusedn(P, q, stride_f, n, e->icgn2d_xcd != 0, e->stream);
             if (err != hipSuccess) return fail(OC_HIP_ERR_HIP, "fused FFTCC3D kernel launch failed: %s", hipGetErrorString(err));
@@ -993,7 +1000,12 @@ int oc_hip_set_tuning(oc_hip_engine* e, const char* key, int value) {
     } else if (k == "fftcc2d_fused") {
         e->fftcc2d_fused = value == 2 ? 2 : (value != 0);
     } else if (k == "fftcc3d_fused") {
-        e->fftcc3d_fused = value != 0;
+#if !OC_BUILD_AB
+        if (value == 2)
+            return fail(OC_HIP_ERR_UNSUPPORTED, "fftcc3d_fused = 2 (the 32^3 kernel of rounds 1 - 5) is an A/B partner that only the A/B build of the "
+                                                "library contains (python -m opencorr_amd.build --ab)");
+#endif
+        e->fftcc3d_fused = value == 2 ? 2 : (value != 0);
     } else if (k == "fftcc3d_tile_vox") {
         if (value < 0 || (value > 0 && value < 8)) return fail(OC_HIP_ERR_INVALID, "fftcc3d_tile_vox must be 0 (off) or >= 8");
         e->fftcc3d_tile_vox = value;

@@ -245,11 +245,15 @@ hipError_t launch_fftcc3d_argmax(const Fftcc3dParams& p, const float* surf, cons
 // ---- fftcc3d_fused.hip -----------------------------------------------------
 // all of FFTCC3D::compute(POI3D*) in one kernel for 32 x 32 x 32 windows (radius 16)
 bool fftcc3d_fused_supported(int rx, int ry, int rz);
-// needs_clamped: fftcc3d_fused_flag_bytes(count) bytes of device scratch (the first launch flags the POIs whose windows are clamped at
-// a volume border and raises one "any" word behind the flags, the second one computes those -- and returns at once when the word is 0)
+hipError_t launch_fftcc3d_fused(const Fftcc3dParams& p, float* pois, int stride_floats, size_t count, bool xcd, hipStream_t stream);
+#if OC_BUILD_AB
+// fftcc3d_fused_r5.hip (A/B build): the decomposition of rounds 1 - 5.  needs_clamped: fftcc3d_fused_flag_bytes(count) bytes of device
+// scratch (its first launch flags the POIs whose windows are clamped at a volume border and raises one "any" word behind the flags,
+// its second one computes those -- and returns at once when the word is 0)
 size_t fftcc3d_fused_flag_bytes(size_t count);
-hipError_t launch_fftcc3d_fused(const Fftcc3dParams& p, float* pois, int stride_floats, size_t count, bool xcd,
-                                unsigned char* needs_clamped, hipStream_t stream);
+hipError_t launch_fftcc3d_fused_r5(const Fftcc3dParams& p, float* pois, int stride_floats, size_t count, bool xcd,
+                                   unsigned char* needs_clamped, hipStream_t stream);
+#endif
 
 // ---- fftcc3d_fusedn.hip ----------------------------------------------------
 // the same for cubic windows of side 8 ... 26 (radius 4 ... 13): the complex volume stays in LDS between the axis passes

@@ -277,3 +277,36 @@ def test_icgn2d_band_kernel_mixed_wave_lifetimes_and_tile_schedule(eng, speckle_
     sample = big[::41].copy()
     fn(prep, r, r, 0.001, 10, sample, order=oracle.ORDER_LANES, lanes=64)
     assert np.array_equal(_bits(sample), _bits(got[::41]))
+
+
+def test_fftcc3d_fused32_against_the_kernel_of_rounds_1_to_5(big_volumes):
+    """fftcc3d_fused.hip (round 6: y-lines gathered side by side in x, mirror-closed waves, the inverse on the Hermitian half, one
+    launch) against fftcc3d_fused_r5.hip (tuning "fftcc3d_fused" = 2): the same integers on every POI -- inner ones with integer
+    guesses that displace the target window, and windows clamped at each of the six volume faces, which the old kernel handed to a
+    second launch -- and ZNCC within 1e-6 (the means are summed in another order; everything behind them is the same arithmetic)."""
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    ref, tar, _ = big_volumes
+    dz, dy, dx = BIG
+    xs, ys, zs = synth.poi_grid_3d(dz, dy, dx, 6, 5, 4, 18)
+    pois = oracle.make_pois3d(xs, ys, zs)
+    P = oracle.P3
+    rng = np.random.default_rng(5)
+    pois[::3, P["u"]] = rng.integers(-3, 4, len(pois[::3]))
+    pois[1::3, P["v"]] = rng.integers(-3, 4, len(pois[1::3]))
+    pois[2::3, P["w"]] = rng.integers(-3, 4, len(pois[2::3]))
+    border = oracle.make_pois3d([3.0, dx - 4.0, 50.0, 50.0, 50.0, 50.0, 2.0], [50.0, 50.0, 5.0, dy - 2.0, 50.0, 50.0, 3.0],
+                                [48.0, 48.0, 48.0, 48.0, 1.0, dz - 6.0, dz - 2.0])
+    pois = np.concatenate([pois, border]).astype(np.float32)
+    f = opencorr_amd.FFTCC3D(16, 16, 16)
+    f.set_images(ref, tar)
+    new = f.compute(pois.copy())
+    f.set_tuning("fftcc3d_fused", 2)
+    old = f.compute(pois.copy())
+    zc = P["zncc"]
+    other = [c for c in range(31) if c != zc]
+    assert np.array_equal(_bits(new[:, other]), _bits(old[:, other]))
+    assert np.abs(new[:, zc] - old[:, zc]).max() <= 1e-6
+    assert (new[:len(xs), zc] > 0.5).mean() > 0.9
+    assert not np.array_equal(new[:, [P["u"], P["v"], P["w"]]], pois[:, [P["u"], P["v"], P["w"]]])

@@ -1,4 +1,4 @@
-"""Runs tests/ab/ -- the bit-exactness checks of the A/B partners (icgn2d variants 0, 6, 8 -- the split launch shape -- and 9 -- the LDS-band kernel --, the ICGN3D1 row mapping) -- in a
+"""Runs tests/ab/ -- the bit-exactness checks of the A/B partners (icgn2d variants 0, 6, 8 -- the split launch shape -- and 9 -- the LDS-band kernel --, the ICGN3D1 row mapping, the fused 32^3 FFTCC3D kernel of rounds 1 - 5) -- in a
 process of its own against the A/B build of the library (lib/ab/libopencorr_hip_ab.so, -DOC_BUILD_AB=1).  The library that
 ships contains none of them and refuses their tuning values, which is asserted here as well."""
 import os
@@ -35,3 +35,7 @@ def test_the_product_library_refuses_the_ab_partners():
     with pytest.raises(Exception, match="A/B"):
         g3.set_tuning("icgn3d_mapping", 1)
     g3.set_tuning("icgn3d_mapping", 0)
+    f3 = opencorr_amd.FFTCC3D(16, 16, 16)
+    with pytest.raises(Exception, match="A/B"):
+        f3.set_tuning("fftcc3d_fused", 2)
+    f3.set_tuning("fftcc3d_fused", 1)
