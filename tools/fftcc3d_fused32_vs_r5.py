@@ -22,12 +22,16 @@ f.set_images(ref, tar)
 p = torch.from_numpy(oc.make_pois3d(xs, ys, zs)).to(dev)
 q = p.clone()
 out, res = {}, {}
-for name, value in (("round 6 (fftcc3d_fused = 1)", 1), ("rounds 1 - 5 (fftcc3d_fused = 2)", 2), ("rocFFT pipeline (fftcc3d_fused = 0)", 0)):
+order = [("round 6 (fftcc3d_fused = 1)", 1), ("rounds 1 - 5 (fftcc3d_fused = 2)", 2), ("rocFFT pipeline (fftcc3d_fused = 0)", 0)]
+if len(sys.argv) > 1 and sys.argv[1] == "reversed":
+    order.reverse()
+for name, value in order:
     f.set_tuning("fftcc3d_fused", value)
     for _ in range(2):
         q.copy_(p)
         f.compute(q)
     torch.cuda.synchronize()
+    f.profile_reset()
     f.profile_enable(True)
     for _ in range(8):
         q.copy_(p)
