@@ -8,7 +8,8 @@
 // with the plan of the 32^3 kernel -- z = ref + i * tar, ONE complex N^3 FFT, R(k) = (Z(k) + conj Z(-k)) / 2,
 // T(k) = (Z(k) - conj Z(-k)) / (2i), C = conj(R) T, inverse FFT, arg-max -- except that the whole complex volume
 // (N^2 (N + 1) x 8 bytes: 35 KB at N = 16, 115 KB at N = 24, 146 KB at N = 26) lives in LDS between the passes:
-//   thread (a, b) owns one line per pass -- (z, y) -> its x-line, (z, x) -> its y-line, (y, x) -> its z-line -- loads it into
+//   thread (a, b) owns one line per pass -- (z, x) -> its y-line (gathered: lanes side by side in x), (z, y) -> its x-line, (y, x) -> its
+//   z-line -- loads it into
 //   registers, transforms it there with the mixed-radix FFT of fft_device.h and writes it back in place.
 // Row pitch N + 1 complex elements (odd): a wave's lanes are adjacent in the line index b, which is the x coordinate in
 // the y and z passes (8-byte stride: conflict-free) and the y coordinate in the x passes (stride (N + 1) x 8 bytes, an odd
@@ -25,7 +26,6 @@ namespace {
 
 using namespace fftdev;
 
-typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned 16-byte load
 
 __device__ __forceinline__ int clampi3n(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -95,32 +95,19 @@ __global__ __launch_bounds__(Cube<N>::BLOCK) void fftcc3d_fusedn_kernel(Fftcc3dP
     }
     __syncthreads();
 
-    // ---- gather: thread (z = a, y = b) reads its x-line of both windows; z = ref + i * tar
+    // ---- gather: thread (z = a, x = b) reads its Y-line of both windows; z = ref + i * tar.  Lanes are adjacent in b, so a load
+    // instruction of a wave covers 64 / N whole rows (round 6; until then thread (z, y) read its x-line with 16-byte loads, one
+    // row per LANE, and the texture path handles about one cache line per cycle whatever the lanes take from it: what that cost the
+    // 32^3 kernel is in fftcc3d_fused.hip).  The y-pass therefore comes first.  Every lane reads the voxel its own clamped x index
+    // names: no special case for windows clamped at a border.
     c2 v[N];
     {
-        const float* __restrict__ rrow = P.ref + ((size_t)tab[2][a] * P.dy + tab[1][b]) * P.dx;
-        const float* __restrict__ trow = P.tar + ((size_t)tab[5][a] * P.dy + tab[4][b]) * P.dx;
-        // both windows' x indices contiguous (true unless a window is clamped at the border): 16-byte loads
-        bool contig = (N % 4) == 0;
-        if constexpr ((N % 4) == 0) contig = tab[0][N - 1] == tab[0][0] + N - 1 && tab[3][N - 1] == tab[3][0] + N - 1;
-        if (contig) {
-            const float* __restrict__ rp = rrow + tab[0][0];
-            const float* __restrict__ tp = trow + tab[3][0];
-            static_for<0, N / 4>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                const float4u r4 = *reinterpret_cast<const float4u*>(rp + 4 * q);
-                const float4u t4 = *reinterpret_cast<const float4u*>(tp + 4 * q);
-                v[4 * q + 0] = mkc(r4.x, t4.x);
-                v[4 * q + 1] = mkc(r4.y, t4.y);
-                v[4 * q + 2] = mkc(r4.z, t4.z);
-                v[4 * q + 3] = mkc(r4.w, t4.w);
-            });
-        } else {
-            static_for<0, N>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                v[k] = mkc(rrow[tab[0][k]], trow[tab[3][k]]);
-            });
-        }
+        const float* __restrict__ rp = P.ref + (size_t)tab[2][a] * P.dy * P.dx + tab[0][b];
+        const float* __restrict__ tp = P.tar + (size_t)tab[5][a] * P.dy * P.dx + tab[3][b];
+        static_for<0, N>([&](auto yc) {
+            constexpr int y = decltype(yc)::value;
+            v[y] = mkc(rp[(size_t)tab[1][y] * P.dx], tp[(size_t)tab[4][y] * P.dx]);
+        });
     }
     // means, zero-mean, sums of squares (src/oc_fftcc.cpp:360-376)
     float rn, tn;
@@ -149,28 +136,28 @@ __global__ __launch_bounds__(Cube<N>::BLOCK) void fftcc3d_fusedn_kernel(Fftcc3dP
         asm volatile("" : "+v"(rn), "+v"(tn));  // formed here, used at the very end (see fftcc3d_fused.hip)
     }
 
-    // ---- forward x: thread (z = a, y = b); the spectrum line goes to vol[z][y][kx]
+    // ---- forward y: thread (z = a, x = b); the spectrum line goes to vol[z][ky][x]
     fft_mixed<false, N>(v);
     if (active) {
-        c2* __restrict__ row = vol + (a * N + b) * NP;
+        c2* __restrict__ colp = vol + a * N * NP + b;
         static_for<0, N>([&](auto kc) {
             constexpr int k = decltype(kc)::value, p = fft_pos(N, k);  // (constexpr: a run-time fft_pos() sends v[] to scratch)
-            row[k] = v[p];
+            colp[k * NP] = v[p];
         });
     }
     __syncthreads();
-    // ---- forward y: thread (z = a, x = b), in place
+    // ---- forward x: thread (z = a, ky = b), in place
     {
-        c2* __restrict__ colp = vol + a * N * NP + b;
+        c2* __restrict__ row = vol + (a * N + b) * NP;
         static_for<0, N>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            v[j] = colp[j * NP];
+            v[j] = row[j];
         });
         fft_mixed<false, N>(v);
         if (active) {
             static_for<0, N>([&](auto kc) {
                 constexpr int k = decltype(kc)::value, p = fft_pos(N, k);
-                colp[k * NP] = v[p];
+                row[k] = v[p];
             });
         }
     }
