@@ -280,7 +280,8 @@ int oc_hip_group_queue(const oc_hip_engine* engine, int member, const void** dev
  *                     up to 26^3, register kernel at 32^3, plane-wise kernel for 28^3 ... 64^3; and for every NON-cubic window
  *                     with all three radii in 4 ... 16 whose complex volume [2rx][2ry][2rz + 1] fits 160 KB of LDS (one kernel,
  *                     sides as run-time values: fftcc3d_box.hip); other non-cubic windows and larger sides run the rocFFT
- *                     pipeline.  0: rocFFT pipeline always
+ *                     pipeline.  0: rocFFT pipeline always.  2 (A/B build of the library only): as 1, but 32^3 windows run the
+ *                     kernel of rounds 1 - 5 (fftcc3d_fused_r5.hip: same integers, ZNCC within 1e-6, 1.45 x the time)
  *   "fftcc3d_planes_blocks"  persistent workgroups (= private scratch volumes) of the plane-wise FFTCC3D kernel; 0 (default) = 256
  *   "fftcc3d_tile_vox"  FFTCC3D single-kernel paths: queues >= 2048 POIs are visited in cubic blocks of this many voxels
  *                     (default 64; 0 = queue order; >= 8)
