@@ -282,34 +282,6 @@ __device__ __forceinline__ float bspline3d_eval_lds(const float* __restrict__ wi
     const float bz[4] = {basis0(fz), basis1(fz), basis2(fz), basis3(fz)};
     const float* __restrict__ base = win + ((zi - 1 - oz) * nxy + (yi - 1 - oy) * nx + (xi - 1 - ox));
     float sum_y[4];
-#if defined(OC_TAP_BATCH) && OC_TAP_BATCH
-    // experiment (A/B builds): the 16 taps of a z-slice are read as ONE group (1: then used; 2: the next slice's group is issued
-    // before this slice's arithmetic), with scheduling barriers so that the compiler keeps it that way
-    typedef const float __attribute__((address_space(3))) * lds_cfp;
-    float r[2][4][4];
-    auto load_slice = [&](int i, float (&dst)[4][4]) {
-        lds_cfp pl = (lds_cfp)(base + i * nxy);
-        if constexpr (PX != 0) asm volatile("" : "+v"(pl));
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            lds_cfp row = pl + j * nx;
-#pragma unroll
-            for (int k = 0; k < 4; k++) dst[j][k] = row[k];
-        }
-    };
-    load_slice(0, r[0]);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (OC_TAP_BATCH == 2 && i < 3) load_slice(i + 1, r[(i + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        float sum_x[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) sum_x[j] = taps4(bx0, bx1, bx2, bx3, r[i & 1][j][0], r[i & 1][j][1], r[i & 1][j][2], r[i & 1][j][3]);
-        sum_y[i] = taps4(by[0], by[1], by[2], by[3], sum_x[0], sum_x[1], sum_x[2], sum_x[3]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (OC_TAP_BATCH == 1 && i < 3) load_slice(i + 1, r[(i + 1) & 1]);
-    }
-#else
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         float sum_x[4];
@@ -325,7 +297,6 @@ __device__ __forceinline__ float bspline3d_eval_lds(const float* __restrict__ wi
         }
         sum_y[i] = taps4(by[0], by[1], by[2], by[3], sum_x[0], sum_x[1], sum_x[2], sum_x[3]);
     }
-#endif
     const float v = taps4(bz[0], bz[1], bz[2], bz[3], sum_y[0], sum_y[1], sum_y[2], sum_y[3]);
     return out ? -1.f : v;
 }
