@@ -256,6 +256,47 @@ def test_fuzz_fftcc3d(seed):
     assert np.abs(got[:, P["zncc"]] - want[:, P["zncc"]]).max() <= 1e-4
 
 
+@pytest.mark.parametrize("seed", range(3 + _EXTRA))
+def test_fuzz_fftcc3d_32_cubed_windows_anywhere(seed):
+    """r = 16, the register-resident kernel (fftcc3d_fused.hip; round 6: every lane reads the voxel its own clamped index names):
+    POIs ANYWHERE in volumes barely larger than the window -- most windows clamped at one or several faces, in either volume, by the
+    position or by the (fractional) guess -- against the rocFFT pipeline (same clamping: integers identical, ZNCC within 5e-6) and,
+    for the windows that lie inside both volumes, against the oracle."""
+    import opencorr_amd
+    import oracle
+    from opencorr_amd import synth
+    rng = np.random.default_rng(7000 + seed)
+    dz, dy, dx = (int(rng.integers(40, 76)) for _ in range(3))
+    ref, tar = synth.speckle_pair_3d(dz, dy, dx, seed=1700 + seed)
+    P = oracle.P3
+    n = 48
+    pois = oracle.make_pois3d(rng.uniform(1, dx - 2, n).astype(np.float32), rng.uniform(1, dy - 2, n).astype(np.float32),
+                              rng.uniform(1, dz - 2, n).astype(np.float32))
+    for k in ("u", "v", "w"):
+        pois[:, P[k]] = rng.uniform(-3.5, 3.5, n)
+    pois[: n // 4, P["u"]:P["u"] + 1] = np.round(pois[: n // 4, P["u"]:P["u"] + 1])
+    pois = pois.astype(np.float32)
+    f = opencorr_amd.FFTCC3D(16, 16, 16)
+    f.set_images(ref, tar)
+    got = f.compute(pois.copy())
+    f.set_tuning("fftcc3d_fused", 0)
+    base = f.compute(pois.copy())
+    for k in ("u", "v", "w", "u0", "v0", "w0"):
+        assert np.array_equal(got[:, P[k]], base[:, P[k]]), (seed, k)
+    assert np.abs(got[:, P["zncc"]] - base[:, P["zncc"]]).max() <= 5e-6, seed
+    inner = np.ones(n, bool)
+    for axis, d in (("x", dx), ("y", dy), ("z", dz)):
+        c = pois[:, P[axis]]
+        g = pois[:, P[{"x": "u", "y": "v", "z": "w"}[axis]]]
+        for lo in (c - 16, c - 16 + g):
+            inner &= (np.trunc(lo) >= 0) & (np.trunc(lo + 31) <= d - 1) & (lo >= 0)
+    if inner.any():
+        want = pois[inner].copy()
+        oracle.fftcc3d(ref, tar, 16, 16, 16, want)
+        for k in ("u", "v", "w"):
+            assert np.array_equal(got[inner][:, P[k]], want[:, P[k]]), (seed, k)
+
+
 def _cloud(rng, ndim, n):
     """Irregular POI positions: a uniform background, a dense blob, a hole and a few far outliers (positions are drawn in
     float32 and never tie: the K-nearest fallback of the reference has no defined result among equidistant neighbours)."""
