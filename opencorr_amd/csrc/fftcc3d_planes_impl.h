@@ -9,8 +9,10 @@
 // between the axis passes.  The five-kernel rocFFT pipeline (fftcc3d.hip) moves ~10 MB per POI through HBM in 13 plans'
 // worth of launches and costs 7.5 us per POI (3.8 ms for the example's 512-POI test queue, round 3).  Here ONE persistent
 // 512-thread workgroup per CU owns a POI at a time and a private scratch volume S of N^3 complex elements:
-//   A  forward planes.  Wave w takes the z-planes w, w + 8, ...: lane y gathers row y of both windows (z = ref + i * tar, 16-byte
-//      loads), transforms it along x in registers (mixed-radix FFT of fft_device.h), the wave transposes the plane through
+//   A  forward planes.  Wave w takes the z-planes w, w + 8, ...: lane x gathers COLUMN x of both windows (z = ref + i * tar; the
+//      lanes side by side in x: round 6 -- inside the kernel the plane is transposed, which only the arg-max has to know; the
+//      description below keeps the old names: read "x" as the register index and "y" as the lane), transforms it in registers
+//      (mixed-radix FFT of fft_device.h), the wave transposes the plane through
 //      its LDS tile (N x (N + 1) floats, real parts then imaginary parts), lane kx transforms along y and writes
 //      S[z][ky][kx] -- N consecutive complex numbers per row: coalesced.
 //   B  z pass.  Thread (row slot, kx) loads its z-line from S (lanes adjacent in kx: coalesced), transforms it, and needs
@@ -41,7 +43,6 @@ namespace planes {
 
 using namespace fftdev;
 
-typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned 16-byte load
 
 constexpr int kPlThreads = 512;
 constexpr int kPlWaves = kPlThreads / kWave;  // 8
@@ -113,7 +114,6 @@ __global__ __launch_bounds__(kPlThreads) void fftcc3d_planes_kernel(Fftcc3dParam
         // running sums small)
         const float c0r = P.ref[((size_t)tab[2][R] * P.dy + tab[1][R]) * P.dx + tab[0][R]];
         const float c0t = P.tar[((size_t)tab[5][R] * P.dy + tab[4][R]) * P.dx + tab[3][R]];
-        const bool contig = (N % 4) == 0 && tab[0][N - 1] == tab[0][0] + N - 1 && tab[3][N - 1] == tab[3][0] + N - 1;
 
         // ================= A: forward planes =================
         float s1r = 0.f, s2r = 0.f, s1t = 0.f, s2t = 0.f;
@@ -121,26 +121,17 @@ __global__ __launch_bounds__(kPlThreads) void fftcc3d_planes_kernel(Fftcc3dParam
         for (int z = wave; z < N; z += kPlWaves) {
             c2 v[N];
             {
-                const float* __restrict__ rrow = P.ref + ((size_t)tab[2][z] * P.dy + tab[1][l]) * P.dx;
-                const float* __restrict__ trow = P.tar + ((size_t)tab[5][z] * P.dy + tab[4][l]) * P.dx;
-                if (contig) {
-                    const float* __restrict__ rp = rrow + tab[0][0];
-                    const float* __restrict__ tp = trow + tab[3][0];
-                    static_for<0, N / 4>([&](auto qc) {
-                        constexpr int q = decltype(qc)::value;
-                        const float4u r4 = *reinterpret_cast<const float4u*>(rp + 4 * q);
-                        const float4u t4 = *reinterpret_cast<const float4u*>(tp + 4 * q);
-                        v[4 * q + 0] = mkc(r4.x, t4.x);
-                        v[4 * q + 1] = mkc(r4.y, t4.y);
-                        v[4 * q + 2] = mkc(r4.z, t4.z);
-                        v[4 * q + 3] = mkc(r4.w, t4.w);
-                    });
-                } else {
-                    static_for<0, N>([&](auto kc) {
-                        constexpr int k = decltype(kc)::value;
-                        v[k] = mkc(rrow[tab[0][k]], trow[tab[3][k]]);
-                    });
-                }
+                // lane x gathers COLUMN x of the plane (round 6): the lanes of the wave sit side by side in x, so a load instruction
+                // covers one row of the window.  (Until then lane y read ROW y with 16-byte loads -- one row per lane, and the texture
+                // path handles about one cache line per cycle whatever the lanes take from it: fftcc3d_fused.hip.)  Inside the kernel
+                // the plane is therefore TRANSPOSED -- lane / row index = x, register / column index = y -- down to the arg-max,
+                // which is where x and y are told apart again.
+                const float* __restrict__ rp = P.ref + (size_t)tab[2][z] * P.dy * P.dx + tab[0][l];
+                const float* __restrict__ tp = P.tar + (size_t)tab[5][z] * P.dy * P.dx + tab[3][l];
+                static_for<0, N>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    v[k] = mkc(rp[(size_t)tab[1][k] * P.dx], tp[(size_t)tab[4][k] * P.dx]);
+                });
             }
             {
                 const c2 c0 = mkc(c0r, c0t);
@@ -309,16 +300,16 @@ __global__ __launch_bounds__(kPlThreads) void fftcc3d_planes_kernel(Fftcc3dParam
             OC_PLANES_T2(x)
             OC_PLANES_T2(y)
 #undef OC_PLANES_T2
-            fft_mixed<true, N>(v);  // lane y: the correlation row (z, y, x) in v[fft_pos(N, x)].x
+            fft_mixed<true, N>(v);  // lane x (the plane is transposed, see the gather): the correlation column (z, y, x = l) in v[fft_pos(N, y)].x
             // arg-max with "strict >, scanning from index 0" (src/oc_fftcc.cpp:391-400): this lane's planes come in
-            // ascending z, its row's values in ascending x -- ascending linear index (z * N + y) * N + x
+            // ascending z, its column's values in ascending y -- ascending linear index (z * N + y) * N + x
             if (act) {
-                static_for<0, N>([&](auto xc) {
-                    constexpr int x = decltype(xc)::value, p = fft_pos(N, x);
+                static_for<0, N>([&](auto yc) {
+                    constexpr int y = decltype(yc)::value, p = fft_pos(N, y);
                     const float val = v[p].x;
                     if (val > best) {
                         best = val;
-                        bidx = (z * N + l) * N + x;
+                        bidx = (z * N + y) * N + l;
                     }
                 });
             }
