@@ -146,51 +146,55 @@ __global__ __launch_bounds__(kBoxMaxThreads) void fftcc3d_box_kernel(Fftcc3dPara
     }
     __syncthreads();
 
-    // ---- gather: thread (a, b) fills its fast line, i.e. the fx consecutive buffer positions s0 ... s0 + fx - 1 with
-    // s0 = (a * fy + b) * fx; position s holds window voxel (k, j, i) = (s % nx, (s / nx) % ny, s / (nx * ny)); z = ref + i * tar
+    // ---- gather (round 6): buffer position s holds window voxel (k, j, i) = (s % nx, (s / nx) % ny, s / (nx * ny)) and is element
+    // (c, b, a) = (s % fx, (s / fx) % fy, s / (fx * fy)) of the transform's array; z = ref + i * tar.  Thread t takes the positions
+    // t, t + T, t + 2T, ...: neighbouring lanes read neighbouring voxels of a window row, so a load instruction covers whole rows.
+    // (Until then thread (a, b) filled ITS line, fx consecutive positions: a wave's loads were fx floats apart, a cache line per
+    // lane -- what that costs is measured in fftcc3d_fused.hip.)  The divisions are multiplications by reciprocals that are exact
+    // for s < 2^16 (the volume fits the LDS: M <= 20 480).
     const int xlines = fz * fy;
     const bool has_xline = tid < xlines;
     const int za = has_xline ? tid / fy : 0, yb = has_xline ? tid - za * fy : 0;
-    c2* __restrict__ xrow = vol + za * plane + yb * NP;
+    c2* __restrict__ xrow = vol + za * plane + yb * NP;   // the thread's line of the fast axis (first and last pass)
+    auto recip = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };   // ceil(2^32 / d)
+    const unsigned inv_nx = recip(nx), inv_ny = recip(ny), inv_fx = recip(fx), inv_fy = recip(fy);
+    auto divmod = [](unsigned s, unsigned inv, int d, int& q, int& r) {
+        q = (int)__umulhi(s, inv);
+        r = (int)s - q * d;
+    };
     float rs = 0.f, ts = 0.f;
-    if (has_xline) {
-        const int s0 = tid * fx;
-        int k = s0 % nx, rem = s0 / nx;
-        int j = rem % ny, i = rem / ny;
+    {
         const size_t pitch = (size_t)P.dx;
-        size_t roff = ((size_t)tab[2 * kBoxMaxSide + i] * P.dy + tab[1 * kBoxMaxSide + j]) * pitch;
-        size_t toff = ((size_t)tab[5 * kBoxMaxSide + i] * P.dy + tab[4 * kBoxMaxSide + j]) * pitch;
-        for (int c = 0; c < fx; c++) {
-            const float r = P.ref[roff + tab[k]], t = P.tar[toff + tab[3 * kBoxMaxSide + k]];
-            xrow[c] = mkc(r, t);
+        for (int s0 = tid; s0 < M; s0 += (int)blockDim.x) {
+            int k, rem, j, i, c, ab, bb, aa;
+            divmod((unsigned)s0, inv_nx, nx, rem, k);
+            divmod((unsigned)rem, inv_ny, ny, i, j);
+            divmod((unsigned)s0, inv_fx, fx, ab, c);
+            divmod((unsigned)ab, inv_fy, fy, aa, bb);
+            const float r = P.ref[((size_t)tab[2 * kBoxMaxSide + i] * P.dy + tab[1 * kBoxMaxSide + j]) * pitch + tab[k]];
+            const float t = P.tar[((size_t)tab[5 * kBoxMaxSide + i] * P.dy + tab[4 * kBoxMaxSide + j]) * pitch + tab[3 * kBoxMaxSide + k]];
+            vol[aa * plane + bb * NP + c] = mkc(r, t);
             rs += r;
             ts += t;
-            if (++k == nx) {   // the next window row
-                k = 0;
-                if (++j == ny) {
-                    j = 0;
-                    i++;
-                }
-                if (i < nz) {
-                    roff = ((size_t)tab[2 * kBoxMaxSide + i] * P.dy + tab[1 * kBoxMaxSide + j]) * pitch;
-                    toff = ((size_t)tab[5 * kBoxMaxSide + i] * P.dy + tab[4 * kBoxMaxSide + j]) * pitch;
-                }
-            }
         }
     }
-    // means, zero-mean, sums of squares (src/oc_fftcc.cpp:360-376); every thread re-reads the line it wrote itself
+    // means, zero-mean, sums of squares (src/oc_fftcc.cpp:360-376); every thread re-reads the elements it wrote itself
     block_sum2b(rs, ts, red, lane, wave, waves);
     float rn = 0.f, tn = 0.f;
-    if (has_xline) {
+    {
         const c2 mean = mkc(rs / M, ts / M);
-        for (int c = 0; c < fx; c++) {
-            const c2 d = xrow[c] - mean;
-            xrow[c] = d;
+        for (int s0 = tid; s0 < M; s0 += (int)blockDim.x) {
+            int c, ab, bb, aa;
+            divmod((unsigned)s0, inv_fx, fx, ab, c);
+            divmod((unsigned)ab, inv_fy, fy, aa, bb);
+            c2* e = vol + aa * plane + bb * NP + c;
+            const c2 d = *e - mean;
+            *e = d;
             rn += d.x * d.x;
             tn += d.y * d.y;
         }
     }
-    block_sum2b(rn, tn, red, lane, wave, waves);
+    block_sum2b(rn, tn, red, lane, wave, waves);   // (its barriers also publish the volume to the line owners of the first pass)
 
     // ---- forward passes along the fast axis (thread (a, b): the line it gathered), the middle axis (thread (a, c)) and the slow
     // axis (thread (b, c)), each in place
